@@ -1,0 +1,103 @@
+/* ivlm_hip.h — C ABI of libivlm_hip.so: the MI355X (gfx950) implementation of InteractVLM's
+ * contact-inference hot path.
+ *
+ * The reference (saidwivedi/InteractVLM) is 100 % Python and has no FFI of its own; each entry
+ * point below names the reference operator it replaces (file:line in /root/reference) and is
+ * what a ctypes/cffi binding on the reference side would bind.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++/torch types; every pointer is a DEVICE pointer unless the
+ *     name ends in _host; all buffers (outputs, workspaces) are owned and allocated by the caller
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work
+ *   - return value: 0 = IVLM_OK, negative = error (ivlm_error_string()); nothing throws
+ *   - row-major contiguous tensors; shapes in comments use the reference's names:
+ *       B images, V views, HW = H*W pixels, Nv mesh vertices, Np points
+ *   - dtype codes: IVLM_F32 = 0, IVLM_BF16 = 1
+ */
+#ifndef IVLM_HIP_H
+#define IVLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVLM_OK 0
+#define IVLM_ERR_INVALID_ARG (-1)
+#define IVLM_ERR_WORKSPACE (-2)
+#define IVLM_ERR_LAUNCH (-3)
+#define IVLM_ERR_UNSUPPORTED (-4)
+
+#define IVLM_F32 0
+#define IVLM_BF16 1
+
+typedef void *ivlm_stream_t;
+
+/* library identity --------------------------------------------------------------------------- */
+int ivlm_abi_version(void);
+const char *ivlm_error_string(int code);
+const char *ivlm_build_arch(void); /* "gfx950" */
+
+/* ---------------------------------------------------------------------------------------------
+ * Render-Localize-Lift: 2D multi-view masks -> per-vertex / per-point contact
+ * ------------------------------------------------------------------------------------------- */
+
+/* One-time inversion of constant pixel->vertex tables into a vertex-major CSR ("lift plan").
+ * Replaces the per-call table handling of HumanContact3DPredictor.__init__/_process_view
+ * (model/components.py:203-218, 253-262): ids outside [0,Nv) in ANY slot drop the whole pixel.
+ *   vid   i32 [V,HW,3]   (the reference's int64 table narrowed once by the host)
+ *   bary  f32 [V,HW,3]
+ *   row_ptr  i32 [V*Nv+1]      out: CSR row starts, row r = v*Nv + vertex
+ *   ent_pix  i32 [cap]         out: pixel index (within the view) of each entry
+ *   ent_w    f32 [cap]         out: barycentric weight of each entry
+ *   cap >= 3*V*HW is always sufficient; *nnz_out (device i32) receives the entry count.
+ * Entries of a row are ordered by (slot k, pixel) — the reference's summation order.
+ */
+size_t ivlm_lift_plan_workspace_bytes(int V, int64_t HW, int Nv);
+int ivlm_lift_plan_build(const int32_t *vid, const float *bary, int V, int64_t HW, int Nv,
+                         int32_t *row_ptr, int32_t *ent_pix, float *ent_w, int64_t cap, int32_t *nnz_out,
+                         void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+
+/* HumanContact3DPredictor.forward (model/components.py:220-277), deterministic vertex-major
+ * gather over a lift plan:  m = sigmoid(clamp(logit,+-clampv)); per view votes/cnt; mean over
+ * views with cnt>0; clamp [0,1].
+ *   logits f32 [B,V,HW]  ->  out f32 [B,Nv];  nviews f32 [B,Nv] (may be NULL)
+ * mode 0 = soft (above); mode 1 = thresholded object-mesh rule (components.py:445-489):
+ *   p = sigmoid(logit) (no clamp), only pixels with p > param vote, no final clamp.
+ */
+int ivlm_lift_mesh_plan(const float *logits, const int32_t *row_ptr, const int32_t *ent_pix,
+                        const float *ent_w, int B, int V, int64_t HW, int Nv, int mode, float param,
+                        float *out, float *nviews, ivlm_stream_t stream);
+
+/* Same operators, streaming directly over the dense tables (single-use tables, e.g. a fresh
+ * lift2d_dict.pkl: ObjectMeshContact3DPredictor.forward_inference, components.py:392-424).
+ * Accumulates with LDS/L2 atomics, so float summation order is not fixed (<= ~1e-6 abs). */
+size_t ivlm_lift_mesh_dense_workspace_bytes(int B, int V, int Nv);
+int ivlm_lift_mesh_dense(const float *logits, const int32_t *vid, const float *bary, int B, int V,
+                         int64_t HW, int Nv, int mode, float param, float *out, float *nviews,
+                         void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+
+/* ObjectPCAfford3DPredictor.forward (model/components.py:289-347; NumPy twin
+ * preprocess_data/utils_obj_pc.py:47-86): per-view mean of the values of the pixels mapped to a
+ * point, then mean over the views that saw it.  No sigmoid, no clamp.
+ *   probs f32 [B,V,HW]; pid i32 [B,V,HW] (or [V,HW] shared by the batch when pid_batched == 0),
+ *   -1 = no point;  out f32 [B,Np];  nviews f32 [B,Np] (may be NULL) */
+size_t ivlm_lift_points_workspace_bytes(int B, int V, int Np);
+int ivlm_lift_points(const float *probs, const int32_t *pid, int pid_batched, int B, int V, int64_t HW,
+                     int Np, float *out, float *nviews, void *workspace, size_t workspace_bytes,
+                     ivlm_stream_t stream);
+
+/* Sam.postprocess_masks (model/segment_anything/modeling/sam.py:137-172): bilinear
+ * (align_corners=False) h x w -> img x img, crop to (in_h,in_w), bilinear -> (oh,ow); fp32 out
+ * whatever the input dtype (sam.py:161).  apply_sigmoid != 0 additionally applies the in-place
+ * sigmoid of InteractVLM.py:452-456 (oafford + 'HM' views).
+ *   low  f32|bf16 [n,h,w]  ->  out f32 [n,oh,ow] */
+int ivlm_postprocess_masks(const void *low, int dtype, int n, int h, int w, int img, int in_h, int in_w,
+                           int oh, int ow, int apply_sigmoid, float *out, ivlm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVLM_HIP_H */

@@ -1,0 +1,152 @@
+"""Thin torch-tensor wrappers over the C ABI (``include/ivlm_hip.h``).
+
+torch is plumbing here: device memory, the current HIP stream and nothing else.  Every function
+requires CUDA(HIP) tensors and raises if the extension is missing — there is no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import IvlmError, check
+
+IVLM_F32, IVLM_BF16 = 0, 1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise IvlmError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise IvlmError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise IvlmError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return IVLM_F32
+    if t.dtype == torch.bfloat16:
+        return IVLM_BF16
+    raise IvlmError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------------
+# lift
+# --------------------------------------------------------------------------------------------
+class LiftPlan:
+    """Vertex-major CSR of constant pixel->vertex tables (built once on the GPU)."""
+
+    def __init__(self, vid: torch.Tensor, bary: torch.Tensor, num_vertices: int):
+        lib = _lib.load()
+        vid = _req(vid, torch.int32, "vid")
+        bary = _req(bary, torch.float32, "bary")
+        assert vid.dim() == 4 and vid.shape[-1] == 3 and vid.shape == bary.shape, "tables must be [V,H,W,3]"
+        V, H, W, _ = vid.shape
+        self.V, self.HW, self.hw_shape, self.num_vertices = V, H * W, (H, W), int(num_vertices)
+        dev = vid.device
+        cap = 3 * V * H * W
+        self.row_ptr = torch.empty(V * self.num_vertices + 1, dtype=torch.int32, device=dev)
+        ent_pix = torch.empty(cap, dtype=torch.int32, device=dev)
+        ent_w = torch.empty(cap, dtype=torch.float32, device=dev)
+        nnz = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws_bytes = lib.ivlm_lift_plan_workspace_bytes(V, self.HW, self.num_vertices)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(lib.ivlm_lift_plan_build(vid.data_ptr(), bary.data_ptr(), V, self.HW, self.num_vertices,
+                                       self.row_ptr.data_ptr(), ent_pix.data_ptr(), ent_w.data_ptr(), cap,
+                                       nnz.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "lift_plan_build")
+        self.nnz = int(nnz.item())
+        # trim to the real size (one-time copy) so the plan holds 8 B per entry, no slack
+        self.ent_pix = ent_pix[: self.nnz].clone()
+        self.ent_w = ent_w[: self.nnz].clone()
+
+    def bytes(self) -> int:
+        return self.nnz * 8 + self.row_ptr.numel() * 4
+
+
+def lift_mesh_plan(logits: torch.Tensor, plan: LiftPlan, mode: int = 0, param: float = 20.0, want_nviews=False):
+    """logits f32 [B,V,H,W] -> contacts f32 [B,Nv] (and nviews) via the CSR plan."""
+    lib = _lib.load()
+    logits = _req(logits, torch.float32, "logits")
+    B, V = logits.shape[0], logits.shape[1]
+    assert V == plan.V and logits[0, 0].numel() == plan.HW, "logit shape does not match the lift plan"
+    out = torch.empty(B, plan.num_vertices, dtype=torch.float32, device=logits.device)
+    nviews = torch.empty_like(out) if want_nviews else None
+    check(lib.ivlm_lift_mesh_plan(logits.data_ptr(), plan.row_ptr.data_ptr(), plan.ent_pix.data_ptr(),
+                                  plan.ent_w.data_ptr(), B, V, plan.HW, plan.num_vertices, mode, float(param),
+                                  out.data_ptr(), _p(nviews), _stream()), "lift_mesh_plan")
+    return (out, nviews) if want_nviews else out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def lift_mesh_dense(logits, vid, bary, num_vertices: int, mode: int = 0, param: float = 20.0, want_nviews=False):
+    """Streaming (atomic) variant over dense tables: vid i32 [V,H,W,3], bary f32 [V,H,W,3]."""
+    lib = _lib.load()
+    logits = _req(logits, torch.float32, "logits")
+    vid = _req(vid, torch.int32, "vid")
+    bary = _req(bary, torch.float32, "bary")
+    B, V = logits.shape[0], logits.shape[1]
+    HW = logits[0, 0].numel()
+    nv = int(num_vertices)
+    out = torch.empty(B, nv, dtype=torch.float32, device=logits.device)
+    nviews = torch.empty_like(out) if want_nviews else None
+    nbytes = lib.ivlm_lift_mesh_dense_workspace_bytes(B, V, nv)
+    ws = _workspace(nbytes, logits.device)
+    check(lib.ivlm_lift_mesh_dense(logits.data_ptr(), vid.data_ptr(), bary.data_ptr(), B, V, HW, nv, mode,
+                                   float(param), out.data_ptr(), _p(nviews), ws.data_ptr(), ws.numel(), _stream()),
+          "lift_mesh_dense")
+    return (out, nviews) if want_nviews else out
+
+
+def lift_points(probs, pid, num_points: int, want_nviews=False):
+    """probs f32 [B,V,H,W]; pid i32 [B,V,H,W] or [V,H,W] (shared) -> f32 [B,Np]."""
+    lib = _lib.load()
+    probs = _req(probs, torch.float32, "probs")
+    pid = _req(pid, torch.int32, "pid")
+    B, V = probs.shape[0], probs.shape[1]
+    HW = probs[0, 0].numel()
+    batched = 1 if pid.dim() == probs.dim() else 0
+    n = int(num_points)
+    out = torch.empty(B, n, dtype=torch.float32, device=probs.device)
+    nviews = torch.empty_like(out) if want_nviews else None
+    nbytes = lib.ivlm_lift_points_workspace_bytes(B, V, n)
+    ws = _workspace(nbytes, probs.device)
+    check(lib.ivlm_lift_points(probs.data_ptr(), pid.data_ptr(), batched, B, V, HW, n, out.data_ptr(), _p(nviews),
+                               ws.data_ptr(), ws.numel(), _stream()), "lift_points")
+    return (out, nviews) if want_nviews else out
+
+
+def postprocess_masks(low_res, input_size, original_size, img_size: int = 1024, apply_sigmoid: bool = False):
+    """low_res f32|bf16 [...,h,w] -> f32 [...,oh,ow] (Sam.postprocess_masks)."""
+    lib = _lib.load()
+    low_res = _req(low_res, None, "low_res")
+    lead = tuple(low_res.shape[:-2])
+    h, w = low_res.shape[-2:]
+    n = 1
+    for s in lead:
+        n *= s
+    oh, ow = int(original_size[0]), int(original_size[1])
+    out = torch.empty(lead + (oh, ow), dtype=torch.float32, device=low_res.device)
+    check(lib.ivlm_postprocess_masks(low_res.data_ptr(), _dt(low_res), n, h, w, int(img_size), int(input_size[0]),
+                                     int(input_size[1]), oh, ow, 1 if apply_sigmoid else 0, out.data_ptr(),
+                                     _stream()), "postprocess_masks")
+    return out
