@@ -39,6 +39,8 @@ typedef void *ivlm_stream_t;
 int ivlm_abi_version(void);
 const char *ivlm_error_string(int code);
 const char *ivlm_build_arch(void); /* "gfx950" */
+/* detail of the most recent IVLM_ERR_LAUNCH on this thread: HIP error text + source location */
+const char *ivlm_last_hip_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Render-Localize-Lift: 2D multi-view masks -> per-vertex / per-point contact

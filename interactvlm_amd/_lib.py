@@ -58,6 +58,7 @@ def load():
         raise IvlmError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Build it with `python -m interactvlm_amd.build` (hipcc --offload-arch=gfx950).")
+    import torch  # noqa: F401  -- first: libivlm_hip.so must bind to torch's HIP runtime instance
     lib = C.CDLL(LIB_PATH)
     for name, (ret, args) in header_prototypes().items():
         try:
@@ -74,4 +75,6 @@ def check(rc: int, what: str = "") -> None:
     if rc != 0:
         lib = load()
         msg = lib.ivlm_error_string(rc)
-        raise IvlmError(f"{what or 'ivlm call'} failed: {msg.decode() if msg else rc} ({rc})")
+        detail = lib.ivlm_last_hip_error() if rc == -3 else b""
+        raise IvlmError(f"{what or 'ivlm call'} failed: {msg.decode() if msg else rc} ({rc})"
+                        + (f" [{detail.decode()}]" if detail else ""))

@@ -34,6 +34,18 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def _torch_lib_dir() -> str:
+    import importlib.util
+
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        raise RuntimeError("torch not found: libivlm_hip.so links against torch's HIP runtime")
+    d = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    if not os.path.exists(os.path.join(d, "libamdhip64.so")):
+        raise RuntimeError(f"{d}/libamdhip64.so missing (not a ROCm build of torch?)")
+    return d
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -69,7 +81,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, hdr_m), srcs))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB, *objs]
+        # Link against the SAME HIP runtime torch uses (its bundled libamdhip64.so), not hipcc's
+        # default /opt/rocm copy: two runtimes in one process do not share streams/events/contexts.
+        tl = _torch_lib_dir()
+        cmd = ["g++", "-shared", "-fPIC", "-o", LIB, *objs, "-L" + tl, "-lamdhip64",
+               "-Wl,-rpath," + tl, "-Wl,--no-undefined", "-Wl,-z,defs"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -1,7 +1,16 @@
 // Library identity + error strings for libivlm_hip.so.
 #include "ivlm_common.h"
 
+static thread_local char g_last_hip_error[512] = "";
+
 extern "C" {
+
+void ivlm_set_last_hip_error(int code, const char* where) {
+    snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s (hipError %d) at %s",
+             hipGetErrorString((hipError_t)code), code, where ? where : "?");
+}
+
+const char* ivlm_last_hip_error(void) { return g_last_hip_error; }
 
 int ivlm_abi_version(void) { return 1; }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/ivlm_hip.h"
 
@@ -12,10 +13,34 @@
         if (!(cond)) return IVLM_ERR_INVALID_ARG; \
     } while (0)
 
-static inline int ivlm_launch_status() {
+// hipGetLastError() is per-thread sticky state shared with every other HIP user in the process
+// (torch, RCCL): clear it on entry so that we only ever report our own launches.
+static inline void ivlm_enter() { (void)hipGetLastError(); }
+
+extern "C" void ivlm_set_last_hip_error(int code, const char* where);
+
+#define ivlm_launch_status() ivlm_launch_status_at(__FILE__, __LINE__)
+static inline int ivlm_launch_status_at(const char* file, int line) {
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? IVLM_OK : IVLM_ERR_LAUNCH;
+    if (e == hipSuccess) return IVLM_OK;
+    char buf[256];
+    const char* base = file;
+    for (const char* c = file; *c; ++c)
+        if (*c == '/') base = c + 1;
+    snprintf(buf, sizeof(buf), "%s:%d", base, line);
+    ivlm_set_last_hip_error((int)e, buf);
+    return IVLM_ERR_LAUNCH;
 }
+
+// run a HIP runtime call; on failure record the detail and return IVLM_ERR_LAUNCH from the caller
+#define IVLM_HIP_TRY(expr)                                        \
+    do {                                                          \
+        hipError_t e_ = (expr);                                   \
+        if (e_ != hipSuccess) {                                   \
+            ivlm_set_last_hip_error((int)e_, #expr);              \
+            return IVLM_ERR_LAUNCH;                               \
+        }                                                         \
+    } while (0)
 
 static inline hipStream_t ivlm_stream(ivlm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

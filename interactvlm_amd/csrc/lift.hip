@@ -394,9 +394,10 @@ int ivlm_lift_plan_build(const int32_t* vid, const float* bary, int V, int64_t H
     IVLM_CHECK_ARG((int64_t)V * Nv < (1ll << 31) - 2 && (int64_t)V * HW * 3 < (1ll << 31));
     if (workspace_bytes < ivlm_lift_plan_workspace_bytes(V, HW, Nv)) return IVLM_ERR_WORKSPACE;
     hipStream_t st = ivlm_stream(stream);
+    ivlm_enter();
     const int R = V * Nv;
     int32_t* row_cnt = static_cast<int32_t*>(workspace);
-    if (hipMemsetAsync(row_cnt, 0, sizeof(int32_t) * (size_t)R, st) != hipSuccess) return IVLM_ERR_LAUNCH;
+    IVLM_HIP_TRY(hipMemsetAsync(row_cnt, 0, sizeof(int32_t) * (size_t)R, st));
     const int64_t n = (int64_t)V * HW;
     const int grid = (int)((n + kBlock - 1) / kBlock < 4096 ? (n + kBlock - 1) / kBlock : 4096);
     plan_count_kernel<<<grid, kBlock, 0, st>>>(vid, V, HW, Nv, row_cnt);
@@ -416,6 +417,7 @@ int ivlm_lift_mesh_plan(const float* logits, const int32_t* row_ptr, const int32
     IVLM_CHECK_ARG(B > 0 && V > 0 && HW > 0 && Nv > 0 && B <= 65535 && (mode == 0 || mode == 1));
     dim3 grid((Nv + kBlock / 64 - 1) / (kBlock / 64), B);
     hipStream_t st = ivlm_stream(stream);
+    ivlm_enter();
     if (mode == 0)
         lift_plan_kernel<0><<<grid, kBlock, 0, st>>>(logits, row_ptr, ent_pix, ent_w, V, HW, Nv, param, out, nviews);
     else
@@ -436,8 +438,9 @@ int ivlm_lift_mesh_dense(const float* logits, const int32_t* vid, const float* b
     const size_t need = ivlm_lift_mesh_dense_workspace_bytes(B, V, Nv);
     if (workspace_bytes < need) return IVLM_ERR_WORKSPACE;
     hipStream_t st = ivlm_stream(stream);
+    ivlm_enter();
     float* ws = static_cast<float*>(workspace);
-    if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return IVLM_ERR_LAUNCH;
+    IVLM_HIP_TRY(hipMemsetAsync(ws, 0, need, st));
     const size_t lds = sizeof(float) * 2 * (size_t)Nv;
     const bool use_lds = lds <= kLdsBudget - 1024;
     dim3 grid(dense_chunks(B, V, HW), V, B);
@@ -472,8 +475,9 @@ int ivlm_lift_points(const float* probs, const int32_t* pid, int pid_batched, in
     const size_t need = ivlm_lift_points_workspace_bytes(B, V, Np);
     if (workspace_bytes < need) return IVLM_ERR_WORKSPACE;
     hipStream_t st = ivlm_stream(stream);
+    ivlm_enter();
     float* ws = static_cast<float*>(workspace);
-    if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return IVLM_ERR_LAUNCH;
+    IVLM_HIP_TRY(hipMemsetAsync(ws, 0, need, st));
     const size_t lds = sizeof(float) * 2 * (size_t)Np;
     const bool use_lds = lds <= kLdsBudget - 1024;
     dim3 grid(dense_chunks(B, V, HW), V, B);

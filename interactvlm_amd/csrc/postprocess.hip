@@ -110,6 +110,7 @@ extern "C" int ivlm_postprocess_masks(const void* low, int dtype, int n, int h, 
     IVLM_CHECK_ARG(n > 0 && h > 0 && w > 0 && img > 0 && oh > 0 && ow > 0);
     IVLM_CHECK_ARG(in_h > 0 && in_w > 0 && in_h <= img && in_w <= img && oh <= 65535 && n <= 65535);
     hipStream_t st = ivlm_stream(stream);
+    ivlm_enter();
     if (dtype == IVLM_F32)
         return launch_postprocess(static_cast<const float*>(low), n, h, w, img, in_h, in_w, oh, ow, apply_sigmoid,
                                   out, st);

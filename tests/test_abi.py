@@ -7,6 +7,8 @@ from interactvlm_amd import _lib, build
 
 
 def test_builds_and_exports_every_declared_symbol():
+    import torch  # noqa: F401  (the library binds to torch's HIP runtime)
+
     path = build.build(verbose=False)
     assert os.path.exists(path)
     protos = _lib.header_prototypes()
