@@ -65,8 +65,9 @@ class LiftPlan:
                                        nnz.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "lift_plan_build")
         self.nnz = int(nnz.item())
         # trim to the real size (one-time copy) so the plan holds 8 B per entry, no slack
-        self.ent_pix = ent_pix[: self.nnz].clone()
-        self.ent_w = ent_w[: self.nnz].clone()
+        keep = max(self.nnz, 1)  # an empty plan still needs valid (never dereferenced) pointers
+        self.ent_pix = ent_pix[:keep].clone()
+        self.ent_w = ent_w[:keep].clone()
 
     def bytes(self) -> int:
         return self.nnz * 8 + self.row_ptr.numel() * 4
