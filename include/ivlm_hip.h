@@ -99,6 +99,30 @@ int ivlm_lift_points(const float *probs, const int32_t *pid, int pid_batched, in
 int ivlm_postprocess_masks(const void *low, int dtype, int n, int h, int w, int img, int in_h, int in_w,
                            int oh, int ow, int apply_sigmoid, float *out, ivlm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense building blocks (bf16 storage, fp32 accumulation) used by the stage runners below and
+ * exposed for unit testing.  Activation codes: 0 none, 1 GELU(erf), 2 quick-GELU, 3 ReLU, 4 SiLU,
+ * 5 SwiGLU over row-interleaved (gate_j, up_j) weights (output has N/2 columns).
+ * ------------------------------------------------------------------------------------------- */
+
+/* nn.Linear: C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[m (% res_mod), N]
+ * (HF LlamaModel / CLIPVisionModel linears; SAM image_encoder.py:222-260, common.py:13-27,
+ * transformer.py:185-242; InteractVLM.py:100-112 text_hidden_fcs; llava_arch.py:35 mm_projector).
+ * bf16 A/W/bias/residual, K % 64 == 0, lda/ldw % 8 == 0; C bf16 or f32 (out_f32).  batch > 1 runs a
+ * strided batch (strides in elements). */
+int ivlm_gemm_bf16(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
+                   const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
+                   int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
+                   int64_t strideR, ivlm_stream_t stream);
+
+/* nn.LayerNorm over the last dim (also SAM LayerNorm2d with NHWC activations, common.py:32-42);
+ * bf16 in/out, fp32 statistics, cols % 8 == 0, cols <= 8192. */
+int ivlm_layernorm_bf16(const void *x, const void *w, const void *b, void *y, int64_t rows, int cols,
+                        float eps, ivlm_stream_t stream);
+/* HF LlamaRMSNorm: y = w * bf16(x * rsqrt(mean(x^2) + eps)). */
+int ivlm_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t rows, int cols, float eps,
+                      ivlm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,247 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual)
+//
+// This one kernel carries every dense contraction of the hot path (reference call sites):
+//   SAM ViT-H qkv/proj/mlp      model/segment_anything/modeling/image_encoder.py:222-260, common.py:13-27
+//   CLIP ViT-L/14 (HF)          model/llava/model/multimodal_encoder/clip_encoder.py:41-57
+//   LLaMA q/k/v/o/gate/up/down  model/llava/model/language_model/llava_llama.py:93-102 (HF LlamaModel)
+//   mm_projector, text_hidden_fcs, SAM decoder linears (transformer.py:185-242, mask_decoder.py:169-191)
+//
+// Design (CDNA4, wave64):
+//   * 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 tiles of
+//     v_mfma_f32_16x16x32_bf16, fp32 accumulators in registers.
+//   * both operands are K-contiguous ([rows][K]), so each MFMA fragment is one ds_read_b128.
+//   * global -> LDS by direct DMA (global_load_lds_dwordx4, 1 KiB per wave instruction), double
+//     buffered; the LDS image is lane-linear, so the bank-conflict-free XOR swizzle is applied to
+//     the per-lane SOURCE address and again on the fragment read (same involution).
+//       16-B chunk c of row r lives at chunk  c ^ ((r >> 1) & 7)   of the 128-B LDS row.
+//   * operands are swapped (D = W_tile . A_tile^T) so that a lane's 4 accumulator registers are 4
+//     consecutive N of one output row: bias/activation/residual and an 8-byte (bf16x4) store.
+//   * epilogues: bias, GELU(erf) / quick-GELU / ReLU / SiLU, SwiGLU over interleaved gate/up rows,
+//     residual add (optionally row-modulo for broadcast tables), bf16 or fp32 output.
+#include "kernels.h"
+
+namespace ivlm {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kTileBytes = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int kStageBytes = 2 * kTileBytes;      // A + W
+constexpr int kLdsBytes = 2 * kStageBytes;       // double buffer = 64 KiB
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    switch (act) {
+        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case ACT_RELU: return fmaxf(x, 0.0f);
+        case ACT_SILU: return x / (1.0f + __expf(-x));
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int bz = blockIdx.z;
+    const bf16_t* __restrict__ A = g.A + (int64_t)bz * g.strideA;
+    const bf16_t* __restrict__ W = g.W + (int64_t)bz * g.strideW;
+
+    // ---- staging addresses: wave w copies pieces w*4 .. w*4+3 (8 rows each) of both tiles ----
+    const bf16_t* srcA[4];
+    const bf16_t* srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source chunk that lands in LDS chunk lane&7
+        int ra = m0 + row;
+        ra = ra < g.M ? ra : g.M - 1;
+        int rw = n0 + row;
+        rw = rw < g.N ? rw : g.N - 1;
+        srcA[i] = A + (int64_t)ra * g.lda + chunk * 8;
+        srcW[i] = W + (int64_t)rw * g.ldw + chunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        unsigned char* base = smem + buf * kStageBytes + wave * 4 * 1024;
+        const int koff = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(srcA[i] + koff, base + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(srcW[i] + koff, base + kTileBytes + i * 1024);
+    };
+
+    // ---- fragment read offsets (bytes within a tile), constant over the K loop ---------------
+    const int wm = wave & 1, wn = wave >> 1;
+    int offA[4], offW[4];  // for k-step 0; k-step 1 flips chunk bit 2 (chunk ^ 4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wm * 64 + i * 16 + (lane & 15);
+        offA[i] = r * 128 + ((((lane >> 4)) ^ ((r >> 1) & 7)) << 4);
+        const int rn = wn * 64 + i * 16 + (lane & 15);
+        offW[i] = rn * 128 + ((((lane >> 4)) ^ ((rn >> 1) & 7)) << 4);
+    }
+
+    f32x4_t acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = g.K / BK;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();  // tile t landed (vmcnt(0) + barrier); everyone is done with tile t-1
+        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        const unsigned char* ta = smem + (t & 1) * kStageBytes;
+        const unsigned char* tw = ta + kTileBytes;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[4], fw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8_t*>(ta + (offA[i] ^ (kk << 6)));
+                fw[i] = *reinterpret_cast<const bf16x8_t*>(tw + (offW[i] ^ (kk << 6)));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = l&15, n = (l>>4)*4 -----------------------------
+    const bf16_t* __restrict__ bias = g.bias;
+    const bf16_t* __restrict__ R = g.residual ? g.residual + (int64_t)bz * g.strideR : nullptr;
+    const bool vec_ok = (g.N & 3) == 0;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + (lane & 15);
+        if (m >= g.M) continue;
+        const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+            if (n >= g.N) continue;
+            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+            if (vec_ok) {
+                if (bias) {
+                    const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
+                    v[0] += bf16_to_f32((bf16_t)(b2.x & 0xffff));
+                    v[1] += bf16_to_f32((bf16_t)(b2.x >> 16));
+                    v[2] += bf16_to_f32((bf16_t)(b2.y & 0xffff));
+                    v[3] += bf16_to_f32((bf16_t)(b2.y >> 16));
+                }
+                if (ACT == ACT_SWIGLU) {
+                    // rows interleaved (gate_j, up_j): out[j] = silu(gate_j) * up_j, two outputs per lane
+                    const float o0 = (v[0] / (1.0f + __expf(-v[0]))) * v[1];
+                    const float o1 = (v[2] / (1.0f + __expf(-v[2]))) * v[3];
+                    const int64_t o = (int64_t)m * g.ldc + (n >> 1);
+                    if (OUT_F32) {
+                        float* C = static_cast<float*>(g.C) + (int64_t)bz * g.strideC;
+                        *reinterpret_cast<float2*>(C + o) = make_float2(o0, o1);
+                    } else {
+                        bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
+                        *reinterpret_cast<uint32_t*>(C + o) = pack_bf16x2(o0, o1);
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], ACT);
+                if (R) {
+                    const uint2 r2 = *reinterpret_cast<const uint2*>(R + rrow * g.ldr + n);
+                    v[0] += bf16_to_f32((bf16_t)(r2.x & 0xffff));
+                    v[1] += bf16_to_f32((bf16_t)(r2.x >> 16));
+                    v[2] += bf16_to_f32((bf16_t)(r2.y & 0xffff));
+                    v[3] += bf16_to_f32((bf16_t)(r2.y >> 16));
+                }
+                const int64_t o = (int64_t)m * g.ldc + n;
+                if (OUT_F32) {
+                    float* C = static_cast<float*>(g.C) + (int64_t)bz * g.strideC;
+                    *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
+                    *reinterpret_cast<uint2*>(C + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            } else {  // ragged N: scalar tail (never on the hot shapes)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j >= g.N) break;
+                    float x = v[j] + (bias ? bf16_to_f32(bias[n + j]) : 0.0f);
+                    x = act_apply(x, ACT);
+                    if (R) x += bf16_to_f32(R[rrow * g.ldr + n + j]);
+                    const int64_t o = (int64_t)m * g.ldc + n + j;
+                    if (OUT_F32)
+                        (static_cast<float*>(g.C) + (int64_t)bz * g.strideC)[o] = x;
+                    else
+                        (static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC)[o] = f32_to_bf16(x);
+                }
+            }
+        }
+    }
+}
+
+template <int ACT>
+int launch(const GemmArgs& g, hipStream_t st) {
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    dim3 grid(tiles, 1, g.batch);
+    if (g.out_f32)
+        gemm_bf16_kernel<ACT, true><<<grid, kThreads, kLdsBytes, st>>>(g);
+    else
+        gemm_bf16_kernel<ACT, false><<<grid, kThreads, kLdsBytes, st>>>(g);
+    return ivlm_launch_status();
+}
+
+}  // namespace
+
+int gemm_bf16(const GemmArgs& g, hipStream_t st) {
+    if (!g.A || !g.W || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return IVLM_ERR_INVALID_ARG;
+    if (g.K % BK != 0) return IVLM_ERR_UNSUPPORTED;  // host pads K (weights are padded once at load)
+    if ((g.lda & 7) || (g.ldw & 7)) return IVLM_ERR_UNSUPPORTED;  // 16-byte DMA granules
+    if (g.act == ACT_SWIGLU && ((g.N & 3) || g.residual)) return IVLM_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) return IVLM_ERR_INVALID_ARG;
+    switch (g.act) {
+        case ACT_NONE: return launch<ACT_NONE>(g, st);
+        case ACT_GELU: return launch<ACT_GELU>(g, st);
+        case ACT_QUICK_GELU: return launch<ACT_QUICK_GELU>(g, st);
+        case ACT_RELU: return launch<ACT_RELU>(g, st);
+        case ACT_SILU: return launch<ACT_SILU>(g, st);
+        case ACT_SWIGLU: return launch<ACT_SWIGLU>(g, st);
+        default: return IVLM_ERR_INVALID_ARG;
+    }
+}
+
+}  // namespace ivlm
+
+extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                              const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N, int K,
+                              int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
+                              int64_t strideR, ivlm_stream_t stream) {
+    ivlm_enter();
+    ivlm::GemmArgs g;
+    g.A = static_cast<const bf16_t*>(A);
+    g.W = static_cast<const bf16_t*>(W);
+    g.C = C;
+    g.bias = static_cast<const bf16_t*>(bias);
+    g.residual = static_cast<const bf16_t*>(residual);
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+    g.res_mod = res_mod;
+    g.M = M; g.N = N; g.K = K;
+    g.act = act;
+    g.out_f32 = out_f32;
+    g.batch = batch < 1 ? 1 : batch;
+    g.strideA = strideA; g.strideW = strideW; g.strideC = strideC; g.strideR = strideR;
+    return ivlm::gemm_bf16(g, ivlm_stream(stream));
+}

@@ -151,3 +151,59 @@ def postprocess_masks(low_res, input_size, original_size, img_size: int = 1024, 
                                      int(input_size[1]), oh, ow, 1 if apply_sigmoid else 0, out.data_ptr(),
                                      _stream()), "postprocess_masks")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# dense building blocks
+# --------------------------------------------------------------------------------------------
+ACT = {"none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "swiglu": 5}
+BF16 = torch.bfloat16
+
+
+def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False):
+    """act(x @ weight.T + bias) + residual.  x [..., K] bf16 (last dim contiguous, uniform row stride),
+    weight [N, K] bf16."""
+    lib = _lib.load()
+    K = x.shape[-1]
+    N = weight.shape[0]
+    assert weight.shape[1] == K and x.dtype == BF16 and weight.dtype == BF16
+    x2 = x.reshape(-1, K)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    n_out = N // 2 if act == "swiglu" else N
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    o2 = out.reshape(-1, n_out)
+    assert o2.stride(-1) == 1 and weight.stride(-1) == 1
+    r2, ldr = None, 0
+    if residual is not None:
+        r2 = residual.reshape(-1, N)
+        assert r2.dtype == BF16 and r2.stride(-1) == 1
+        ldr = r2.stride(0)
+    if bias is not None:
+        assert bias.dtype == BF16 and bias.is_contiguous()
+    check(lib.ivlm_gemm_bf16(x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(),
+                             o2.stride(0), _p(bias), _p(r2), ldr, int(res_mod), M, N, K, ACT[act],
+                             1 if out.dtype == torch.float32 else 0, 1, 0, 0, 0, 0, _stream()), "gemm_bf16")
+    return out
+
+
+def layernorm(x, weight, bias, eps=1e-5):
+    lib = _lib.load()
+    x = _req(x, BF16, "x")
+    y = torch.empty_like(x)
+    cols = x.shape[-1]
+    check(lib.ivlm_layernorm_bf16(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), x.numel() // cols,
+                                  cols, float(eps), _stream()), "layernorm")
+    return y
+
+
+def rmsnorm(x, weight, eps=1e-5):
+    lib = _lib.load()
+    x = _req(x, BF16, "x")
+    y = torch.empty_like(x)
+    cols = x.shape[-1]
+    check(lib.ivlm_rmsnorm_bf16(x.data_ptr(), weight.data_ptr(), y.data_ptr(), x.numel() // cols, cols, float(eps),
+                                _stream()), "rmsnorm")
+    return y

@@ -1,0 +1,137 @@
+"""GPU parity of the dense building blocks (bf16 MFMA GEMM + epilogues, LayerNorm, RMSNorm) against
+plain PyTorch fp32 on the same bf16-rounded inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    import torch
+
+    return t.to(torch.bfloat16)
+
+
+def _ref_act(x, act):
+    import torch
+    import torch.nn.functional as F
+
+    if act == "gelu":
+        return F.gelu(x)
+    if act == "quick_gelu":
+        return x * torch.sigmoid(1.702 * x)
+    if act == "relu":
+        return F.relu(x)
+    if act == "silu":
+        return F.silu(x)
+    return x
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 1024, 1024), (330, 4096, 4096), (1000, 1280, 5120),
+                                   (9, 256, 256), (1, 128, 2048), (4096, 128, 256), (131, 36, 192)])
+@pytest.mark.parametrize("act", ["none", "gelu"])
+def test_gemm_shapes(hip_lib, cuda, M, N, K, act):
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    x = _bf(torch.randn(M, K, generator=g))
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = _bf(torch.randn(N, generator=g) * 0.1)
+    r = _bf(torch.randn(M, N, generator=g))
+    ref = _ref_act(x.float() @ w.float().T + b.float(), act) + r.float()
+    got = ops.linear(x.to(cuda), w.to(cuda), b.to(cuda), act=act, residual=r.to(cuda))
+    assert got.dtype == torch.bfloat16 and got.shape == (M, N)
+    err = (got.float().cpu() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 4e-3  # one bf16 ulp of the result + accumulation-order noise
+    assert bool((err <= tol).all()), f"max err {err.max().item()} at {M}x{N}x{K}"
+    got32 = ops.linear(x.to(cuda), w.to(cuda), b.to(cuda), act=act, residual=r.to(cuda), out_f32=True)
+    assert got32.dtype == torch.float32
+    assert torch.allclose(got32.cpu(), ref, atol=3e-3, rtol=1e-3)
+
+
+def test_gemm_transpose_detecting(hip_lib, cuda):
+    """A = I (padded) with an ASYMMETRIC W catches row/col swaps in the MFMA C layout."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    K = 128
+    x = torch.zeros(96, K)
+    x[torch.arange(96), torch.arange(96)] = 1.0
+    w = (torch.arange(200)[:, None] * 0.5 + torch.arange(K)[None, :] * 0.01)
+    got = ops.linear(_bf(x).to(cuda), _bf(w).to(cuda), out_f32=True).cpu()
+    assert torch.allclose(got, _bf(w).float().T[:96], atol=1e-6)
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "relu", "silu"])
+def test_gemm_activations_no_bias(hip_lib, cuda, act):
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = _bf(torch.randn(300, 256, generator=g))
+    w = _bf(torch.randn(512, 256, generator=g) / 16)
+    ref = _ref_act(x.float() @ w.float().T, act)
+    got = ops.linear(x.to(cuda), w.to(cuda), act=act, out_f32=True).cpu()
+    assert torch.allclose(got, ref, atol=3e-3, rtol=2e-3)
+
+
+def test_gemm_swiglu_and_rowmod_residual(hip_lib, cuda):
+    import torch
+    import torch.nn.functional as F
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    M, K, I = 77, 512, 384
+    x = _bf(torch.randn(M, K, generator=g))
+    wg = _bf(torch.randn(I, K, generator=g) / K ** 0.5)
+    wu = _bf(torch.randn(I, K, generator=g) / K ** 0.5)
+    inter = torch.stack([wg, wu], dim=1).reshape(2 * I, K).contiguous()  # rows (gate_j, up_j)
+    ref = F.silu(x.float() @ wg.float().T) * (x.float() @ wu.float().T)
+    got = ops.linear(x.to(cuda), inter.to(cuda), act="swiglu", out_f32=True).cpu()
+    assert got.shape == (M, I)
+    assert torch.allclose(got, ref, atol=3e-3, rtol=2e-3)
+    # residual broadcast with row modulo (pos_embed-style table)
+    tab = _bf(torch.randn(11, 2 * I, generator=g))
+    ref2 = x.float() @ inter.float().T + tab.float()[torch.arange(M) % 11]
+    got2 = ops.linear(x.to(cuda), inter.to(cuda), residual=tab.to(cuda), res_mod=11, out_f32=True).cpu()
+    assert torch.allclose(got2, ref2, atol=3e-3, rtol=2e-3)
+
+
+def test_gemm_strided_input_rows(hip_lib, cuda):
+    """Row stride > K (reading q out of a fused qkv buffer)."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    big = _bf(torch.randn(50, 3 * 128, generator=g)).to(cuda)
+    w = _bf(torch.randn(64, 128, generator=g) / 11).to(cuda)
+    x = big[:, 128:256]
+    got = ops.linear(x, w, out_f32=True).cpu()
+    assert torch.allclose(got, x.float().cpu() @ w.float().cpu().T, atol=3e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("cols,eps", [(256, 1e-5), (1024, 1e-5), (1280, 1e-6), (4096, 1e-5), (5120, 1e-5)])
+def test_layernorm_rmsnorm(hip_lib, cuda, cols, eps):
+    import torch
+    import torch.nn.functional as F
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(cols)
+    x = _bf(torch.randn(37, cols, generator=g) * 3 + 0.5)
+    w = _bf(1 + 0.1 * torch.randn(cols, generator=g))
+    b = _bf(0.1 * torch.randn(cols, generator=g))
+    ref = F.layer_norm(x.float(), (cols,), w.float(), b.float(), eps)
+    got = ops.layernorm(x.to(cuda), w.to(cuda), b.to(cuda), eps).float().cpu()
+    assert torch.allclose(got, ref, atol=2e-2, rtol=2 ** -7)
+    xf = x.float()
+    n = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(torch.bfloat16)
+    ref_r = (w * n).float()  # HF LlamaRMSNorm: bf16 weight * bf16 normalised
+    got_r = ops.rmsnorm(x.to(cuda), w.to(cuda), eps).float().cpu()
+    assert torch.allclose(got_r, ref_r, atol=2e-2, rtol=2 ** -7)
