@@ -123,6 +123,22 @@ int ivlm_layernorm_bf16(const void *x, const void *w, const void *b, void *y, in
 int ivlm_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t rows, int cols, float eps,
                       ivlm_stream_t stream);
 
+/* Fused multi-head attention: o = softmax(scale * q.k^T + bias + mask) . v, never materialising
+ * the score matrix (SAM image_encoder.py:235-260, transformer.py:220-242; HF CLIP / LLaMA attention).
+ *   q [B,H,Sq,D], k/v [B/kv_batch_div,H,Sk,D], o [B,H,Sq,D] addressed through element strides
+ *   strides[12] = {q_b,q_h,q_row, k_b,k_h,k_row, v_b,v_h,v_row, o_b,o_h,o_row} (multiples of 8; o: of 4)
+ *   D in {16,32,64,80,128};  causal: key j visible to query i iff j <= i + q_pos0 (KV cache offset)
+ *   rel_h f32 [B*H,Sq,rel_kh], rel_w f32 [B*H,Sq,rel_kw] (or NULL): bias[q,k] = rel_h[q,k/rel_kw] + rel_w[q,k%rel_kw] */
+int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, const int64_t *strides_host, int B,
+                        int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float *rel_h,
+                        const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, ivlm_stream_t stream);
+
+/* add_decomposed_rel_pos operands (image_encoder.py:354-392), q_size == k_size == (SH,SW):
+ *   rel_h[bh,q,kh] = q . rel_pos_h[qh-kh+SH-1],  rel_w[bh,q,kw] = q . rel_pos_w[qw-kw+SW-1]  (rounded to bf16
+ *   like the reference's model-dtype einsum, stored f32).  tab_h bf16 [2*SH-1,D], tab_w bf16 [2*SW-1,D]. */
+int ivlm_relpos_bias(const void *q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void *tab_h, const void *tab_w,
+                     int B, int H, int SH, int SW, int D, float *rel_h, float *rel_w, ivlm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

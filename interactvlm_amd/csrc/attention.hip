@@ -1,0 +1,389 @@
+// Fused (flash-style) multi-head attention forward for gfx950, bf16 in/out, fp32 softmax.
+//
+// One kernel family serves every attention on the hot path (reference call sites):
+//   SAM ViT-H windowed (196 tok) / global (4096 tok), head dim 80, decomposed rel-pos bias
+//       model/segment_anything/modeling/image_encoder.py:235-260, 354-392
+//   CLIP ViT-L/14 (257 tok, head dim 64) and LLaMA (causal, head dim 128, fp32 softmax)   HF transformers
+//   SAM two-way decoder attention (head dim 32 / 16)     modeling/transformer.py:220-242
+//
+// Design (wave64, MFMA 16x16x32 bf16):
+//   * block = 4 waves x 32 queries; K/V tiles of 64 keys are staged once per block through
+//     registers into LDS (issue-early / write-late, so HBM latency hides under the MFMAs).
+//   * both products are computed TRANSPOSED:  S^T = K.Q^T  and  O^T = V^T.P^T.  A lane then owns ONE
+//     query (column l&15) in every accumulator: the running max / sum / rescale are lane-local
+//     (two xor-shuffles across the four 16-lane groups), and P never leaves registers: the four
+//     scores a lane holds per 16-key tile are exactly the K-slots it must feed to the next MFMA
+//     once the key order inside each 32-key step is permuted consistently for P and V.
+//   * V is stored transposed in LDS ([d][key], +8 pad) so that permuted slot order is two 8-byte
+//     reads; K rows are padded (+8) => conflict-free ds_read_b128.  Head dim 80 pads to 96 for QK^T.
+//   * the S x S score matrix is never materialised (the reference materialises [B*16,4096,4096]).
+#include "kernels.h"
+
+namespace ivlm {
+
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+// native vector (NOT HIP's uint4 struct): arrays of it are promoted to registers across the K/V loop
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+constexpr int kQPerWave = 32, kWaves = 4, kQPerBlock = kQPerWave * kWaves, kKV = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kNegBig = -1.0e30f;
+
+template <int DQK, int DV, bool CAUSAL, bool RELPOS>
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
+    constexpr int KS = DQK / 32;        // MFMA k-steps over the head dim
+    constexpr int DT = DV / 16;         // 16-wide output tiles over the head dim
+    constexpr int KROW = DQK + 8;       // padded K row (elements)
+    constexpr int VROW = kKV + 8;       // padded V^T row (elements)
+    constexpr int DCH = DV / 8;         // 16-byte chunks per K/V row actually present in memory
+    constexpr int NCH = kKV * DCH;      // chunks per K (or V) tile
+    constexpr int CPT = (NCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[kKV * KROW];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[DV * VROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_blk0 = blockIdx.x * kQPerBlock;
+    const int q0 = q_blk0 + wave * kQPerWave;
+    const int bkv = b / a.kv_batch_div;
+    const bf16_t* __restrict__ Q = a.q + b * a.q_bs + h * a.q_hs;
+    const bf16_t* __restrict__ K = a.k + bkv * a.k_bs + h * a.k_hs;
+    const bf16_t* __restrict__ V = a.v + bkv * a.v_bs + h * a.v_hs;
+
+    // ---- zero the pad columns of K once (head dim < DQK, and the +8 row pad) -------------------
+    if (DV < KROW) {
+        constexpr int PADW = KROW - DV;
+        for (int i = tid; i < kKV * PADW; i += 256) Ks[(i / PADW) * KROW + DV + (i % PADW)] = 0;
+    }
+
+    // ---- Q fragments (B operand): lane holds Q[q0 + qt*16 + l15][(s*4+g)*8 .. +8] ---------------
+    bf16x8_t qf[2][KS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int qi = q0 + qt * 16 + l15;
+        qi = qi < a.Sq ? qi : a.Sq - 1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int d0 = (s * 4 + g) * 8;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (d0 < DV) u = *reinterpret_cast<const uint4*>(Q + (int64_t)qi * a.q_rs + d0);
+            qf[qt][s] = *reinterpret_cast<bf16x8_t*>(&u);
+        }
+    }
+
+    f32x4_t o[2][DT];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {kNegBig, kNegBig}, l_run[2] = {0.f, 0.f};
+
+    int ntiles = (a.Sk + kKV - 1) / kKV;
+    if (CAUSAL) {
+        int last_q = q_blk0 + kQPerBlock - 1;
+        last_q = last_q < a.Sq ? last_q : a.Sq - 1;
+        const int last_key = last_q + a.q_pos0;  // inclusive
+        const int lim = last_key / kKV + 1;
+        ntiles = ntiles < lim ? ntiles : lim;
+    }
+
+    // ---- register staging of one K/V tile ------------------------------------------------------
+    u32x4_t kreg[CPT], vreg[CPT];
+    auto gload = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            // unconditional (clamped) loads keep kreg/vreg in registers across the loop
+            int c = tid + i * 256;
+            c = c < NCH ? c : NCH - 1;
+            int key = t * kKV + c / DCH;
+            key = key < a.Sk ? key : a.Sk - 1;
+            const int dch = c % DCH;
+            kreg[i] = *reinterpret_cast<const u32x4_t*>(K + (int64_t)key * a.k_rs + dch * 8);
+            vreg[i] = *reinterpret_cast<const u32x4_t*>(V + (int64_t)key * a.v_rs + dch * 8);
+        }
+    };
+    auto lds_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * 256;
+            if (c < NCH) {
+                const int key = c / DCH, dch = c % DCH;
+                *reinterpret_cast<u32x4_t*>(&Ks[key * KROW + dch * 8]) = kreg[i];
+                const uint32_t vw[4] = {vreg[i][0], vreg[i][1], vreg[i][2], vreg[i][3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    Vt[(dch * 8 + 2 * e) * VROW + key] = (bf16_t)(vw[e] & 0xffffu);
+                    Vt[(dch * 8 + 2 * e + 1) * VROW + key] = (bf16_t)(vw[e] >> 16);
+                }
+            }
+        }
+    };
+
+    // rel-pos rows of this lane's two queries
+    const float *rh[2] = {nullptr, nullptr}, *rw[2] = {nullptr, nullptr};
+    if (RELPOS) {
+        const int64_t bh = (int64_t)b * a.H + h;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            int qi = q0 + qt * 16 + l15;
+            qi = qi < a.Sq ? qi : a.Sq - 1;
+            rh[qt] = a.rel_h + (bh * a.Sq + qi) * a.rel_kh;
+            rw[qt] = a.rel_w + (bh * a.Sq + qi) * a.rel_kw;
+        }
+    }
+    const float sc2 = a.scale * kLog2e;
+
+    gload(0);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();  // all waves done reading the previous tile
+        lds_store();
+        __syncthreads();
+        if (t + 1 < ntiles) gload(t + 1);
+
+        // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query l15 ------------------
+        f32x4_t s[2][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t kf =
+                    *reinterpret_cast<const bf16x8_t*>(&Ks[(kt * 16 + l15) * KROW + (ks * 4 + g) * 8]);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
+            }
+        }
+
+        // ---- scale, bias, mask, online softmax (log2 domain) -----------------------------------
+        const int kv0 = t * kKV;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qi = q0 + qt * 16 + l15;
+            float mx = kNegBig;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int kb = kv0 + kt * 16 + g * 4;
+                int kh = 0, kw = 0;
+                if (RELPOS) {
+                    kh = kb / a.rel_kw;
+                    kw = kb - kh * a.rel_kw;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb + r;
+                    float x = s[qt][kt][r] * sc2;
+                    if (RELPOS) {
+                        if (key < a.Sk) x += (rh[qt][kh] + rw[qt][kw]) * kLog2e;
+                        if (++kw == a.rel_kw) {
+                            kw = 0;
+                            ++kh;
+                        }
+                    }
+                    bool ok = key < a.Sk;
+                    if (CAUSAL) ok = ok && (key <= qi + a.q_pos0);
+                    x = ok ? x : kNegBig;
+                    s[qt][kt][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float alpha = exp2f(m_run[qt] - m_new);
+            float rs = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // fully masked entries: exp2(-1e30 - m) == 0 unless the whole row is masked so far
+                    const float p = s[qt][kt][r] <= kNegBig ? 0.0f : exp2f(s[qt][kt][r] - m_new);
+                    s[qt][kt][r] = p;
+                    rs += p;
+                }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            l_run[qt] = l_run[qt] * alpha + rs;
+            m_run[qt] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                o[qt][dt][0] *= alpha;
+                o[qt][dt][1] *= alpha;
+                o[qt][dt][2] *= alpha;
+                o[qt][dt][3] *= alpha;
+            }
+        }
+
+        // ---- P^T fragments straight from the score registers (key order permuted per 32-step) --
+        bf16x8_t pf[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint4 u;
+                u.x = pack_bf16x2(s[qt][2 * s2][0], s[qt][2 * s2][1]);
+                u.y = pack_bf16x2(s[qt][2 * s2][2], s[qt][2 * s2][3]);
+                u.z = pack_bf16x2(s[qt][2 * s2 + 1][0], s[qt][2 * s2 + 1][1]);
+                u.w = pack_bf16x2(s[qt][2 * s2 + 1][2], s[qt][2 * s2 + 1][3]);
+                pf[qt][s2] = *reinterpret_cast<bf16x8_t*>(&u);
+            }
+
+        // ---- O^T += V^T . P^T -------------------------------------------------------------------
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16_t* vrow = &Vt[(dt * 16 + l15) * VROW + g * 4];
+                uint4 u;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vrow + (2 * s2) * 16);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (2 * s2 + 1) * 16);
+                u.x = lo.x; u.y = lo.y; u.z = hi.x; u.w = hi.y;
+                const bf16x8_t vf = *reinterpret_cast<bf16x8_t*>(&u);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s2], o[qt][dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise and store: lane holds O[query l15][d = dt*16 + g*4 + r] ---------------------
+    bf16_t* __restrict__ O = a.o + b * a.o_bs + h * a.o_hs;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = q0 + qt * 16 + l15;
+        if (qi >= a.Sq) continue;
+        const float inv = l_run[qt] > 0.0f ? 1.0f / l_run[qt] : 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const uint2 w = make_uint2(pack_bf16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv),
+                                       pack_bf16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
+            *reinterpret_cast<uint2*>(O + (int64_t)qi * a.o_rs + dt * 16 + g * 4) = w;
+        }
+    }
+}
+
+template <int DQK, int DV>
+int launch_d(const AttnArgs& a, hipStream_t st) {
+    dim3 grid((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B);
+    const bool rel = a.rel_h != nullptr;
+    if (a.causal) {
+        if (rel) return IVLM_ERR_UNSUPPORTED;
+        attn_kernel<DQK, DV, true, false><<<grid, 256, 0, st>>>(a);
+    } else if (rel) {
+        attn_kernel<DQK, DV, false, true><<<grid, 256, 0, st>>>(a);
+    } else {
+        attn_kernel<DQK, DV, false, false><<<grid, 256, 0, st>>>(a);
+    }
+    return ivlm_launch_status();
+}
+
+// rel_h[bh,q,kh] = q_vec . rel_pos_h[qh - kh + KH - 1],  rel_w[bh,q,kw] = q_vec . rel_pos_w[qw - kw + KW - 1]
+// (image_encoder.py:321-392 with q_size == k_size).  One thread per output element.
+__global__ __launch_bounds__(256) void relpos_kernel(const bf16_t* __restrict__ q, int64_t q_bs, int64_t q_hs,
+                                                     int64_t q_rs, const bf16_t* __restrict__ tab_h,
+                                                     const bf16_t* __restrict__ tab_w, int B, int H, int SH, int SW,
+                                                     int D, float* __restrict__ rel_h, float* __restrict__ rel_w) {
+    const int S = SH * SW;
+    const int per_q = SH + SW;
+    const int64_t total = (int64_t)B * H * S * per_q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i % per_q);
+        const int64_t bq = i / per_q;
+        const int qi = (int)(bq % S);
+        const int64_t bh = bq / S;
+        const int b = (int)(bh / H), h = (int)(bh % H);
+        const int qh = qi / SW, qw = qi - qh * SW;
+        const bf16_t* qv = q + b * q_bs + h * q_hs + (int64_t)qi * q_rs;
+        const bf16_t* tv;
+        if (j < SH) tv = tab_h + (int64_t)(qh - j + SH - 1) * D;
+        else tv = tab_w + (int64_t)(qw - (j - SH) + SW - 1) * D;
+        float acc = 0.0f;
+        for (int c = 0; c < D; c += 8) {
+            const uint4 a4 = *reinterpret_cast<const uint4*>(qv + c);
+            const uint4 t4 = *reinterpret_cast<const uint4*>(tv + c);
+            const bf16_t* ae = reinterpret_cast<const bf16_t*>(&a4);
+            const bf16_t* te = reinterpret_cast<const bf16_t*>(&t4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += bf16_to_f32(ae[e]) * bf16_to_f32(te[e]);
+        }
+        // the reference materialises rel_h/rel_w in the model dtype (bf16): round like it does
+        acc = bf16_to_f32(f32_to_bf16(acc));
+        if (j < SH) rel_h[bq * SH + j] = acc;
+        else rel_w[bq * SW + (j - SH)] = acc;
+    }
+}
+
+}  // namespace
+
+int attention_bf16(const AttnArgs& a, hipStream_t st) {
+    if (!a.q || !a.k || !a.v || !a.o || a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return IVLM_ERR_INVALID_ARG;
+    if (a.H > 65535 || a.B > 65535 || a.kv_batch_div <= 0) return IVLM_ERR_INVALID_ARG;
+    if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.q_hs | a.k_hs | a.v_hs | a.q_bs | a.k_bs | a.v_bs) & 7)
+        return IVLM_ERR_UNSUPPORTED;  // 16-byte row chunks
+    if ((a.o_rs | a.o_hs | a.o_bs) & 3) return IVLM_ERR_UNSUPPORTED;
+    if (a.rel_h && (!a.rel_w || a.rel_kh <= 0 || a.rel_kw <= 0)) return IVLM_ERR_INVALID_ARG;
+    switch (a.D) {
+        case 16: return launch_d<32, 16>(a, st);
+        case 32: return launch_d<32, 32>(a, st);
+        case 64: return launch_d<64, 64>(a, st);
+        case 80: return launch_d<96, 80>(a, st);
+        case 128: return launch_d<128, 128>(a, st);
+        default: return IVLM_ERR_UNSUPPORTED;
+    }
+}
+
+int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const bf16_t* tab_h, const bf16_t* tab_w,
+                int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, hipStream_t st) {
+    if (!q || !tab_h || !tab_w || !rel_h || !rel_w || (D & 7)) return IVLM_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)B * H * SH * SW * (SH + SW);
+    const int grid = (int)((total + 255) / 256 < 65535 * 4 ? (total + 255) / 256 : 65535 * 4);
+    relpos_kernel<<<grid, 256, 0, st>>>(q, q_bs, q_hs, q_rs, tab_h, tab_w, B, H, SH, SW, D, rel_h, rel_w);
+    return ivlm_launch_status();
+}
+
+}  // namespace ivlm
+
+extern "C" {
+
+int ivlm_attention_bf16(const void* q, const void* k, const void* v, void* o, const int64_t* strides /*[12]*/, int B,
+                        int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float* rel_h,
+                        const float* rel_w, int rel_kh, int rel_kw, int kv_batch_div, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!strides) return IVLM_ERR_INVALID_ARG;
+    ivlm::AttnArgs a;
+    a.q = static_cast<const bf16_t*>(q);
+    a.k = static_cast<const bf16_t*>(k);
+    a.v = static_cast<const bf16_t*>(v);
+    a.o = static_cast<bf16_t*>(o);
+    a.q_bs = strides[0]; a.q_hs = strides[1]; a.q_rs = strides[2];
+    a.k_bs = strides[3]; a.k_hs = strides[4]; a.k_rs = strides[5];
+    a.v_bs = strides[6]; a.v_hs = strides[7]; a.v_rs = strides[8];
+    a.o_bs = strides[9]; a.o_hs = strides[10]; a.o_rs = strides[11];
+    a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.D = D;
+    a.scale = scale;
+    a.causal = causal;
+    a.q_pos0 = q_pos0;
+    a.rel_h = rel_h;
+    a.rel_w = rel_w;
+    a.rel_kh = rel_kh;
+    a.rel_kw = rel_kw;
+    a.kv_batch_div = kv_batch_div < 1 ? 1 : kv_batch_div;
+    return ivlm::attention_bf16(a, ivlm_stream(stream));
+}
+
+int ivlm_relpos_bias(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* tab_h, const void* tab_w,
+                     int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, ivlm_stream_t stream) {
+    ivlm_enter();
+    return ivlm::relpos_bias(static_cast<const bf16_t*>(q), q_bs, q_hs, q_rs, static_cast<const bf16_t*>(tab_h),
+                             static_cast<const bf16_t*>(tab_w), B, H, SH, SW, D, rel_h, rel_w, ivlm_stream(stream));
+}
+
+}  // extern "C"

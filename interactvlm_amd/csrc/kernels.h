@@ -33,4 +33,28 @@ int layernorm_bf16(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y,
 // y = x * rsqrt(mean(x^2)+eps) * w  (LLaMA RMSNorm; fp32 statistics, HF casts back before the weight multiply)
 int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int cols, float eps, hipStream_t st);
 
+// ---- attention ---------------------------------------------------------------------------------
+struct AttnArgs {
+    const bf16_t *q, *k, *v;
+    bf16_t* o;
+    int64_t q_bs, q_hs, q_rs;  // batch / head / row strides in elements
+    int64_t k_bs, k_hs, k_rs;
+    int64_t v_bs, v_hs, v_rs;
+    int64_t o_bs, o_hs, o_rs;
+    int B, H, Sq, Sk, D;
+    float scale;
+    int causal;    // key j visible to query i iff j <= i + q_pos0
+    int q_pos0;
+    const float* rel_h;  // [B*H, Sq, rel_kh] or null
+    const float* rel_w;  // [B*H, Sq, rel_kw]
+    int rel_kh, rel_kw;
+    int kv_batch_div;    // key/value batch index = b / kv_batch_div (broadcast K/V over query batches)
+};
+
+// softmax(scale * Q.K^T (+ rel-pos bias) (+ causal mask)) . V ; bf16 in/out, fp32 softmax. D in {16,32,64,80,128}.
+int attention_bf16(const AttnArgs& a, hipStream_t st);
+// decomposed relative-position bias terms of SAM's ViT (image_encoder.py:354-392) as fp32 tables
+int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const bf16_t* tab_h, const bf16_t* tab_w,
+                int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, hipStream_t st);
+
 }  // namespace ivlm

@@ -207,3 +207,43 @@ def rmsnorm(x, weight, eps=1e-5):
     check(lib.ivlm_rmsnorm_bf16(x.data_ptr(), weight.data_ptr(), y.data_ptr(), x.numel() // cols, cols, float(eps),
                                 _stream()), "rmsnorm")
     return y
+
+
+def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None):
+    """q [B,H,Sq,D], k/v [Bk,H,Sk,D] (arbitrary strides, last dim contiguous; B % Bk == 0: K/V of batch
+    b // (B//Bk)) -> o [B,H,Sq,D] as a view of a [B,Sq,H,D] buffer (so o.transpose(1,2) is contiguous).
+    rel = (rel_h f32 [B*H,Sq,KH], rel_w f32 [B*H,Sq,KW]) adds SAM's decomposed rel-pos bias."""
+    import ctypes
+
+    lib = _lib.load()
+    B, H, Sq, D = q.shape
+    Bk, Sk = k.shape[0], k.shape[2]
+    assert q.dtype == BF16 and k.dtype == BF16 and v.dtype == BF16
+    assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1 and B % Bk == 0
+    if out is None:
+        out = torch.empty(B, Sq, H, D, dtype=BF16, device=q.device).permute(0, 2, 1, 3)
+    assert out.stride(3) == 1
+    st = (ctypes.c_int64 * 12)(q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                               v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2))
+    rel_h = rel_w = None
+    kh = kw = 0
+    if rel is not None:
+        rel_h, rel_w = rel
+        assert rel_h.dtype == torch.float32 and rel_h.is_contiguous() and rel_w.is_contiguous()
+        kh, kw = rel_h.shape[-1], rel_w.shape[-1]
+    check(lib.ivlm_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                  ctypes.cast(st, ctypes.c_void_p), B, H, Sq, Sk, D, float(scale), 1 if causal else 0,
+                                  int(q_pos0), _p(rel_h), _p(rel_w), kh, kw, B // Bk, _stream()), "attention")
+    return out
+
+
+def relpos_bias(q, tab_h, tab_w, SH, SW):
+    """q [B,H,S=SH*SW,D] -> (rel_h f32 [B*H,S,SH], rel_w f32 [B*H,S,SW])."""
+    lib = _lib.load()
+    B, H, S, D = q.shape
+    assert S == SH * SW and q.stride(3) == 1 and tab_h.is_contiguous() and tab_w.is_contiguous()
+    rel_h = torch.empty(B * H, S, SH, dtype=torch.float32, device=q.device)
+    rel_w = torch.empty(B * H, S, SW, dtype=torch.float32, device=q.device)
+    check(lib.ivlm_relpos_bias(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), tab_h.data_ptr(), tab_w.data_ptr(),
+                               B, H, SH, SW, D, rel_h.data_ptr(), rel_w.data_ptr(), _stream()), "relpos_bias")
+    return rel_h, rel_w
