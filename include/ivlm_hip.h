@@ -128,10 +128,12 @@ int ivlm_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t rows, int c
  *   q [B,H,Sq,D], k/v [B/kv_batch_div,H,Sk,D], o [B,H,Sq,D] addressed through element strides
  *   strides[12] = {q_b,q_h,q_row, k_b,k_h,k_row, v_b,v_h,v_row, o_b,o_h,o_row} (multiples of 8; o: of 4)
  *   D in {16,32,64,80,128};  causal: key j visible to query i iff j <= i + q_pos0 (KV cache offset)
+ *   prescale_q: 1 = scores are bf16(q*scale).k (SAM image_encoder.py:244, HF CLIP); 0 = (q.k)*scale (HF LLaMA)
  *   rel_h f32 [B*H,Sq,rel_kh], rel_w f32 [B*H,Sq,rel_kw] (or NULL): bias[q,k] = rel_h[q,k/rel_kw] + rel_w[q,k%rel_kw] */
 int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, const int64_t *strides_host, int B,
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float *rel_h,
-                        const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, ivlm_stream_t stream);
+                        const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q,
+                        ivlm_stream_t stream);
 
 /* add_decomposed_rel_pos operands (image_encoder.py:354-392), q_size == k_size == (SH,SW):
  *   rel_h[bh,q,kh] = q . rel_pos_h[qh-kh+SH-1],  rel_w[bh,q,kw] = q . rel_pos_w[qw-kw+SW-1]  (rounded to bf16

@@ -33,7 +33,11 @@ constexpr int kQPerWave = 32, kWaves = 4, kQPerBlock = kQPerWave * kWaves, kKV =
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kNegBig = -1.0e30f;
 
-template <int DQK, int DV, bool CAUSAL, bool RELPOS>
+// REL: 0 no bias; 1 rel-pos folded into the QK^T MFMA (KH + KW <= 32: one extra k-step whose Q' operand is
+// [rel_h | rel_w] and whose K' operand is the one-hot (kh, KH + kw) code of the key: exact, no VALU);
+// 2 rel_kw == 64 == key-tile: rel_w is tile-invariant (held as packed bf16 in registers), rel_h is one
+// value per (query, tile).
+template <int DQK, int DV, bool CAUSAL, int REL>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     constexpr int KS = DQK / 32;        // MFMA k-steps over the head dim
     constexpr int DT = DV / 16;         // 16-wide output tiles over the head dim
@@ -72,6 +76,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
             const int d0 = (s * 4 + g) * 8;
             uint4 u = make_uint4(0, 0, 0, 0);
             if (d0 < DV) u = *reinterpret_cast<const uint4*>(Q + (int64_t)qi * a.q_rs + d0);
+            if (a.prescale_q) {  // (q * scale) rounded to bf16 BEFORE the dot product, like SAM / HF-CLIP do
+                u.x = pack_bf16x2(__uint_as_float(u.x << 16) * a.scale, __uint_as_float(u.x & 0xffff0000u) * a.scale);
+                u.y = pack_bf16x2(__uint_as_float(u.y << 16) * a.scale, __uint_as_float(u.y & 0xffff0000u) * a.scale);
+                u.z = pack_bf16x2(__uint_as_float(u.z << 16) * a.scale, __uint_as_float(u.z & 0xffff0000u) * a.scale);
+                u.w = pack_bf16x2(__uint_as_float(u.w << 16) * a.scale, __uint_as_float(u.w & 0xffff0000u) * a.scale);
+            }
             qf[qt][s] = *reinterpret_cast<bf16x8_t*>(&u);
         }
     }
@@ -124,19 +134,40 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         }
     };
 
-    // rel-pos rows of this lane's two queries
-    const float *rh[2] = {nullptr, nullptr}, *rw[2] = {nullptr, nullptr};
-    if (RELPOS) {
+    // ---- rel-pos operands of this lane's two queries -------------------------------------------
+    bf16x8_t qrel[2];       // REL 1: [rel_h(KH) | rel_w(KW) | 0] features g*8 .. g*8+7
+    uint32_t rwp[2][8];     // REL 2: rel_w[q][kt*16 + g*4 + r] as packed bf16 pairs
+    const float* rhp[2] = {nullptr, nullptr};
+    if (REL != 0) {
         const int64_t bh = (int64_t)b * a.H + h;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             int qi = q0 + qt * 16 + l15;
             qi = qi < a.Sq ? qi : a.Sq - 1;
-            rh[qt] = a.rel_h + (bh * a.Sq + qi) * a.rel_kh;
-            rw[qt] = a.rel_w + (bh * a.Sq + qi) * a.rel_kw;
+            const float* rh = a.rel_h + (bh * a.Sq + qi) * a.rel_kh;
+            const float* rw = a.rel_w + (bh * a.Sq + qi) * a.rel_kw;
+            if (REL == 1) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int fi = g * 8 + e;
+                    f[e] = fi < a.rel_kh ? rh[fi] : (fi < a.rel_kh + a.rel_kw ? rw[fi - a.rel_kh] : 0.0f);
+                }
+                uint4 u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                                     pack_bf16x2(f[6], f[7]));
+                qrel[qt] = *reinterpret_cast<bf16x8_t*>(&u);
+            } else {
+                rhp[qt] = rh;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(rw + kt * 16 + g * 4);
+                    rwp[qt][2 * kt] = pack_bf16x2(w4.x, w4.y);
+                    rwp[qt][2 * kt + 1] = pack_bf16x2(w4.z, w4.w);
+                }
+            }
         }
     }
-    const float sc2 = a.scale * kLog2e;
+    const float sc2 = a.prescale_q ? kLog2e : a.scale * kLog2e;
 
     gload(0);
     for (int t = 0; t < ntiles; ++t) {
@@ -161,6 +192,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
                 for (int qt = 0; qt < 2; ++qt)
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
             }
+            if (REL == 1) {
+                const int key = t * kKV + kt * 16 + l15;
+                const int kh = key / a.rel_kw;
+                const int f1 = kh - g * 8, f2 = a.rel_kh + (key - kh * a.rel_kw) - g * 8;  // hot slots e
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t lo = (f1 == 2 * j || f2 == 2 * j) ? 0x3F80u : 0u;
+                    const uint32_t hi = (f1 == 2 * j + 1 || f2 == 2 * j + 1) ? 0x3F800000u : 0u;
+                    w[j] = lo | hi;
+                }
+                uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
+                const bf16x8_t hot = *reinterpret_cast<bf16x8_t*>(&u);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel[qt], s[qt][kt], 0, 0, 0);
+            }
         }
 
         // ---- scale, bias, mask, online softmax (log2 domain) -----------------------------------
@@ -169,25 +217,20 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         for (int qt = 0; qt < 2; ++qt) {
             const int qi = q0 + qt * 16 + l15;
             float mx = kNegBig;
+            float rh_t = 0.0f;
+            if (REL == 2) rh_t = rhp[qt][t < a.rel_kh ? t : a.rel_kh - 1];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const int kb = kv0 + kt * 16 + g * 4;
-                int kh = 0, kw = 0;
-                if (RELPOS) {
-                    kh = kb / a.rel_kw;
-                    kw = kb - kh * a.rel_kw;
-                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb + r;
-                    float x = s[qt][kt][r] * sc2;
-                    if (RELPOS) {
-                        if (key < a.Sk) x += (rh[qt][kh] + rw[qt][kw]) * kLog2e;
-                        if (++kw == a.rel_kw) {
-                            kw = 0;
-                            ++kh;
-                        }
+                    float x = s[qt][kt][r];
+                    if (REL == 2) {
+                        const uint32_t pw = rwp[qt][2 * kt + (r >> 1)];
+                        x += rh_t + __uint_as_float((r & 1) ? (pw & 0xffff0000u) : (pw << 16));
                     }
+                    x *= sc2;
                     bool ok = key < a.Sk;
                     if (CAUSAL) ok = ok && (key <= qi + a.q_pos0);
                     x = ok ? x : kNegBig;
@@ -276,11 +319,18 @@ int launch_d(const AttnArgs& a, hipStream_t st) {
     const bool rel = a.rel_h != nullptr;
     if (a.causal) {
         if (rel) return IVLM_ERR_UNSUPPORTED;
-        attn_kernel<DQK, DV, true, false><<<grid, 256, 0, st>>>(a);
+        attn_kernel<DQK, DV, true, 0><<<grid, 256, 0, st>>>(a);
     } else if (rel) {
-        attn_kernel<DQK, DV, false, true><<<grid, 256, 0, st>>>(a);
+        if (DV != 80) return IVLM_ERR_UNSUPPORTED;  // only SAM's ViT uses rel-pos; keeps the build small
+        if (!a.prescale_q) return IVLM_ERR_UNSUPPORTED;
+        if (a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw)
+            attn_kernel<DQK, DV, false, DV == 80 ? 2 : 0><<<grid, 256, 0, st>>>(a);
+        else if (a.rel_kh + a.rel_kw <= 32)
+            attn_kernel<DQK, DV, false, DV == 80 ? 1 : 0><<<grid, 256, 0, st>>>(a);
+        else
+            return IVLM_ERR_UNSUPPORTED;
     } else {
-        attn_kernel<DQK, DV, false, false><<<grid, 256, 0, st>>>(a);
+        attn_kernel<DQK, DV, false, 0><<<grid, 256, 0, st>>>(a);
     }
     return ivlm_launch_status();
 }
@@ -355,7 +405,7 @@ extern "C" {
 
 int ivlm_attention_bf16(const void* q, const void* k, const void* v, void* o, const int64_t* strides /*[12]*/, int B,
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float* rel_h,
-                        const float* rel_w, int rel_kh, int rel_kw, int kv_batch_div, ivlm_stream_t stream) {
+                        const float* rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q, ivlm_stream_t stream) {
     ivlm_enter();
     if (!strides) return IVLM_ERR_INVALID_ARG;
     ivlm::AttnArgs a;
@@ -376,6 +426,7 @@ int ivlm_attention_bf16(const void* q, const void* k, const void* v, void* o, co
     a.rel_kh = rel_kh;
     a.rel_kw = rel_kw;
     a.kv_batch_div = kv_batch_div < 1 ? 1 : kv_batch_div;
+    a.prescale_q = prescale_q;
     return ivlm::attention_bf16(a, ivlm_stream(stream));
 }
 

@@ -49,6 +49,7 @@ struct AttnArgs {
     const float* rel_w;  // [B*H, Sq, rel_kw]
     int rel_kh, rel_kw;
     int kv_batch_div;    // key/value batch index = b / kv_batch_div (broadcast K/V over query batches)
+    int prescale_q;      // 1: scores = bf16(q*scale).k (SAM, HF-CLIP); 0: scores = (q.k)*scale (HF-LLaMA)
 };
 
 // softmax(scale * Q.K^T (+ rel-pos bias) (+ causal mask)) . V ; bf16 in/out, fp32 softmax. D in {16,32,64,80,128}.

@@ -209,7 +209,7 @@ def rmsnorm(x, weight, eps=1e-5):
     return y
 
 
-def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None):
+def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, prescale_q=False):
     """q [B,H,Sq,D], k/v [Bk,H,Sk,D] (arbitrary strides, last dim contiguous; B % Bk == 0: K/V of batch
     b // (B//Bk)) -> o [B,H,Sq,D] as a view of a [B,Sq,H,D] buffer (so o.transpose(1,2) is contiguous).
     rel = (rel_h f32 [B*H,Sq,KH], rel_w f32 [B*H,Sq,KW]) adds SAM's decomposed rel-pos bias."""
@@ -233,7 +233,8 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None):
         kh, kw = rel_h.shape[-1], rel_w.shape[-1]
     check(lib.ivlm_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                   ctypes.cast(st, ctypes.c_void_p), B, H, Sq, Sk, D, float(scale), 1 if causal else 0,
-                                  int(q_pos0), _p(rel_h), _p(rel_w), kh, kw, B // Bk, _stream()), "attention")
+                                  int(q_pos0), _p(rel_h), _p(rel_w), kh, kw, B // Bk,
+                                  1 if (prescale_q or rel is not None) else 0, _stream()), "attention")
     return out
 
 

@@ -75,7 +75,9 @@ def fill_state_dict(module, seed: int = 0, prefix: str = "") -> None:
     import torch
 
     with torch.no_grad():
-        for name, t in list(module.named_parameters()) + list(module.named_buffers()):
+        # state_dict() = parameters + PERSISTENT buffers only (e.g. SAM's PE gaussian matrix); derived
+        # non-persistent buffers such as rotary ``inv_freq`` must keep their computed values.
+        for name, t in module.state_dict().items():
             if not t.dtype.is_floating_point:
                 continue
             v = synth_param(prefix + name, tuple(t.shape), seed)

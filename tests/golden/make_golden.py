@@ -126,7 +126,211 @@ def gen_lift_points():
               num_points=np.int64(NP), expected=out)
 
 
-GENERATORS = {"lift": gen_lift, "lift_points": gen_lift_points}
+# ------------------------------------------------------------------------------------------
+# F4: SAM prompt encoder + mask decoder + postprocess (segment_anything/modeling/*)
+# ------------------------------------------------------------------------------------------
+def _sub(t, step=16):
+    return np.ascontiguousarray(t[..., ::step, ::step])
+
+
+def gen_sam_decoder():
+    import torch
+    _ref_shims.install()
+    from model.segment_anything.modeling import MaskDecoder, PromptEncoder, TwoWayTransformer
+    from model.segment_anything.modeling.sam import Sam
+    from interactvlm_amd.weights import SAM_PREFIX
+
+    torch.manual_seed(0)
+    pe = PromptEncoder(embed_dim=256, image_embedding_size=(64, 64), input_image_size=(1024, 1024), mask_in_chans=16)
+    md = MaskDecoder(num_multimask_outputs=3, transformer=TwoWayTransformer(depth=2, embedding_dim=256, mlp_dim=2048,
+                     num_heads=8), transformer_dim=256, iou_head_depth=3, iou_head_hidden_dim=256)
+    synth.fill_state_dict(pe, 0, SAM_PREFIX + ".prompt_encoder.")
+    synth.fill_state_dict(md, 0, SAM_PREFIX + ".mask_decoder.")
+    pe.eval(), md.eval()
+
+    class _Enc:  # postprocess_masks only reads image_encoder.img_size
+        img_size = 1024
+
+    post = lambda m, i, o: Sam.postprocess_masks(type("S", (), {"image_encoder": _Enc})(), m, i, o)
+    for V in (4, 1):
+        emb = torch.from_numpy(synth.synth_normal(f"samdec/image_emb/{V}", (V, 256, 64, 64), 1.0, 0))
+        text = torch.from_numpy(synth.synth_normal(f"samdec/text/{V}", (1, V, 256), 1.0, 0))
+        with torch.no_grad():
+            sparse, dense = pe(points=None, boxes=None, masks=None, text_embeds=text)
+            low, iou = md(image_embeddings=emb, image_pe=pe.get_dense_pe(), sparse_prompt_embeddings=sparse,
+                          dense_prompt_embeddings=dense, multimask_output=False)
+            full = post(low, (1024, 1024), (1024, 1024))
+            odd = post(low, (1024, 683), (750, 500))
+        _save(f"sam_decoder_V{V}.npz", low_res=low.numpy(), iou=iou.numpy(), dense_pe_sub=_sub(pe.get_dense_pe().numpy(), 8),
+              post_sub=_sub(full.numpy()), post_sum=np.float64(full.double().sum()),
+              post_odd_sub=_sub(odd.numpy(), 10), post_odd_shape=np.array(odd.shape))
+
+
+# ------------------------------------------------------------------------------------------
+# F5: camera-pose encoders + process_embeddings (components.py:491-572, InteractVLM.py:268-294)
+# ------------------------------------------------------------------------------------------
+def gen_cam():
+    import types
+    import torch
+    _ref_shims.install(full_model=True)
+    import model.components as RC
+    from model.InteractVLM import InteractVLMForCausalLM
+    from interactvlm_amd.constants import HUMAN_VIEW_DICT, normalize_cam_params
+
+    cams = torch.stack([normalize_cam_params(c) for c in HUMAN_VIEW_DICT["4MV-Z_Vitru"]["cam_params"].values()])
+    emb = torch.from_numpy(synth.synth_normal("cam/seg_emb", (1, 1, 256), 1.0, 0)).repeat(1, 4, 1)
+    out = {"cam_params": cams.numpy()}
+    for kind, cls in (("simple", RC.CamPoseEncoder), ("view_index", RC.ViewIndexCamPoseEncoder),
+                      ("vi_v1", RC.VIv1CamPoseEncoder)):
+        enc = cls() if kind == "simple" else cls(num_views=4)
+        synth.fill_state_dict(enc, 0, "cam_pose_encoder.")
+        for tt in ("Gen", "Gen-Hu-Obj"):
+            ns = types.SimpleNamespace(multiview_cam_cond=True, cam_encoder_type=kind, cam_pose_encoder=enc,
+                                       multiview_channels=4, base_token_type=tt, hseg_token_idx=32003,
+                                       oseg_token_idx=32004)
+            if tt != "Gen":
+                ns.attention_splitter = RC.AttentionSplitter()
+                synth.fill_state_dict(ns.attention_splitter, 0, "attention_splitter.")
+            for token in ((32000,) if tt == "Gen" else (32000, 32003, 32004)):
+                with torch.no_grad():
+                    r = InteractVLMForCausalLM.process_embeddings(ns, emb.clone(), cams, token)
+                out[f"{kind}/{tt}/{token}"] = r.numpy()
+    _save("cam_encoders.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------
+# F6: SAM ViT image encoder, reduced width/depth, real head_dim 80 / window 14 / padding / rel-pos
+# ------------------------------------------------------------------------------------------
+SAM_SMALL = dict(embed_dim=160, depth=2, num_heads=2, global_attn_indexes=(1,), img_size=480)
+
+
+def gen_sam_encoder():
+    from functools import partial
+    import torch
+    _ref_shims.install()
+    from model.segment_anything.modeling import ImageEncoderViT
+    from interactvlm_amd.weights import SAM_PREFIX
+
+    c = SAM_SMALL
+    enc = ImageEncoderViT(depth=c["depth"], embed_dim=c["embed_dim"], img_size=c["img_size"], mlp_ratio=4,
+                          norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=c["num_heads"], patch_size=16,
+                          qkv_bias=True, use_rel_pos=True, global_attn_indexes=c["global_attn_indexes"], window_size=14,
+                          out_chans=256)
+    synth.fill_state_dict(enc, 0, SAM_PREFIX + ".image_encoder.")
+    enc.eval()
+    x = torch.from_numpy(synth.synth_normal("samenc/x", (2, 3, c["img_size"], c["img_size"]), 1.0, 0))
+    with torch.no_grad():
+        y = enc(x)
+    _save("sam_encoder_small.npz", out=y.numpy())
+
+
+# ------------------------------------------------------------------------------------------
+# F7/F8: the facade — InteractVLMForCausalLM.model_forward(inference=True) on a toy LLaMA/CLIP
+# ------------------------------------------------------------------------------------------
+TOY = dict(hidden=128, layers=2, heads=4, inter=256, vocab=32003, clip_hidden=64, clip_layers=3, clip_heads=2,
+           clip_inter=128, clip_image=224, clip_patch=14)
+
+
+def gen_model_forward():
+    import json
+    import torch
+    _ref_shims.install(full_model=True)
+    import model.InteractVLM as RI
+    from model.segment_anything.build_sam import _build_sam
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from interactvlm_amd.constants import HUMAN_VIEW_DICT, normalize_cam_params, view_names
+    from interactvlm_amd.synth import synth_mesh_tables
+
+    t = TOY
+    # reduced SAM encoder (reference's own builder, smaller arguments); img_size stays 1024
+    RI.build_sam_vit_h = lambda ckpt=None: _build_sam(encoder_embed_dim=160, encoder_depth=2, encoder_num_heads=2,
+                                                     encoder_global_attn_indexes=[1], checkpoint=None)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        clip_dir = os.path.join(td, "clip-toy")
+        os.makedirs(clip_dir)
+        ccfg = CLIPVisionConfig(hidden_size=t["clip_hidden"], intermediate_size=t["clip_inter"],
+                                num_hidden_layers=t["clip_layers"], num_attention_heads=t["clip_heads"],
+                                image_size=t["clip_image"], patch_size=t["clip_patch"], hidden_act="quick_gelu")
+        ccfg.save_pretrained(clip_dir)
+        NV = 6890
+        vid, bary = synth_mesh_tables(4, 1024, 1024, NV, fg=0.4, seed=0, patch=8)
+        names = view_names(HUMAN_VIEW_DICT["4MV-Z_Vitru"])
+        d = os.path.join(td, "data", "hcontact_vitruvian")
+        os.makedirs(d)
+        np.savez(os.path.join(d, "pixel_to_vertex_map_1024.npz"), **{n: vid[i] for i, n in enumerate(names)})
+        np.savez(os.path.join(d, "bary_coords_map_1024.npz"), **{n: bary[i] for i, n in enumerate(names)})
+        cfg = RI.LlavaLlamaForCausalLM.config_class(
+            hidden_size=t["hidden"], intermediate_size=t["inter"], num_hidden_layers=t["layers"],
+            num_attention_heads=t["heads"], num_key_value_heads=t["heads"], vocab_size=t["vocab"], rms_norm_eps=1e-5,
+            max_position_embeddings=1024, attn_implementation="eager")
+        for k, v in dict(vision_tower=clip_dir, mm_vision_tower=clip_dir, mm_hidden_size=t["clip_hidden"],
+                         mm_use_im_start_end=True, mm_vision_select_layer=-2, use_fusion=False, use_uncertainty=False,
+                         img_emb_len=255, seg_token_idx=32000, hseg_token_idx=None, oseg_token_idx=None, token_type="Gen",
+                         hC_sam_view_type="4MV-Z_Vitru", oC_sam_view_type="4MV-Z_HM", hC_loss_weight=1.0,
+                         oC_loss_weight=0.0, multiview_channels=4, multiview_cam_cond=True, cam_encoder_type="vi_v1",
+                         train_mask_decoder=True, out_dim=256).items():
+            setattr(cfg, k, v)
+        os.chdir(td)
+        try:
+            torch.manual_seed(0)
+            m = RI.InteractVLMForCausalLM(cfg)
+            vt = m.get_model().get_vision_tower()
+            vt.vision_tower = CLIPVisionModel(ccfg)
+            vt.is_loaded = True
+        finally:
+            os.chdir(cwd)
+        m.eval()
+        synth.fill_state_dict(m, 0, "")
+        # transformers>=5 flattens CLIPVisionModel (no ".vision_model." level); the reference's pinned 4.31 and
+        # the openai/clip-vit-large-patch14 checkpoint have it, and so do our keys: re-pour under that name.
+        if not any(k.startswith("vision_model.") for k in vt.vision_tower.state_dict()):
+            synth.fill_state_dict(vt.vision_tower, 0, "model.vision_tower.vision_tower.vision_model.")
+        # ids: 40 prompt ids with <im_start> <image> <im_end> at 10..12, then a 12-token answer with [SEG]
+        rng = np.random.default_rng(0)
+        ids = rng.integers(3, 31000, size=52)
+        ids[10], ids[11], ids[12] = 32001, -200, 32002
+        ids[47] = 32000
+        ids[51] = 2
+        input_ids = torch.from_numpy(ids)[None]
+        images_clip = torch.from_numpy(synth.synth_normal("mf/images_clip", (1, 3, 224, 224), 1.0, 0))
+        images = torch.from_numpy(synth.synth_normal("mf/images", (1, 4, 3, 1024, 1024), 1.0, 0))
+        cams = torch.stack([normalize_cam_params(c) for c in HUMAN_VIEW_DICT["4MV-Z_Vitru"]["cam_params"].values()])[None]
+        # Taps are recorded DURING the one real call: under transformers 5.x a second call of the CLIP tower
+        # returns a doubled hidden_states tuple (output-recorder hooks accumulate), so re-calling sub-modules
+        # afterwards would tap a different computation than the one that produced pred_masks.
+        taps = {}
+
+        def tap(name, pick=lambda o: o):
+            def hook(mod, a, o):  # must return None: a returned value would REPLACE the module output
+                taps.setdefault(name, pick(o).detach().clone())
+            return hook
+
+        gm = m.get_model()
+        h1 = gm.mm_projector.register_forward_hook(tap("clip_feat"))
+        h2 = gm.norm.register_forward_hook(tap("hidden_last"))
+        h3 = gm.text_hidden_fcs[0].register_forward_hook(tap("fcs"))
+        h4 = gm.visual_model.image_encoder.register_forward_hook(tap("sam_emb"))
+        h5 = gm.visual_model.mask_decoder.register_forward_hook(tap("low_res", lambda o: o[0]))
+        with torch.no_grad():
+            out = m.model_forward(images=images, images_clip=images_clip, input_ids=input_ids, labels=None,
+                                  attention_masks=torch.ones_like(input_ids), offset=torch.tensor([0, 1]),
+                                  masks_list=[torch.zeros(4, 1, 1024, 1024)], label_list=[torch.zeros(1024, 1024)],
+                                  gt_contact_3d_list=None, cam_params=cams, resize_list=[(1024, 1024)],
+                                  ds_name_list=["hcontact"], mask_paths_list=[None], inference=True)
+        for h in (h1, h2, h3, h4, h5):
+            h.remove()
+        clip_feat, hid, img_emb = taps["clip_feat"], taps["hidden_last"], taps["sam_emb"]
+    pm = out["pred_masks"][0].numpy()
+    _save("model_forward_toy.npz", input_ids=ids, cam_params=cams.numpy(), toy=json.dumps(TOY),
+          clip_feat=clip_feat.numpy(), hidden_last=hid.numpy(), sam_emb_sub=_sub(img_emb.numpy(), 4),
+          seg_fcs=taps["fcs"].numpy(), low_res=taps["low_res"].numpy(),
+          pred_masks_sub=_sub(pm), pred_masks_sum=np.float64(pm.astype(np.float64).sum()),
+          pred_contact=out["pred_human_3d_contact"].numpy())
+
+
+GENERATORS = {"lift": gen_lift, "lift_points": gen_lift_points, "sam_decoder": gen_sam_decoder, "cam": gen_cam,
+              "sam_encoder": gen_sam_encoder, "model_forward": gen_model_forward}
 
 
 def main():

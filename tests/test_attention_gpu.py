@@ -91,7 +91,8 @@ def test_relpos_attention(hip_lib, cuda, SH, SW, B, H):
     rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw).to(bf).float()
     bias = (rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).reshape(B, H, S, S)
     scale = D ** -0.5
-    ref = _ref(q, k, v, scale, bias=bias)
+    q_s = (q.float() * scale).to(bf)  # (q * self.scale) @ k^T in the model dtype (image_encoder.py:244)
+    ref = _ref(q_s, k, v, 1.0, bias=bias)
     gh, gw = ops.relpos_bias(q.to(cuda), tab_h.to(cuda), tab_w.to(cuda), SH, SW)
     assert torch.allclose(gh.cpu(), rel_h.reshape(B * H, S, SH), atol=2e-2, rtol=1e-2)
     assert torch.allclose(gw.cpu(), rel_w.reshape(B * H, S, SW), atol=2e-2, rtol=1e-2)

@@ -1,0 +1,103 @@
+"""Pins the PyTorch-CPU oracle of the neural part (oracle/nn.py, oracle/pipeline.py) to golden vectors
+produced by running the reference's own modules (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from interactvlm_amd import synth
+from interactvlm_amd import weights as Wt
+from interactvlm_amd.weights import SAM_PREFIX
+from oracle import nn as O
+from oracle import pipeline as P
+
+torch.set_grad_enabled(False)
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("V", [4, 1])
+def test_sam_decoder_chain(golden_dir, V):
+    d = _g(golden_dir, f"sam_decoder_V{V}.npz")
+    w = Wt.synth_weights({**Wt.prompt_encoder_spec(), **Wt.mask_decoder_spec()})
+    emb = torch.from_numpy(synth.synth_normal(f"samdec/image_emb/{V}", (V, 256, 64, 64), 1.0, 0))
+    text = torch.from_numpy(synth.synth_normal(f"samdec/text/{V}", (1, V, 256), 1.0, 0))
+    pe = O.dense_pe(w, SAM_PREFIX + ".prompt_encoder", (64, 64))
+    sp, de = O.prompt_encoder_text(w, SAM_PREFIX + ".prompt_encoder", text, (64, 64))
+    low, iou = O.mask_decoder(w, SAM_PREFIX + ".mask_decoder", emb, pe, sp, de)
+    # multi-view broadcasting: V views become TOKENS (9 = 1 iou + 4 mask + V text), batch V after cross-attn
+    assert low.shape == (V, 1, 256, 256) and iou.shape == (V, 1)
+    np.testing.assert_allclose(low.numpy(), d["low_res"], atol=1e-5)
+    np.testing.assert_allclose(iou.numpy(), d["iou"], atol=1e-5)
+    np.testing.assert_allclose(pe.numpy()[..., ::8, ::8], d["dense_pe_sub"], atol=1e-6)
+    full = O.postprocess_masks(low, (1024, 1024), (1024, 1024))
+    np.testing.assert_allclose(full.numpy()[..., ::16, ::16], d["post_sub"], atol=1e-5)
+    assert abs(float(full.double().sum()) - float(d["post_sum"])) < 1e-2
+    odd = O.postprocess_masks(low, (1024, 683), (750, 500))
+    assert tuple(odd.shape) == tuple(d["post_odd_shape"])
+    np.testing.assert_allclose(odd.numpy()[..., ::10, ::10], d["post_odd_sub"], atol=1e-5)
+
+
+def test_cam_encoders_and_process_embeddings(golden_dir):
+    d = _g(golden_dir, "cam_encoders.npz")
+    cams = torch.from_numpy(d["cam_params"])
+    # normalisation restated in constants.normalize_cam_params (base_contact_dataset.py:37-50)
+    np.testing.assert_allclose(cams[1].numpy(), [0.2, 0.875, 0.875, 0.5, 0.65], atol=1e-6)
+    emb = torch.from_numpy(synth.synth_normal("cam/seg_emb", (1, 1, 256), 1.0, 0)).repeat(1, 4, 1)
+    for k in d.files:
+        if k == "cam_params":
+            continue
+        kind, tt, token = k.split("/")
+        w = Wt.synth_weights({**Wt.cam_encoder_spec(kind), **Wt.attention_splitter_spec()})
+        cfg = dict(multiview_cam_cond=True, cam_encoder_type=kind, multiview_channels=4, base_token_type=tt,
+                   hseg_token_idx=32003, oseg_token_idx=32004)
+        r = O.process_embeddings(w, emb.clone(), cams, int(token), cfg)
+        np.testing.assert_allclose(r.numpy(), d[k], atol=1e-6, err_msg=k)
+
+
+def test_sam_image_encoder_small(golden_dir):
+    d = _g(golden_dir, "sam_encoder_small.npz")
+    c = Wt.SamEncCfg(embed_dim=160, depth=2, num_heads=2, global_attn_indexes=(1,), img_size=480)
+    w = Wt.synth_weights(Wt.sam_encoder_spec(c))
+    x = torch.from_numpy(synth.synth_normal("samenc/x", (2, 3, 480, 480), 1.0, 0))
+    y = O.sam_image_encoder(w, SAM_PREFIX + ".image_encoder", x, 2, 2, (1,))
+    np.testing.assert_allclose(y.numpy(), d["out"], atol=1e-5)
+
+
+def toy_cfg(t):
+    return Wt.IvlmCfg(
+        llama=Wt.LlamaCfg(hidden=t["hidden"], layers=t["layers"], heads=t["heads"], inter=t["inter"], vocab=t["vocab"]),
+        clip=Wt.ClipCfg(hidden=t["clip_hidden"], layers=t["clip_layers"], heads=t["clip_heads"], inter=t["clip_inter"]),
+        sam=Wt.SamEncCfg(embed_dim=160, depth=2, num_heads=2, global_attn_indexes=(1,)))
+
+
+def toy_inputs(d):
+    ids = torch.from_numpy(d["input_ids"])
+    images_clip = torch.from_numpy(synth.synth_normal("mf/images_clip", (1, 3, 224, 224), 1.0, 0))
+    images = torch.from_numpy(synth.synth_normal("mf/images", (1, 4, 3, 1024, 1024), 1.0, 0))[0]
+    cams = torch.from_numpy(d["cam_params"])[0]
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    return ids, images_clip, images, cams, tables
+
+
+def test_model_forward_end_to_end(golden_dir):
+    """InteractVLMForCausalLM.model_forward(inference=True) of the reference vs the oracle pipeline."""
+    d = _g(golden_dir, "model_forward_toy.npz")
+    cfg = toy_cfg(json.loads(str(d["toy"])))
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    ids, images_clip, images, cams, tables = toy_inputs(d)
+    o = P.model_forward(w, cfg, images, images_clip, ids, cams, tables)
+    np.testing.assert_allclose(o["clip_feat"].numpy(), d["clip_feat"][0], atol=2e-5)
+    np.testing.assert_allclose(o["hidden"].numpy(), d["hidden_last"][0], atol=2e-5)
+    assert o["hidden"].shape[0] == len(ids) + cfg.img_emb_len  # one -200 expands to 256 rows
+    np.testing.assert_allclose(o["low_res"].numpy(), d["low_res"], atol=5e-5)
+    pm = o["pred_masks"].numpy()
+    np.testing.assert_allclose(pm[..., ::16, ::16], d["pred_masks_sub"], atol=5e-5)
+    np.testing.assert_allclose(o["pred_contact"].numpy(), d["pred_contact"], atol=1e-5)
+    # [SEG] at id-index 47 selects hidden row 47 - 1 + 255 (InteractVLM.py:331-341)
+    rows = O.seg_rows(ids, [32000], 255, model_forward=True)
+    assert rows.nonzero().flatten().tolist() == [47 - 1 + 255]

@@ -41,5 +41,22 @@ def main():
         print(name, f"{t*1e6:.1f} us", f"{fl/t/1e12:.1f} TFLOP/s", flush=True)
 
 
+def bench_relpos():
+    dev = torch.device("cuda:0")
+    for name, B, H, SH in (("relpos_global", 4, 16, 64), ("relpos_window", 100, 16, 14)):
+        q = torch.randn(B, H, SH * SH, 80, device=dev).to(torch.bfloat16)
+        th = torch.randn(2 * SH - 1, 80, device=dev).to(torch.bfloat16)
+        ops.relpos_bias(q, th, th, SH, SH)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            ops.relpos_bias(q, th, th, SH, SH)
+        e.record()
+        torch.cuda.synchronize()
+        print(name, f"{s.elapsed_time(e) / 10 * 1e3:.1f} us", flush=True)
+
+
 if __name__ == "__main__":
+    bench_relpos()
     main()
