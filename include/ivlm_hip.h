@@ -102,23 +102,25 @@ int ivlm_postprocess_masks(const void *low, int dtype, int n, int h, int w, int 
 /* ---------------------------------------------------------------------------------------------
  * Dense building blocks (bf16 storage, fp32 accumulation) used by the stage runners below and
  * exposed for unit testing.  Activation codes: 0 none, 1 GELU(erf), 2 quick-GELU, 3 ReLU, 4 SiLU,
- * 5 SwiGLU over row-interleaved (gate_j, up_j) weights (output has N/2 columns).
+ * 5 SwiGLU over row-interleaved (gate_j, up_j) weights (output has N/2 columns), 6 sigmoid.
  * ------------------------------------------------------------------------------------------- */
 
 /* nn.Linear: C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[m (% res_mod), N]
  * (HF LlamaModel / CLIPVisionModel linears; SAM image_encoder.py:222-260, common.py:13-27,
  * transformer.py:185-242; InteractVLM.py:100-112 text_hidden_fcs; llava_arch.py:35 mm_projector).
- * bf16 A/W/bias/residual, K % 64 == 0, lda/ldw % 8 == 0; C bf16 or f32 (out_f32).  batch > 1 runs a
- * strided batch (strides in elements). */
+ * bf16 A/W/bias/residual, K % 8 == 0, lda/ldw % 8 == 0; C bf16 or f32 (out_f32).  batch > 1 runs a
+ * strided batch (strides in elements).  M <= 8 takes the weight-streaming GEMV path (batch-1 decode:
+ * HF greedy search under InteractVLM.evaluate, model/InteractVLM.py:524-531), K % 8 == 0 suffices there. */
 int ivlm_gemm_bf16(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
                    const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
                    int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
                    int64_t strideR, ivlm_stream_t stream);
 
 /* nn.LayerNorm over the last dim (also SAM LayerNorm2d with NHWC activations, common.py:32-42);
- * bf16 in/out, fp32 statistics, cols % 8 == 0, cols <= 8192. */
+ * bf16 in/out, fp32 statistics, cols % 8 == 0, cols <= 8192.  gelu_after != 0 fuses the exact-erf GELU that
+ * follows LayerNorm2d in the mask decoder's upscaler (mask_decoder.py:53-63). */
 int ivlm_layernorm_bf16(const void *x, const void *w, const void *b, void *y, int64_t rows, int cols,
-                        float eps, ivlm_stream_t stream);
+                        float eps, int gelu_after, ivlm_stream_t stream);
 /* HF LlamaRMSNorm: y = w * bf16(x * rsqrt(mean(x^2) + eps)). */
 int ivlm_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t rows, int cols, float eps,
                       ivlm_stream_t stream);
@@ -140,6 +142,39 @@ int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, co
  *   like the reference's model-dtype einsum, stored f32).  tab_h bf16 [2*SH-1,D], tab_w bf16 [2*SW-1,D]. */
 int ivlm_relpos_bias(const void *q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void *tab_h, const void *tab_w,
                      int B, int H, int SH, int SW, int D, float *rel_h, float *rel_w, ivlm_stream_t stream);
+
+/* torch.argmax(logits, -1) of HF greedy search (first maximal index); x f32 [rows, cols] -> out i32 [rows]. */
+int ivlm_argmax_f32(const float *x, int rows, int cols, int32_t *out, ivlm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Data movement on the path (all bf16, 16-byte granules: cols/strides % 8 == 0)
+ * ------------------------------------------------------------------------------------------- */
+/* Conv2d(kernel = stride = ks) as GEMM operand: out[(b,gy,gx), (c,ky,kx)] zero-padded to Kpad columns
+ * (SAM PatchEmbed image_encoder.py:404-426; HF CLIP patch_embedding). x [B,C,H,W] */
+int ivlm_im2col_nchw(const void *x, void *out, int B, int C, int H, int W, int ks, int stride, int Kpad,
+                     ivlm_stream_t stream);
+/* 3x3 / pad 1 conv operand from channels-last x [B,H,W,C] -> [(b,y,x), (ky,kx,c)] (SAM neck, image_encoder.py:92-108) */
+int ivlm_im2col3x3_nhwc(const void *x, void *out, int B, int H, int W, int C, ivlm_stream_t stream);
+/* dst[r] = (idx[r] >= 0 ? src[idx[r]] : 0) + (add ? add[r] : 0): window_partition / window_unpartition + shortcut
+ * (image_encoder.py:263-318, 177-193), embed_tokens gather (llava_arch.py:185-208). */
+int ivlm_gather_rows(void *dst, int64_t ldd, const void *src, int64_t lds, const int32_t *idx, const void *add,
+                     int64_t lda, int64_t rows, int cols, ivlm_stream_t stream);
+/* out[r] = a[r] (op 0: +, op 1: *) b[r % b_rows]  (queries + query_pe, keys + key_pe: transformer.py:160-176;
+ * [SEG] embedding * view encoding: InteractVLM.py:275-282) */
+int ivlm_add_rows(void *out, const void *a, const void *b, int64_t rows, int cols, int64_t b_rows, int op,
+                  ivlm_stream_t stream);
+/* PositionEmbeddingRandom.forward (prompt_encoder.py:219-229): gauss f32 [2,F] -> pe bf16 [h*w, 2F]
+ * (the table is a constant of the weights: computed once at load, in fp32) */
+int ivlm_dense_pe(const void *gauss, void *pe, int h, int w, int F, ivlm_stream_t stream);
+/* HF LlamaAttention rotary (rotate-half, base theta) applied in place to q,k of qkv [T,3,H,D] (row stride ld) at
+ * positions pos0+t, and KV-cache append (kcache/vcache [Tmax,H,D], may be NULL). */
+int ivlm_rope_kv(void *qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void *kcache, void *vcache,
+                 ivlm_stream_t stream);
+/* masks = hyper_in @ upscaled_embedding (mask_decoder.py:150-153) for one mask token: up bf16
+ * [B,gh,gw,2,2,2,2,C] (output of the two k2s2 transposed convs, channels last), hyper bf16 [B,C]
+ * -> low f32 [B,4gh,4gw] */
+int ivlm_mask_dot(const void *up, const void *hyper, float *low, int B, int gh, int gw, int C,
+                  ivlm_stream_t stream);
 
 #ifdef __cplusplus
 }

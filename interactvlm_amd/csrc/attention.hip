@@ -36,7 +36,7 @@ constexpr float kNegBig = -1.0e30f;
 // REL: 0 no bias; 1 rel-pos folded into the QK^T MFMA (KH + KW <= 32: one extra k-step whose Q' operand is
 // [rel_h | rel_w] and whose K' operand is the one-hot (kh, KH + kw) code of the key: exact, no VALU);
 // 2 rel_kw == 64 == key-tile: rel_w is tile-invariant (held as packed bf16 in registers), rel_h is one
-// value per (query, tile).
+// value per (query, tile); 3 any other grid: per-score table lookups (slow, non-SAM-H sizes only).
 template <int DQK, int DV, bool CAUSAL, int REL>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     constexpr int KS = DQK / 32;        // MFMA k-steps over the head dim
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     bf16x8_t qrel[2];       // REL 1: [rel_h(KH) | rel_w(KW) | 0] features g*8 .. g*8+7
     uint32_t rwp[2][8];     // REL 2: rel_w[q][kt*16 + g*4 + r] as packed bf16 pairs
     const float* rhp[2] = {nullptr, nullptr};
+    const float* rwg[2] = {nullptr, nullptr};  // REL 3
     if (REL != 0) {
         const int64_t bh = (int64_t)b * a.H + h;
 #pragma unroll
@@ -156,6 +157,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
                 uint4 u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
                                      pack_bf16x2(f[6], f[7]));
                 qrel[qt] = *reinterpret_cast<bf16x8_t*>(&u);
+            } else if (REL == 3) {
+                rhp[qt] = rh;
+                rwg[qt] = rw;
             } else {
                 rhp[qt] = rh;
 #pragma unroll
@@ -222,10 +226,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const int kb = kv0 + kt * 16 + g * 4;
+                int gkh = 0, gkw = 0;
+                if (REL == 3) {
+                    gkh = kb / a.rel_kw;
+                    gkw = kb - gkh * a.rel_kw;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb + r;
                     float x = s[qt][kt][r];
+                    if (REL == 3) {
+                        if (key < a.Sk) x += rhp[qt][gkh] + rwg[qt][gkw];
+                        if (++gkw == a.rel_kw) {
+                            gkw = 0;
+                            ++gkh;
+                        }
+                    }
                     if (REL == 2) {
                         const uint32_t pw = rwp[qt][2 * kt + (r >> 1)];
                         x += rh_t + __uint_as_float((r & 1) ? (pw & 0xffff0000u) : (pw << 16));
@@ -328,7 +344,7 @@ int launch_d(const AttnArgs& a, hipStream_t st) {
         else if (a.rel_kh + a.rel_kw <= 32)
             attn_kernel<DQK, DV, false, DV == 80 ? 1 : 0><<<grid, 256, 0, st>>>(a);
         else
-            return IVLM_ERR_UNSUPPORTED;
+            attn_kernel<DQK, DV, false, DV == 80 ? 3 : 0><<<grid, 256, 0, st>>>(a);
     } else {
         attn_kernel<DQK, DV, false, 0><<<grid, 256, 0, st>>>(a);
     }

@@ -1,0 +1,297 @@
+// Data-movement / elementwise kernels of the contact-inference path (gfx950).  All HBM-bound: 16-byte
+// coalesced accesses, no LDS, grid-stride.
+//   im2col_nchw        patch embedding as GEMM   (SAM image_encoder.py:404-426; HF CLIP patch_embedding)
+//   im2col3x3_nhwc     SAM neck 3x3 conv as GEMM (image_encoder.py:92-108)
+//   gather_rows        window partition / unpartition(+residual), token-embedding gather, CLS drop
+//                      (image_encoder.py:263-318; llava_arch.py:185-208)
+//   add_rows           x + pe with row-modulo broadcast (transformer.py:160-176)
+//   dense_pe           PositionEmbeddingRandom over the 64x64 grid (prompt_encoder.py:189-229)
+//   rope_kv            rotate-half RoPE on q,k in the fused qkv buffer + KV-cache append (HF LlamaAttention)
+//   mask_dot           masks = hyper_in @ upscaled  (mask_decoder.py:150-153) with the pixel un-shuffle of
+//                      the two k2s2 transposed convolutions
+#include "kernels.h"
+
+namespace ivlm {
+namespace {
+
+constexpr int kT = 256;
+
+inline int grid_for(int64_t work_items, int max_blocks = 8192) {
+    int64_t b = (work_items + kT - 1) / kT;
+    if (b < 1) b = 1;
+    return (int)(b < max_blocks ? b : max_blocks);
+}
+
+// out[(b,gy,gx), (c,ky,kx)] = x[b,c,gy*s+ky,gx*s+kx], zero-padded to Kpad columns. 8 outputs per thread.
+__global__ __launch_bounds__(kT) void im2col_nchw_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B,
+                                                         int C, int H, int W, int ks, int stride, int Kpad) {
+    const int gh = (H - ks) / stride + 1, gw = (W - ks) / stride + 1;
+    const int K = C * ks * ks;
+    const int64_t total = (int64_t)B * gh * gw * (Kpad >> 3);
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+        const int c8 = (int)(i % (Kpad >> 3));
+        const int64_t row = i / (Kpad >> 3);
+        const int gx = (int)(row % gw), gy = (int)((row / gw) % gh), b = (int)(row / ((int64_t)gw * gh));
+        bf16_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = c8 * 8 + e;
+            bf16_t val = 0;
+            if (col < K) {
+                const int c = col / (ks * ks), r = col - c * ks * ks, ky = r / ks, kx = r - ky * ks;
+                val = x[(((int64_t)b * C + c) * H + gy * stride + ky) * W + gx * stride + kx];
+            }
+            v[e] = val;
+        }
+        *reinterpret_cast<uint4*>(out + row * Kpad + c8 * 8) = *reinterpret_cast<const uint4*>(v);
+    }
+}
+
+// x [B,H,W,C] -> out [(b,y,x), (ky,kx,c)] with zero padding 1; C % 8 == 0
+__global__ __launch_bounds__(kT) void im2col3x3_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                            int B, int H, int W, int C) {
+    const int c8n = C >> 3;
+    const int64_t total = (int64_t)B * H * W * 9 * c8n;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+        const int c8 = (int)(i % c8n);
+        const int tap = (int)((i / c8n) % 9);
+        const int64_t row = i / ((int64_t)c8n * 9);
+        const int xx = (int)(row % W), yy = (int)((row / W) % H), b = (int)(row / ((int64_t)W * H));
+        const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W)
+            v = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + sy) * W + sx) * C + c8 * 8);
+        *reinterpret_cast<uint4*>(out + row * (9 * (int64_t)C) + tap * C + c8 * 8) = v;
+    }
+}
+
+__device__ __forceinline__ uint4 mul8(const uint4& a, const uint4& b) {
+    uint4 r;
+    const uint32_t* pa = &a.x;
+    const uint32_t* pb = &b.x;
+    uint32_t* pr = &r.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        pr[j] = pack_bf16x2(__uint_as_float(pa[j] << 16) * __uint_as_float(pb[j] << 16),
+                            __uint_as_float(pa[j] & 0xffff0000u) * __uint_as_float(pb[j] & 0xffff0000u));
+    return r;
+}
+
+__device__ __forceinline__ uint4 add8(const uint4& a, const uint4& b) {
+    uint4 r;
+    const uint32_t* pa = &a.x;
+    const uint32_t* pb = &b.x;
+    uint32_t* pr = &r.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        pr[j] = pack_bf16x2(__uint_as_float(pa[j] << 16) + __uint_as_float(pb[j] << 16),
+                            __uint_as_float(pa[j] & 0xffff0000u) + __uint_as_float(pb[j] & 0xffff0000u));
+    return r;
+}
+
+// dst[r] = (idx[r] >= 0 ? src[idx[r]] : 0) (+ add[r]);  cols % 8 == 0; row strides in elements
+__global__ __launch_bounds__(kT) void gather_rows_kernel(bf16_t* __restrict__ dst, int64_t ldd,
+                                                         const bf16_t* __restrict__ src, int64_t lds_,
+                                                         const int32_t* __restrict__ idx,
+                                                         const bf16_t* __restrict__ add, int64_t lda, int64_t rows,
+                                                         int cols) {
+    const int c8n = cols >> 3;
+    const int64_t total = rows * c8n;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+        const int c8 = (int)(i % c8n);
+        const int64_t r = i / c8n;
+        const int s = idx[r];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (s >= 0) v = *reinterpret_cast<const uint4*>(src + (int64_t)s * lds_ + c8 * 8);
+        if (add) v = add8(v, *reinterpret_cast<const uint4*>(add + r * lda + c8 * 8));
+        *reinterpret_cast<uint4*>(dst + r * ldd + c8 * 8) = v;
+    }
+}
+
+// out[r] = a[r] (+|*) b[r % b_rows]
+__global__ __launch_bounds__(kT) void add_rows_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ a,
+                                                      const bf16_t* __restrict__ b, int64_t rows, int cols,
+                                                      int64_t b_rows, int op) {
+    const int c8n = cols >> 3;
+    const int64_t total = rows * c8n;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+        const int c8 = (int)(i % c8n);
+        const int64_t r = i / c8n;
+        const uint4 va = *reinterpret_cast<const uint4*>(a + r * cols + c8 * 8);
+        const uint4 vb = *reinterpret_cast<const uint4*>(b + (r % b_rows) * cols + c8 * 8);
+        *reinterpret_cast<uint4*>(out + r * cols + c8 * 8) = op ? mul8(va, vb) : add8(va, vb);
+    }
+}
+
+// pe[(y,x), c]: c < F -> sin, c >= F -> cos of 2*pi*((2*(x+.5)/w-1)*g[0,c'] + (2*(y+.5)/h-1)*g[1,c'])
+__global__ __launch_bounds__(kT) void dense_pe_kernel(const float* __restrict__ gauss /*[2,F]*/,
+                                                      bf16_t* __restrict__ pe /*[h*w, 2F]*/, int h, int w, int F) {
+    const int64_t total = (int64_t)h * w * 2 * F;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+        const int c = (int)(i % (2 * F));
+        const int64_t p = i / (2 * F);
+        const int xx = (int)(p % w), yy = (int)(p / w);
+        const int f = c < F ? c : c - F;
+        // fp32 throughout (the reference's bf16 model would round the grid itself; we stay closer to fp32)
+        const float cx = 2.0f * (((float)xx + 0.5f) / (float)w) - 1.0f;
+        const float cy = 2.0f * (((float)yy + 0.5f) / (float)h) - 1.0f;
+        float t = cx * gauss[f] + cy * gauss[F + f];
+        t = 6.283185307179586f * t;
+        pe[i] = f32_to_bf16(c < F ? sinf(t) : cosf(t));
+    }
+}
+
+// qkv [T, 3, H, D] (row stride ld): rotate-half RoPE in place on q and k at positions pos0 + t; append
+// roped k and v to the caches [Tmax, H, D] at row pos0 + t.  One thread per (t, h, pair j < D/2).
+__global__ __launch_bounds__(kT) void rope_kv_kernel(bf16_t* __restrict__ qkv, int64_t ld, int T, int H, int D,
+                                                     int pos0, float theta, bf16_t* __restrict__ kcache,
+                                                     bf16_t* __restrict__ vcache) {
+    const int half = D >> 1;
+    const int64_t total = (int64_t)T * H * half;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+        const int j = (int)(i % half);
+        const int h = (int)((i / half) % H);
+        const int t = (int)(i / ((int64_t)half * H));
+        const int pos = pos0 + t;
+        // HF: inv_freq = theta^(-2j/D) (fp32), freqs = pos*inv_freq, cos/sin in fp32; we keep fp32 products and
+        // round q/k once (the reference's bf16 model rounds cos/sin and every product: more noise, same maths)
+        const float inv = powf(theta, -(float)(2 * j) / (float)D);
+        const float ang = (float)pos * inv;
+        const float c = cosf(ang), s = sinf(ang);
+        bf16_t* row = qkv + (int64_t)t * ld;
+        bf16_t* q = row + h * D;
+        bf16_t* k = row + (int64_t)H * D + h * D;
+        const bf16_t* v = row + 2 * (int64_t)H * D + h * D;
+        const float q0 = bf16_to_f32(q[j]), q1 = bf16_to_f32(q[j + half]);
+        const float k0 = bf16_to_f32(k[j]), k1 = bf16_to_f32(k[j + half]);
+        // q*cos + rotate_half(q)*sin
+        const bf16_t qa = f32_to_bf16(q0 * c - q1 * s), qb = f32_to_bf16(q1 * c + q0 * s);
+        const bf16_t ka = f32_to_bf16(k0 * c - k1 * s), kb = f32_to_bf16(k1 * c + k0 * s);
+        q[j] = qa;
+        q[j + half] = qb;
+        k[j] = ka;
+        k[j + half] = kb;
+        if (kcache) {
+            bf16_t* kc = kcache + ((int64_t)pos * H + h) * D;
+            bf16_t* vc = vcache + ((int64_t)pos * H + h) * D;
+            kc[j] = ka;
+            kc[j + half] = kb;
+            vc[j] = v[j];
+            vc[j + half] = v[j + half];
+        }
+    }
+}
+
+// up [B, gh, gw, 2,2, 2,2, C] (two k2s2 transposed convs, channels last)  x  hyper [B, C]
+//   -> low [B, 4gh, 4gw] fp32 at (4y + 2dy + dy2, 4x + 2dx + dx2)
+__global__ __launch_bounds__(kT) void mask_dot_kernel(const bf16_t* __restrict__ up, const bf16_t* __restrict__ hyper,
+                                                      float* __restrict__ low, int B, int gh, int gw, int C) {
+    const int64_t total = (int64_t)B * gh * gw * 16;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+        const int sub = (int)(i & 15);
+        const int64_t cell = i >> 4;
+        const int xx = (int)(cell % gw), yy = (int)((cell / gw) % gh), b = (int)(cell / ((int64_t)gw * gh));
+        const int dy = sub >> 3, dx = (sub >> 2) & 1, dy2 = (sub >> 1) & 1, dx2 = sub & 1;
+        const bf16_t* u = up + i * C;
+        const bf16_t* hv = hyper + (int64_t)b * C;
+        float acc = 0.0f;
+        for (int c = 0; c < C; c += 8) {
+            const uint4 a4 = *reinterpret_cast<const uint4*>(u + c);
+            const uint4 h4 = *reinterpret_cast<const uint4*>(hv + c);
+            const uint32_t* pa = &a4.x;
+            const uint32_t* ph = &h4.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc += __uint_as_float(pa[j] << 16) * __uint_as_float(ph[j] << 16);
+                acc += __uint_as_float(pa[j] & 0xffff0000u) * __uint_as_float(ph[j] & 0xffff0000u);
+            }
+        }
+        const int Y = 4 * yy + 2 * dy + dy2, X = 4 * xx + 2 * dx + dx2;
+        low[((int64_t)b * 4 * gh + Y) * (4 * gw) + X] = acc;
+    }
+}
+
+}  // namespace
+
+int im2col_nchw(const bf16_t* x, bf16_t* out, int B, int C, int H, int W, int ks, int stride, int Kpad,
+                hipStream_t st) {
+    if (!x || !out || (Kpad & 7) || Kpad < C * ks * ks) return IVLM_ERR_INVALID_ARG;
+    const int gh = (H - ks) / stride + 1, gw = (W - ks) / stride + 1;
+    im2col_nchw_kernel<<<grid_for((int64_t)B * gh * gw * (Kpad >> 3)), kT, 0, st>>>(x, out, B, C, H, W, ks, stride, Kpad);
+    return ivlm_launch_status();
+}
+int im2col3x3_nhwc(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st) {
+    if (!x || !out || (C & 7)) return IVLM_ERR_INVALID_ARG;
+    im2col3x3_nhwc_kernel<<<grid_for((int64_t)B * H * W * 9 * (C >> 3)), kT, 0, st>>>(x, out, B, H, W, C);
+    return ivlm_launch_status();
+}
+int gather_rows(bf16_t* dst, int64_t ldd, const bf16_t* src, int64_t lds_, const int32_t* idx, const bf16_t* add,
+                int64_t lda, int64_t rows, int cols, hipStream_t st) {
+    if (!dst || !src || !idx || rows <= 0 || (cols & 7) || (ldd & 7) || (lds_ & 7) || (lda & 7))
+        return IVLM_ERR_INVALID_ARG;
+    gather_rows_kernel<<<grid_for(rows * (cols >> 3)), kT, 0, st>>>(dst, ldd, src, lds_, idx, add, lda, rows, cols);
+    return ivlm_launch_status();
+}
+int add_rows(bf16_t* out, const bf16_t* a, const bf16_t* b, int64_t rows, int cols, int64_t b_rows, hipStream_t st,
+             int op) {
+    if (!out || !a || !b || rows <= 0 || b_rows <= 0 || (cols & 7)) return IVLM_ERR_INVALID_ARG;
+    add_rows_kernel<<<grid_for(rows * (cols >> 3)), kT, 0, st>>>(out, a, b, rows, cols, b_rows, op);
+    return ivlm_launch_status();
+}
+int dense_pe(const float* gauss, bf16_t* pe, int h, int w, int F, hipStream_t st) {
+    if (!gauss || !pe) return IVLM_ERR_INVALID_ARG;
+    dense_pe_kernel<<<grid_for((int64_t)h * w * 2 * F), kT, 0, st>>>(gauss, pe, h, w, F);
+    return ivlm_launch_status();
+}
+int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, bf16_t* kcache, bf16_t* vcache,
+            hipStream_t st) {
+    if (!qkv || T <= 0 || (D & 1) || (kcache && !vcache)) return IVLM_ERR_INVALID_ARG;
+    rope_kv_kernel<<<grid_for((int64_t)T * H * (D >> 1)), kT, 0, st>>>(qkv, ld, T, H, D, pos0, theta, kcache, vcache);
+    return ivlm_launch_status();
+}
+int mask_dot(const bf16_t* up, const bf16_t* hyper, float* low, int B, int gh, int gw, int C, hipStream_t st) {
+    if (!up || !hyper || !low || (C & 7)) return IVLM_ERR_INVALID_ARG;
+    mask_dot_kernel<<<grid_for((int64_t)B * gh * gw * 16), kT, 0, st>>>(up, hyper, low, B, gh, gw, C);
+    return ivlm_launch_status();
+}
+
+}  // namespace ivlm
+
+extern "C" {
+#define BF(p) static_cast<bf16_t*>(p)
+#define CBF(p) static_cast<const bf16_t*>(p)
+int ivlm_im2col_nchw(const void* x, void* out, int B, int C, int H, int W, int ks, int stride, int Kpad,
+                     ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::im2col_nchw(CBF(x), BF(out), B, C, H, W, ks, stride, Kpad, ivlm_stream(s));
+}
+int ivlm_im2col3x3_nhwc(const void* x, void* out, int B, int H, int W, int C, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::im2col3x3_nhwc(CBF(x), BF(out), B, H, W, C, ivlm_stream(s));
+}
+int ivlm_gather_rows(void* dst, int64_t ldd, const void* src, int64_t lds_, const int32_t* idx, const void* add,
+                     int64_t lda, int64_t rows, int cols, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::gather_rows(BF(dst), ldd, CBF(src), lds_, idx, CBF(add), lda, rows, cols, ivlm_stream(s));
+}
+int ivlm_add_rows(void* out, const void* a, const void* b, int64_t rows, int cols, int64_t b_rows, int op,
+                  ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::add_rows(BF(out), CBF(a), CBF(b), rows, cols, b_rows, ivlm_stream(s), op);
+}
+int ivlm_dense_pe(const void* gauss, void* pe, int h, int w, int F, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::dense_pe(static_cast<const float*>(gauss), BF(pe), h, w, F, ivlm_stream(s));
+}
+int ivlm_rope_kv(void* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void* kcache, void* vcache,
+                 ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::rope_kv(BF(qkv), ld, T, H, D, pos0, theta, BF(kcache), BF(vcache), ivlm_stream(s));
+}
+int ivlm_mask_dot(const void* up, const void* hyper, float* low, int B, int gh, int gw, int C, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::mask_dot(CBF(up), CBF(hyper), low, B, gh, gw, C, ivlm_stream(s));
+}
+#undef BF
+#undef CBF
+}  // extern "C"

@@ -38,9 +38,13 @@ __device__ __forceinline__ float act_apply(float x, int act) {
         case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
         case ACT_RELU: return fmaxf(x, 0.0f);
         case ACT_SILU: return x / (1.0f + __expf(-x));
+        case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
         default: return x;
     }
 }
+
+// 16 zero bytes: DMA source for the K tail (K % 64 != 0) so that partial tiles contribute nothing
+__device__ __attribute__((aligned(16))) const uint32_t kZeroChunk[4] = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -62,10 +66,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     // ---- staging addresses: wave w copies pieces w*4 .. w*4+3 (8 rows each) of both tiles ----
     const bf16_t* srcA[4];
     const bf16_t* srcW[4];
+    int kcol[4];  // first K index of the chunk this lane copies (per piece)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source chunk that lands in LDS chunk lane&7
+        kcol[i] = chunk * 8;
         int ra = m0 + row;
         ra = ra < g.M ? ra : g.M - 1;
         int rw = n0 + row;
@@ -76,10 +82,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     auto stage = [&](int buf, int kt) {
         unsigned char* base = smem + buf * kStageBytes + wave * 4 * 1024;
         const int koff = kt * BK;
+        const bf16_t* zero = reinterpret_cast<const bf16_t*>(kZeroChunk);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(srcA[i] + koff, base + i * 1024);
+        for (int i = 0; i < 4; ++i) glds16(kcol[i] + koff < g.K ? srcA[i] + koff : zero, base + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(srcW[i] + koff, base + kTileBytes + i * 1024);
+        for (int i = 0; i < 4; ++i)
+            glds16(kcol[i] + koff < g.K ? srcW[i] + koff : zero, base + kTileBytes + i * 1024);
     };
 
     // ---- fragment read offsets (bytes within a tile), constant over the K loop ---------------
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = g.K / BK;
+    const int nt = (g.K + BK - 1) / BK;
     stage(0, 0);
     for (int t = 0; t < nt; ++t) {
         __syncthreads();  // tile t landed (vmcnt(0) + barrier); everyone is done with tile t-1
@@ -208,7 +216,7 @@ int launch(const GemmArgs& g, hipStream_t st) {
 
 int gemm_bf16(const GemmArgs& g, hipStream_t st) {
     if (!g.A || !g.W || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return IVLM_ERR_INVALID_ARG;
-    if (g.K % BK != 0) return IVLM_ERR_UNSUPPORTED;  // host pads K (weights are padded once at load)
+    if (g.K % 8 != 0) return IVLM_ERR_UNSUPPORTED;  // 16-byte K granules; a K % 64 tail is zero-filled in LDS
     if ((g.lda & 7) || (g.ldw & 7)) return IVLM_ERR_UNSUPPORTED;  // 16-byte DMA granules
     if (g.act == ACT_SWIGLU && ((g.N & 3) || g.residual)) return IVLM_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) return IVLM_ERR_INVALID_ARG;
@@ -219,8 +227,15 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
         case ACT_RELU: return launch<ACT_RELU>(g, st);
         case ACT_SILU: return launch<ACT_SILU>(g, st);
         case ACT_SWIGLU: return launch<ACT_SWIGLU>(g, st);
+        case ACT_SIGMOID: return launch<ACT_SIGMOID>(g, st);
         default: return IVLM_ERR_INVALID_ARG;
     }
+}
+
+// dispatch: weight-streaming GEMV for M <= 8, MFMA tile kernel otherwise
+int linear_bf16(const GemmArgs& g, hipStream_t st) {
+    if (g.M <= 8 && g.batch == 1) return gemv_bf16(g, st);
+    return gemm_bf16(g, st);
 }
 
 }  // namespace ivlm
@@ -243,5 +258,5 @@ extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     g.out_f32 = out_f32;
     g.batch = batch < 1 ? 1 : batch;
     g.strideA = strideA; g.strideW = strideW; g.strideC = strideC; g.strideR = strideR;
-    return ivlm::gemm_bf16(g, ivlm_stream(stream));
+    return ivlm::linear_bf16(g, ivlm_stream(stream));
 }

@@ -5,7 +5,7 @@
 namespace ivlm {
 
 // ---- epilogue activation codes (also exposed through the C ABI) --------------------------------
-enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICK_GELU = 2, ACT_RELU = 3, ACT_SILU = 4, ACT_SWIGLU = 5 };
+enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICK_GELU = 2, ACT_RELU = 3, ACT_SILU = 4, ACT_SWIGLU = 5, ACT_SIGMOID = 6 };
 
 struct GemmArgs {
     const bf16_t* A = nullptr;  // activations [M,K], row stride lda (elements)
@@ -25,11 +25,13 @@ struct GemmArgs {
 
 // bf16 x bf16 -> fp32-accumulate MFMA GEMM with fused bias/activation/residual epilogue.
 int gemm_bf16(const GemmArgs& g, hipStream_t st);
+// nn.Linear dispatch: GEMV (M <= 8) or the MFMA tile kernel
+int linear_bf16(const GemmArgs& g, hipStream_t st);
 
 // ---- normalisation ---------------------------------------------------------------------------
 // y = (x-mean)/sqrt(var+eps)*w+b over the last dim (rows x cols); bf16 in/out, fp32 statistics.
 int layernorm_bf16(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int64_t rows, int cols, float eps,
-                   hipStream_t st);
+                   hipStream_t st, int gelu = 0);
 // y = x * rsqrt(mean(x^2)+eps) * w  (LLaMA RMSNorm; fp32 statistics, HF casts back before the weight multiply)
 int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int cols, float eps, hipStream_t st);
 
@@ -57,5 +59,21 @@ int attention_bf16(const AttnArgs& a, hipStream_t st);
 // decomposed relative-position bias terms of SAM's ViT (image_encoder.py:354-392) as fp32 tables
 int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const bf16_t* tab_h, const bf16_t* tab_w,
                 int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, hipStream_t st);
+
+// ---- data movement / elementwise (elementwise.hip) -----------------------------------------------
+int im2col_nchw(const bf16_t* x, bf16_t* out, int B, int C, int H, int W, int ks, int stride, int Kpad, hipStream_t st);
+int im2col3x3_nhwc(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st);
+int gather_rows(bf16_t* dst, int64_t ldd, const bf16_t* src, int64_t lds_, const int32_t* idx, const bf16_t* add,
+                int64_t lda, int64_t rows, int cols, hipStream_t st);
+int add_rows(bf16_t* out, const bf16_t* a, const bf16_t* b, int64_t rows, int cols, int64_t b_rows, hipStream_t st,
+             int op = 0);  // op 0: a + b, 1: a * b
+int dense_pe(const float* gauss, bf16_t* pe, int h, int w, int F, hipStream_t st);
+int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, bf16_t* kcache, bf16_t* vcache,
+            hipStream_t st);
+int mask_dot(const bf16_t* up, const bf16_t* hyper, float* low, int B, int gh, int gw, int C, hipStream_t st);
+
+// ---- skinny GEMM (gemv.hip): M <= 8 rows of activations against streamed weights -------------------
+int gemv_bf16(const GemmArgs& g, hipStream_t st);
+int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st);
 
 }  // namespace ivlm

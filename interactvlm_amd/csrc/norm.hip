@@ -21,7 +21,7 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
                       pack_bf16x2(f[6], f[7]));
 }
 
-template <bool RMS, int MAXC>
+template <bool RMS, int MAXC, bool GELU>
 __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                    const bf16_t* __restrict__ b, bf16_t* __restrict__ y, int64_t rows,
                                                    int cols, float eps) {
@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
                 float bv[8];
                 unpack8(br[idx], bv);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wv[j] + bv[j];
+                for (int j = 0; j < 8; ++j) {
+                    o[j] = (v[c][j] - mean) * rstd * wv[j] + bv[j];
+                    if (GELU) o[j] = 0.5f * o[j] * (1.0f + erff(o[j] * 0.70710678118654752f));
+                }
             }
             yr[idx] = pack8(o);
         }
@@ -87,13 +90,18 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
 }  // namespace
 
 int layernorm_bf16(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int64_t rows, int cols, float eps,
-                   hipStream_t st) {
+                   hipStream_t st, int gelu) {
     if (!x || !w || !b || !y || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
     if ((cols & 7) || cols > kMaxChunks * 512) return IVLM_ERR_UNSUPPORTED;
-    if (cols <= 4 * 512)
-        norm_kernel<false, 4><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(x, w, b, y, rows, cols, eps);
-    else
-        norm_kernel<false, kMaxChunks><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(x, w, b, y, rows, cols, eps);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (gelu) {
+        if (cols > 4 * 512) return IVLM_ERR_UNSUPPORTED;
+        norm_kernel<false, 4, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps);
+    } else if (cols <= 4 * 512) {
+        norm_kernel<false, 4, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps);
+    } else {
+        norm_kernel<false, kMaxChunks, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps);
+    }
     return ivlm_launch_status();
 }
 
@@ -101,9 +109,9 @@ int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int 
     if (!x || !w || !y || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
     if ((cols & 7) || cols > kMaxChunks * 512) return IVLM_ERR_UNSUPPORTED;
     if (cols <= 4 * 512)
-        norm_kernel<true, 4><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(x, w, nullptr, y, rows, cols, eps);
+        norm_kernel<true, 4, false><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(x, w, nullptr, y, rows, cols, eps);
     else
-        norm_kernel<true, kMaxChunks><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(x, w, nullptr, y, rows, cols, eps);
+        norm_kernel<true, kMaxChunks, false><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(x, w, nullptr, y, rows, cols, eps);
     return ivlm_launch_status();
 }
 
@@ -112,11 +120,11 @@ int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int 
 extern "C" {
 
 int ivlm_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int64_t rows, int cols, float eps,
-                        ivlm_stream_t stream) {
+                        int gelu, ivlm_stream_t stream) {
     ivlm_enter();
     return ivlm::layernorm_bf16(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w),
                                 static_cast<const bf16_t*>(b), static_cast<bf16_t*>(y), rows, cols, eps,
-                                ivlm_stream(stream));
+                                ivlm_stream(stream), gelu);
 }
 
 int ivlm_rmsnorm_bf16(const void* x, const void* w, void* y, int64_t rows, int cols, float eps,

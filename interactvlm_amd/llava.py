@@ -1,0 +1,117 @@
+"""CLIP ViT-L/14 tower + mm_projector + LLaMA decoder (KV-cached) on the HIP kernels.
+
+Mirrors the arithmetic the reference gets from HF ``CLIPVisionModel`` / ``LlamaModel`` through
+model/llava/model/{llava_arch.py, language_model/llava_llama.py, multimodal_encoder/clip_encoder.py}.
+MI355X-first differences (same numbers, less work):
+  * CLIP is encoded ONCE per image; the reference re-encodes it for every generated token
+    (InteractVLM.py:128 use_cache=False -> llava_arch.py:98-123 on every step);
+  * decode uses a KV cache (the reference re-runs the full prefix each step);
+  * q/k/v and gate/up projections are fused GEMMs over concatenated / row-interleaved weights, SwiGLU and
+    residual adds live in GEMM epilogues, image features are written straight into the LLM input buffer.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .sam import _LN, _Lin, _dev
+from .weights import CLIP_PREFIX, ClipCfg, LlamaCfg
+
+BF16 = torch.bfloat16
+
+
+class ClipTower:
+    """CLIPVisionTower.forward + feature_select('patch', layer -2) (clip_encoder.py:31-60)."""
+
+    def __init__(self, w, cfg: ClipCfg, device, prefix=CLIP_PREFIX):
+        self.cfg, self.device = cfg, device
+        e = prefix + ".embeddings"
+        K = 3 * cfg.patch * cfg.patch
+        self.kpad = ((K + 63) // 64) * 64
+        pw = w[e + ".patch_embedding.weight"].reshape(cfg.hidden, K)
+        self.patch_w = _dev(torch.nn.functional.pad(pw, (0, self.kpad - K)), device)
+        pos = w[e + ".position_embedding.weight"]
+        self.pos = _dev(pos, device)
+        self.cls_row = _dev((w[e + ".class_embedding"].float() + pos[0].float()).reshape(1, -1), device)
+        self.pre_ln = _LN(w, prefix + ".pre_layrnorm", device, cfg.eps)
+        n_run = cfg.layers + 1 + cfg.select_layer if cfg.select_layer < 0 else cfg.select_layer
+        self.layers = []
+        for i in range(n_run):  # hidden_states[-2] is the output of layer L-1: the last layer is never needed
+            p = f"{prefix}.encoder.layers.{i}"
+            qkv_w = torch.cat([w[f"{p}.self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+            qkv_b = torch.cat([w[f"{p}.self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+            self.layers.append(dict(
+                ln1=_LN(w, p + ".layer_norm1", device, cfg.eps), ln2=_LN(w, p + ".layer_norm2", device, cfg.eps),
+                qkv_w=_dev(qkv_w, device), qkv_b=_dev(qkv_b, device), out=_Lin(w, p + ".self_attn.out_proj", device),
+                fc1=_Lin(w, p + ".mlp.fc1", device), fc2=_Lin(w, p + ".mlp.fc2", device)))
+
+    def __call__(self, images):
+        """images [B,3,S,S] bf16 -> patch features [B, T-1, hidden]."""
+        c = self.cfg
+        B = images.shape[0]
+        T, Hh, hd = c.tokens, c.heads, c.hidden // c.heads
+        cols = ops.im2col_nchw(images.to(BF16).contiguous(), c.patch, c.patch, self.kpad)  # [B*(T-1), kpad]
+        x = torch.empty(B, T, c.hidden, dtype=BF16, device=images.device)
+        for b in range(B):  # patch GEMM writes rows 1..T-1 and adds their position embeddings in the epilogue
+            ops.linear(cols[b * (T - 1): (b + 1) * (T - 1)], self.patch_w, residual=self.pos[1:], out=x[b, 1:])
+            x[b, 0:1].copy_(self.cls_row)  # class_embedding + position_embedding[0] (precomputed constant)
+        x = self.pre_ln(x.view(B * T, c.hidden))
+        for L in self.layers:
+            y = L["ln1"](x)
+            qkv = ops.linear(y, L["qkv_w"], L["qkv_b"]).view(B, T, 3, Hh, hd)
+            q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+            a = ops.attention(q, k, v, hd ** -0.5, prescale_q=True)
+            x = L["out"](a.permute(0, 2, 1, 3).reshape(B * T, c.hidden), residual=x)
+            x = L["fc2"](L["fc1"](L["ln2"](x), act="quick_gelu"), residual=x)
+        return x.view(B, T, c.hidden)[:, 1:]
+
+
+class Llama:
+    """HF LlamaModel + lm_head with a KV cache, one sequence (batch 1) per instance call."""
+
+    def __init__(self, w, cfg: LlamaCfg, device, prefix="model", max_len=640):
+        self.cfg, self.device, self.max_len = cfg, device, max_len
+        self.embed = _dev(w[prefix + ".embed_tokens.weight"], device)
+        self.layers = []
+        for i in range(cfg.layers):
+            p = f"{prefix}.layers.{i}"
+            qkv = torch.cat([w[f"{p}.self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+            gu = torch.stack([w[p + ".mlp.gate_proj.weight"], w[p + ".mlp.up_proj.weight"]], 1).reshape(
+                2 * cfg.inter, cfg.hidden)  # rows (gate_j, up_j) interleaved for the SwiGLU epilogue
+            self.layers.append(dict(
+                ln1=_dev(w[p + ".input_layernorm.weight"], device), ln2=_dev(w[p + ".post_attention_layernorm.weight"], device),
+                qkv=_dev(qkv, device), o=_dev(w[p + ".self_attn.o_proj.weight"], device), gu=_dev(gu, device),
+                down=_dev(w[p + ".mlp.down_proj.weight"], device)))
+        self.norm = _dev(w[prefix + ".norm.weight"], device)
+        self.lm_head = _dev(w["lm_head.weight"], device)
+        H, hd = cfg.heads, cfg.hidden // cfg.heads
+        self.kcache = torch.zeros(cfg.layers, max_len, H, hd, dtype=BF16, device=device)
+        self.vcache = torch.zeros(cfg.layers, max_len, H, hd, dtype=BF16, device=device)
+
+    def embed_ids(self, ids_i32, out=None):
+        """embed_tokens gather: ids int32 [n] -> [n, hidden]."""
+        return ops.gather_rows(self.embed, ids_i32, out=out)
+
+    def forward(self, x, pos0):
+        """x [T, hidden] input embeddings at positions pos0..pos0+T-1 -> final-norm hidden [T, hidden];
+        appends to the KV cache (prefill: T = prompt, decode: T = 1)."""
+        c = self.cfg
+        T = x.shape[0]
+        H, hd = c.heads, c.hidden // c.heads
+        assert pos0 + T <= self.max_len
+        for li, L in enumerate(self.layers):
+            y = ops.rmsnorm(x, L["ln1"], c.eps)
+            qkv = ops.linear(y, L["qkv"])  # [T, 3*hidden] == [T, 3, H, hd]
+            ops.rope_kv(qkv, H, hd, pos0, c.theta, self.kcache[li], self.vcache[li])
+            q = qkv.view(T, 3, H, hd)[:, 0].permute(1, 0, 2).unsqueeze(0)  # [1,H,T,hd]
+            k = self.kcache[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
+            v = self.vcache[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
+            a = ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=pos0)
+            x = ops.linear(a.permute(0, 2, 1, 3).reshape(T, c.hidden), L["o"], residual=x)
+            h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps), L["gu"], act="swiglu")
+            x = ops.linear(h, L["down"], residual=x)
+        return ops.rmsnorm(x, self.norm, c.eps)
+
+    def logits(self, hidden_rows):
+        """lm_head on [n, hidden] -> f32 [n, vocab]."""
+        return ops.linear(hidden_rows, self.lm_head, out_f32=True)

@@ -1,0 +1,304 @@
+"""InteractVLMForCausalLM — drop-in host facade of the contact-inference path on MI355X.
+
+Same public surface as the reference's model/InteractVLM.py (forward / model_forward / evaluate /
+get_visual_embs / process_embeddings, same argument names and result-dict keys), same
+sub-module attribute names (``model.visual_model.{image_encoder,prompt_encoder,mask_decoder}``,
+``human_3d_contact_predictor`` ...).  All arithmetic is in libivlm_hip.so; this file only sequences launches.
+
+MI355X-first restructuring that leaves results unchanged:
+  * CLIP runs once per image, the LLM decodes against a KV cache (reference: full re-forward incl. CLIP per
+    generated token, InteractVLM.py:128,524-531);
+  * text_hidden_fcs runs on the selected [SEG] rows only (reference: whole sequence, then boolean-mask select);
+  * lift tables are resident in HBM as a vertex-major plan (reference: 150 MB H2D per view per call).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .components import HumanContact3DPredictor, ObjectMeshContact3DPredictor, ObjectPCAfford3DPredictor
+from .constants import IGNORE_LABEL, IMAGE_TOKEN_INDEX
+from .llava import ClipTower, Llama
+from .sam import SamImageEncoder, SamMaskDecoder, _Lin, _dev, postprocess_masks
+from .weights import IvlmCfg
+
+BF16 = torch.bfloat16
+
+
+class _CamPoseEncoder:
+    """CamPoseEncoder / ViewIndexCamPoseEncoder / VIv1CamPoseEncoder (components.py:491-572).
+    The 5-wide first layer is zero-padded to K=8 (16-byte rows) for the streaming GEMV."""
+
+    def __init__(self, w, kind, V, device, prefix="cam_pose_encoder"):
+        self.kind, self.V = kind, V
+
+        def lin(name, pad_k=None):
+            W, b = w[name + ".weight"], w[name + ".bias"]
+            if pad_k:
+                W = torch.nn.functional.pad(W, (0, pad_k - W.shape[1]))
+            return _dev(W, device), _dev(b, device)
+
+        if kind == "simple":
+            self.l1 = lin(prefix + ".linear1", 8)
+        else:
+            self.s0 = lin(prefix + ".spatial_encoder.0", 8)
+            self.s2 = lin(prefix + ".spatial_encoder.2")
+            self.views = [lin(f"{prefix}.view_transforms.{v}") for v in range(V)]
+
+    def __call__(self, cam_params):
+        """cam_params [V,5] -> view encodings bf16 [V,256] (row v = encoder(cam_params[v], view_idx=v))."""
+        c = torch.nn.functional.pad(cam_params.to(BF16), (0, 3)).contiguous()
+        if self.kind == "simple":
+            return ops.linear(c, self.l1[0], self.l1[1], act="relu")
+        if self.kind == "view_index":  # Linear-ReLU-Linear-Sigmoid, then per-view Linear
+            h = ops.linear(c, self.s0[0], self.s0[1], act="relu")
+            base = ops.linear(h, self.s2[0], self.s2[1], act="sigmoid")
+            return torch.cat([ops.linear(base[v: v + 1], *self.views[v]) for v in range(self.V)], 0)
+        h = ops.linear(c, self.s0[0], self.s0[1], act="relu")
+        base = ops.linear(h, self.s2[0], self.s2[1], act="relu")
+        return torch.cat([ops.linear(base[v: v + 1], *self.views[v], act="sigmoid") for v in range(self.V)], 0)
+
+
+class InteractVLMForCausalLM:
+    def __init__(self, config: IvlmCfg, weights: dict, device="cuda:0", lift_tables=None, metadata_root="./data",
+                 max_len=640):
+        c = self.config = config
+        self.device = dev = torch.device(device)
+        w = weights
+        self.hC_sam_view_type, self.oC_sam_view_type = c.hC_sam_view_type, c.oC_sam_view_type
+        self.hC_loss_weight, self.oC_loss_weight = c.hC_loss_weight, c.oC_loss_weight
+        self.seg_token_idx, self.hseg_token_idx, self.oseg_token_idx = c.seg_token_idx, c.hseg_token_idx, c.oseg_token_idx
+        self.token_type, self.img_emb_len = c.token_type, c.img_emb_len
+        self.multiview_channels, self.multiview_cam_cond = c.multiview_channels, c.multiview_cam_cond
+        self.cam_encoder_type = c.cam_encoder_type
+        self.base_token_type = c.token_type.replace("-DifDe", "")
+        self.use_fusion = self.use_uncertainty = False  # off in every released config (scripts/run_train.sh:61-62)
+
+        self.vision_tower = ClipTower(w, c.clip, dev)
+        self.mm_projector = _Lin(w, "model.mm_projector", dev)
+        self.llm = Llama(w, c.llama, dev, max_len=max_len)
+        self.text_hidden_fcs = (_Lin(w, "model.text_hidden_fcs.0.0", dev), _Lin(w, "model.text_hidden_fcs.0.2", dev))
+        vm = SimpleNamespace()
+        vm.image_encoder = SamImageEncoder(w, c.sam, dev)
+        vm.mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid)
+        vm.prompt_encoder = vm.mask_decoder  # text path of the prompt encoder is folded into the decoder object
+        vm.postprocess_masks = lambda m, input_size, original_size: postprocess_masks(
+            m, input_size, original_size, c.sam.img_size)
+        self.model = SimpleNamespace(visual_model=vm, text_hidden_fcs=self.text_hidden_fcs,
+                                     mm_projector=self.mm_projector, vision_tower=self.vision_tower)
+        self.lm_head = self.llm.lm_head
+        self.human_3d_contact_predictor = self.object_3d_afford_predictor = self.object_3d_contact_predictor = None
+        if c.hC_loss_weight > 0:
+            self.human_3d_contact_predictor = HumanContact3DPredictor(
+                c.hC_sam_view_type, c.multiview_channels, metadata_root=metadata_root, tables=lift_tables)
+        if c.oC_loss_weight > 0:
+            self.object_3d_afford_predictor = ObjectPCAfford3DPredictor(c.oC_sam_view_type, c.multiview_channels)
+            self.object_3d_contact_predictor = ObjectMeshContact3DPredictor(c.oC_sam_view_type, c.multiview_channels)
+        self.cam_pose_encoder = (_CamPoseEncoder(w, c.cam_encoder_type, c.multiview_channels, dev)
+                                 if c.multiview_cam_cond else None)
+        self.attention_splitter = None
+        if self.base_token_type in ("Gen-Hu-Obj", "Gen-Int"):
+            self.attention_splitter = {n: _Lin(w, "attention_splitter." + n, dev) for n in
+                                       ("input_proj", "query_human", "query_object", "key", "value", "output_proj")}
+
+    # ------------------------------------------------------------------------------------------
+    def eval(self):
+        return self
+
+    def get_visual_embs(self, pixel_values):
+        """[B,V,3,S,S] -> image embeddings; returned in the reference's [B,V,256,g,g] shape (a strided view of the
+        channels-last buffer the decoder consumes) — InteractVLM.py:251-261."""
+        B, V = pixel_values.shape[:2]
+        g = self.config.sam.grid
+        emb = self.model.visual_model.image_encoder(pixel_values.reshape((B * V,) + tuple(pixel_values.shape[2:])))
+        return emb.view(B, V, g, g, -1).permute(0, 1, 4, 2, 3)
+
+    def forward(self, **kwargs):
+        if "past_key_values" in kwargs:
+            raise NotImplementedError("the HF generate() protocol is replaced by the KV-cached loop in evaluate()")
+        return self.model_forward(**kwargs)
+
+    def process_embeddings(self, embedding, cam_params, token):
+        """[n_seg,V,256] view conditioning (InteractVLM.py:268-294)."""
+        n_seg, V, C = embedding.shape
+        if self.multiview_cam_cond:
+            enc = self.cam_pose_encoder(cam_params.to(self.device))  # [V,256]
+            if self.cam_encoder_type == "simple":
+                embedding = ops.add_rows(embedding.reshape(n_seg * V, C).contiguous(), enc).view(n_seg, V, C)
+            else:
+                embedding = ops.add_rows(embedding.reshape(n_seg * V, C).contiguous(), enc, op="mul").view(n_seg, V, C)
+        if self.base_token_type == "Gen":
+            return embedding
+        if token == self.hseg_token_idx or token == self.oseg_token_idx:
+            return self._split(embedding, human=(token == self.hseg_token_idx))
+        return embedding
+
+    def _split(self, x, human):
+        """AttentionSplitter (components.py:155-193) on [n,V,256]: one softmax over V keys of width 128."""
+        a = self.attention_splitter
+        n, V, C = x.shape
+        xp = a["input_proj"](x.reshape(n * V, C).contiguous())
+        k, v = a["key"](xp), a["value"](xp)
+        q = a["query_human" if human else "query_object"](xp)
+        hd = q.shape[-1]
+        one_head = lambda t: t.view(n, 1, V, hd)  # a single head of width 128
+        o = ops.attention(one_head(q), one_head(k), one_head(v), hd ** -0.5)
+        return a["output_proj"](o.reshape(n * V, hd)).view(n, V, C)
+
+    # ------------------------------------------------------------------------------------------
+    def _input_embeds(self, ids_row, image_features):
+        """prepare_inputs_labels_for_multimodal, mm_use_im_start_end branch (llava_arch.py:185-208):
+        embed_tokens gather with the single IMAGE_TOKEN_INDEX replaced by the 256 projected CLIP rows."""
+        ids = ids_row.to(self.device)
+        pos = int((ids == IMAGE_TOKEN_INDEX).nonzero()[0])
+        n_img = image_features.shape[0]
+        L = ids.numel()
+        x = torch.empty(L - 1 + n_img, self.config.llama.hidden, dtype=BF16, device=self.device)
+        idx = ids.clamp(min=0).to(torch.int32)
+        self.llm.embed_ids(idx[:pos].contiguous(), out=x[:pos])
+        x[pos: pos + n_img].copy_(image_features)
+        if L - pos - 1 > 0:
+            self.llm.embed_ids(idx[pos + 1:].contiguous(), out=x[pos + n_img:])
+        return x
+
+    def encode_images(self, images_clip):
+        """llava_arch.py:93-96."""
+        f = self.vision_tower(images_clip.to(self.device))
+        B, T, C = f.shape
+        return self.mm_projector(f.reshape(B * T, C)).view(B, T, -1)
+
+    def _seg_token_ids(self):
+        ids = [self.seg_token_idx]
+        if self.base_token_type in ("Gen-Hu-Obj", "Gen-Int"):
+            ids += [self.hseg_token_idx, self.oseg_token_idx]
+        return [i for i in ids if i is not None]
+
+    def _seg_rows(self, ids, extra_false_col):
+        """Boolean row mask over the (len(ids) - 1 [+1]) + img_emb_len hidden rows (InteractVLM.py:331-341/545-549)."""
+        m = torch.zeros_like(ids, dtype=torch.bool)
+        for s in self._seg_token_ids():
+            m |= ids == s
+        m = m[1:]
+        if extra_false_col:
+            m = torch.cat([m, torch.zeros(1, dtype=torch.bool, device=m.device)])
+        return torch.cat([torch.zeros(self.img_emb_len, dtype=torch.bool, device=m.device), m])
+
+    def _decode_sample(self, hidden, rows_mask, ids, cam_params, image_embeddings, input_size, original_size):
+        """[SEG] rows -> pred_mask [V,H,W] fp32 for one sample (InteractVLM.py:416-442 / 585-612)."""
+        rows = rows_mask.nonzero().flatten()
+        V = self.multiview_channels
+        if rows.numel() == 0:
+            return torch.zeros((0,) + tuple(original_size), dtype=torch.float32, device=self.device), None
+        sel = hidden[rows.to(hidden.device)].contiguous()
+        emb = self.text_hidden_fcs[1](self.text_hidden_fcs[0](sel, act="relu"))  # [n_seg, 256]
+        k = int(rows[0]) - self.img_emb_len + 1
+        token = int(ids[k]) if k > 0 else None
+        emb = emb.unsqueeze(1)
+        if V > 1:
+            emb = emb.repeat(1, V, 1)
+        emb = self.process_embeddings(emb, cam_params, token)
+        low, iou = self.model.visual_model.mask_decoder(image_embeddings, emb)
+        return postprocess_masks(low, input_size, original_size, self.config.sam.img_size)[:, 0], iou
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def model_forward(self, images, images_clip, input_ids, labels=None, attention_masks=None, offset=None,
+                      masks_list=None, label_list=None, gt_contact_3d_list=None, cam_params=None, resize_list=None,
+                      ds_name_list=None, mask_paths_list=None, inference=False, **kwargs):
+        """Teacher-forced single pass (InteractVLM.py:296-474); inference=True only (training is out of scope)."""
+        if not inference:
+            raise NotImplementedError("training (loss) path is out of scope of the inference hot path")
+        B = images.shape[0]
+        assert offset is None or B == len(offset) - 1
+        assert images_clip.shape[0] == 1 or images_clip.shape[0] == B
+        feats = self.encode_images(images_clip)
+        emb_sam = self.model.visual_model.image_encoder(
+            images.to(self.device).reshape((B * images.shape[1],) + tuple(images.shape[2:])))
+        V = images.shape[1]
+        emb_sam = emb_sam.view(B, V, emb_sam.shape[1], emb_sam.shape[2])
+        pred_masks, gt_masks = [], []
+        for i in range(B):
+            ids = input_ids[i].to(self.device)
+            x = self._input_embeds(ids, feats[i if feats.shape[0] > 1 else 0])
+            hidden = self.llm.forward(x, 0)
+            rows = self._seg_rows(ids, extra_false_col=True)
+            osz = tuple(label_list[i].shape[-2:]) if label_list is not None else tuple(resize_list[i])
+            pm, _ = self._decode_sample(hidden, rows, ids, cam_params[i], emb_sam[i], resize_list[i], osz)
+            pred_masks.append(pm)
+            gt_masks.append(masks_list[i][:, 0] if masks_list is not None else None)
+        ds_name_list = ds_name_list or ["hcontact"] * B
+        for idx, ds_name in enumerate(ds_name_list):  # InteractVLM.py:452-456
+            if "oafford" in ds_name and "HM" in (self.oC_sam_view_type or ""):
+                valid = gt_masks[idx].to(self.device) != IGNORE_LABEL
+                pred_masks[idx] = torch.where(valid, torch.sigmoid(pred_masks[idx]), pred_masks[idx])
+        result = {"gt_masks": gt_masks, "pred_masks": pred_masks}
+        if self.hC_loss_weight > 0:
+            result["pred_human_3d_contact"] = self.human_3d_contact_predictor(pred_masks, ds_name_list)
+        if self.oC_loss_weight > 0:
+            result["pred_object_3d_contact"] = self.object_3d_contact_predictor(pred_masks, ds_name_list, mask_paths_list)
+            result["pred_object_3d_afford"] = self.object_3d_afford_predictor(pred_masks, ds_name_list, mask_paths_list)
+        return result
+
+    @torch.no_grad()
+    def generate(self, images_clip, input_ids, max_new_tokens=32, eos_token_id=2, forced_new_tokens=None):
+        """Greedy search with a KV cache for ONE sequence.  Returns (output_ids [1, L+n], hidden [L+n-1+255, H]).
+        forced_new_tokens (extension for weight-free benchmarking): feed these ids instead of the argmax (the
+        argmax/lm_head work is still done every step), like the reference's inference_type='forward'."""
+        feats = self.encode_images(images_clip)[0]
+        ids = input_ids[0].to(self.device)
+        x = self._input_embeds(ids, feats)
+        T0 = x.shape[0]
+        n_max = len(forced_new_tokens) if forced_new_tokens is not None else max_new_tokens
+        hidden_all = torch.empty(T0 + n_max, self.config.llama.hidden, dtype=BF16, device=self.device)
+        h = self.llm.forward(x, 0)
+        hidden_all[:T0].copy_(h)
+        new_ids = []
+        last = h[T0 - 1: T0]
+        pos = T0
+        forced_dev = None
+        if forced_new_tokens is not None:
+            forced_dev = torch.tensor([int(t) for t in forced_new_tokens], dtype=torch.int32, device=self.device)
+        self.last_argmax = []
+        for step in range(n_max):
+            nxt = ops.argmax(self.llm.logits(last))  # int32 [1] on device
+            self.last_argmax.append(nxt)
+            if forced_new_tokens is not None:
+                tok = int(forced_new_tokens[step])
+                tok_t = forced_dev[step: step + 1]
+            else:
+                tok = int(nxt.item())
+                tok_t = nxt
+            new_ids.append(tok)
+            if tok == eos_token_id or step == n_max - 1:
+                break
+            e = self.llm.embed_ids(tok_t)
+            last = self.llm.forward(e, pos)
+            hidden_all[pos: pos + 1].copy_(last)
+            pos += 1
+        out_ids = torch.cat([ids.cpu(), torch.tensor(new_ids, dtype=ids.dtype)])[None]
+        return out_ids, hidden_all[:pos]
+
+    @torch.no_grad()
+    def evaluate(self, images_clip, images, input_ids, cam_params, resize_list, original_size_list,
+                 lift2d_dict_path=None, contact_type="hcontact", max_new_tokens=32, tokenizer=None,
+                 forced_new_tokens=None, eos_token_id=2):
+        """Generate -> [SEG] hidden state -> SAM decode -> lift (InteractVLM.py:510-638)."""
+        assert input_ids.shape[0] == 1, "the reference only ever calls evaluate with batch 1 (evaluate.py:479)"
+        output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, eos_token_id, forced_new_tokens)
+        rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)
+        image_embeddings = self.model.visual_model.image_encoder(images[0].to(self.device))
+        pm, _ = self._decode_sample(hidden, rows, output_ids[0], cam_params[0], image_embeddings, resize_list[0],
+                                    original_size_list[0])
+        pred_masks = [pm]
+        pred_contact_3d = None
+        if pred_masks[0].shape[0] > 0:
+            if self.hC_loss_weight > 0 and "hcontact" in contact_type:
+                pred_contact_3d = self.human_3d_contact_predictor(pred_masks)
+            elif (self.oC_loss_weight > 0 and "ocontact" in contact_type) or "oafford" in contact_type:
+                # same operator precedence as the reference (InteractVLM.py:626): 'oafford' always takes the mesh lift
+                pred_contact_3d = self.object_3d_contact_predictor(pred_masks, ds_names=["ocontact"],
+                                                                   lift2d_dict_path=lift2d_dict_path)
+        return {"output_ids": output_ids, "pred_masks": pred_masks, "pred_contact_3d": pred_contact_3d}

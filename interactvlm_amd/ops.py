@@ -156,7 +156,7 @@ def postprocess_masks(low_res, input_size, original_size, img_size: int = 1024, 
 # --------------------------------------------------------------------------------------------
 # dense building blocks
 # --------------------------------------------------------------------------------------------
-ACT = {"none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "swiglu": 5}
+ACT = {"none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "swiglu": 5, "sigmoid": 6}
 BF16 = torch.bfloat16
 
 
@@ -189,13 +189,13 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     return out
 
 
-def layernorm(x, weight, bias, eps=1e-5):
+def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None):
     lib = _lib.load()
     x = _req(x, BF16, "x")
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     cols = x.shape[-1]
     check(lib.ivlm_layernorm_bf16(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), x.numel() // cols,
-                                  cols, float(eps), _stream()), "layernorm")
+                                  cols, float(eps), 1 if gelu else 0, _stream()), "layernorm")
     return y
 
 
@@ -248,3 +248,94 @@ def relpos_bias(q, tab_h, tab_w, SH, SW):
     check(lib.ivlm_relpos_bias(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), tab_h.data_ptr(), tab_w.data_ptr(),
                                B, H, SH, SW, D, rel_h.data_ptr(), rel_w.data_ptr(), _stream()), "relpos_bias")
     return rel_h, rel_w
+
+
+def argmax(logits):
+    lib = _lib.load()
+    logits = _req(logits, torch.float32, "logits")
+    rows, cols = logits.shape
+    out = torch.empty(rows, dtype=torch.int32, device=logits.device)
+    check(lib.ivlm_argmax_f32(logits.data_ptr(), rows, cols, out.data_ptr(), _stream()), "argmax")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# data movement
+# --------------------------------------------------------------------------------------------
+def im2col_nchw(x, ks, stride, kpad=None):
+    lib = _lib.load()
+    x = _req(x, BF16, "x")
+    B, C, H, W = x.shape
+    K = C * ks * ks
+    kpad = kpad or ((K + 63) // 64) * 64
+    gh, gw = (H - ks) // stride + 1, (W - ks) // stride + 1
+    out = torch.empty(B * gh * gw, kpad, dtype=BF16, device=x.device)
+    check(lib.ivlm_im2col_nchw(x.data_ptr(), out.data_ptr(), B, C, H, W, ks, stride, kpad, _stream()), "im2col_nchw")
+    return out
+
+
+def im2col3x3_nhwc(x):
+    lib = _lib.load()
+    x = _req(x, BF16, "x")
+    B, H, W, C = x.shape
+    out = torch.empty(B * H * W, 9 * C, dtype=BF16, device=x.device)
+    check(lib.ivlm_im2col3x3_nhwc(x.data_ptr(), out.data_ptr(), B, H, W, C, _stream()), "im2col3x3")
+    return out
+
+
+def gather_rows(src, idx, add=None, out=None):
+    """out[r] = src[idx[r]] (zeros where idx < 0) (+ add[r]); src [R,C] / add [n,C] rows may be strided."""
+    lib = _lib.load()
+    assert src.dtype == BF16 and src.stride(-1) == 1 and idx.dtype == torch.int32 and idx.is_contiguous()
+    rows, cols = idx.numel(), src.shape[-1]
+    if out is None:
+        out = torch.empty(rows, cols, dtype=BF16, device=src.device)
+    assert out.stride(-1) == 1
+    lda = 0
+    if add is not None:
+        assert add.dtype == BF16 and add.stride(-1) == 1
+        lda = add.stride(0)
+    check(lib.ivlm_gather_rows(out.data_ptr(), out.stride(0), src.data_ptr(), src.stride(0), idx.data_ptr(), _p(add),
+                               lda, rows, cols, _stream()), "gather_rows")
+    return out
+
+
+def add_rows(a, b, out=None, op="add"):
+    """a [R,C] (+|*) b [r,C] broadcast with row modulo (R % r == 0 not required)."""
+    lib = _lib.load()
+    a = _req(a, BF16, "a")
+    b = _req(b, BF16, "b")
+    cols = a.shape[-1]
+    out = torch.empty_like(a) if out is None else out
+    check(lib.ivlm_add_rows(out.data_ptr(), a.data_ptr(), b.data_ptr(), a.numel() // cols, cols, b.numel() // cols,
+                            1 if op == "mul" else 0, _stream()), "add_rows")
+    return out
+
+
+def dense_pe(gauss, h, w):
+    lib = _lib.load()
+    gauss = _req(gauss, torch.float32, "gauss")
+    F = gauss.shape[1]
+    pe = torch.empty(h * w, 2 * F, dtype=BF16, device=gauss.device)
+    check(lib.ivlm_dense_pe(gauss.data_ptr(), pe.data_ptr(), h, w, F, _stream()), "dense_pe")
+    return pe
+
+
+def rope_kv(qkv, H, D, pos0, theta, kcache=None, vcache=None):
+    """qkv [T, 3*H*D] (in place)."""
+    lib = _lib.load()
+    assert qkv.dtype == BF16 and qkv.stride(-1) == 1
+    T = qkv.shape[0]
+    check(lib.ivlm_rope_kv(qkv.data_ptr(), qkv.stride(0), T, H, D, int(pos0), float(theta), _p(kcache), _p(vcache),
+                           _stream()), "rope_kv")
+    return qkv
+
+
+def mask_dot(up, hyper, B, gh, gw):
+    lib = _lib.load()
+    up = _req(up, BF16, "up")
+    hyper = _req(hyper, BF16, "hyper")
+    C = hyper.shape[-1]
+    low = torch.empty(B, 4 * gh, 4 * gw, dtype=torch.float32, device=up.device)
+    check(lib.ivlm_mask_dot(up.data_ptr(), hyper.data_ptr(), low.data_ptr(), B, gh, gw, C, _stream()), "mask_dot")
+    return low

@@ -1,0 +1,239 @@
+"""SAM ViT image encoder, prompt encoder (text path) and two-way mask decoder on the HIP kernels.
+
+Host-side orchestration only (buffers, views, launch order); every FLOP runs in libivlm_hip.so.
+Mirrors model/segment_anything/modeling/{image_encoder,prompt_encoder,mask_decoder,transformer,sam}.py of the
+reference.  Activations are kept channels-last ([tokens, C]) end to end: LayerNorm2d becomes a row LayerNorm,
+the 1x1 / 3x3 / transposed convolutions become GEMMs, and the decoder consumes the encoder output without the
+NCHW<->NHWC permutes the reference performs (transformer.py:82-84, mask_decoder.py:141).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .weights import SAM_PREFIX, SamEncCfg
+
+BF16 = torch.bfloat16
+
+
+def _dev(t, device):
+    return t.to(device=device, dtype=BF16).contiguous()
+
+
+class _Lin:
+    def __init__(self, w, prefix, device, bias=True):
+        self.w = _dev(w[prefix + ".weight"].reshape(w[prefix + ".weight"].shape[0], -1), device)
+        self.b = _dev(w[prefix + ".bias"], device) if bias and (prefix + ".bias") in w else None
+
+    def __call__(self, x, act="none", residual=None, res_mod=0, out=None, out_f32=False):
+        return ops.linear(x, self.w, self.b, act=act, residual=residual, res_mod=res_mod, out=out, out_f32=out_f32)
+
+
+class _LN:
+    def __init__(self, w, prefix, device, eps):
+        self.w, self.b, self.eps = _dev(w[prefix + ".weight"], device), _dev(w[prefix + ".bias"], device), eps
+
+    def __call__(self, x, gelu=False):
+        return ops.layernorm(x, self.w, self.b, self.eps, gelu=gelu)
+
+
+# ================================================================================================
+# image encoder
+# ================================================================================================
+class SamImageEncoder:
+    """ImageEncoderViT.forward (image_encoder.py:110-125): [V,3,S,S] bf16 -> [V, g*g, 256] bf16 (channels last)."""
+
+    def __init__(self, w, cfg: SamEncCfg, device, prefix=SAM_PREFIX + ".image_encoder"):
+        self.cfg, self.device = cfg, device
+        p = prefix
+        D = cfg.embed_dim
+        self.patch = _Lin(w, p + ".patch_embed.proj", device)
+        self.pos_embed = _dev(w[p + ".pos_embed"].reshape(-1, D), device)
+        self.blocks = []
+        for i in range(cfg.depth):
+            bp = f"{p}.blocks.{i}"
+            self.blocks.append(dict(
+                glob=i in cfg.global_attn_indexes,
+                norm1=_LN(w, bp + ".norm1", device, 1e-6), norm2=_LN(w, bp + ".norm2", device, 1e-6),
+                qkv=_Lin(w, bp + ".attn.qkv", device), proj=_Lin(w, bp + ".attn.proj", device),
+                rel_h=_dev(w[bp + ".attn.rel_pos_h"], device), rel_w=_dev(w[bp + ".attn.rel_pos_w"], device),
+                lin1=_Lin(w, bp + ".mlp.lin1", device), lin2=_Lin(w, bp + ".mlp.lin2", device)))
+        self.neck0 = _Lin(w, p + ".neck.0", device, bias=False)
+        self.neck1 = _LN(w, p + ".neck.1", device, 1e-6)
+        # conv3x3 weight [O, I, ky, kx] -> GEMM weight [O, (ky, kx, I)] matching im2col3x3_nhwc
+        w2 = w[p + ".neck.2.weight"]
+        self.neck2_w = _dev(w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1), device)
+        self.neck3 = _LN(w, p + ".neck.3", device, 1e-6)
+        self._maps = {}
+
+    def _window_maps(self, V):
+        """Row maps of window_partition / window_unpartition (image_encoder.py:263-318) incl. zero padding."""
+        if V not in self._maps:
+            g, ws = self.cfg.grid, self.cfg.window
+            nw = (g + ws - 1) // ws
+            gp = nw * ws
+            v = torch.arange(V).view(V, 1, 1, 1, 1)
+            wy = torch.arange(nw).view(1, nw, 1, 1, 1)
+            wx = torch.arange(nw).view(1, 1, nw, 1, 1)
+            iy = torch.arange(ws).view(1, 1, 1, ws, 1)
+            ix = torch.arange(ws).view(1, 1, 1, 1, ws)
+            y, x = wy * ws + iy, wx * ws + ix
+            src = (v * g + y) * g + x
+            part = torch.where((y < g) & (x < g), src, torch.full_like(src, -1)).reshape(-1)
+            yy = torch.arange(g).view(1, g, 1)
+            xx = torch.arange(g).view(1, 1, g)
+            vv = torch.arange(V).view(V, 1, 1)
+            unpart = (((vv * nw + yy // ws) * nw + xx // ws) * ws + yy % ws) * ws + xx % ws
+            self._maps[V] = (part.to(torch.int32).to(self.device), unpart.reshape(-1).to(torch.int32).to(self.device),
+                             nw, gp)
+        return self._maps[V]
+
+    def _attention(self, blk, xn, V, side, nwin):
+        """Attention.forward (image_encoder.py:235-260) on rows laid out [nwin, side*side, D]."""
+        c = self.cfg
+        H, hd = c.num_heads, c.embed_dim // c.num_heads
+        S = side * side
+        qkv = blk["qkv"](xn)  # [nwin*S, 3*D] == [nwin, S, 3, H, hd]
+        qkv5 = qkv.view(nwin, S, 3, H, hd)
+        q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side)
+        o = ops.attention(q, k, v, hd ** -0.5, rel=rel)  # view of a [nwin, S, H, hd] buffer
+        return o.permute(0, 2, 1, 3).reshape(nwin * S, H * hd)
+
+    def __call__(self, images):
+        c = self.cfg
+        V = images.shape[0]
+        g, D = c.grid, c.embed_dim
+        cols = ops.im2col_nchw(images.to(BF16).contiguous(), c.patch, c.patch)
+        x = self.patch(cols, residual=self.pos_embed, res_mod=g * g)  # + pos_embed broadcast over views
+        part, unpart, nw, gp = self._window_maps(V)
+        for blk in self.blocks:
+            xn = blk["norm1"](x)
+            if blk["glob"]:
+                a = self._attention(blk, xn, V, g, V)
+                x = blk["proj"](a, residual=x)
+            else:
+                xw = ops.gather_rows(xn, part)  # zero rows where the 14x14 windows overhang the 64x64 grid
+                a = self._attention(blk, xw, V, c.window, V * nw * nw)
+                pw = blk["proj"](a)
+                x = ops.gather_rows(pw, unpart, add=x)  # window_unpartition + shortcut
+            h = blk["lin1"](blk["norm2"](x), act="gelu")
+            x = blk["lin2"](h, residual=x)
+        y = self.neck1(self.neck0(x))
+        y = ops.linear(ops.im2col3x3_nhwc(y.view(V, g, g, c.out_chans)), self.neck2_w)
+        return self.neck3(y).view(V, g * g, c.out_chans)
+
+
+# ================================================================================================
+# prompt encoder (text-embedding path) + mask decoder + postprocess
+# ================================================================================================
+class SamMaskDecoder:
+    """PromptEncoder.forward(text_embeds=...) + MaskDecoder.forward(multimask_output=False)
+    (prompt_encoder.py:140-186, mask_decoder.py:75-164, transformer.py:62-242)."""
+
+    def __init__(self, w, device, grid=64, prefix=SAM_PREFIX):
+        self.device, self.grid = device, grid
+        pe, md = prefix + ".prompt_encoder", prefix + ".mask_decoder"
+        self.C = C = w[md + ".iou_token.weight"].shape[1]
+        self.no_mask = _dev(w[pe + ".no_mask_embed.weight"].reshape(1, C), device)
+        gauss = w[pe + ".pe_layer.positional_encoding_gaussian_matrix"].to(device=device, dtype=torch.float32).contiguous()
+        self.key_pe = ops.dense_pe(gauss, grid, grid)  # [g*g, C] constant: computed once, not per call
+        self.out_tokens = _dev(torch.cat([w[md + ".iou_token.weight"], w[md + ".mask_tokens.weight"]], 0), device)
+        self.n_mask = w[md + ".mask_tokens.weight"].shape[0]
+        tp = md + ".transformer"
+
+        def attn(p):
+            return dict(q=_Lin(w, p + ".q_proj", device), k=_Lin(w, p + ".k_proj", device),
+                        v=_Lin(w, p + ".v_proj", device), o=_Lin(w, p + ".out_proj", device))
+
+        self.layers = []
+        i = 0
+        while f"{tp}.layers.{i}.norm1.weight" in w:
+            lp = f"{tp}.layers.{i}"
+            self.layers.append(dict(
+                self_attn=attn(lp + ".self_attn"), t2i=attn(lp + ".cross_attn_token_to_image"),
+                i2t=attn(lp + ".cross_attn_image_to_token"),
+                norm1=_LN(w, lp + ".norm1", device, 1e-5), norm2=_LN(w, lp + ".norm2", device, 1e-5),
+                norm3=_LN(w, lp + ".norm3", device, 1e-5), norm4=_LN(w, lp + ".norm4", device, 1e-5),
+                lin1=_Lin(w, lp + ".mlp.lin1", device), lin2=_Lin(w, lp + ".mlp.lin2", device)))
+            i += 1
+        self.final_attn = attn(tp + ".final_attn_token_to_image")
+        self.norm_final = _LN(w, tp + ".norm_final_attn", device, 1e-5)
+        # ConvTranspose2d(k=2,s=2) as GEMM: weight [ci, co, dy, dx] -> [(dy, dx, co), ci]; bias tiled over (dy,dx)
+        w0 = w[md + ".output_upscaling.0.weight"]
+        self.up0_w = _dev(w0.permute(2, 3, 1, 0).reshape(-1, w0.shape[0]), device)
+        self.up0_b = _dev(w[md + ".output_upscaling.0.bias"].repeat(4), device)
+        self.up_ln = _LN(w, md + ".output_upscaling.1", device, 1e-6)
+        w1 = w[md + ".output_upscaling.3.weight"]
+        self.up1_w = _dev(w1.permute(2, 3, 1, 0).reshape(-1, w1.shape[0]), device)
+        self.up1_b = _dev(w[md + ".output_upscaling.3.bias"].repeat(4), device)
+        self.c_mid, self.c_up = w0.shape[1], w1.shape[1]
+        self.hyper0 = [_Lin(w, f"{md}.output_hypernetworks_mlps.0.layers.{j}", device) for j in range(3)]
+        self.iou = [_Lin(w, f"{md}.iou_prediction_head.layers.{j}", device) for j in range(3)]
+
+    def _attn(self, a, q_in, k_in, v_in, B, Sq, Sk, heads=8, kv_batch=None):
+        """Attention.forward (transformer.py:220-242). *_in are [B*S, C] row matrices."""
+        q, k, v = a["q"](q_in), a["k"](k_in), a["v"](v_in)
+        inner = q.shape[-1]
+        d = inner // heads
+        Bk = B if kv_batch is None else kv_batch
+        q4 = q.view(B, Sq, heads, d).permute(0, 2, 1, 3)
+        k4 = k.view(Bk, Sk, heads, d).permute(0, 2, 1, 3)
+        v4 = v.view(Bk, Sk, heads, d).permute(0, 2, 1, 3)
+        o = ops.attention(q4, k4, v4, 1.0 / math.sqrt(d))
+        return o.permute(0, 2, 1, 3).reshape(B * Sq, inner)
+
+    def __call__(self, image_embeddings, text_embeds):
+        """image_embeddings [V, g*g, C] bf16 (channels last); text_embeds [1, T, C] (the views as TOKENS)
+        -> low_res_masks f32 [V,1,4g,4g], iou f32 [V,1].
+
+        Batch semantics follow torch broadcasting in the reference exactly: one token set of
+        5+T tokens; the first self-attention sees batch 1, every later op batch V.  We carry V identical copies
+        from the start (same numbers) so that every kernel sees a fixed batch of V."""
+        V, HW, C = image_embeddings.shape
+        g = self.grid
+        assert text_embeds.shape[0] == 1, "n_seg > 1 with multi-view mis-broadcasts in the reference (SURVEY §7)"
+        tokens = torch.cat([self.out_tokens, text_embeds[0].to(BF16)], dim=0)  # [Nt, C]
+        Nt = tokens.shape[0]
+        query_pe = tokens.unsqueeze(0).expand(V, Nt, C).reshape(V * Nt, C).contiguous()
+        queries = query_pe
+        keys = ops.add_rows(image_embeddings.reshape(V * HW, C).contiguous(), self.no_mask)  # src = emb + dense (no-mask embed)
+        key_pe = self.key_pe  # [HW, C], broadcast over V by row modulo
+        for li, L in enumerate(self.layers):
+            if li == 0:  # skip_first_layer_pe: queries = self_attn(q=k=v=queries), no residual
+                sa = self._attn(L["self_attn"], queries, queries, queries, V, Nt, Nt)
+                queries = L["self_attn"]["o"](sa)
+            else:
+                q = ops.add_rows(queries, query_pe)
+                sa = self._attn(L["self_attn"], q, q, queries, V, Nt, Nt)
+                queries = L["self_attn"]["o"](sa, residual=queries)
+            queries = L["norm1"](queries)
+            q = ops.add_rows(queries, query_pe)
+            k = ops.add_rows(keys, key_pe)
+            ca = self._attn(L["t2i"], q, k, keys, V, Nt, HW)
+            queries = L["norm2"](L["t2i"]["o"](ca, residual=queries))
+            queries = L["norm3"](L["lin2"](L["lin1"](queries, act="relu"), residual=queries))
+            q = ops.add_rows(queries, query_pe)
+            ia = self._attn(L["i2t"], k, q, queries, V, HW, Nt)  # image attends to tokens (q=k_img, k=q_tok)
+            keys = L["norm4"](L["i2t"]["o"](ia, residual=keys))
+        q = ops.add_rows(queries, query_pe)
+        k = ops.add_rows(keys, key_pe)
+        fa = self._attn(self.final_attn, q, k, keys, V, Nt, HW)
+        hs = self.norm_final(self.final_attn["o"](fa, residual=queries)).view(V, Nt, C)
+        iou_tok = hs[:, 0, :].contiguous()
+        mask_tok0 = hs[:, 1, :].contiguous()  # mask token 0: multimask_output=False keeps masks[:, 0:1]
+        # output_upscaling: ConvT(256->64) -> LayerNorm2d -> GELU -> ConvT(64->32) -> GELU, as GEMMs on pixels
+        u = ops.linear(keys, self.up0_w, self.up0_b)  # [V*HW, (dy,dx,64)]
+        u = self.up_ln(u.view(-1, self.c_mid), gelu=True)  # per output pixel over 64 channels
+        u = ops.linear(u, self.up1_w, self.up1_b, act="gelu")  # [V*HW*4, (dy2,dx2,32)]
+        h = self.hyper0[2](self.hyper0[1](self.hyper0[0](mask_tok0, act="relu"), act="relu"))  # [V, 32]
+        low = ops.mask_dot(u, h, V, g, g)  # f32 [V, 4g, 4g]
+        iou = self.iou[2](self.iou[1](self.iou[0](iou_tok, act="relu"), act="relu"), out_f32=True)
+        return low.unsqueeze(1), iou[:, 0:1]
+
+
+def postprocess_masks(low_res, input_size, original_size, img_size=1024, apply_sigmoid=False):
+    """Sam.postprocess_masks (sam.py:137-172)."""
+    return ops.postprocess_masks(low_res.contiguous(), input_size, original_size, img_size, apply_sigmoid)

@@ -28,7 +28,7 @@ def _ref_act(x, act):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 1024, 1024), (330, 4096, 4096), (1000, 1280, 5120),
-                                   (9, 256, 256), (1, 128, 2048), (4096, 128, 256), (131, 36, 192)])
+                                   (9, 256, 256), (1, 128, 2048), (4096, 128, 256), (131, 36, 192), (300, 480, 160), (77, 64, 8)])
 @pytest.mark.parametrize("act", ["none", "gelu"])
 def test_gemm_shapes(hip_lib, cuda, M, N, K, act):
     import torch

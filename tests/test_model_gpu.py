@@ -1,0 +1,190 @@
+"""GPU parity of the model stages (SAM encoder / decoder, CLIP, LLaMA, the InteractVLM facade) against the
+reference-generated goldens and the fp32 CPU oracle, on synthetic weights rounded to bf16.
+
+Tolerances: the HIP path stores activations in bf16 (like the reference's bf16 model), the oracle is fp32 with
+the SAME bf16-rounded weights.  A bf16 activation carries 2^-9 relative rounding per op, so stage outputs are
+compared at a few 1e-2 of their dynamic range; the final per-vertex contact probabilities are compared at the
+north star's 1e-3 (they average thousands of pixels through a sigmoid)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_weights(spec, seed=0):
+    """fp32 weights whose values are exactly bf16-representable (shared by oracle and HIP path)."""
+    import torch
+
+    from interactvlm_amd import weights as Wt
+
+    w = Wt.synth_weights(spec, seed)
+    return {k: v.to(torch.bfloat16).float() for k, v in w.items()}
+
+
+def _rel_err(got, ref):
+    import torch
+
+    got, ref = got.float().cpu(), ref.float().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+
+
+def test_sam_decoder_vs_reference_golden(hip_lib, cuda, golden_dir):
+    """HIP prompt-encoder/mask-decoder/postprocess vs the reference's own outputs (fp32 weights there)."""
+    import torch
+
+    from interactvlm_amd import sam, synth
+    from interactvlm_amd import weights as Wt
+
+    w = Wt.synth_weights({**Wt.prompt_encoder_spec(), **Wt.mask_decoder_spec()})
+    dec = sam.SamMaskDecoder(w, cuda)
+    for V in (4, 1):
+        d = np.load(os.path.join(golden_dir, f"sam_decoder_V{V}.npz"))
+        emb = torch.from_numpy(synth.synth_normal(f"samdec/image_emb/{V}", (V, 256, 64, 64), 1.0, 0))
+        text = torch.from_numpy(synth.synth_normal(f"samdec/text/{V}", (1, V, 256), 1.0, 0))
+        emb_cl = emb.permute(0, 2, 3, 1).reshape(V, 4096, 256).to(torch.bfloat16).to(cuda)
+        low, iou = dec(emb_cl, text.to(torch.bfloat16).to(cuda))
+        assert low.shape == (V, 1, 256, 256) and low.dtype == torch.float32 and iou.shape == (V, 1)
+        ref = torch.from_numpy(d["low_res"])
+        assert _rel_err(low, ref) < 4e-2, _rel_err(low, ref)
+        assert float((iou.cpu() - torch.from_numpy(d["iou"])).abs().max()) < 5e-2
+        full = sam.postprocess_masks(low, (1024, 1024), (1024, 1024))
+        assert _rel_err(full[..., ::16, ::16], torch.from_numpy(d["post_sub"])) < 4e-2
+        pe = dec.key_pe.float().cpu().view(64, 64, 256).permute(2, 0, 1)[None]
+        assert float((pe[..., ::8, ::8] - torch.from_numpy(d["dense_pe_sub"])).abs().max()) < 2e-2
+
+
+def test_sam_encoder_small_vs_reference_golden(hip_lib, cuda, golden_dir):
+    import torch
+
+    from interactvlm_amd import sam, synth
+    from interactvlm_amd import weights as Wt
+
+    d = np.load(os.path.join(golden_dir, "sam_encoder_small.npz"))
+    c = Wt.SamEncCfg(embed_dim=160, depth=2, num_heads=2, global_attn_indexes=(1,), img_size=480)
+    w = Wt.synth_weights(Wt.sam_encoder_spec(c))
+    enc = sam.SamImageEncoder(w, c, cuda)
+    x = torch.from_numpy(synth.synth_normal("samenc/x", (2, 3, 480, 480), 1.0, 0)).to(torch.bfloat16).to(cuda)
+    y = enc(x)  # [2, 900, 256] channels last
+    ref = torch.from_numpy(d["out"]).permute(0, 2, 3, 1).reshape(2, 900, 256)
+    assert _rel_err(y, ref) < 5e-2, _rel_err(y, ref)
+
+
+def test_sam_block_full_dims_vs_oracle(hip_lib, cuda):
+    """One windowed + one global block at ViT-H width (1280 / 16 heads / head dim 80) on a 64x64 grid."""
+    import torch
+
+    from interactvlm_amd import sam
+    from interactvlm_amd import weights as Wt
+    from oracle import nn as O
+
+    c = Wt.SamEncCfg(embed_dim=1280, depth=2, num_heads=16, global_attn_indexes=(1,), img_size=1024)
+    w = _bf16_weights(Wt.sam_encoder_spec(c))
+    enc = sam.SamImageEncoder(w, c, cuda)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 3, 1024, 1024, generator=g).to(torch.bfloat16)
+    y = enc(x.to(cuda))
+    ref = O.sam_image_encoder(w, Wt.SAM_PREFIX + ".image_encoder", x.float(), 2, 16, (1,))
+    ref = ref.permute(0, 2, 3, 1).reshape(1, 4096, 256)
+    assert _rel_err(y, ref) < 5e-2, _rel_err(y, ref)
+
+
+def test_clip_and_llama_vs_oracle(hip_lib, cuda):
+    import torch
+
+    from interactvlm_amd import llava
+    from interactvlm_amd import weights as Wt
+    from oracle import nn as O
+
+    cc = Wt.ClipCfg(hidden=256, layers=4, heads=4, inter=512)
+    w = _bf16_weights(Wt.clip_spec(cc))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, 224, 224, generator=g).to(torch.bfloat16)
+    got = llava.ClipTower(w, cc, cuda)(x.to(cuda))
+    ref = O.clip_vision(w, Wt.CLIP_PREFIX, x.float(), 4, 4)
+    assert got.shape == (2, 256, 256)
+    assert _rel_err(got, ref) < 4e-2, _rel_err(got, ref)
+
+    lc = Wt.LlamaCfg(hidden=512, layers=3, heads=4, inter=1024, vocab=1000)  # head dim 128 like LLaMA-2
+    w = _bf16_weights(Wt.llama_spec(lc))
+    llm = llava.Llama(w, lc, cuda, max_len=128)
+    emb = (torch.randn(70, 512, generator=g) * 0.5).to(torch.bfloat16)
+    ref = O.llama(w, "model", emb.float()[None], 3, 4)[0]
+    full = llm.forward(emb.to(cuda), 0)
+    assert _rel_err(full, ref) < 4e-2, _rel_err(full, ref)
+    # prefill 50 + 20 single-token decode steps through the KV cache == one 70-token pass
+    llm2 = llava.Llama(w, lc, cuda, max_len=128)
+    h = [llm2.forward(emb[:50].to(cuda), 0)]
+    for t in range(50, 70):
+        h.append(llm2.forward(emb[t: t + 1].to(cuda), t))
+    inc = torch.cat(h, 0)
+    assert _rel_err(inc, ref) < 4e-2
+    assert _rel_err(inc, full) < 2e-2  # GEMV vs MFMA accumulation order only
+    lg = llm.logits(full[-1:]).cpu()
+    ref_lg = ref[-1:] @ w["lm_head.weight"].T
+    assert _rel_err(lg, ref_lg) < 4e-2
+    from interactvlm_amd import ops
+    assert int(ops.argmax(llm.logits(full[-1:]))[0]) == int(lg.argmax())
+
+
+def _toy(golden_dir):
+    import torch
+
+    from interactvlm_amd import synth
+    from interactvlm_amd import weights as Wt
+
+    d = np.load(os.path.join(golden_dir, "model_forward_toy.npz"))
+    t = json.loads(str(d["toy"]))
+    cfg = Wt.IvlmCfg(
+        llama=Wt.LlamaCfg(hidden=t["hidden"], layers=t["layers"], heads=t["heads"], inter=t["inter"], vocab=t["vocab"]),
+        clip=Wt.ClipCfg(hidden=t["clip_hidden"], layers=t["clip_layers"], heads=t["clip_heads"], inter=t["clip_inter"]),
+        sam=Wt.SamEncCfg(embed_dim=160, depth=2, num_heads=2, global_attn_indexes=(1,)))
+    ids = torch.from_numpy(d["input_ids"])
+    images_clip = torch.from_numpy(synth.synth_normal("mf/images_clip", (1, 3, 224, 224), 1.0, 0))
+    images = torch.from_numpy(synth.synth_normal("mf/images", (1, 4, 3, 1024, 1024), 1.0, 0))
+    cams = torch.from_numpy(d["cam_params"])
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    return d, cfg, ids, images_clip, images, cams, tables
+
+
+def test_model_forward_vs_reference_golden(hip_lib, cuda, golden_dir):
+    """The facade end to end: HIP model_forward(inference=True) vs the reference's own output."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import weights as Wt
+
+    d, cfg, ids, images_clip, images, cams, tables = _toy(golden_dir)
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    bf = torch.bfloat16
+    out = m.model_forward(images=images.to(bf).to(cuda), images_clip=images_clip.to(bf).to(cuda), input_ids=ids[None],
+                          labels=None, attention_masks=torch.ones(1, len(ids)), offset=torch.tensor([0, 1]),
+                          masks_list=[torch.zeros(4, 1, 1024, 1024)], label_list=[torch.zeros(1024, 1024)],
+                          gt_contact_3d_list=None, cam_params=cams, resize_list=[(1024, 1024)],
+                          ds_name_list=["hcontact"], mask_paths_list=[None], inference=True)
+    assert set(out) == {"gt_masks", "pred_masks", "pred_human_3d_contact"}
+    pm = out["pred_masks"][0]
+    assert pm.shape == (4, 1024, 1024) and pm.dtype == torch.float32
+    ref_pm = torch.from_numpy(d["pred_masks_sub"])
+    e_mask = float((pm[..., ::16, ::16].cpu() - ref_pm).abs().max())
+    contact = out["pred_human_3d_contact"].float().cpu()
+    ref_c = torch.from_numpy(d["pred_contact"])
+    e_c = float((contact - ref_c).abs().max())
+    print(f"\n[model_forward toy] max|dmask| = {e_mask:.4f} (range {float(ref_pm.abs().max()):.2f}), "
+          f"max|dp_contact| = {e_c:.2e}")
+    assert contact.shape == (1, 6890)
+    assert e_mask < 0.08 * float(ref_pm.abs().max())
+    assert e_c < 1e-3, e_c  # north-star tolerance on per-vertex contact probabilities
+
+    # evaluate(): KV-cached generation with the forced answer == teacher-forced pass (same [SEG] row)
+    L0 = 40
+    ev = m.evaluate(images_clip.to(bf).to(cuda), images.to(bf).to(cuda), ids[None, :L0], cams, [(1024, 1024)],
+                    [(1024, 1024)], contact_type="hcontact", forced_new_tokens=ids[L0:].tolist())
+    assert ev["output_ids"].shape == (1, len(ids)) and torch.equal(ev["output_ids"][0], ids)
+    e2 = float((ev["pred_contact_3d"].float().cpu() - contact).abs().max())
+    print(f"[evaluate vs model_forward] max|dp| = {e2:.2e}")
+    assert e2 < 1e-3
+    assert float((ev["pred_masks"][0] - pm).abs().max()) < 0.08 * float(ref_pm.abs().max())
