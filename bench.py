@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the InteractVLM contact-inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+One step = one pass of the hot path over one synthetic image per rank (BASELINE.json configs[1]:
+LLaVA-1.5-7B + CLIP ViT-L/14 + SAM ViT-H dims, bf16, 4 views of 1024x1024, 6890 vertices):
+  InteractVLMForCausalLM.evaluate = CLIP encode -> LLaMA prefill (330 positions) -> 24 greedy decode steps
+  (KV cache, lm_head + argmax every step, forced [SEG] answer) -> text_hidden_fcs -> SAM ViT-H encoder on the 4
+  views -> prompt encoder + two-way mask decoder -> postprocess to 4 x 1024^2 fp32 -> lift to 6890 vertices,
+then ONE all-gather of the per-vertex contacts across ranks (RCCL) and the D2H copy on rank 0.
+Inputs are resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 (MI355X_MICROARCH.md: ~2.5 PF dense; 5 PF figure is 2:1 sparse)
+PEAK_HBM_GBPS = 8000.0     # HBM3E spec peak (6.3 TB/s achievable by a float4 copy)
+
+
+def flops_per_image(cfg, T0, n_new, V):
+    """Algorithmic FLOPs (2*MAC) of one image, KV-cached formulation."""
+    L, C, S = cfg.llama, cfg.clip, cfg.sam
+    t = C.tokens
+    clip = (C.layers - 1) * (2 * t * C.hidden * (4 * C.hidden + 2 * C.inter) + 4 * t * t * C.hidden) \
+        + 2 * (t - 1) * 3 * C.patch * C.patch * C.hidden + 2 * (t - 1) * C.hidden * L.hidden
+    per_tok = 2 * L.hidden * (4 * L.hidden + 3 * L.inter)
+    llm = L.layers * (T0 * per_tok + 4 * T0 * T0 * L.hidden / 2)
+    llm += (n_new - 1) * L.layers * per_tok + n_new * 2 * L.hidden * L.vocab
+    g2 = S.grid * S.grid
+    D = S.embed_dim
+    blk = 2 * g2 * D * (4 * D + 2 * S.mlp_ratio * D)
+    n_glob = len(S.global_attn_indexes)
+    attn = n_glob * 4 * g2 * g2 * D + (S.depth - n_glob) * 4 * g2 * (S.window ** 2) * D
+    sam = V * (S.depth * blk + attn + 2 * g2 * 3 * S.patch ** 2 * D + 2 * g2 * D * 256 + 2 * g2 * 2304 * 256)
+    return {"clip": clip, "llm": llm, "sam_encoder": sam, "total": clip + llm + sam + 14.6e9}
+
+
+def cpu_baseline(cfg, T0, n_new, V):
+    """The CPU oracle ("port" of the reference's PyTorch path, pinned to reference goldens) timed on this box's
+    host cores on a bounded sample: one layer of each repeated stage at full width, scaled by the layer count."""
+    import numpy as np
+
+    from interactvlm_amd import synth
+    from interactvlm_amd import weights as Wt
+    from oracle import cref
+    from oracle import nn as O
+
+    torch.set_grad_enabled(False)
+    cores = torch.get_num_threads()
+    t = {}
+
+    def clock(fn, reps=1):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+
+    # --- SAM ViT-H: one windowed + one global block on ONE view
+    sc = Wt.SamEncCfg(depth=2, global_attn_indexes=(1,))
+    w = Wt.synth_weights({k: v for k, v in Wt.sam_encoder_spec(sc).items() if ".blocks." in k})
+    x = torch.randn(1, 64, 64, 1280)
+    p = Wt.SAM_PREFIX + ".image_encoder"
+    t_win = clock(lambda: O.sam_block(w, p + ".blocks.0", x, 16, 14))
+    t_glob = clock(lambda: O.sam_block(w, p + ".blocks.1", x, 16, 0))
+    n_glob = len(cfg.sam.global_attn_indexes)
+    t["sam_encoder"] = V * ((cfg.sam.depth - n_glob) * t_win + n_glob * t_glob)
+    # --- LLaMA: one layer over the teacher-forced sequence (the reference's own uncached loop costs ~n_new x this)
+    lc = Wt.LlamaCfg(hidden=cfg.llama.hidden, layers=1, heads=cfg.llama.heads, inter=cfg.llama.inter, vocab=8)
+    w = Wt.synth_weights({k: v for k, v in Wt.llama_spec(lc).items() if "layers.0" in k or k == "model.norm.weight"})
+    e = torch.randn(1, T0 + n_new - 1, cfg.llama.hidden)
+    t["llm"] = cfg.llama.layers * clock(lambda: O.llama(w, "model", e, 1, cfg.llama.heads))
+    # --- CLIP: one layer
+    cc = Wt.ClipCfg(layers=1)
+    w = Wt.synth_weights(Wt.clip_spec(cc))
+    xi = torch.randn(1, 3, 224, 224)
+    t["clip"] = (cfg.clip.layers - 1) * clock(lambda: O.clip_vision(w, Wt.CLIP_PREFIX, xi, 1, 16, select_layer=-1))
+    # --- SAM decoder + postprocess + lift at full size
+    w = Wt.synth_weights({**Wt.prompt_encoder_spec(), **Wt.mask_decoder_spec()})
+    emb, text = torch.randn(V, 256, 64, 64), torch.randn(1, V, 256)
+    pe = O.dense_pe(w, Wt.SAM_PREFIX + ".prompt_encoder", (64, 64))
+    sp, de = O.prompt_encoder_text(w, Wt.SAM_PREFIX + ".prompt_encoder", text, (64, 64))
+    low = [None]
+
+    def dec():
+        low[0] = O.mask_decoder(w, Wt.SAM_PREFIX + ".mask_decoder", emb, pe, sp, de)[0]
+    t["sam_decoder"] = clock(dec)
+    masks = [None]
+
+    def post():
+        masks[0] = cref.postprocess_masks(low[0].numpy(), (1024, 1024), (1024, 1024))
+    t["postprocess"] = clock(post)
+    vid, bary = synth.synth_mesh_tables(V, 1024, 1024, 6890, fg=0.4, seed=0, patch=6)
+    vid32 = vid.astype(np.int32)
+    t["lift"] = clock(lambda: cref.lift_mesh_soft(masks[0][:, 0][None], vid32, bary, 6890), reps=3)
+    total = sum(t.values())
+    return {"value": 1.0 / total, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "PyTorch-CPU fp32 oracle (oracle/nn.py, pinned to reference goldens) + C lift oracle: one "
+                      "SAM windowed + one global block on 1 view, one LLaMA layer over the teacher-forced sequence, "
+                      "one CLIP layer, full SAM decoder / postprocess / lift; scaled by layer and view counts",
+            "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import ops, synth, synthetic
+    from interactvlm_amd.dist import gather_contacts
+
+    cfg = {"7b": synthetic.config_7b, "13b": synthetic.config_13b, "tiny": synthetic.config_tiny}[args.model]()
+    V = cfg.multiview_channels
+    weights = synthetic.device_weights(cfg, dev, seed=0)
+    vid, bary = synth.synth_mesh_tables(V, 1024, 1024, 6890, fg=0.4, seed=0, patch=6)
+    model = M.InteractVLMForCausalLM(cfg, weights, dev, lift_tables=(vid, bary))
+    del weights
+    ids, forced = synthetic.prompt_ids(cfg)
+    cams = synthetic.human_cam_params()
+    images_clip, images = synthetic.images(cfg, dev, seed=rank)
+    S = cfg.sam.img_size
+    T0 = ids.shape[1] + cfg.img_emb_len
+
+    def step():
+        out = model.evaluate(images_clip, images, ids, cams, [(S, S)], [(S, S)], contact_type="hcontact",
+                             forced_new_tokens=forced)
+        allc = gather_contacts(out["pred_contact_3d"])  # ONE all-gather of [1,6890] fp32 per rank
+        return allc.cpu() if rank == 0 else allc
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert res.shape == (world, 6890)
+
+    roof = roof_lift = breakdown = None
+    if not args.no_roofline:  # same steps again with per-launch HIP events on the launch stream
+        ops.TIMER.start()
+        for _ in range(max(1, min(args.steps, 3))):
+            step()
+        ops.TIMER.stop()
+        sm = ops.TIMER.summary()
+        g = sm["gemm_bf16_mfma"]
+        ach = g["work"] / g["total_s"] / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_image": g["launches"] // max(1, min(args.steps, 3)), "avg_us": round(g["avg_us"], 2)}
+        l = sm["lift_mesh_plan"]
+        la = l["work"] / l["total_s"] / 1e9
+        roof_lift = {"bound": "hbm", "kernel": "lift_plan_kernel", "achieved": round(la, 1), "peak": PEAK_HBM_GBPS,
+                     "unit": "GB/s", "frac": round(la / PEAK_HBM_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes": int(l["work"] / l["launches"]), "avg_us": round(l["avg_us"], 2)}
+        gv = sm.get("gemv_bf16")
+        if gv:
+            breakdown = {"gemv_weight_stream_GBps": round(gv["work"] / gv["total_s"] / 1e9, 1),
+                         "gemv_total_ms_per_image": round(gv["total_s"] / max(1, min(args.steps, 3)) * 1e3, 2),
+                         "gemm_total_ms_per_image": round(g["total_s"] / max(1, min(args.steps, 3)) * 1e3, 2)}
+        pj = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pj):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
+            pm = json.load(open(pj))
+            roof["traffic"] = pm.get("gemm_bf16_kernel")
+            roof_lift["traffic"] = pm.get("lift_plan_kernel")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, T0, len(forced), V)
+
+    if rank == 0:
+        fl = flops_per_image(cfg, T0, len(forced), V)
+        line = {
+            "metric": "images/sec end-to-end contact inference", "value": round(world * args.steps / dt, 4),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "interactvlm-3d-hcontact-damon shape: LLaVA-1.5-7B + CLIP ViT-L/14 + SAM ViT-H, "
+                                   "evaluate() with 75-id prompt (330 positions) + 24 KV-cached greedy steps, 4 views "
+                                   "1024x1024, 6890 vertices, batch 1 per GPU" if args.model == "7b" else args.model,
+                       "images_per_gpu_per_step": 1, "parallelism": f"dp{world}",
+                       "collective": "one all_gather of [1,6890] f32 contacts per step"},
+            "algorithmic_tflop_per_image": round(fl["total"] / 1e12, 2),
+            "roofline": roof, "roofline_lift": roof_lift, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,7 @@ class InteractVLMForCausalLM:
         self.cam_encoder_type = c.cam_encoder_type
         self.base_token_type = c.token_type.replace("-DifDe", "")
         self.use_fusion = self.use_uncertainty = False  # off in every released config (scripts/run_train.sh:61-62)
+        self.debug_taps = None  # set to a dict to record intermediate tensors (tests / diagnostics only)
 
         self.vision_tower = ClipTower(w, c.clip, dev)
         self.mm_projector = _Lin(w, "model.mm_projector", dev)
@@ -194,6 +195,8 @@ class InteractVLMForCausalLM:
             return torch.zeros((0,) + tuple(original_size), dtype=torch.float32, device=self.device), None
         sel = hidden[rows.to(hidden.device)].contiguous()
         emb = self.text_hidden_fcs[1](self.text_hidden_fcs[0](sel, act="relu"))  # [n_seg, 256]
+        if self.debug_taps is not None:
+            self.debug_taps.update(hidden=hidden, seg_emb=emb, sam_emb=image_embeddings)
         k = int(rows[0]) - self.img_emb_len + 1
         token = int(ids[k]) if k > 0 else None
         emb = emb.unsqueeze(1)
@@ -201,6 +204,8 @@ class InteractVLMForCausalLM:
             emb = emb.repeat(1, V, 1)
         emb = self.process_embeddings(emb, cam_params, token)
         low, iou = self.model.visual_model.mask_decoder(image_embeddings, emb)
+        if self.debug_taps is not None:
+            self.debug_taps.update(prompt_emb=emb, low_res=low, iou=iou)
         return postprocess_masks(low, input_size, original_size, self.config.sam.img_size)[:, 0], iou
 
     # ------------------------------------------------------------------------------------------
@@ -215,6 +220,8 @@ class InteractVLMForCausalLM:
         assert offset is None or B == len(offset) - 1
         assert images_clip.shape[0] == 1 or images_clip.shape[0] == B
         feats = self.encode_images(images_clip)
+        if self.debug_taps is not None:
+            self.debug_taps["clip_feat"] = feats
         emb_sam = self.model.visual_model.image_encoder(
             images.to(self.device).reshape((B * images.shape[1],) + tuple(images.shape[2:])))
         V = images.shape[1]

@@ -17,6 +17,43 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """HIP-event timing of individual kernel launches (bench.py's roofline leg).  Events are recorded on the
+    stream the kernels are launched on (torch's current stream).  Off by default: zero overhead."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}  # name -> list[(start_event, end_event, work)]
+
+    def start(self):
+        self.enabled, self.records = True, {}
+
+    def stop(self):
+        self.enabled = False
+
+    def time(self, name, work, fn):
+        if not self.enabled:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.records.setdefault(name, []).append((a, b, work))
+        return r
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, rec in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in rec]
+            out[name] = {"launches": len(rec), "total_s": sum(ms) * 1e-3, "avg_us": sum(ms) / len(ms) * 1e3,
+                         "work": float(sum(w for _, _, w in rec))}
+        return out
+
+
+TIMER = KernelTimer()
+
+
 def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise IvlmError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
@@ -81,9 +118,13 @@ def lift_mesh_plan(logits: torch.Tensor, plan: LiftPlan, mode: int = 0, param: f
     assert V == plan.V and logits[0, 0].numel() == plan.HW, "logit shape does not match the lift plan"
     out = torch.empty(B, plan.num_vertices, dtype=torch.float32, device=logits.device)
     nviews = torch.empty_like(out) if want_nviews else None
-    check(lib.ivlm_lift_mesh_plan(logits.data_ptr(), plan.row_ptr.data_ptr(), plan.ent_pix.data_ptr(),
-                                  plan.ent_w.data_ptr(), B, V, plan.HW, plan.num_vertices, mode, float(param),
-                                  out.data_ptr(), _p(nviews), _stream()), "lift_mesh_plan")
+    call = lambda: check(lib.ivlm_lift_mesh_plan(
+        logits.data_ptr(), plan.row_ptr.data_ptr(), plan.ent_pix.data_ptr(), plan.ent_w.data_ptr(), B, V, plan.HW,
+        plan.num_vertices, mode, float(param), out.data_ptr(), _p(nviews), _stream()), "lift_mesh_plan")
+    if TIMER.enabled:  # algorithmic bytes of the dense formulation: 28 B/pixel + 8 B/vertex
+        TIMER.time("lift_mesh_plan", float(B) * (V * plan.HW * 28 + 2 * plan.num_vertices * 4), call)
+    else:
+        call()
     return (out, nviews) if want_nviews else out
 
 
@@ -183,9 +224,17 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
         ldr = r2.stride(0)
     if bias is not None:
         assert bias.dtype == BF16 and bias.is_contiguous()
-    check(lib.ivlm_gemm_bf16(x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(),
-                             o2.stride(0), _p(bias), _p(r2), ldr, int(res_mod), M, N, K, ACT[act],
-                             1 if out.dtype == torch.float32 else 0, 1, 0, 0, 0, 0, _stream()), "gemm_bf16")
+    call = lambda: check(lib.ivlm_gemm_bf16(
+        x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
+        _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == torch.float32 else 0, 1, 0, 0, 0, 0,
+        _stream()), "gemm_bf16")
+    if TIMER.enabled:  # work = algorithmic FLOPs (MFMA path) or weight bytes (GEMV path)
+        if M > 8:
+            TIMER.time("gemm_bf16_mfma", 2.0 * M * N * K, call)
+        else:
+            TIMER.time("gemv_bf16", 2.0 * N * K, call)
+    else:
+        call()
     return out
 
 
