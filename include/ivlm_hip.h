@@ -110,11 +110,12 @@ int ivlm_postprocess_masks(const void *low, int dtype, int n, int h, int w, int 
  * transformer.py:185-242; InteractVLM.py:100-112 text_hidden_fcs; llava_arch.py:35 mm_projector).
  * bf16 A/W/bias/residual, K % 8 == 0, lda/ldw % 8 == 0; C bf16 or f32 (out_f32).  batch > 1 runs a
  * strided batch (strides in elements).  M <= 8 takes the weight-streaming GEMV path (batch-1 decode:
- * HF greedy search under InteractVLM.evaluate, model/InteractVLM.py:524-531), K % 8 == 0 suffices there. */
+ * HF greedy search under InteractVLM.evaluate, model/InteractVLM.py:524-531), K % 8 == 0 suffices there.
+ * rms_w != NULL (M <= 8 only) fuses the preceding HF LlamaRMSNorm: C = act((A * rsqrt(mean(A^2)+rms_eps) * rms_w) . W^T). */
 int ivlm_gemm_bf16(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
                    const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
                    int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
-                   int64_t strideR, ivlm_stream_t stream);
+                   int64_t strideR, const void *rms_w, float rms_eps, ivlm_stream_t stream);
 
 /* nn.LayerNorm over the last dim (also SAM LayerNorm2d with NHWC activations, common.py:32-42);
  * bf16 in/out, fp32 statistics, cols % 8 == 0, cols <= 8192.  gelu_after != 0 fuses the exact-erf GELU that
@@ -142,6 +143,12 @@ int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, co
  *   like the reference's model-dtype einsum, stored f32).  tab_h bf16 [2*SH-1,D], tab_w bf16 [2*SW-1,D]. */
 int ivlm_relpos_bias(const void *q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void *tab_h, const void *tab_w,
                      int B, int H, int SH, int SW, int D, float *rel_h, float *rel_w, ivlm_stream_t stream);
+
+/* One decode step of HF LlamaAttention with a KV cache, for the newest token only: rotate-half RoPE of q,k at
+ * position pos, append k,v to kcache/vcache [Tmax,H,D], o = softmax(q.K[0..pos]^T * scale).V[0..pos].
+ * qkv bf16 [3,H,D] (output of the fused q|k|v projection), o bf16 [H,D]; D <= 128, pos < 4096. */
+int ivlm_llama_decode_attn(const void *qkv, void *kcache, void *vcache, void *o, int H, int D, int pos,
+                           float theta, float scale, ivlm_stream_t stream);
 
 /* torch.argmax(logits, -1) of HF greedy search (first maximal index); x f32 [rows, cols] -> out i32 [rows]. */
 int ivlm_argmax_f32(const float *x, int rows, int cols, int32_t *out, ivlm_stream_t stream);

@@ -235,6 +235,7 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
 // dispatch: weight-streaming GEMV for M <= 8, MFMA tile kernel otherwise
 int linear_bf16(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 8 && g.batch == 1) return gemv_bf16(g, st);
+    if (g.rms_w) return IVLM_ERR_UNSUPPORTED;  // the RMSNorm fusion exists on the decode (GEMV) path only
     return gemm_bf16(g, st);
 }
 
@@ -243,9 +244,11 @@ int linear_bf16(const GemmArgs& g, hipStream_t st) {
 extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                               const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N, int K,
                               int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
-                              int64_t strideR, ivlm_stream_t stream) {
+                              int64_t strideR, const void* rms_w, float rms_eps, ivlm_stream_t stream) {
     ivlm_enter();
     ivlm::GemmArgs g;
+    g.rms_w = static_cast<const bf16_t*>(rms_w);
+    g.rms_eps = rms_eps;
     g.A = static_cast<const bf16_t*>(A);
     g.W = static_cast<const bf16_t*>(W);
     g.C = C;

@@ -35,7 +35,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     }
 }
 
-template <int M>
+template <int M, bool RMS>
 __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -46,9 +46,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
         const int n0 = 2 * pr, n1 = (n0 + 1 < g.N) ? n0 + 1 : n0;
         const u32x4_t* w0 = reinterpret_cast<const u32x4_t*>(g.W + (int64_t)n0 * g.ldw);
         const u32x4_t* w1 = reinterpret_cast<const u32x4_t*>(g.W + (int64_t)n1 * g.ldw);
-        float a0[M], a1[M];
+        float a0[M], a1[M], ssq[M];
 #pragma unroll
-        for (int m = 0; m < M; ++m) a0[m] = a1[m] = 0.0f;
+        for (int m = 0; m < M; ++m) a0[m] = a1[m] = ssq[m] = 0.0f;
         for (int c = lane; c < nchunk; c += 256) {  // 4 chunks x 2 rows = 8 loads in flight per lane
             u32x4_t wa[4], wb[4];
 #pragma unroll
@@ -63,9 +63,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
             for (int u = 0; u < 4; ++u) {
                 const int cc = c + u * 64;
                 if (cc < nchunk) {
+                    u32x4_t gv;
+                    if (RMS) gv = *(reinterpret_cast<const u32x4_t*>(g.rms_w) + cc);
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
-                        const u32x4_t xv = *(reinterpret_cast<const u32x4_t*>(g.A + (int64_t)m * g.lda) + cc);
+                        u32x4_t xv = *(reinterpret_cast<const u32x4_t*>(g.A + (int64_t)m * g.lda) + cc);
+                        if (RMS) {  // x * gamma in fp32 (rounded once to bf16); the row scale rstd is applied at the end
+                            ssq[m] += dot8(xv, xv);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                xv[j] = pack_bf16x2(__uint_as_float(xv[j] << 16) * __uint_as_float(gv[j] << 16),
+                                                    __uint_as_float(xv[j] & 0xffff0000u) *
+                                                        __uint_as_float(gv[j] & 0xffff0000u));
+                        }
                         a0[m] += dot8(wa[u], xv);
                         a1[m] += dot8(wb[u], xv);
                     }
@@ -76,6 +86,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
         for (int m = 0; m < M; ++m) {
             a0[m] = wave_sum(a0[m]);
             a1[m] = wave_sum(a1[m]);
+            if (RMS) {
+                const float rstd = rsqrtf(wave_sum(ssq[m]) / (float)g.K + g.rms_eps);
+                a0[m] *= rstd;
+                a1[m] *= rstd;
+            }
         }
         if (lane == 0) {
 #pragma unroll
@@ -158,7 +173,11 @@ int gemv_bf16(const GemmArgs& g, hipStream_t st) {
     int blocks = (npairs + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     switch (g.M) {
-#define IVLM_GEMV_CASE(MM) case MM: gemv_kernel<MM><<<blocks, 256, 0, st>>>(g); break;
+#define IVLM_GEMV_CASE(MM)                                                   \
+    case MM:                                                                 \
+        if (g.rms_w) gemv_kernel<MM, true><<<blocks, 256, 0, st>>>(g);       \
+        else gemv_kernel<MM, false><<<blocks, 256, 0, st>>>(g);              \
+        break;
         IVLM_GEMV_CASE(1) IVLM_GEMV_CASE(2) IVLM_GEMV_CASE(3) IVLM_GEMV_CASE(4)
         IVLM_GEMV_CASE(5) IVLM_GEMV_CASE(6) IVLM_GEMV_CASE(7) IVLM_GEMV_CASE(8)
 #undef IVLM_GEMV_CASE

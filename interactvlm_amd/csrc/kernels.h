@@ -21,6 +21,9 @@ struct GemmArgs {
     // batched (strided) variant: blockIdx.z = batch
     int batch = 1;
     int64_t strideA = 0, strideW = 0, strideC = 0, strideR = 0;
+    // GEMV path only: fuse the preceding RMSNorm, out = W . (x * rsqrt(mean(x^2)+eps) * rms_w)
+    const bf16_t* rms_w = nullptr;
+    float rms_eps = 0.0f;
 };
 
 // bf16 x bf16 -> fp32-accumulate MFMA GEMM with fused bias/activation/residual epilogue.
@@ -71,6 +74,10 @@ int dense_pe(const float* gauss, bf16_t* pe, int h, int w, int F, hipStream_t st
 int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, bf16_t* kcache, bf16_t* vcache,
             hipStream_t st);
 int mask_dot(const bf16_t* up, const bf16_t* hyper, float* low, int B, int gh, int gw, int C, hipStream_t st);
+
+// ---- single-token decode (decode.hip) ---------------------------------------------------------------
+int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
+                      float scale, hipStream_t st);
 
 // ---- skinny GEMM (gemv.hip): M <= 8 rows of activations against streamed weights -------------------
 int gemv_bf16(const GemmArgs& g, hipStream_t st);

@@ -99,6 +99,8 @@ class Llama:
         T = x.shape[0]
         H, hd = c.heads, c.hidden // c.heads
         assert pos0 + T <= self.max_len
+        if T == 1:
+            return self._decode_step(x, pos0)
         for li, L in enumerate(self.layers):
             y = ops.rmsnorm(x, L["ln1"], c.eps)
             qkv = ops.linear(y, L["qkv"])  # [T, 3*hidden] == [T, 3, H, hd]
@@ -109,6 +111,19 @@ class Llama:
             a = ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=pos0)
             x = ops.linear(a.permute(0, 2, 1, 3).reshape(T, c.hidden), L["o"], residual=x)
             h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps), L["gu"], act="swiglu")
+            x = ops.linear(h, L["down"], residual=x)
+        return ops.rmsnorm(x, self.norm, c.eps)
+
+    def _decode_step(self, x, pos):
+        """One new token: 5 launches per layer (RMSNorm fused into the q|k|v and gate|up GEMVs, RoPE + cache append
+        fused into the attention kernel, residual adds and SwiGLU in the GEMV epilogues)."""
+        c = self.cfg
+        H, hd = c.heads, c.hidden // c.heads
+        for li, L in enumerate(self.layers):
+            qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps))
+            a = ops.llama_decode_attn(qkv, self.kcache[li], self.vcache[li], H, hd, pos, c.theta, hd ** -0.5)
+            x = ops.linear(a, L["o"], residual=x)
+            h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))
             x = ops.linear(h, L["down"], residual=x)
         return ops.rmsnorm(x, self.norm, c.eps)
 

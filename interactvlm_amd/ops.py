@@ -201,7 +201,7 @@ ACT = {"none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "swiglu": 5,
 BF16 = torch.bfloat16
 
 
-def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False):
+def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False, rms=None):
     """act(x @ weight.T + bias) + residual.  x [..., K] bf16 (last dim contiguous, uniform row stride),
     weight [N, K] bf16."""
     lib = _lib.load()
@@ -227,7 +227,7 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     call = lambda: check(lib.ivlm_gemm_bf16(
         x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
         _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == torch.float32 else 0, 1, 0, 0, 0, 0,
-        _stream()), "gemm_bf16")
+        _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, _stream()), "gemm_bf16")
     if TIMER.enabled:  # work = algorithmic FLOPs (MFMA path) or weight bytes (GEMV path)
         if M > 8:
             TIMER.time("gemm_bf16_mfma", 2.0 * M * N * K, call)
@@ -388,3 +388,14 @@ def mask_dot(up, hyper, B, gh, gw):
     low = torch.empty(B, 4 * gh, 4 * gw, dtype=torch.float32, device=up.device)
     check(lib.ivlm_mask_dot(up.data_ptr(), hyper.data_ptr(), low.data_ptr(), B, gh, gw, C, _stream()), "mask_dot")
     return low
+
+
+def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None):
+    """qkv bf16 [1, 3*H*D] of the newest token -> o bf16 [1, H*D]; RoPE + cache append fused."""
+    lib = _lib.load()
+    assert qkv.dtype == BF16 and qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
+    if out is None:
+        out = torch.empty(1, H * D, dtype=BF16, device=qkv.device)
+    check(lib.ivlm_llama_decode_attn(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), H, D,
+                                     int(pos), float(theta), float(scale), _stream()), "llama_decode_attn")
+    return out
