@@ -35,61 +35,120 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     }
 }
 
-template <int M, bool RMS>
+// ROWS weight rows per wave (2: enables the SwiGLU epilogue and doubles the loads in flight; 1: small N, more
+// waves).  XLDS: the activation rows (optionally RMS-normalised: x * gamma, bf16) are staged ONCE per block in LDS
+// together with their row scale, instead of every wave re-deriving them from global memory for every weight row.
+template <int M, int ROWS, bool RMS, bool XLDS>
 __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
-    const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float s_red[4][M];
+    __shared__ float s_rstd[M];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = g.K >> 3;  // 16-byte chunks per row
-    const int npairs = (g.N + 1) >> 1;
-    for (int pr = wave_global; pr < npairs; pr += nwaves) {
-        const int n0 = 2 * pr, n1 = (n0 + 1 < g.N) ? n0 + 1 : n0;
+    u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);  // [M][nchunk] when XLDS
+
+    constexpr int U = ROWS == 2 ? 4 : 8;  // 8 x 16-byte weight loads in flight per lane per step
+    const int wave_global = blockIdx.x * 4 + wave;
+    const int nwaves = gridDim.x * 4;
+    const int ngroups = (g.N + ROWS - 1) / ROWS;
+    const int nbatch = (nchunk + 64 * U - 1) / (64 * U);
+    const int my_groups = wave_global < ngroups ? (ngroups - wave_global + nwaves - 1) / nwaves : 0;
+    const int nsteps = my_groups * nbatch;
+
+    auto issue = [&](u32x4_t (&wa)[U], u32x4_t (&wb)[U], int step) __attribute__((always_inline)) {
+        const int pr = wave_global + (step / nbatch) * nwaves;
+        const int n0 = ROWS * pr, n1 = (ROWS == 2 && n0 + 1 < g.N) ? n0 + 1 : n0;
         const u32x4_t* w0 = reinterpret_cast<const u32x4_t*>(g.W + (int64_t)n0 * g.ldw);
         const u32x4_t* w1 = reinterpret_cast<const u32x4_t*>(g.W + (int64_t)n1 * g.ldw);
-        float a0[M], a1[M], ssq[M];
+        const int c0 = (step % nbatch) * (64 * U) + lane;
 #pragma unroll
-        for (int m = 0; m < M; ++m) a0[m] = a1[m] = ssq[m] = 0.0f;
-        for (int c = lane; c < nchunk; c += 256) {  // 4 chunks x 2 rows = 8 loads in flight per lane
-            u32x4_t wa[4], wb[4];
+        for (int u = 0; u < U; ++u) {
+            int cc = c0 + u * 64;
+            cc = cc < nchunk ? cc : nchunk - 1;  // clamped (unconditional) loads keep the buffers in registers
+            wa[u] = __builtin_nontemporal_load(w0 + cc);
+            if (ROWS == 2) wb[u] = __builtin_nontemporal_load(w1 + cc);
+        }
+    };
+
+    // ---- block prologue: stage x (x*gamma) in LDS, reduce sum(x^2) -----------------------------------
+    auto prologue = [&]() __attribute__((always_inline)) {
+        float ssq[M];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int cc = c + u * 64;
-                if (cc < nchunk) {
-                    wa[u] = __builtin_nontemporal_load(w0 + cc);
-                    wb[u] = __builtin_nontemporal_load(w1 + cc);
+        for (int m = 0; m < M; ++m) ssq[m] = 0.0f;
+        for (int c = threadIdx.x; c < nchunk; c += 256) {
+            u32x4_t gv;
+            if (RMS) gv = *(reinterpret_cast<const u32x4_t*>(g.rms_w) + c);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                u32x4_t xv = *(reinterpret_cast<const u32x4_t*>(g.A + (int64_t)m * g.lda) + c);
+                if (RMS) {
+                    ssq[m] += dot8(xv, xv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        xv[j] = pack_bf16x2(__uint_as_float(xv[j] << 16) * __uint_as_float(gv[j] << 16),
+                                            __uint_as_float(xv[j] & 0xffff0000u) * __uint_as_float(gv[j] & 0xffff0000u));
                 }
+                if (XLDS) xs[m * nchunk + c] = xv;
             }
+        }
+        if (RMS) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int cc = c + u * 64;
-                if (cc < nchunk) {
-                    u32x4_t gv;
-                    if (RMS) gv = *(reinterpret_cast<const u32x4_t*>(g.rms_w) + cc);
+            for (int m = 0; m < M; ++m) {
+                const float v = wave_sum(ssq[m]);
+                if (lane == 0) s_red[wave][m] = v;
+            }
+        }
+        __syncthreads();
+        if (RMS) {
+            if (threadIdx.x < M)
+                s_rstd[threadIdx.x] = rsqrtf((s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] +
+                                              s_red[3][threadIdx.x]) / (float)g.K + g.rms_eps);
+            __syncthreads();
+        }
+        };
+
+    float a0[M], a1[M];
 #pragma unroll
-                    for (int m = 0; m < M; ++m) {
-                        u32x4_t xv = *(reinterpret_cast<const u32x4_t*>(g.A + (int64_t)m * g.lda) + cc);
-                        if (RMS) {  // x * gamma in fp32 (rounded once to bf16); the row scale rstd is applied at the end
-                            ssq[m] += dot8(xv, xv);
+    for (int m = 0; m < M; ++m) a0[m] = a1[m] = 0.0f;
+
+    auto consume = [&](const u32x4_t (&wa)[U], const u32x4_t (&wb)[U], int step) __attribute__((always_inline)) {
+        const int pr = wave_global + (step / nbatch) * nwaves;
+        const int c0 = (step % nbatch) * (64 * U) + lane;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cc = c0 + u * 64;
+            if (cc < nchunk) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    u32x4_t xv;
+                    if (XLDS) {
+                        xv = xs[m * nchunk + cc];
+                    } else {
+                        xv = *(reinterpret_cast<const u32x4_t*>(g.A + (int64_t)m * g.lda) + cc);
+                        if (RMS) {
+                            const u32x4_t gv = *(reinterpret_cast<const u32x4_t*>(g.rms_w) + cc);
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                xv[j] = pack_bf16x2(__uint_as_float(xv[j] << 16) * __uint_as_float(gv[j] << 16),
-                                                    __uint_as_float(xv[j] & 0xffff0000u) *
-                                                        __uint_as_float(gv[j] & 0xffff0000u));
+                                xv[j] = pack_bf16x2(
+                                    __uint_as_float(xv[j] << 16) * __uint_as_float(gv[j] << 16),
+                                    __uint_as_float(xv[j] & 0xffff0000u) * __uint_as_float(gv[j] & 0xffff0000u));
                         }
-                        a0[m] += dot8(wa[u], xv);
-                        a1[m] += dot8(wb[u], xv);
                     }
+                    a0[m] += dot8(wa[u], xv);
+                    if (ROWS == 2) a1[m] += dot8(wb[u], xv);
                 }
             }
         }
+        if ((step % nbatch) != nbatch - 1) return;
+        // ---- last batch of this row group: reduce + epilogue ------------------------------------------
+        const int n0 = ROWS * pr, n1 = (ROWS == 2 && n0 + 1 < g.N) ? n0 + 1 : n0;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             a0[m] = wave_sum(a0[m]);
-            a1[m] = wave_sum(a1[m]);
+            if (ROWS == 2) a1[m] = wave_sum(a1[m]);
             if (RMS) {
-                const float rstd = rsqrtf(wave_sum(ssq[m]) / (float)g.K + g.rms_eps);
-                a0[m] *= rstd;
-                a1[m] *= rstd;
+                a0[m] *= s_rstd[m];
+                a1[m] *= s_rstd[m];
             }
         }
         if (lane == 0) {
@@ -97,7 +156,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
             for (int m = 0; m < M; ++m) {
                 float v0 = a0[m] + (g.bias ? bf16_to_f32(g.bias[n0]) : 0.0f);
                 float v1 = a1[m] + (g.bias ? bf16_to_f32(g.bias[n1]) : 0.0f);
-                if (g.act == ACT_SWIGLU) {
+                if (ROWS == 2 && g.act == ACT_SWIGLU) {
                     const float o = (v0 / (1.0f + __expf(-v0))) * v1;
                     const int64_t idx = (int64_t)m * g.ldc + pr;
                     if (g.out_f32) static_cast<float*>(g.C)[idx] = o;
@@ -121,6 +180,22 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
                     if (n1 != n0) C[n1] = f32_to_bf16(v1);
                 }
             }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) a0[m] = a1[m] = 0.0f;
+    };
+
+    // ---- software pipeline over (row group, chunk batch) steps: the loads of step s+1 are in flight while
+    //      step s is consumed, including across row groups and across the block prologue ---------------------
+    u32x4_t wa0[U], wb0[U], wa1[U], wb1[U];
+    if (nsteps > 0) issue(wa0, wb0, 0);
+    if (XLDS || RMS) prologue();
+    for (int s2 = 0; s2 < nsteps; s2 += 2) {
+        if (s2 + 1 < nsteps) issue(wa1, wb1, s2 + 1);
+        consume(wa0, wb0, s2);
+        if (s2 + 1 < nsteps) {
+            if (s2 + 2 < nsteps) issue(wa0, wb0, s2 + 2);
+            consume(wa1, wb1, s2 + 1);
         }
     }
 }
@@ -165,24 +240,42 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x
 
 }  // namespace
 
+template <int M>
+static int launch_gemv(const GemmArgs& g, hipStream_t st) {
+    const size_t xbytes = (size_t)M * g.K * 2;
+    const bool xlds = xbytes <= 48 * 1024;
+    const bool rows2 = g.act == ACT_SWIGLU || g.N > 8192;  // small N: one row per wave = twice the waves
+    const int ngroups = rows2 ? (g.N + 1) / 2 : g.N;
+    int blocks = (ngroups + 3) / 4;
+    const int cap = 256 * 4;  // 4 resident blocks per CU; waves stride over the remaining rows
+    if (blocks > cap) blocks = cap;
+    const size_t lds = xlds ? xbytes : 0;
+#define IVLM_GEMV_GO(ROWS, RMS, XL) gemv_kernel<M, ROWS, RMS, XL><<<blocks, 256, lds, st>>>(g)
+    if (rows2) {
+        if (g.rms_w) { if (xlds) IVLM_GEMV_GO(2, true, true); else IVLM_GEMV_GO(2, true, false); }
+        else { if (xlds) IVLM_GEMV_GO(2, false, true); else IVLM_GEMV_GO(2, false, false); }
+    } else {
+        if (g.rms_w) { if (xlds) IVLM_GEMV_GO(1, true, true); else IVLM_GEMV_GO(1, true, false); }
+        else { if (xlds) IVLM_GEMV_GO(1, false, true); else IVLM_GEMV_GO(1, false, false); }
+    }
+#undef IVLM_GEMV_GO
+    return ivlm_launch_status();
+}
+
 int gemv_bf16(const GemmArgs& g, hipStream_t st) {
     if (!g.A || !g.W || !g.C || g.M <= 0 || g.M > kMaxM || g.N <= 0 || g.K <= 0) return IVLM_ERR_INVALID_ARG;
     if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || g.batch != 1) return IVLM_ERR_UNSUPPORTED;
     if (g.act == ACT_SWIGLU && ((g.N & 1) || g.residual)) return IVLM_ERR_UNSUPPORTED;
-    const int npairs = (g.N + 1) / 2;
-    int blocks = (npairs + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
     switch (g.M) {
-#define IVLM_GEMV_CASE(MM)                                                   \
-    case MM:                                                                 \
-        if (g.rms_w) gemv_kernel<MM, true><<<blocks, 256, 0, st>>>(g);       \
-        else gemv_kernel<MM, false><<<blocks, 256, 0, st>>>(g);              \
-        break;
-        IVLM_GEMV_CASE(1) IVLM_GEMV_CASE(2) IVLM_GEMV_CASE(3) IVLM_GEMV_CASE(4)
-        IVLM_GEMV_CASE(5) IVLM_GEMV_CASE(6) IVLM_GEMV_CASE(7) IVLM_GEMV_CASE(8)
-#undef IVLM_GEMV_CASE
+        case 1: return launch_gemv<1>(g, st);
+        case 2: return launch_gemv<2>(g, st);
+        case 3: return launch_gemv<3>(g, st);
+        case 4: return launch_gemv<4>(g, st);
+        case 5: return launch_gemv<5>(g, st);
+        case 6: return launch_gemv<6>(g, st);
+        case 7: return launch_gemv<7>(g, st);
+        default: return launch_gemv<8>(g, st);
     }
-    return ivlm_launch_status();
 }
 
 int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st) {
