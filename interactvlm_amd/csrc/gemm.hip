@@ -56,8 +56,23 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- XCD-aware, grouped tile raster -------------------------------------------------------------
+    // The dispatcher places block b on XCD b % 8 (private 4 MiB L2 each).  Give every XCD one CONTIGUOUS range of
+    // the tile sequence (bijective for any tile count), and order that sequence in groups of kGroupM tile-rows
+    // with the row index fastest, so the ~64 tiles an XCD runs concurrently form an ~8x8 patch that shares 8 A
+    // panels + 8 W panels per K step instead of ~47 (measured: fabric traffic 6x the algorithmic bytes before).
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    constexpr int kXcd = 8, kGroupM = 8;
+    const int xcd = blockIdx.x % kXcd, loc = blockIdx.x / kXcd;
+    const int q = nwg / kXcd, r = nwg % kXcd;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int per_group = kGroupM * tiles_n;
+    const int first_m = (lin / per_group) * kGroupM;
+    const int gsz = tiles_m - first_m < kGroupM ? tiles_m - first_m : kGroupM;
+    const int in_group = lin % per_group;
+    const int tm = first_m + in_group % gsz, tn = in_group / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
     const int bz = blockIdx.z;
     const bf16_t* __restrict__ A = g.A + (int64_t)bz * g.strideA;
