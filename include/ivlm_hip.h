@@ -183,6 +183,24 @@ int ivlm_rope_kv(void *qkv, int64_t ld, int T, int H, int D, int pos0, float the
 int ivlm_mask_dot(const void *up, const void *hyper, float *low, int B, int gh, int gw, int C,
                   ivlm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * "Render" of Render-Localize-Lift: rasterise a mesh / point cloud into the lift tables.
+ * pytorch3d semantics (preprocess_data/render_mesh_utils.py:115-174, utils_obj_pc.py:28-42,88-113,
+ * utils/demo_utils.py:171-257): FoV-perspective camera, X_view = X_world.R + T, NDC +X left / +Y up,
+ * faces_per_pixel = 1, blur_radius = 0, perspective-correct barycentrics, nearest z wins.
+ *   cam12_host: HOST pointer to 12 floats = R (row-major 3x3) then T, from look_at_view_transform(d,e,a) with the
+ *   x/y translation already added to T.  fov_deg = 60 in the reference.
+ * ------------------------------------------------------------------------------------------- */
+size_t ivlm_raster_workspace_bytes(int n_verts_or_points, int H, int W);
+/* verts f32 [Nv,3], faces i32 [Nf,3] -> p2v i32 [H,W,3] (-1 background), bary f32 [H,W,3] (-1 background),
+ * pix_to_face i32 [H,W] (may be NULL) */
+int ivlm_rasterize_mesh(const float *verts, int nv, const int32_t *faces, int nf, const float *cam12_host,
+                        float fov_deg, int H, int W, int32_t *p2v, float *bary, int32_t *pix_to_face,
+                        void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* pts f32 [Np,3], disc radius in NDC units -> map i32 [H,W] = index of the nearest covering point, -1 none */
+int ivlm_rasterize_points(const float *pts, int np, const float *cam12_host, float fov_deg, float radius, int H,
+                          int W, int32_t *map, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,14 @@ int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta,
             hipStream_t st);
 int mask_dot(const bf16_t* up, const bf16_t* hyper, float* low, int B, int gh, int gw, int C, hipStream_t st);
 
+// ---- rasterisation (raster.hip) -------------------------------------------------------------------
+size_t raster_workspace_bytes(int n_prims_verts, int H, int W);
+int rasterize_mesh(const float* verts, int nv, const int32_t* faces, int nf, const float* cam12_host, float fov_deg,
+                   int H, int W, int32_t* p2v, float* bary, int32_t* pix_to_face, void* ws, size_t ws_bytes,
+                   hipStream_t st);
+int rasterize_points(const float* pts, int np, const float* cam12_host, float fov_deg, float radius, int H, int W,
+                     int32_t* map, void* ws, size_t ws_bytes, hipStream_t st);
+
 // ---- single-token decode (decode.hip) ---------------------------------------------------------------
 int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
                       float scale, hipStream_t st);
