@@ -177,6 +177,11 @@ int ivlm_dense_pe(const void *gauss, void *pe, int h, int w, int F, ivlm_stream_
  * positions pos0+t, and KV-cache append (kcache/vcache [Tmax,H,D], may be NULL). */
 int ivlm_rope_kv(void *qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void *kcache, void *vcache,
                  ivlm_stream_t stream);
+/* Caller-side image preprocessing (run_demo.py:65-79 `preprocess`: (x - mean)/std then zero-pad to the square model
+ * input; HF CLIPImageProcessor: centre crop, 1/255 rescale, normalise): src u8 [H,W,3] RGB on the device, crop
+ * (y0,x0,ch,cw) -> out bf16|f32 [3,OH,OW].  mean3/std3 are HOST pointers in 0..255 units. */
+int ivlm_normalize_pad_u8(const uint8_t *src, int H, int W, int y0, int x0, int ch, int cw, const float *mean3_host,
+                          const float *std3_host, void *out, int out_bf16, int OH, int OW, ivlm_stream_t stream);
 /* masks = hyper_in @ upscaled_embedding (mask_decoder.py:150-153) for one mask token: up bf16
  * [B,gh,gw,2,2,2,2,C] (output of the two k2s2 transposed convs, channels last), hyper bf16 [B,C]
  * -> low f32 [B,4gh,4gw] */

@@ -16,7 +16,7 @@ _lib = None
 
 _CTYPES = {
     "int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "size_t": C.c_size_t, "float": C.c_float,
-    "ivlm_stream_t": C.c_void_p, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64,
+    "ivlm_stream_t": C.c_void_p, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64, "uint8_t": C.c_uint8,
 }
 
 

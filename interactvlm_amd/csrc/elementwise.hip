@@ -211,7 +211,48 @@ __global__ __launch_bounds__(kT) void mask_dot_kernel(const bf16_t* __restrict__
     }
 }
 
+// uint8 HWC crop -> (x - mean) / std, zero-padded to [3, OH, OW] (pad AFTER the normalisation, like the reference)
+template <typename T>
+__global__ __launch_bounds__(kT) void normalize_pad_kernel(const uint8_t* __restrict__ src, int W, int y0, int x0,
+                                                           int ch, int cw, float m0, float m1, float m2, float s0,
+                                                           float s1, float s2, T* __restrict__ out, int OH, int OW) {
+    const int64_t total = (int64_t)OH * OW;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+        const int x = (int)(i % OW), y = (int)(i / OW);
+        float r = 0.f, g = 0.f, b = 0.f;
+        if (y < ch && x < cw) {
+            const uint8_t* p = src + ((int64_t)(y0 + y) * W + (x0 + x)) * 3;
+            r = ((float)p[0] - m0) / s0;
+            g = ((float)p[1] - m1) / s1;
+            b = ((float)p[2] - m2) / s2;
+        }
+        if (sizeof(T) == 2) {
+            reinterpret_cast<bf16_t*>(out)[i] = f32_to_bf16(r);
+            reinterpret_cast<bf16_t*>(out)[total + i] = f32_to_bf16(g);
+            reinterpret_cast<bf16_t*>(out)[2 * total + i] = f32_to_bf16(b);
+        } else {
+            reinterpret_cast<float*>(out)[i] = r;
+            reinterpret_cast<float*>(out)[total + i] = g;
+            reinterpret_cast<float*>(out)[2 * total + i] = b;
+        }
+    }
+}
+
 }  // namespace
+
+int normalize_pad_u8(const uint8_t* src, int H, int W, int y0, int x0, int ch, int cw, const float* mean3,
+                     const float* std3, void* out, int out_bf16, int OH, int OW, hipStream_t st) {
+    if (!src || !out || !mean3 || !std3 || y0 < 0 || x0 < 0 || y0 + ch > H || x0 + cw > W || ch > OH || cw > OW)
+        return IVLM_ERR_INVALID_ARG;
+    const int grid = grid_for((int64_t)OH * OW);
+    if (out_bf16)
+        normalize_pad_kernel<bf16_t><<<grid, kT, 0, st>>>(src, W, y0, x0, ch, cw, mean3[0], mean3[1], mean3[2], std3[0],
+                                                          std3[1], std3[2], static_cast<bf16_t*>(out), OH, OW);
+    else
+        normalize_pad_kernel<float><<<grid, kT, 0, st>>>(src, W, y0, x0, ch, cw, mean3[0], mean3[1], mean3[2], std3[0],
+                                                         std3[1], std3[2], static_cast<float*>(out), OH, OW);
+    return ivlm_launch_status();
+}
 
 int im2col_nchw(const bf16_t* x, bf16_t* out, int B, int C, int H, int W, int ks, int stride, int Kpad,
                 hipStream_t st) {
@@ -291,6 +332,12 @@ int ivlm_rope_kv(void* qkv, int64_t ld, int T, int H, int D, int pos0, float the
 int ivlm_mask_dot(const void* up, const void* hyper, float* low, int B, int gh, int gw, int C, ivlm_stream_t s) {
     ivlm_enter();
     return ivlm::mask_dot(CBF(up), CBF(hyper), low, B, gh, gw, C, ivlm_stream(s));
+}
+int ivlm_normalize_pad_u8(const uint8_t* src, int H, int W, int y0, int x0, int ch, int cw, const float* mean3_host,
+                          const float* std3_host, void* out, int out_bf16, int OH, int OW, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::normalize_pad_u8(src, H, W, y0, x0, ch, cw, mean3_host, std3_host, out, out_bf16, OH, OW,
+                                  ivlm_stream(s));
 }
 #undef BF
 #undef CBF
