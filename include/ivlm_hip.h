@@ -117,6 +117,9 @@ int ivlm_gemm_bf16(const void *A, int64_t lda, const void *W, int64_t ldw, void 
                    int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
                    int64_t strideR, const void *rms_w, float rms_eps, ivlm_stream_t stream);
 
+/* Benchmark/test hook: force the GEMM block tile (64 = 128x64, 128, 256; 0 = automatic choice). Returns the previous value. */
+int ivlm_gemm_tile_override(int tile);
+
 /* nn.LayerNorm over the last dim (also SAM LayerNorm2d with NHWC activations, common.py:32-42);
  * bf16 in/out, fp32 statistics, cols % 8 == 0, cols <= 8192.  gelu_after != 0 fuses the exact-erf GELU that
  * follows LayerNorm2d in the mask decoder's upscaler (mask_decoder.py:53-63). */

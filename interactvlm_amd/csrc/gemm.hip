@@ -26,11 +26,22 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kThreads = 256;
-constexpr int kTileBytes = BM * BK * 2;          // 16 KiB per operand tile
-constexpr int kStageBytes = 2 * kTileBytes;      // A + W
-constexpr int kLdsBytes = 2 * kStageBytes;       // double buffer = 64 KiB
+constexpr int BK = 64;
+
+// Tile configuration: WM x WN waves, each owning (MI*16) x (NI*16) of the output.
+//   <2,2,4,4>: 128x128 block, 256 threads, 64 KiB LDS, 2 blocks/CU  (small / skinny problems)
+//   <2,4,8,4>: 256x256 block, 512 threads, 128 KiB LDS, 1 block/CU  (per-wave 128x64: 32 MFMAs per 12 fragment
+//              reads instead of 16 per 8, and half the global->LDS bytes per FLOP)
+template <int WM_, int WN_, int MI_, int NI_>
+struct TileCfg {
+    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_;
+    static constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+    static constexpr int kWaves = WM * WN, kThreads = kWaves * 64;
+    static constexpr int kTileBytesA = BM * BK * 2, kTileBytesW = BN * BK * 2;
+    static constexpr int kStageBytes = kTileBytesA + kTileBytesW;
+    static constexpr int kLdsBytes = 2 * kStageBytes;
+    static constexpr int PA = BM / 8 / kWaves, PW = BN / 8 / kWaves;  // 1-KiB DMA pieces per wave per tile
+};
 
 __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
@@ -50,8 +61,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int ACT, bool OUT_F32>
-__global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
+template <int ACT, bool OUT_F32, typename CFG>
+__global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
+    constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NI = CFG::NI, PA = CFG::PA, PW = CFG::PW;
+    constexpr int kTileBytesA = CFG::kTileBytesA, kStageBytes = CFG::kStageBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -79,48 +92,57 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     const bf16_t* __restrict__ W = g.W + (int64_t)bz * g.strideW;
 
     // ---- staging addresses: wave w copies pieces w*4 .. w*4+3 (8 rows each) of both tiles ----
-    const bf16_t* srcA[4];
-    const bf16_t* srcW[4];
-    int kcol[4];  // first K index of the chunk this lane copies (per piece)
+    const bf16_t* srcA[PA];
+    const bf16_t* srcW[PW];
+    int kcolA[PA], kcolW[PW];  // first K index of the chunk this lane copies (per piece)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < PA; ++i) {
+        const int row = (wave * PA + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source chunk that lands in LDS chunk lane&7
-        kcol[i] = chunk * 8;
+        kcolA[i] = chunk * 8;
         int ra = m0 + row;
         ra = ra < g.M ? ra : g.M - 1;
+        srcA[i] = A + (int64_t)ra * g.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int row = (wave * PW + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        kcolW[i] = chunk * 8;
         int rw = n0 + row;
         rw = rw < g.N ? rw : g.N - 1;
-        srcA[i] = A + (int64_t)ra * g.lda + chunk * 8;
         srcW[i] = W + (int64_t)rw * g.ldw + chunk * 8;
     }
     auto stage = [&](int buf, int kt) {
-        unsigned char* base = smem + buf * kStageBytes + wave * 4 * 1024;
+        unsigned char* baseA = smem + buf * kStageBytes + wave * PA * 1024;
+        unsigned char* baseW = smem + buf * kStageBytes + kTileBytesA + wave * PW * 1024;
         const int koff = kt * BK;
         const bf16_t* zero = reinterpret_cast<const bf16_t*>(kZeroChunk);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(kcol[i] + koff < g.K ? srcA[i] + koff : zero, base + i * 1024);
+        for (int i = 0; i < PA; ++i) glds16(kcolA[i] + koff < g.K ? srcA[i] + koff : zero, baseA + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            glds16(kcol[i] + koff < g.K ? srcW[i] + koff : zero, base + kTileBytes + i * 1024);
+        for (int i = 0; i < PW; ++i) glds16(kcolW[i] + koff < g.K ? srcW[i] + koff : zero, baseW + i * 1024);
     };
 
     // ---- fragment read offsets (bytes within a tile), constant over the K loop ---------------
-    const int wm = wave & 1, wn = wave >> 1;
-    int offA[4], offW[4];  // for k-step 0; k-step 1 flips chunk bit 2 (chunk ^ 4)
+    const int wm = wave % CFG::WM, wn = wave / CFG::WM;
+    int offA[MI], offW[NI];  // for k-step 0; k-step 1 flips chunk bit 2 (chunk ^ 4)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wm * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < MI; ++i) {
+        const int r = wm * (MI * 16) + i * 16 + (lane & 15);
         offA[i] = r * 128 + ((((lane >> 4)) ^ ((r >> 1) & 7)) << 4);
-        const int rn = wn * 64 + i * 16 + (lane & 15);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int rn = wn * (NI * 16) + i * 16 + (lane & 15);
         offW[i] = rn * 128 + ((((lane >> 4)) ^ ((rn >> 1) & 7)) << 4);
     }
 
-    f32x4_t acc[4][4];  // [ni][mi]
+    f32x4_t acc[NI][MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nt = (g.K + BK - 1) / BK;
     stage(0, 0);
@@ -128,19 +150,18 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
         __syncthreads();  // tile t landed (vmcnt(0) + barrier); everyone is done with tile t-1
         if (t + 1 < nt) stage((t + 1) & 1, t + 1);
         const unsigned char* ta = smem + (t & 1) * kStageBytes;
-        const unsigned char* tw = ta + kTileBytes;
+        const unsigned char* tw = ta + kTileBytesA;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t fa[4], fw[4];
+            bf16x8_t fa[MI], fw[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8_t*>(ta + (offA[i] ^ (kk << 6)));
-                fw[i] = *reinterpret_cast<const bf16x8_t*>(tw + (offW[i] ^ (kk << 6)));
-            }
+            for (int i = 0; i < NI; ++i) fw[i] = *reinterpret_cast<const bf16x8_t*>(tw + (offW[i] ^ (kk << 6)));
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(ta + (offA[i] ^ (kk << 6)));
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
         }
     }
@@ -150,13 +171,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     const bf16_t* __restrict__ R = g.residual ? g.residual + (int64_t)bz * g.strideR : nullptr;
     const bool vec_ok = (g.N & 3) == 0;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + (lane & 15);
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * (MI * 16) + mi * 16 + (lane & 15);
         if (m >= g.M) continue;
         const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * (NI * 16) + ni * 16 + (lane >> 4) * 4;
             if (n >= g.N) continue;
             float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
             if (vec_ok) {
@@ -216,15 +237,51 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
+using Cfg128 = TileCfg<2, 2, 4, 4>;
+using Cfg256 = TileCfg<2, 4, 8, 4>;
+
+template <int ACT, bool OUT_F32, typename CFG>
+int launch_cfg(const GemmArgs& g, hipStream_t st) {
+    const int tiles = ((g.M + CFG::BM - 1) / CFG::BM) * ((g.N + CFG::BN - 1) / CFG::BN);
+    dim3 grid(tiles, 1, g.batch);
+    auto kfn = gemm_bf16_kernel<ACT, OUT_F32, CFG>;
+    if (CFG::kLdsBytes > 64 * 1024) {
+        static bool attr_set = false;  // per instantiation
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      CFG::kLdsBytes);
+            attr_set = true;
+        }
+    }
+    kfn<<<grid, CFG::kThreads, CFG::kLdsBytes, st>>>(g);
+    return ivlm_launch_status();
+}
+
+using Cfg128x64 = TileCfg<2, 2, 4, 2>;  // 128 x 64 block: more tiles for skinny problems (LLM prefill o/down)
+
+// Pick the block tile from the tile counts (measured with tools/bench_gemm.py):
+//   * fewer than ~400 tiles of 128^2 (under one resident wave at 2 blocks/CU): halve the tile (128x64) to
+//     put more CUs to work (LLM prefill o/down, CLIP: +15-30 %);
+//   * 256^2 (+10 % on SAM qkv / mlp1) when it fills whole waves of the 256 CUs (quantisation efficiency >= 0.85);
+//   * 128^2 otherwise.
+inline int choose_tile(const GemmArgs& g) {
+    if (g.tile == 128 || g.tile == 256 || g.tile == 64) return g.tile;
+    const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
+    if (t128 < 400) return 64;
+    const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
+    const double q = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+    const double edge = (double)(((g.M + 255) / 256) * 256) * (((g.N + 255) / 256) * 256) / ((double)g.M * g.N);
+    if (t256 >= 512 && q >= 0.85 && edge < 1.1) return 256;
+    return 128;
+}
+
 template <int ACT>
 int launch(const GemmArgs& g, hipStream_t st) {
-    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    dim3 grid(tiles, 1, g.batch);
-    if (g.out_f32)
-        gemm_bf16_kernel<ACT, true><<<grid, kThreads, kLdsBytes, st>>>(g);
-    else
-        gemm_bf16_kernel<ACT, false><<<grid, kThreads, kLdsBytes, st>>>(g);
-    return ivlm_launch_status();
+    switch (choose_tile(g)) {
+        case 256: return g.out_f32 ? launch_cfg<ACT, true, Cfg256>(g, st) : launch_cfg<ACT, false, Cfg256>(g, st);
+        case 64: return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64>(g, st) : launch_cfg<ACT, false, Cfg128x64>(g, st);
+        default: return g.out_f32 ? launch_cfg<ACT, true, Cfg128>(g, st) : launch_cfg<ACT, false, Cfg128>(g, st);
+    }
 }
 
 }  // namespace
@@ -256,6 +313,14 @@ int linear_bf16(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace ivlm
 
+static int g_tile_override = 0;
+
+extern "C" int ivlm_gemm_tile_override(int tile) {
+    const int prev = g_tile_override;
+    if (tile == 0 || tile == 64 || tile == 128 || tile == 256) g_tile_override = tile;
+    return prev;
+}
+
 extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                               const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N, int K,
                               int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
@@ -264,6 +329,7 @@ extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     ivlm::GemmArgs g;
     g.rms_w = static_cast<const bf16_t*>(rms_w);
     g.rms_eps = rms_eps;
+    g.tile = g_tile_override;
     g.A = static_cast<const bf16_t*>(A);
     g.W = static_cast<const bf16_t*>(W);
     g.C = C;

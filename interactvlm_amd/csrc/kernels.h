@@ -21,6 +21,7 @@ struct GemmArgs {
     // batched (strided) variant: blockIdx.z = batch
     int batch = 1;
     int64_t strideA = 0, strideW = 0, strideC = 0, strideR = 0;
+    int tile = 0;  // 0: choose, 128 / 256: force the block tile (benchmarks, tests)
     // GEMV path only: fuse the preceding RMSNorm, out = W . (x * rsqrt(mean(x^2)+eps) * rms_w)
     const bf16_t* rms_w = nullptr;
     float rms_eps = 0.0f;

@@ -51,6 +51,28 @@ def test_gemm_shapes(hip_lib, cuda, M, N, K, act):
     assert torch.allclose(got32.cpu(), ref, atol=3e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("tile", [64, 128, 256])
+def test_gemm_forced_tiles(hip_lib, cuda, tile):
+    """Both block-tile configurations on a shape with ragged M/N edges and a K tail."""
+    import torch
+
+    from interactvlm_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(tile)
+    M, N, K = 700, 900, 1096
+    x = _bf(torch.randn(M, K, generator=g))
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = _bf(torch.randn(N, generator=g) * 0.1)
+    r = _bf(torch.randn(M, N, generator=g))
+    ref = _ref_act(x.float() @ w.float().T + b.float(), "gelu") + r.float()
+    prev = _lib.load().ivlm_gemm_tile_override(tile)
+    try:
+        got = ops.linear(x.to(cuda), w.to(cuda), b.to(cuda), act="gelu", residual=r.to(cuda), out_f32=True)
+    finally:
+        _lib.load().ivlm_gemm_tile_override(prev)
+    assert torch.allclose(got.cpu(), ref, atol=3e-3, rtol=1e-3)
+
+
 def test_gemm_transpose_detecting(hip_lib, cuda):
     """A = I (padded) with an ASYMMETRIC W catches row/col swaps in the MFMA C layout."""
     import torch

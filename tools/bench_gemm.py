@@ -19,8 +19,12 @@ SHAPES = [  # (name, M, N, K)
 
 
 def main():
+    from interactvlm_amd import _lib
     dev = torch.device("cuda:0")
     res = {}
+    tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    _lib.load().ivlm_gemm_tile_override(tile)
+    print("tile override:", tile)
     for name, M, N, K in SHAPES:
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
