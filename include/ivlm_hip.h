@@ -151,7 +151,8 @@ int ivlm_relpos_bias(const void *q, int64_t q_bs, int64_t q_hs, int64_t q_rs, co
  * position pos, append k,v to kcache/vcache [Tmax,H,D], o = softmax(q.K[0..pos]^T * scale).V[0..pos].
  * qkv bf16 [3,H,D] (output of the fused q|k|v projection), o bf16 [H,D]; D <= 128, pos < 4096. */
 int ivlm_llama_decode_attn(const void *qkv, void *kcache, void *vcache, void *o, int H, int D, int pos,
-                           float theta, float scale, ivlm_stream_t stream);
+                           float theta, float scale, const float *cos_tab, const float *sin_tab,
+                           ivlm_stream_t stream);
 
 /* torch.argmax(logits, -1) of HF greedy search (first maximal index); x f32 [rows, cols] -> out i32 [rows]. */
 int ivlm_argmax_f32(const float *x, int rows, int cols, int32_t *out, ivlm_stream_t stream);
@@ -179,7 +180,9 @@ int ivlm_dense_pe(const void *gauss, void *pe, int h, int w, int F, ivlm_stream_
 /* HF LlamaAttention rotary (rotate-half, base theta) applied in place to q,k of qkv [T,3,H,D] (row stride ld) at
  * positions pos0+t, and KV-cache append (kcache/vcache [Tmax,H,D], may be NULL). */
 int ivlm_rope_kv(void *qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void *kcache, void *vcache,
-                 ivlm_stream_t stream);
+                 const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
+/* fp32 rotary tables cos/sin [T, D/2] (optional inputs of ivlm_rope_kv / ivlm_llama_decode_attn; NULL = compute) */
+int ivlm_rope_table(float *cos_tab, float *sin_tab, int T, int D, float theta, ivlm_stream_t stream);
 /* Caller-side image preprocessing (run_demo.py:65-79 `preprocess`: (x - mean)/std then zero-pad to the square model
  * input; HF CLIPImageProcessor: centre crop, 1/255 rescale, normalise): src u8 [H,W,3] RGB on the device, crop
  * (y0,x0,ch,cw) -> out bf16|f32 [3,OH,OW].  mean3/std3 are HOST pointers in 0..255 units. */

@@ -18,7 +18,9 @@ constexpr int kDecThreads = 1024, kDecGroups = kDecThreads / 16;  // 64 key rows
 __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_kernel(const bf16_t* __restrict__ qkv /*[3,H,D]*/,
                                                                 bf16_t* __restrict__ kcache /*[Tmax,H,D]*/,
                                                                 bf16_t* __restrict__ vcache, bf16_t* __restrict__ o,
-                                                                int H, int D, int pos, float theta, float scale) {
+                                                                int H, int D, int pos, float theta, float scale,
+                                                                const float* __restrict__ ct,
+                                                                const float* __restrict__ stab) {
     __shared__ float q_s[kMaxD];
     __shared__ float knew_s[kMaxD];
     __shared__ float vnew_s[kMaxD];
@@ -31,9 +33,15 @@ __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_kernel(const bf
     if (t < half) {
         const bf16_t* q = qkv + h * D;
         const bf16_t* k = qkv + (int64_t)H * D + h * D;
-        const float inv = powf(theta, -(float)(2 * t) / (float)D);
-        const float ang = (float)pos * inv;
-        const float c = cosf(ang), s = sinf(ang);
+        float c, s;
+        if (ct) {
+            c = ct[pos * half + t];
+            s = stab[pos * half + t];
+        } else {
+            const float ang = (float)pos * powf(theta, -(float)(2 * t) / (float)D);
+            c = cosf(ang);
+            s = sinf(ang);
+        }
         const float q0 = bf16_to_f32(q[t]), q1 = bf16_to_f32(q[t + half]);
         const float k0 = bf16_to_f32(k[t]), k1 = bf16_to_f32(k[t + half]);
         // round q, k to bf16 exactly like the prefill path (rope_kv_kernel) so both paths see the same values
@@ -143,19 +151,20 @@ __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_kernel(const bf
 }  // namespace
 
 int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
-                      float scale, hipStream_t st) {
+                      float scale, hipStream_t st, const float* cos_tab, const float* sin_tab) {
     if (!qkv || !kcache || !vcache || !o || H <= 0 || D <= 0 || D > kMaxD || (D & 15) || pos < 0 || pos >= kMaxT)
         return IVLM_ERR_INVALID_ARG;
-    llama_decode_attn_kernel<<<H, kDecThreads, 0, st>>>(qkv, kcache, vcache, o, H, D, pos, theta, scale);
+    llama_decode_attn_kernel<<<H, kDecThreads, 0, st>>>(qkv, kcache, vcache, o, H, D, pos, theta, scale, cos_tab, sin_tab);
     return ivlm_launch_status();
 }
 
 }  // namespace ivlm
 
 extern "C" int ivlm_llama_decode_attn(const void* qkv, void* kcache, void* vcache, void* o, int H, int D, int pos,
-                                      float theta, float scale, ivlm_stream_t stream) {
+                                      float theta, float scale, const float* cos_tab, const float* sin_tab,
+                                      ivlm_stream_t stream) {
     ivlm_enter();
     return ivlm::llama_decode_attn(static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(kcache),
                                    static_cast<bf16_t*>(vcache), static_cast<bf16_t*>(o), H, D, pos, theta, scale,
-                                   ivlm_stream(stream));
+                                   ivlm_stream(stream), cos_tab, sin_tab);
 }

@@ -143,9 +143,22 @@ __global__ __launch_bounds__(kT) void dense_pe_kernel(const float* __restrict__ 
 
 // qkv [T, 3, H, D] (row stride ld): rotate-half RoPE in place on q and k at positions pos0 + t; append
 // roped k and v to the caches [Tmax, H, D] at row pos0 + t.  One thread per (t, h, pair j < D/2).
+// cos/sin table [T, D/2] in fp32 (HF computes them in fp32 as well)
+__global__ __launch_bounds__(kT) void rope_table_kernel(float* __restrict__ ct, float* __restrict__ st, int T, int D,
+                                                        float theta) {
+    const int half = D >> 1;
+    const int i = blockIdx.x * kT + threadIdx.x;
+    if (i >= T * half) return;
+    const int j = i % half, pos = i / half;
+    const float ang = (float)pos * powf(theta, -(float)(2 * j) / (float)D);
+    ct[i] = cosf(ang);
+    st[i] = sinf(ang);
+}
+
 __global__ __launch_bounds__(kT) void rope_kv_kernel(bf16_t* __restrict__ qkv, int64_t ld, int T, int H, int D,
                                                      int pos0, float theta, bf16_t* __restrict__ kcache,
-                                                     bf16_t* __restrict__ vcache) {
+                                                     bf16_t* __restrict__ vcache, const float* __restrict__ ct,
+                                                     const float* __restrict__ stab) {
     const int half = D >> 1;
     const int64_t total = (int64_t)T * H * half;
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
@@ -155,9 +168,15 @@ __global__ __launch_bounds__(kT) void rope_kv_kernel(bf16_t* __restrict__ qkv, i
         const int pos = pos0 + t;
         // HF: inv_freq = theta^(-2j/D) (fp32), freqs = pos*inv_freq, cos/sin in fp32; we keep fp32 products and
         // round q/k once (the reference's bf16 model rounds cos/sin and every product: more noise, same maths)
-        const float inv = powf(theta, -(float)(2 * j) / (float)D);
-        const float ang = (float)pos * inv;
-        const float c = cosf(ang), s = sinf(ang);
+        float c, s;
+        if (ct) {
+            c = ct[pos * half + j];
+            s = stab[pos * half + j];
+        } else {
+            const float ang = (float)pos * powf(theta, -(float)(2 * j) / (float)D);
+            c = cosf(ang);
+            s = sinf(ang);
+        }
         bf16_t* row = qkv + (int64_t)t * ld;
         bf16_t* q = row + h * D;
         bf16_t* k = row + (int64_t)H * D + h * D;
@@ -285,9 +304,15 @@ int dense_pe(const float* gauss, bf16_t* pe, int h, int w, int F, hipStream_t st
     return ivlm_launch_status();
 }
 int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, bf16_t* kcache, bf16_t* vcache,
-            hipStream_t st) {
-    if (!qkv || T <= 0 || (D & 1) || (kcache && !vcache)) return IVLM_ERR_INVALID_ARG;
-    rope_kv_kernel<<<grid_for((int64_t)T * H * (D >> 1)), kT, 0, st>>>(qkv, ld, T, H, D, pos0, theta, kcache, vcache);
+            hipStream_t st, const float* cos_tab, const float* sin_tab) {
+    if (!qkv || T <= 0 || (D & 1) || (kcache && !vcache) || (cos_tab && !sin_tab)) return IVLM_ERR_INVALID_ARG;
+    rope_kv_kernel<<<grid_for((int64_t)T * H * (D >> 1)), kT, 0, st>>>(qkv, ld, T, H, D, pos0, theta, kcache, vcache,
+                                                                       cos_tab, sin_tab);
+    return ivlm_launch_status();
+}
+int rope_table(float* cos_tab, float* sin_tab, int T, int D, float theta, hipStream_t st) {
+    if (!cos_tab || !sin_tab || T <= 0 || (D & 1)) return IVLM_ERR_INVALID_ARG;
+    rope_table_kernel<<<(T * (D >> 1) + kT - 1) / kT, kT, 0, st>>>(cos_tab, sin_tab, T, D, theta);
     return ivlm_launch_status();
 }
 int mask_dot(const bf16_t* up, const bf16_t* hyper, float* low, int B, int gh, int gw, int C, hipStream_t st) {
@@ -325,9 +350,13 @@ int ivlm_dense_pe(const void* gauss, void* pe, int h, int w, int F, ivlm_stream_
     return ivlm::dense_pe(static_cast<const float*>(gauss), BF(pe), h, w, F, ivlm_stream(s));
 }
 int ivlm_rope_kv(void* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void* kcache, void* vcache,
-                 ivlm_stream_t s) {
+                 const float* cos_tab, const float* sin_tab, ivlm_stream_t s) {
     ivlm_enter();
-    return ivlm::rope_kv(BF(qkv), ld, T, H, D, pos0, theta, BF(kcache), BF(vcache), ivlm_stream(s));
+    return ivlm::rope_kv(BF(qkv), ld, T, H, D, pos0, theta, BF(kcache), BF(vcache), ivlm_stream(s), cos_tab, sin_tab);
+}
+int ivlm_rope_table(float* cos_tab, float* sin_tab, int T, int D, float theta, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::rope_table(cos_tab, sin_tab, T, D, theta, ivlm_stream(s));
 }
 int ivlm_mask_dot(const void* up, const void* hyper, float* low, int B, int gh, int gw, int C, ivlm_stream_t s) {
     ivlm_enter();

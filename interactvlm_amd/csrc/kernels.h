@@ -73,7 +73,8 @@ int add_rows(bf16_t* out, const bf16_t* a, const bf16_t* b, int64_t rows, int co
              int op = 0);  // op 0: a + b, 1: a * b
 int dense_pe(const float* gauss, bf16_t* pe, int h, int w, int F, hipStream_t st);
 int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, bf16_t* kcache, bf16_t* vcache,
-            hipStream_t st);
+            hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr);
+int rope_table(float* cos_tab, float* sin_tab, int T, int D, float theta, hipStream_t st);
 int normalize_pad_u8(const uint8_t* src, int H, int W, int y0, int x0, int ch, int cw, const float* mean3,
                      const float* std3, void* out, int out_bf16, int OH, int OW, hipStream_t st);
 int mask_dot(const bf16_t* up, const bf16_t* hyper, float* low, int B, int gh, int gw, int C, hipStream_t st);
@@ -88,7 +89,7 @@ int rasterize_points(const float* pts, int np, const float* cam12_host, float fo
 
 // ---- single-token decode (decode.hip) ---------------------------------------------------------------
 int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
-                      float scale, hipStream_t st);
+                      float scale, hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr);
 
 // ---- skinny GEMM (gemv.hip): M <= 8 rows of activations against streamed weights -------------------
 int gemv_bf16(const GemmArgs& g, hipStream_t st);

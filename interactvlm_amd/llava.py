@@ -87,6 +87,7 @@ class Llama:
         H, hd = cfg.heads, cfg.hidden // cfg.heads
         self.kcache = torch.zeros(cfg.layers, max_len, H, hd, dtype=BF16, device=device)
         self.vcache = torch.zeros(cfg.layers, max_len, H, hd, dtype=BF16, device=device)
+        self.rope = ops.rope_table(max_len, hd, cfg.theta, device)  # fp32 cos/sin, computed once
 
     def embed_ids(self, ids_i32, out=None):
         """embed_tokens gather: ids int32 [n] -> [n, hidden]."""
@@ -104,7 +105,7 @@ class Llama:
         for li, L in enumerate(self.layers):
             y = ops.rmsnorm(x, L["ln1"], c.eps)
             qkv = ops.linear(y, L["qkv"])  # [T, 3*hidden] == [T, 3, H, hd]
-            ops.rope_kv(qkv, H, hd, pos0, c.theta, self.kcache[li], self.vcache[li])
+            ops.rope_kv(qkv, H, hd, pos0, c.theta, self.kcache[li], self.vcache[li], table=self.rope)
             q = qkv.view(T, 3, H, hd)[:, 0].permute(1, 0, 2).unsqueeze(0)  # [1,H,T,hd]
             k = self.kcache[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
             v = self.vcache[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
@@ -121,7 +122,7 @@ class Llama:
         H, hd = c.heads, c.hidden // c.heads
         for li, L in enumerate(self.layers):
             qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps))
-            a = ops.llama_decode_attn(qkv, self.kcache[li], self.vcache[li], H, hd, pos, c.theta, hd ** -0.5)
+            a = ops.llama_decode_attn(qkv, self.kcache[li], self.vcache[li], H, hd, pos, c.theta, hd ** -0.5, table=self.rope)
             x = ops.linear(a, L["o"], residual=x)
             h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))
             x = ops.linear(h, L["down"], residual=x)

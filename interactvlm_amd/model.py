@@ -117,6 +117,10 @@ class InteractVLMForCausalLM:
         emb = self.model.visual_model.image_encoder(pixel_values.reshape((B * V,) + tuple(pixel_values.shape[2:])))
         return emb.view(B, V, g, g, -1).permute(0, 1, 4, 2, 3)
 
+    def precompute_visual_embs(self, images_views):
+        """[V,3,S,S] -> channels-last SAM embeddings [V, g*g, 256] to pass as evaluate(image_embeddings=...)."""
+        return self.model.visual_model.image_encoder(images_views.to(self.device))
+
     def forward(self, **kwargs):
         if "past_key_values" in kwargs:
             raise NotImplementedError("the HF generate() protocol is replaced by the KV-cached loop in evaluate()")
@@ -291,12 +295,17 @@ class InteractVLMForCausalLM:
     @torch.no_grad()
     def evaluate(self, images_clip, images, input_ids, cam_params, resize_list, original_size_list,
                  lift2d_dict_path=None, contact_type="hcontact", max_new_tokens=32, tokenizer=None,
-                 forced_new_tokens=None, eos_token_id=2):
-        """Generate -> [SEG] hidden state -> SAM decode -> lift (InteractVLM.py:510-638)."""
+                 forced_new_tokens=None, eos_token_id=2, image_embeddings=None):
+        """Generate -> [SEG] hidden state -> SAM decode -> lift (InteractVLM.py:510-638).
+
+        image_embeddings (extension): pre-computed SAM embeddings [V, g*g, 256] of ``images``
+        (``precompute_visual_embs``).  For hcontact the SAM inputs are the SAME four canonical body renders for
+        every sample (run_demo.py:279-292, datasets/hcontact_3d.py:268-271), so they can be encoded once."""
         assert input_ids.shape[0] == 1, "the reference only ever calls evaluate with batch 1 (evaluate.py:479)"
         output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, eos_token_id, forced_new_tokens)
         rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)
-        image_embeddings = self.model.visual_model.image_encoder(images[0].to(self.device))
+        if image_embeddings is None:
+            image_embeddings = self.model.visual_model.image_encoder(images[0].to(self.device))
         pm, _ = self._decode_sample(hidden, rows, output_ids[0], cam_params[0], image_embeddings, resize_list[0],
                                     original_size_list[0])
         pred_masks = [pm]

@@ -370,14 +370,22 @@ def dense_pe(gauss, h, w):
     return pe
 
 
-def rope_kv(qkv, H, D, pos0, theta, kcache=None, vcache=None):
-    """qkv [T, 3*H*D] (in place)."""
+def rope_kv(qkv, H, D, pos0, theta, kcache=None, vcache=None, table=None):
+    """qkv [T, 3*H*D] (in place). table = (cos, sin) fp32 [Tmax, D/2] from rope_table()."""
     lib = _lib.load()
     assert qkv.dtype == BF16 and qkv.stride(-1) == 1
     T = qkv.shape[0]
     check(lib.ivlm_rope_kv(qkv.data_ptr(), qkv.stride(0), T, H, D, int(pos0), float(theta), _p(kcache), _p(vcache),
-                           _stream()), "rope_kv")
+                           _p(table[0]) if table else 0, _p(table[1]) if table else 0, _stream()), "rope_kv")
     return qkv
+
+
+def rope_table(T, D, theta, device):
+    lib = _lib.load()
+    c = torch.empty(T, D // 2, dtype=torch.float32, device=device)
+    s = torch.empty_like(c)
+    check(lib.ivlm_rope_table(c.data_ptr(), s.data_ptr(), T, D, float(theta), _stream()), "rope_table")
+    return c, s
 
 
 def mask_dot(up, hyper, B, gh, gw):
@@ -390,12 +398,13 @@ def mask_dot(up, hyper, B, gh, gw):
     return low
 
 
-def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None):
+def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, table=None):
     """qkv bf16 [1, 3*H*D] of the newest token -> o bf16 [1, H*D]; RoPE + cache append fused."""
     lib = _lib.load()
     assert qkv.dtype == BF16 and qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
     if out is None:
         out = torch.empty(1, H * D, dtype=BF16, device=qkv.device)
     check(lib.ivlm_llama_decode_attn(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), H, D,
-                                     int(pos), float(theta), float(scale), _stream()), "llama_decode_attn")
+                                     int(pos), float(theta), float(scale), _p(table[0]) if table else 0,
+                                     _p(table[1]) if table else 0, _stream()), "llama_decode_attn")
     return out

@@ -201,3 +201,8 @@ def test_model_forward_vs_reference_golden(hip_lib, cuda, golden_dir):
     print(f"[evaluate vs model_forward] max|dp| = {e2:.2e}")
     assert e2 < 2e-3  # same arithmetic, different GEMM path (GEMV decode vs MFMA prefill) for the answer tokens
     assert float((ev["pred_masks"][0] - pm).abs().max()) < 0.08 * float(ref_pm.abs().max())
+    # cached SAM embeddings give bit-identical results
+    emb = m.precompute_visual_embs(images[0].to(bf).to(cuda))
+    ev2 = m.evaluate(images_clip.to(bf).to(cuda), images.to(bf).to(cuda), ids[None, :L0], cams, [(1024, 1024)],
+                     [(1024, 1024)], contact_type="hcontact", forced_new_tokens=ids[L0:].tolist(), image_embeddings=emb)
+    assert torch.equal(ev2["pred_contact_3d"], ev["pred_contact_3d"])
