@@ -112,6 +112,40 @@ def cpu_baseline(cfg, T0, n_new, V):
             "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
 
 
+def parity_vs_oracle(dev):
+    """The "per-vertex F1 vs ref" half of the metric: run evaluate() of a small, structurally complete configuration
+    (real head dims, 14x14 windows + global blocks, 1024^2 x 4 views, 6890 vertices) on the GPU and on the fp32 CPU
+    oracle (pinned to the reference's goldens) with identical bf16-representable weights and inputs."""
+    from interactvlm_amd import model as M
+    from interactvlm_amd import ops, synth, synthetic
+    from interactvlm_amd import weights as Wt
+    from oracle import metrics as OM
+    from oracle import pipeline as P
+
+    cfg = synthetic.config_tiny()
+    w = {k: v.to(torch.bfloat16).float() for k, v in Wt.synth_weights(Wt.ivlm_spec(cfg)).items()}
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    m = M.InteractVLMForCausalLM(cfg, w, dev, lift_tables=tables)
+    ids, forced = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=8)
+    cams = synthetic.human_cam_params()
+    ic, im = synthetic.images(cfg, dev)
+    out = m.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced)
+    full_ids = torch.cat([ids[0], torch.tensor(forced)])
+    ref = P.model_forward(w, cfg, im[0].float().cpu(), ic.float().cpu(), full_ids, cams[0], tables)
+    got = out["pred_contact_3d"].float()
+    refc = ref["pred_contact"].float()
+    thr = float(refc.median())  # random weights put every contact near 0.5: threshold at the oracle's median
+    f1 = ops.contact_prf((refc >= thr).float().to(dev), got, thr).cpu()[0]
+    f1_cpu = OM.h_contact_metrics((refc >= thr).float(), got.cpu(), thr)[0]
+    return {"config": "tiny (2-layer LLaMA hd128, 3-layer CLIP, 2-block SAM ViT hd80, full SAM decoder, 4x1024^2, 6890 v)",
+            "max_abs_dp": round(float((got.cpu() - refc).abs().max()), 6),
+            "rms_dp": round(float((got.cpu() - refc).pow(2).mean().sqrt()), 6),
+            "f1_vs_oracle": round(float(f1[0]), 5), "precision": round(float(f1[1]), 5), "recall": round(float(f1[2]), 5),
+            "f1_device_equals_cpu_metric": bool(abs(float(f1[0]) - float(f1_cpu[0])) < 1e-6),
+            "threshold": round(thr, 4), "visibility_set_equal": bool(torch.equal(
+                torch.from_numpy(ref["nviews"] > 0), (got.cpu() > -1) & torch.from_numpy(ref["nviews"] > 0)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,8 +258,11 @@ def main():
             roof["traffic"] = pm.get("gemm_bf16_kernel")
             roof_lift["traffic"] = pm.get("lift_plan_kernel")
 
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del model
+        torch.cuda.empty_cache()
+        parity = parity_vs_oracle(dev)
         cpu = cpu_baseline(cfg, T0, len(forced), V)
 
     if rank == 0:
@@ -242,7 +279,7 @@ def main():
                        "collective": "one all_gather of [1,6890] f32 contacts per step"},
             "algorithmic_tflop_per_image": round(fl["total"] / 1e12, 2),
             "roofline": roof, "roofline_lift": roof_lift, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
-            "variant_cached_sam_embeddings": cached,
+            "variant_cached_sam_embeddings": cached, "parity_vs_oracle": parity,
         }
         print(json.dumps(line))
     if world > 1:

@@ -195,6 +195,17 @@ int ivlm_mask_dot(const void *up, const void *hyper, float *low, int B, int gh, 
                   ivlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Right after the path
+ * ------------------------------------------------------------------------------------------- */
+/* get_h_contact_metrics (utils/eval_utils.py:63-94): per sample F1 / precision / recall of (pred >= thr) against
+ * (gt > 0); gt, pred f32 [B,n] -> out f32 [B,3] = (f1, precision, recall). */
+int ivlm_contact_prf(const float *gt, const float *pred, int B, int n, float thr, float *out, ivlm_stream_t stream);
+/* convert_contacts (utils/utils.py:428-443): y[b] = M . x[b] with the SMPL->SMPL-X matrix M [rows,cols] held in CSR
+ * (row_ptr i32 [rows+1], col i32 [nnz], val f32 [nnz]) instead of the reference's dense 10475x6890 bmm. */
+int ivlm_spmv_csr(const int32_t *row_ptr, const int32_t *col, const float *val, const float *x, int B, int rows,
+                  int cols, float *y, ivlm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * "Render" of Render-Localize-Lift: rasterise a mesh / point cloud into the lift tables.
  * pytorch3d semantics (preprocess_data/render_mesh_utils.py:115-174, utils_obj_pc.py:28-42,88-113,
  * utils/demo_utils.py:171-257): FoV-perspective camera, X_view = X_world.R + T, NDC +X left / +Y up,

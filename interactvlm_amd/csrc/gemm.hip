@@ -18,13 +18,10 @@
 //     consecutive N of one output row: bias/activation/residual and an 8-byte (bf16x4) store.
 //   * epilogues: bias, GELU(erf) / quick-GELU / ReLU / SiLU, SwiGLU over interleaved gate/up rows,
 //     residual add (optionally row-modulo for broadcast tables), bf16 or fp32 output.
-#include "kernels.h"
+#include "gemm_common.h"
 
 namespace ivlm {
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int BK = 64;
 
@@ -43,24 +40,6 @@ struct TileCfg {
     static constexpr int PA = BM / 8 / kWaves, PW = BN / 8 / kWaves;  // 1-KiB DMA pieces per wave per tile
 };
 
-__device__ __forceinline__ float act_apply(float x, int act) {
-    switch (act) {
-        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-        case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
-        case ACT_RELU: return fmaxf(x, 0.0f);
-        case ACT_SILU: return x / (1.0f + __expf(-x));
-        case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
-        default: return x;
-    }
-}
-
-// 16 zero bytes: DMA source for the K tail (K % 64 != 0) so that partial tiles contribute nothing
-__device__ __attribute__((aligned(16))) const uint32_t kZeroChunk[4] = {0u, 0u, 0u, 0u};
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
 template <int ACT, bool OUT_F32, typename CFG>
 __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NI = CFG::NI, PA = CFG::PA, PW = CFG::PW;
@@ -69,24 +48,11 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- XCD-aware, grouped tile raster -------------------------------------------------------------
-    // The dispatcher places block b on XCD b % 8 (private 4 MiB L2 each).  Give every XCD one CONTIGUOUS range of
-    // the tile sequence (bijective for any tile count), and order that sequence in groups of kGroupM tile-rows
-    // with the row index fastest, so the ~64 tiles an XCD runs concurrently form an ~8x8 patch that shares 8 A
-    // panels + 8 W panels per K step instead of ~47 (measured: fabric traffic 6x the algorithmic bytes before).
-    const int tiles_n = (g.N + BN - 1) / BN;
-    const int tiles_m = (g.M + BM - 1) / BM;
-    const int nwg = tiles_m * tiles_n;
-    constexpr int kXcd = 8, kGroupM = 8;
-    const int xcd = blockIdx.x % kXcd, loc = blockIdx.x / kXcd;
-    const int q = nwg / kXcd, r = nwg % kXcd;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int per_group = kGroupM * tiles_n;
-    const int first_m = (lin / per_group) * kGroupM;
-    const int gsz = tiles_m - first_m < kGroupM ? tiles_m - first_m : kGroupM;
-    const int in_group = lin % per_group;
-    const int tm = first_m + in_group % gsz, tn = in_group / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
+    // XCD-aware, grouped tile raster: every XCD (private 4 MiB L2) gets one contiguous range of the tile sequence,
+    // ordered in groups of 8 tile-rows with the row fastest, so the ~64 tiles it runs concurrently form an ~8x8
+    // patch sharing 8 A + 8 W panels per K step (measured: fabric traffic halved, profiles/r01_pmc_traffic*.txt).
+    int m0, n0;
+    gemm_tile_origin(g, BM, BN, m0, n0);
     const int bz = blockIdx.z;
     const bf16_t* __restrict__ A = g.A + (int64_t)bz * g.strideA;
     const bf16_t* __restrict__ W = g.W + (int64_t)bz * g.strideW;
@@ -117,7 +83,7 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
         unsigned char* baseA = smem + buf * kStageBytes + wave * PA * 1024;
         unsigned char* baseW = smem + buf * kStageBytes + kTileBytesA + wave * PW * 1024;
         const int koff = kt * BK;
-        const bf16_t* zero = reinterpret_cast<const bf16_t*>(kZeroChunk);
+        const bf16_t* zero = reinterpret_cast<const bf16_t*>(kGemmZeroChunk);
 #pragma unroll
         for (int i = 0; i < PA; ++i) glds16(kcolA[i] + koff < g.K ? srcA[i] + koff : zero, baseA + i * 1024);
 #pragma unroll
@@ -167,72 +133,13 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
     }
 
     // ---- epilogue: lane holds C[m][n..n+3], m = l&15, n = (l>>4)*4 -----------------------------
-    const bf16_t* __restrict__ bias = g.bias;
-    const bf16_t* __restrict__ R = g.residual ? g.residual + (int64_t)bz * g.strideR : nullptr;
-    const bool vec_ok = (g.N & 3) == 0;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm * (MI * 16) + mi * 16 + (lane & 15);
-        if (m >= g.M) continue;
-        const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n = n0 + wn * (NI * 16) + ni * 16 + (lane >> 4) * 4;
-            if (n >= g.N) continue;
-            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-            if (vec_ok) {
-                if (bias) {
-                    const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
-                    v[0] += bf16_to_f32((bf16_t)(b2.x & 0xffff));
-                    v[1] += bf16_to_f32((bf16_t)(b2.x >> 16));
-                    v[2] += bf16_to_f32((bf16_t)(b2.y & 0xffff));
-                    v[3] += bf16_to_f32((bf16_t)(b2.y >> 16));
-                }
-                if (ACT == ACT_SWIGLU) {
-                    // rows interleaved (gate_j, up_j): out[j] = silu(gate_j) * up_j, two outputs per lane
-                    const float o0 = (v[0] / (1.0f + __expf(-v[0]))) * v[1];
-                    const float o1 = (v[2] / (1.0f + __expf(-v[2]))) * v[3];
-                    const int64_t o = (int64_t)m * g.ldc + (n >> 1);
-                    if (OUT_F32) {
-                        float* C = static_cast<float*>(g.C) + (int64_t)bz * g.strideC;
-                        *reinterpret_cast<float2*>(C + o) = make_float2(o0, o1);
-                    } else {
-                        bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
-                        *reinterpret_cast<uint32_t*>(C + o) = pack_bf16x2(o0, o1);
-                    }
-                    continue;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], ACT);
-                if (R) {
-                    const uint2 r2 = *reinterpret_cast<const uint2*>(R + rrow * g.ldr + n);
-                    v[0] += bf16_to_f32((bf16_t)(r2.x & 0xffff));
-                    v[1] += bf16_to_f32((bf16_t)(r2.x >> 16));
-                    v[2] += bf16_to_f32((bf16_t)(r2.y & 0xffff));
-                    v[3] += bf16_to_f32((bf16_t)(r2.y >> 16));
-                }
-                const int64_t o = (int64_t)m * g.ldc + n;
-                if (OUT_F32) {
-                    float* C = static_cast<float*>(g.C) + (int64_t)bz * g.strideC;
-                    *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
-                    *reinterpret_cast<uint2*>(C + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                }
-            } else {  // ragged N: scalar tail (never on the hot shapes)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (n + j >= g.N) break;
-                    float x = v[j] + (bias ? bf16_to_f32(bias[n + j]) : 0.0f);
-                    x = act_apply(x, ACT);
-                    if (R) x += bf16_to_f32(R[rrow * g.ldr + n + j]);
-                    const int64_t o = (int64_t)m * g.ldc + n + j;
-                    if (OUT_F32)
-                        (static_cast<float*>(g.C) + (int64_t)bz * g.strideC)[o] = x;
-                    else
-                        (static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC)[o] = f32_to_bf16(x);
-                }
-            }
+            gemm_epilogue4<ACT, OUT_F32>(g, bz, m, n, acc[ni][mi]);
         }
     }
 }

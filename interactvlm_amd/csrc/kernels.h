@@ -79,6 +79,11 @@ int normalize_pad_u8(const uint8_t* src, int H, int W, int y0, int x0, int ch, i
                      const float* std3, void* out, int out_bf16, int OH, int OW, hipStream_t st);
 int mask_dot(const bf16_t* up, const bf16_t* hyper, float* low, int B, int gh, int gw, int C, hipStream_t st);
 
+// ---- metrics / SMPL-X transfer (metrics.hip) ------------------------------------------------------------
+int contact_prf(const float* gt, const float* pred, int B, int n, float thr, float* out, hipStream_t st);
+int spmv_csr(const int32_t* row_ptr, const int32_t* col, const float* val, const float* x, int B, int rows, int cols,
+             float* y, hipStream_t st);
+
 // ---- rasterisation (raster.hip) -------------------------------------------------------------------
 size_t raster_workspace_bytes(int n_prims_verts, int H, int W);
 int rasterize_mesh(const float* verts, int nv, const int32_t* faces, int nf, const float* cam12_host, float fov_deg,

@@ -408,3 +408,40 @@ def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, ta
                                      int(pos), float(theta), float(scale), _p(table[0]) if table else 0,
                                      _p(table[1]) if table else 0, _stream()), "llama_decode_attn")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# right after the path: metrics, SMPL -> SMPL-X transfer
+# --------------------------------------------------------------------------------------------
+def contact_prf(gt, pred, threshold=0.5):
+    """get_h_contact_metrics (utils/eval_utils.py:63-94) -> f32 [B,3] = (f1, precision, recall) per sample."""
+    lib = _lib.load()
+    gt = _req(gt, torch.float32, "gt")
+    pred = _req(pred, torch.float32, "pred")
+    B, n = pred.shape
+    out = torch.empty(B, 3, dtype=torch.float32, device=pred.device)
+    check(lib.ivlm_contact_prf(gt.data_ptr(), pred.data_ptr(), B, n, float(threshold), out.data_ptr(), _stream()),
+          "contact_prf")
+    return out
+
+
+class SparseRows:
+    """CSR copy of a (mostly empty) dense matrix, e.g. the SMPL->SMPL-X transfer matrix [10475, 6890]."""
+
+    def __init__(self, dense: torch.Tensor, device):
+        d = dense.detach().float().cpu()
+        self.rows, self.cols = d.shape
+        nz = d != 0
+        self.row_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), nz.sum(1).cumsum(0)]).to(torch.int32).to(device)
+        r, c = nz.nonzero(as_tuple=True)
+        self.col = c.to(torch.int32).to(device)
+        self.val = d[r, c].contiguous().to(device)
+
+    def matvec(self, x):
+        """x f32 [B, cols] -> f32 [B, rows] (convert_contacts, utils/utils.py:428-443)."""
+        lib = _lib.load()
+        x = _req(x, torch.float32, "x")
+        y = torch.empty(x.shape[0], self.rows, dtype=torch.float32, device=x.device)
+        check(lib.ivlm_spmv_csr(self.row_ptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr(), x.data_ptr(),
+                                x.shape[0], self.rows, self.cols, y.data_ptr(), _stream()), "spmv_csr")
+        return y
