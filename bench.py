@@ -230,28 +230,38 @@ def main():
                   "note": "SAM ViT-H embeddings of the input-independent hcontact renders pre-computed (SURVEY 8f-1); "
                           "NOT the headline metric"}
 
-    roof = roof_lift = breakdown = None
-    if not args.no_roofline:  # same steps again with per-launch HIP events on the launch stream
+    roof = roof_lift = breakdown = roof_serial = None
+
+    def timed_pass(nsteps):
         ops.TIMER.start()
-        for _ in range(max(1, min(args.steps, 3))):
+        for _ in range(nsteps):
             step()
         ops.TIMER.stop()
         sm = ops.TIMER.summary()
-        g = sm["gemm_bf16_mfma"]
+        g, l, gv = sm["gemm_bf16_mfma"], sm["lift_mesh_plan"], sm.get("gemv_bf16")
         ach = g["work"] / g["total_s"] / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "launches_per_image": g["launches"] // max(1, min(args.steps, 3)), "avg_us": round(g["avg_us"], 2)}
-        l = sm["lift_mesh_plan"]
+        r = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+             "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+             "launches_per_image": g["launches"] // nsteps, "avg_us": round(g["avg_us"], 2)}
         la = l["work"] / l["total_s"] / 1e9
-        roof_lift = {"bound": "hbm", "kernel": "lift_plan_kernel", "achieved": round(la, 1), "peak": PEAK_HBM_GBPS,
-                     "unit": "GB/s", "frac": round(la / PEAK_HBM_GBPS, 4), "traffic": None,
-                     "algorithmic_bytes": int(l["work"] / l["launches"]), "avg_us": round(l["avg_us"], 2)}
-        gv = sm.get("gemv_bf16")
+        rl = {"bound": "hbm", "kernel": "lift_plan_kernel", "achieved": round(la, 1), "peak": PEAK_HBM_GBPS,
+              "unit": "GB/s", "frac": round(la / PEAK_HBM_GBPS, 4), "traffic": None,
+              "algorithmic_bytes": int(l["work"] / l["launches"]), "avg_us": round(l["avg_us"], 2)}
+        bd = None
         if gv:
-            breakdown = {"gemv_weight_stream_GBps": round(gv["work"] / gv["total_s"] / 1e9, 1),
-                         "gemv_total_ms_per_image": round(gv["total_s"] / max(1, min(args.steps, 3)) * 1e3, 2),
-                         "gemm_total_ms_per_image": round(g["total_s"] / max(1, min(args.steps, 3)) * 1e3, 2)}
+            bd = {"gemv_weight_stream_GBps": round(gv["work"] / gv["total_s"] / 1e9, 1),
+                  "gemv_total_ms_per_image": round(gv["total_s"] / nsteps * 1e3, 2),
+                  "gemm_total_ms_per_image": round(g["total_s"] / nsteps * 1e3, 2)}
+        return r, rl, bd
+
+    if not args.no_roofline:  # the same steps again with per-launch HIP events on the launch stream(s)
+        ns = max(1, min(args.steps, 3))
+        roof, roof_lift, breakdown = timed_pass(ns)  # as timed: SAM encoder overlapped with the LLM on a 2nd stream
+        model.overlap_sam_encoder = False
+        rs, rls, bds = timed_pass(ns)                # kernels one at a time: isolates kernel quality from overlap
+        model.overlap_sam_encoder = True
+        roof_serial = {"note": "same steps with the two-stream overlap disabled (kernels run alone)", "gemm": rs,
+                       "lift": rls, "breakdown": bds}
         pj = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pj):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
             pm = json.load(open(pj))
@@ -279,7 +289,7 @@ def main():
                        "collective": "one all_gather of [1,6890] f32 contacts per step"},
             "algorithmic_tflop_per_image": round(fl["total"] / 1e12, 2),
             "roofline": roof, "roofline_lift": roof_lift, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
-            "variant_cached_sam_embeddings": cached, "parity_vs_oracle": parity,
+            "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "parity_vs_oracle": parity,
         }
         print(json.dumps(line))
     if world > 1:

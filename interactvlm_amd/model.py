@@ -77,6 +77,8 @@ class InteractVLMForCausalLM:
         self.base_token_type = c.token_type.replace("-DifDe", "")
         self.use_fusion = self.use_uncertainty = False  # off in every released config (scripts/run_train.sh:61-62)
         self.debug_taps = None  # set to a dict to record intermediate tensors (tests / diagnostics only)
+        self.overlap_sam_encoder = True
+        self._side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
 
         self.vision_tower = ClipTower(w, c.clip, dev)
         self.mm_projector = _Lin(w, "model.mm_projector", dev)
@@ -302,8 +304,23 @@ class InteractVLMForCausalLM:
         (``precompute_visual_embs``).  For hcontact the SAM inputs are the SAME four canonical body renders for
         every sample (run_demo.py:279-292, datasets/hcontact_3d.py:268-271), so they can be encoded once."""
         assert input_ids.shape[0] == 1, "the reference only ever calls evaluate with batch 1 (evaluate.py:479)"
+        # The SAM ViT-H encoder (MFMA-bound, ~60 ms) does not depend on the language model (CLIP -> prefill -> decode:
+        # HBM-bound weight streaming that leaves the matrix cores idle): run it on a second HIP stream and join
+        # before the mask decoder.  The reference runs them back to back (InteractVLM.py:524-531, 578).
+        side = ev = None
+        if image_embeddings is None and self.overlap_sam_encoder:
+            main = torch.cuda.current_stream(self.device)
+            side = self._side_stream
+            side.wait_stream(main)  # inputs were produced on the caller's stream
+            with torch.cuda.stream(side):
+                image_embeddings = self.model.visual_model.image_encoder(images[0].to(self.device))
+                ev = torch.cuda.Event()
+                ev.record(side)
         output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, eos_token_id, forced_new_tokens)
         rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)
+        if side is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            image_embeddings.record_stream(torch.cuda.current_stream(self.device))
         if image_embeddings is None:
             image_embeddings = self.model.visual_model.image_encoder(images[0].to(self.device))
         pm, _ = self._decode_sample(hidden, rows, output_ids[0], cam_params[0], image_embeddings, resize_list[0],
