@@ -73,6 +73,13 @@ int ivlm_lift_mesh_plan(const float *logits, const int32_t *row_ptr, const int32
                         const float *ent_w, int B, int V, int64_t HW, int Nv, int mode, float param,
                         float *out, float *nviews, ivlm_stream_t stream);
 
+/* Fused postprocess + lift: identical result to ivlm_postprocess_masks followed by ivlm_lift_mesh_plan,
+ * but the logit of each table entry is evaluated on the fly from the low-res masks (low f32|bf16 [B,V,lh,lw]) with
+ * the arithmetic of Sam.postprocess_masks; the plan must have been built for (oh, ow) pixel maps. */
+int ivlm_lift_mesh_plan_lowres(const void *low, int dtype, int lh, int lw, int img, int in_h, int in_w, int oh, int ow,
+                               const int32_t *row_ptr, const int32_t *ent_pix, const float *ent_w, int B, int V,
+                               int Nv, int mode, float param, float *out, float *nviews, ivlm_stream_t stream);
+
 /* Same operators, streaming directly over the dense tables (single-use tables, e.g. a fresh
  * lift2d_dict.pkl: ObjectMeshContact3DPredictor.forward_inference, components.py:392-424).
  * Accumulates with LDS/L2 atomics, so float summation order is not fixed (<= ~1e-6 abs). */
@@ -116,6 +123,15 @@ int ivlm_gemm_bf16(const void *A, int64_t lda, const void *W, int64_t ldw, void 
                    const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
                    int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
                    int64_t strideR, const void *rms_w, float rms_eps, ivlm_stream_t stream);
+
+/* Split-K variant for small-M GEMMs (LLaMA prefill, CLIP: too few output tiles for 256 CUs): same result contract as
+ * ivlm_gemm_bf16 (batch 1, act != SwiGLU, no RMS fusion); K % (8*splits) == 0, N % 4 == 0.  fp32 partial sums of the
+ * `splits` K-slices go to the caller's workspace (ivlm_gemm_splitk_workspace_bytes) and are summed in slice order. */
+size_t ivlm_gemm_splitk_workspace_bytes(int M, int N, int splits);
+int ivlm_gemm_bf16_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
+                          const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
+                          int act, int out_f32, int splits, void *workspace, size_t workspace_bytes,
+                          ivlm_stream_t stream);
 
 /* Benchmark/test hook: force the GEMM block tile (64 = 128x64, 128, 256; 0 = automatic choice). Returns the previous value. */
 int ivlm_gemm_tile_override(int tile);

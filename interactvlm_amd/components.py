@@ -53,8 +53,8 @@ class HumanContact3DPredictor(torch.nn.Module):
         else:
             vid, bary = tables
         # kept as plain attributes (not buffers) like the reference => absent from checkpoints
-        self.pixel_to_vertex_map = torch.as_tensor(np.asarray(vid))
-        self.bary_coord_map = torch.as_tensor(np.asarray(bary))
+        self.pixel_to_vertex_map = vid if torch.is_tensor(vid) else torch.as_tensor(np.asarray(vid))
+        self.bary_coord_map = bary if torch.is_tensor(bary) else torch.as_tensor(np.asarray(bary))
         self._plan = None
         self._plan_nv = None
         self._device = device
@@ -78,6 +78,14 @@ class HumanContact3DPredictor(torch.nn.Module):
         if any(skip):  # components.py:230-231: other samples keep zeros
             out[torch.tensor(skip, device=device)] = 0.0
         return out.to(dtype)
+
+
+    def forward_lowres(self, low_res_list, input_size, original_size, img_size=1024):
+        """Extension: same result as forward([postprocess_masks(l) ...]) without reading the
+        full-resolution masks back: low_res_list = B x [V,1,h,w] (or [V,h,w]) low-res decoder outputs."""
+        lows = [l.reshape(l.shape[0], l.shape[-2], l.shape[-1]) for l in low_res_list]
+        low = torch.stack(lows, 0)[:, : self.multiview_channels].contiguous()
+        return ops.lift_mesh_plan_lowres(low, self._get_plan(low.device), input_size, original_size, img_size)
 
 
 class ObjectMeshContact3DPredictor(torch.nn.Module):

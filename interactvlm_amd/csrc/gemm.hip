@@ -211,6 +211,68 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
     }
 }
 
+// ---- split-K ---------------------------------------------------------------------------------------------------
+// Small-M GEMMs (LLaMA prefill M ~ 330, CLIP M = 257) produce too few output tiles to fill 256 CUs and each tile walks
+// the whole K serially.  K is cut into `splits` slices that run as the batch dimension of the same MFMA kernel
+// (fp32 partials in a caller-owned workspace); one pass sums the slices in slice order (deterministic) and applies
+// bias / activation / residual.
+namespace {
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, GemmArgs g) {
+    const int n4 = g.N >> 2;
+    const int64_t total = (int64_t)g.M * n4;
+    const int64_t slice = (int64_t)g.M * g.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+        const float* p = part + (int64_t)m * g.N + n;
+        float4 acc = *reinterpret_cast<const float4*>(p);
+        for (int sidx = 1; sidx < splits; ++sidx) {
+            const float4 t = *reinterpret_cast<const float4*>(p + sidx * slice);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (g.bias) v[j] += bf16_to_f32(g.bias[n + j]);
+            v[j] = gemm_act(v[j], g.act);
+            if (g.residual) {
+                const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
+                v[j] += bf16_to_f32(g.residual[rrow * g.ldr + n + j]);
+            }
+        }
+        const int64_t o = (int64_t)m * g.ldc + n;
+        if (OUT_F32) *reinterpret_cast<float4*>(static_cast<float*>(g.C) + o) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+}
+}  // namespace
+
+int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st) {
+    if (splits < 2 || g.batch != 1 || g.act == ACT_SWIGLU || g.rms_w || !workspace) return IVLM_ERR_INVALID_ARG;
+    if (g.K % (splits * 8) != 0 || (g.N & 3) || (g.ldc & 3)) return IVLM_ERR_UNSUPPORTED;
+    if (ws_bytes < (size_t)splits * g.M * g.N * sizeof(float)) return IVLM_ERR_WORKSPACE;
+    GemmArgs p = g;
+    p.K = g.K / splits;
+    p.batch = splits;
+    p.strideA = p.K;
+    p.strideW = p.K;
+    p.strideC = (int64_t)g.M * g.N;
+    p.strideR = 0;
+    p.C = workspace;
+    p.ldc = g.N;
+    p.out_f32 = 1;
+    p.bias = nullptr;
+    p.residual = nullptr;
+    p.act = ACT_NONE;
+    const int rc = gemm_bf16(p, st);
+    if (rc != IVLM_OK) return rc;
+    const int64_t total = (int64_t)g.M * (g.N >> 2);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
+    if (g.out_f32) splitk_reduce_kernel<true><<<blocks, 256, 0, st>>>(workspace, splits, g);
+    else splitk_reduce_kernel<false><<<blocks, 256, 0, st>>>(workspace, splits, g);
+    return ivlm_launch_status();
+}
+
 // dispatch: weight-streaming GEMV for M <= 8, MFMA tile kernel otherwise
 int linear_bf16(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 8 && g.batch == 1) return gemv_bf16(g, st);
@@ -250,4 +312,28 @@ extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     g.batch = batch < 1 ? 1 : batch;
     g.strideA = strideA; g.strideW = strideW; g.strideC = strideC; g.strideR = strideR;
     return ivlm::linear_bf16(g, ivlm_stream(stream));
+}
+
+extern "C" size_t ivlm_gemm_splitk_workspace_bytes(int M, int N, int splits) {
+    return (size_t)(splits < 1 ? 1 : splits) * (size_t)M * (size_t)N * sizeof(float);
+}
+
+extern "C" int ivlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                     const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N,
+                                     int K, int act, int out_f32, int splits, void* workspace, size_t workspace_bytes,
+                                     ivlm_stream_t stream) {
+    ivlm_enter();
+    ivlm::GemmArgs g;
+    g.tile = g_tile_override;
+    g.A = static_cast<const bf16_t*>(A);
+    g.W = static_cast<const bf16_t*>(W);
+    g.C = C;
+    g.bias = static_cast<const bf16_t*>(bias);
+    g.residual = static_cast<const bf16_t*>(residual);
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+    g.res_mod = res_mod;
+    g.M = M; g.N = N; g.K = K;
+    g.act = act;
+    g.out_f32 = out_f32;
+    return ivlm::gemm_bf16_splitk(g, splits, static_cast<float*>(workspace), workspace_bytes, ivlm_stream(stream));
 }

@@ -9,9 +9,22 @@ namespace ivlm {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
+// exact-GELU x * Phi(x) with Phi through erfc (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7, no cancellation for x < 0):
+// ~14 VALU ops instead of ~45 for ocml erff - the GELU epilogue of the 16384x5120x1280 SAM MLP GEMM was 30 % of its time
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float q = 0.5f * p * t * __expf(-z * z);  // 0.5 * erfc(z)
+    return x * (x < 0.0f ? q : 1.0f - q);
+}
+
 __device__ __forceinline__ float gemm_act(float x, int act) {
     switch (act) {
-        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case ACT_GELU: return gelu_erf_fast(x);
         case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
         case ACT_RELU: return fmaxf(x, 0.0f);
         case ACT_SILU: return x / (1.0f + __expf(-x));

@@ -13,7 +13,7 @@
 //   * "dense" (pixel-major streaming): for single-use tables. 16-byte coalesced loads of
 //     logits/ids/weights, votes privatised in LDS (2*Nv floats <= 160 KB), one flush per block.
 // Both are HBM/L2-bound byte shuffles: no MFMA here by design.
-#include "ivlm_common.h"
+#include "bilinear.h"
 
 namespace {
 
@@ -173,8 +173,78 @@ __global__ __launch_bounds__(kBlock) void plan_sort_kernel(const int32_t* __rest
 }
 
 // =============================================================================================
-// plan gather: one wave per (image, vertex), all views
+// plan gather: one block per (image, vertex), its waves stride the views
 // =============================================================================================
+// The rows of a vertex are short (~180 entries per view for SMPL in 1024^2 renders), so the kernel is bound by the
+// dependent-load chain row_ptr -> entry -> logit, not by bytes.  One wave per (vertex, view) keeps that chain at three
+// round trips, and the 4-deep predicated unroll puts every entry load of a typical row in flight at once.
+// Summation order is fixed: lane-strided partial sums in index order, butterfly wave_sum, views added in view order
+// by one thread - bit-reproducible run to run.
+template <int MODE, typename Fetch>
+__device__ __forceinline__ void lift_plan_body(Fetch fetch, const int32_t* __restrict__ row_ptr,
+                                               const int32_t* __restrict__ ent_pix, const float* __restrict__ ent_w,
+                                               int V, int nv, float param, float* __restrict__ out,
+                                               float* __restrict__ nviews) {
+    constexpr int kWaves = kBlock / 64;
+    __shared__ float s_ratio[kWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of vertex ids, i.e. (for a mesh
+    // numbered coherently, like SMPL) one region of each view, so its L2 fetches ~1/8 of the masks instead of all
+    const int chunk = gridDim.x >> 3;
+    const int vert = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3), b = blockIdx.y;
+    if (vert >= nv) return;  // whole block
+    float pred = 0.0f, seen_views = 0.0f;  // thread 0 only
+    for (int v0 = 0; v0 < V; v0 += kWaves) {
+        const int v = v0 + wave;
+        float ratio = -1.0f;  // "vertex not seen in this view"
+        if (v < V) {
+            const int row = v * nv + vert;
+            const int s = row_ptr[row], e = row_ptr[row + 1];
+            float votes = 0.0f, cnt = 0.0f;
+            for (int i = s + lane; i < e; i += 256) {
+                int p[4];
+                float w[4], x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = min(i + 64 * k, e - 1);  // clamped: the load is always legal, the add is predicated
+                    p[k] = ent_pix[j];
+                    w[k] = ent_w[j];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = fetch(v, p[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (MODE == 0) x[k] = fminf(fmaxf(x[k], -param), param);
+                    const float m = sigmoid_f32(x[k]);
+                    if (i + 64 * k < e && (MODE == 0 || m > param)) {
+                        votes += w[k] * m;
+                        cnt += w[k];
+                    }
+                }
+            }
+            votes = wave_sum(votes);
+            cnt = wave_sum(cnt);
+            if (cnt > 0.0f) ratio = votes / cnt;  // components.py:273-277
+        }
+        if (lane == 0) s_ratio[wave] = ratio;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < kWaves && v0 + k < V; ++k)
+                if (s_ratio[k] >= 0.0f) {
+                    pred += s_ratio[k];
+                    seen_views += 1.0f;
+                }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (seen_views > 0.0f) pred = pred / seen_views;           // components.py:240-241
+        if (MODE == 0) pred = fminf(fmaxf(pred, 0.0f), 1.0f);      // components.py:242 (soft only)
+        out[(int64_t)b * nv + vert] = pred;
+        if (nviews) nviews[(int64_t)b * nv + vert] = seen_views;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void lift_plan_kernel(const float* __restrict__ logits,
                                                            const int32_t* __restrict__ row_ptr,
@@ -182,58 +252,30 @@ __global__ __launch_bounds__(kBlock) void lift_plan_kernel(const float* __restri
                                                            const float* __restrict__ ent_w, int V, int64_t HW, int nv,
                                                            float param, float* __restrict__ out,
                                                            float* __restrict__ nviews) {
-    const int lane = threadIdx.x & 63;
-    const int vert = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    if (vert >= nv) return;
-    float pred = 0.0f, seen_views = 0.0f;
-    for (int v = 0; v < V; ++v) {
-        const float* __restrict__ lg = logits + ((int64_t)b * V + v) * HW;
-        const int row = v * nv + vert;
-        const int s = row_ptr[row], e = row_ptr[row + 1];
-        float votes = 0.0f, cnt = 0.0f;
-        int i = s + lane;
-        // 2-way unroll: two independent gather chains per lane
-        for (; i + 64 < e; i += 128) {
-            const int p0 = ent_pix[i], p1 = ent_pix[i + 64];
-            const float w0 = ent_w[i], w1 = ent_w[i + 64];
-            float x0 = lg[p0], x1 = lg[p1];
-            if (MODE == 0) {
-                x0 = fminf(fmaxf(x0, -param), param);
-                x1 = fminf(fmaxf(x1, -param), param);
-            }
-            const float m0 = sigmoid_f32(x0), m1 = sigmoid_f32(x1);
-            if (MODE == 0) {
-                votes += w0 * m0;
-                cnt += w0;
-                votes += w1 * m1;
-                cnt += w1;
-            } else {
-                if (m0 > param) { votes += w0 * m0; cnt += w0; }
-                if (m1 > param) { votes += w1 * m1; cnt += w1; }
-            }
-        }
-        if (i < e) {
-            const int p0 = ent_pix[i];
-            const float w0 = ent_w[i];
-            float x0 = lg[p0];
-            if (MODE == 0) x0 = fminf(fmaxf(x0, -param), param);
-            const float m0 = sigmoid_f32(x0);
-            if (MODE == 0 || m0 > param) { votes += w0 * m0; cnt += w0; }
-        }
-        votes = wave_sum(votes);
-        cnt = wave_sum(cnt);
-        if (cnt > 0.0f) {  // components.py:273-277
-            pred += votes / cnt;
-            seen_views += 1.0f;
-        }
-    }
-    if (lane == 0) {
-        if (seen_views > 0.0f) pred = pred / seen_views;           // components.py:240-241
-        if (MODE == 0) pred = fminf(fmaxf(pred, 0.0f), 1.0f);      // components.py:242 (soft only)
-        out[(int64_t)b * nv + vert] = pred;
-        if (nviews) nviews[(int64_t)b * nv + vert] = seen_views;
-    }
+    const float* __restrict__ lg = logits + (int64_t)blockIdx.y * V * HW;
+    lift_plan_body<MODE>([&](int v, int p) { return lg[(int64_t)v * HW + p]; }, row_ptr, ent_pix, ent_w, V, nv, param,
+                         out, nviews);
+}
+
+// Same gather, but the logit of a pixel is evaluated on the fly from the 256x256 low-res mask with the exact
+// arithmetic of Sam.postprocess_masks (bilinear.h): the full-resolution masks are never read back.
+// Measured (profiles/r01_lift_microbench.json): four L1/L2 gathers + address math per entry cost more than the one
+// gather from the freshly written (Infinity-Cache resident) full-res mask, so the two-step path stays the default.
+template <int MODE, typename T>
+__global__ __launch_bounds__(kBlock) void lift_plan_lowres_kernel(const T* __restrict__ low, int lh, int lw, int img,
+                                                                  int in_h, int in_w, int oh, int ow,
+                                                                  const int32_t* __restrict__ row_ptr,
+                                                                  const int32_t* __restrict__ ent_pix,
+                                                                  const float* __restrict__ ent_w, int V, int nv,
+                                                                  float param, float* __restrict__ out,
+                                                                  float* __restrict__ nviews) {
+    const T* __restrict__ lo = low + (int64_t)blockIdx.y * V * lh * lw;
+    lift_plan_body<MODE>(
+        [&](int v, int p) {
+            const int y = p / ow, x = p - y * ow;
+            return ivlm_bilinear::postprocess_at(lo + (int64_t)v * lh * lw, lh, lw, img, in_h, in_w, oh, ow, y, x);
+        },
+        row_ptr, ent_pix, ent_w, V, nv, param, out, nviews);
 }
 
 // =============================================================================================
@@ -415,13 +457,36 @@ int ivlm_lift_mesh_plan(const float* logits, const int32_t* row_ptr, const int32
                         ivlm_stream_t stream) {
     IVLM_CHECK_ARG(logits && row_ptr && ent_pix && ent_w && out);
     IVLM_CHECK_ARG(B > 0 && V > 0 && HW > 0 && Nv > 0 && B <= 65535 && (mode == 0 || mode == 1));
-    dim3 grid((Nv + kBlock / 64 - 1) / (kBlock / 64), B);
+    dim3 grid(8 * ((Nv + 7) / 8), B);
     hipStream_t st = ivlm_stream(stream);
     ivlm_enter();
     if (mode == 0)
         lift_plan_kernel<0><<<grid, kBlock, 0, st>>>(logits, row_ptr, ent_pix, ent_w, V, HW, Nv, param, out, nviews);
     else
         lift_plan_kernel<1><<<grid, kBlock, 0, st>>>(logits, row_ptr, ent_pix, ent_w, V, HW, Nv, param, out, nviews);
+    return ivlm_launch_status();
+}
+
+int ivlm_lift_mesh_plan_lowres(const void* low, int dtype, int lh, int lw, int img, int in_h, int in_w, int oh, int ow,
+                               const int32_t* row_ptr, const int32_t* ent_pix, const float* ent_w, int B, int V, int Nv,
+                               int mode, float param, float* out, float* nviews, ivlm_stream_t stream) {
+    IVLM_CHECK_ARG(low && row_ptr && ent_pix && ent_w && out);
+    IVLM_CHECK_ARG(B > 0 && V > 0 && Nv > 0 && B <= 65535 && (mode == 0 || mode == 1));
+    IVLM_CHECK_ARG(lh > 0 && lw > 0 && img > 0 && in_h > 0 && in_w > 0 && in_h <= img && in_w <= img && oh > 0 && ow > 0);
+    dim3 grid(8 * ((Nv + 7) / 8), B);
+    hipStream_t st = ivlm_stream(stream);
+    ivlm_enter();
+#define IVLM_LL(MODE, T)                                                                                          \
+    lift_plan_lowres_kernel<MODE, T><<<grid, kBlock, 0, st>>>(static_cast<const T*>(low), lh, lw, img, in_h, in_w, oh, \
+                                                              ow, row_ptr, ent_pix, ent_w, V, Nv, param, out, nviews)
+    if (dtype == IVLM_F32) {
+        if (mode == 0) IVLM_LL(0, float); else IVLM_LL(1, float);
+    } else if (dtype == IVLM_BF16) {
+        if (mode == 0) IVLM_LL(0, bf16_t); else IVLM_LL(1, bf16_t);
+    } else {
+        return IVLM_ERR_UNSUPPORTED;
+    }
+#undef IVLM_LL
     return ivlm_launch_status();
 }
 

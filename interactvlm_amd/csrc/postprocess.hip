@@ -3,47 +3,10 @@
 // One pass, no img x img intermediate: every output pixel composes the two resizes on the fly
 // (4 taps when the second resize is the identity, 16 otherwise).  The low-res source (256 KB per
 // view) stays L2-resident; the kernel is bound by the fp32 store stream (16-byte stores).
-#include "ivlm_common.h"
+#include "bilinear.h"
 
 namespace {
-
-struct Axis {
-    int i0, i1;
-    float l0, l1;
-};
-
-// torch area_pixel_compute_source_index + upsample_bilinear2d index/lambda rule
-__device__ __forceinline__ Axis axis_src(int dst, float scale, int n_in) {
-    float s = ((float)dst + 0.5f) * scale - 0.5f;
-    s = s < 0.0f ? 0.0f : s;
-    int i0 = (int)s;
-    i0 = i0 > n_in - 1 ? n_in - 1 : i0;
-    Axis a;
-    a.i0 = i0;
-    a.i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
-    a.l1 = s - (float)i0;
-    a.l0 = 1.0f - a.l1;
-    return a;
-}
-
-template <typename T>
-__device__ __forceinline__ float ld(const T* p);
-template <>
-__device__ __forceinline__ float ld<float>(const float* p) { return *p; }
-template <>
-__device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
-
-// value of the (virtual) img x img intermediate at integer pixel (yy, xx)
-template <typename T>
-__device__ __forceinline__ float stage1(const T* __restrict__ low, int h, int w, float s1y, float s1x, int yy,
-                                        int xx) {
-    const Axis ay = axis_src(yy, s1y, h), ax = axis_src(xx, s1x, w);
-    const T* r0 = low + (size_t)ay.i0 * w;
-    const T* r1 = low + (size_t)ay.i1 * w;
-    const float t = ld(r0 + ax.i0) * ax.l0 + ld(r0 + ax.i1) * ax.l1;
-    const float b = ld(r1 + ax.i0) * ax.l0 + ld(r1 + ax.i1) * ax.l1;
-    return t * ay.l0 + b * ay.l1;
-}
+using namespace ivlm_bilinear;
 
 template <typename T, bool IDENT2, bool SIGMOID>
 __global__ __launch_bounds__(256) void postprocess_kernel(const T* __restrict__ low, int h, int w, int img, int in_h,

@@ -78,6 +78,7 @@ class InteractVLMForCausalLM:
         self.use_fusion = self.use_uncertainty = False  # off in every released config (scripts/run_train.sh:61-62)
         self.debug_taps = None  # set to a dict to record intermediate tensors (tests / diagnostics only)
         self.overlap_sam_encoder = True
+        self.fused_lowres_lift = False  # measured slower than lifting the (cache-resident) full-res masks
         self._side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
 
         self.vision_tower = ClipTower(w, c.clip, dev)
@@ -212,6 +213,7 @@ class InteractVLMForCausalLM:
         low, iou = self.model.visual_model.mask_decoder(image_embeddings, emb)
         if self.debug_taps is not None:
             self.debug_taps.update(prompt_emb=emb, low_res=low, iou=iou)
+        self._last_low = (low, tuple(input_size), tuple(original_size))
         return postprocess_masks(low, input_size, original_size, self.config.sam.img_size)[:, 0], iou
 
     # ------------------------------------------------------------------------------------------
@@ -329,7 +331,13 @@ class InteractVLMForCausalLM:
         pred_contact_3d = None
         if pred_masks[0].shape[0] > 0:
             if self.hC_loss_weight > 0 and "hcontact" in contact_type:
-                pred_contact_3d = self.human_3d_contact_predictor(pred_masks)
+                low, isz, osz = self._last_low
+                if self.fused_lowres_lift and low.shape[0] == self.multiview_channels:
+                    # same numbers as lifting pred_masks, without re-reading the full-resolution masks (8f-1)
+                    pred_contact_3d = self.human_3d_contact_predictor.forward_lowres(
+                        [low], isz, osz, self.config.sam.img_size)
+                else:
+                    pred_contact_3d = self.human_3d_contact_predictor(pred_masks)
             elif (self.oC_loss_weight > 0 and "ocontact" in contact_type) or "oafford" in contact_type:
                 # same operator precedence as the reference (InteractVLM.py:626): 'oafford' always takes the mesh lift
                 pred_contact_3d = self.object_3d_contact_predictor(pred_masks, ds_names=["ocontact"],

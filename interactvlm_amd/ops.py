@@ -31,23 +31,34 @@ class KernelTimer:
     def stop(self):
         self.enabled = False
 
-    def time(self, name, work, fn):
+    def time(self, name, work, fn, tag=None):
         if not self.enabled:
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         r = fn()
         b.record()
-        self.records.setdefault(name, []).append((a, b, work))
+        self.records.setdefault(name, []).append((a, b, work, tag))
         return r
+
+    def by_tag(self, name):
+        """per-tag (e.g. GEMM shape) totals of one record family: tag -> {launches, total_s, work}."""
+        torch.cuda.synchronize()
+        out = {}
+        for a, b, w, tag in self.records.get(name, []):
+            d = out.setdefault(tag, {"launches": 0, "total_s": 0.0, "work": 0.0})
+            d["launches"] += 1
+            d["total_s"] += a.elapsed_time(b) * 1e-3
+            d["work"] += w
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for name, rec in self.records.items():
-            ms = [a.elapsed_time(b) for a, b, _ in rec]
+            ms = [a.elapsed_time(b) for a, b, _, _ in rec]
             out[name] = {"launches": len(rec), "total_s": sum(ms) * 1e-3, "avg_us": sum(ms) / len(ms) * 1e3,
-                         "work": float(sum(w for _, _, w in rec))}
+                         "work": float(sum(r[2] for r in rec))}
         return out
 
 
@@ -128,6 +139,27 @@ def lift_mesh_plan(logits: torch.Tensor, plan: LiftPlan, mode: int = 0, param: f
     return (out, nviews) if want_nviews else out
 
 
+def lift_mesh_plan_lowres(low, plan: LiftPlan, input_size, original_size, img_size=1024, mode=0, param=20.0,
+                          want_nviews=False):
+    """low f32|bf16 [B,V,lh,lw] -> contacts [B,Nv]: == lift_mesh_plan(postprocess_masks(low)), fused."""
+    lib = _lib.load()
+    low = _req(low, None, "low")
+    B, V, lh, lw = low.shape
+    oh, ow = int(original_size[0]), int(original_size[1])
+    assert V == plan.V and oh * ow == plan.HW, "plan was built for a different mask size"
+    out = torch.empty(B, plan.num_vertices, dtype=torch.float32, device=low.device)
+    nviews = torch.empty_like(out) if want_nviews else None
+    call = lambda: check(lib.ivlm_lift_mesh_plan_lowres(
+        low.data_ptr(), _dt(low), lh, lw, int(img_size), int(input_size[0]), int(input_size[1]), oh, ow,
+        plan.row_ptr.data_ptr(), plan.ent_pix.data_ptr(), plan.ent_w.data_ptr(), B, V, plan.num_vertices, mode,
+        float(param), out.data_ptr(), _p(nviews), _stream()), "lift_mesh_plan_lowres")
+    if TIMER.enabled:
+        TIMER.time("lift_mesh_plan", float(B) * (V * plan.HW * 28 + 2 * plan.num_vertices * 4), call)
+    else:
+        call()
+    return (out, nviews) if want_nviews else out
+
+
 _ws_cache = {}
 
 
@@ -201,6 +233,23 @@ ACT = {"none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "swiglu": 5,
 BF16 = torch.bfloat16
 
 
+SPLITK = True  # small-M GEMMs (prefill, CLIP): cut K so that >= ~3 tiles per CU are in flight
+
+
+def _splitk_choice(M, N, K, act, rms):
+    """number of K slices (1 = plain kernel): only where the 128x64 tiling leaves most of the 256 CUs idle."""
+    if not SPLITK or M <= 8 or M > 1024 or act == "swiglu" or rms is not None or N % 4 or K % 64:
+        return 1
+    tiles = ((M + 127) // 128) * ((N + 63) // 64)
+    if tiles >= 256:
+        return 1
+    best, k64 = 1, K // 64
+    for sp in range(2, min(8, 1024 // tiles) + 1):
+        if k64 % sp == 0 and K // sp >= 512:
+            best = sp
+    return best
+
+
 def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False, rms=None):
     """act(x @ weight.T + bias) + residual.  x [..., K] bf16 (last dim contiguous, uniform row stride),
     weight [N, K] bf16."""
@@ -228,11 +277,18 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
         x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
         _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == torch.float32 else 0, 1, 0, 0, 0, 0,
         _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, _stream()), "gemm_bf16")
+    splits = _splitk_choice(M, N, K, act, rms)
+    if splits > 1 and o2.stride(0) % 4 == 0:
+        ws = torch.empty(splits * M * N, dtype=torch.float32, device=x.device)  # caching allocator: stream-safe
+        call = lambda: check(lib.ivlm_gemm_bf16_splitk(
+            x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
+            _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out_f32 else 0, splits, ws.data_ptr(),
+            ws.numel() * 4, _stream()), "gemm_bf16_splitk")
     if TIMER.enabled:  # work = algorithmic FLOPs (MFMA path) or weight bytes (GEMV path)
         if M > 8:
-            TIMER.time("gemm_bf16_mfma", 2.0 * M * N * K, call)
+            TIMER.time("gemm_bf16_mfma", 2.0 * M * N * K, call, tag=(M, N, K, act))
         else:
-            TIMER.time("gemv_bf16", 2.0 * N * K, call)
+            TIMER.time("gemv_bf16", 2.0 * N * K, call, tag=(M, N, K, act))
     else:
         call()
     return out

@@ -81,3 +81,35 @@ def images(cfg: IvlmCfg, device, seed: int = 0, batch: int = 1):
     ic = torch.randn(batch, 3, cfg.clip.image_size, cfg.clip.image_size, generator=g, device=device).to(BF16)
     im = torch.randn(batch, cfg.multiview_channels, 3, S, S, generator=g, device=device).to(BF16)
     return ic, im
+
+
+def body_mesh(n_rings: int = 82, n_seg: int = 84, semi_axes=(0.5, 0.85, 0.22)):
+    """A closed 6890-vertex / 13776-face stand-in for the SMPL template (same counts: 2 + 82*84 vertices,
+    2*84 + 81*84*2 faces): a lobed ellipsoid about the size of a vitruvian-pose body, vertices numbered ring by ring
+    so that neighbouring ids are neighbours on the surface, as in SMPL.  -> (verts f32 [Nv,3], faces i32 [Nf,3])."""
+    th = (np.arange(1, n_rings + 1, dtype=np.float64) / (n_rings + 1)) * np.pi
+    ph = np.arange(n_seg, dtype=np.float64) / n_seg * 2 * np.pi
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    lobes = 1.0 + 0.25 * np.cos(4 * P) * np.sin(T) ** 2  # limb-like bulges
+    a, b, c = semi_axes
+    ring = np.stack([a * lobes * np.sin(T) * np.cos(P), b * np.cos(T), c * lobes * np.sin(T) * np.sin(P)], -1)
+    verts = np.concatenate([[[0.0, b, 0.0]], ring.reshape(-1, 3), [[0.0, -b, 0.0]]]).astype(np.float32)
+    idx = lambda r, s: 1 + r * n_seg + (s % n_seg)
+    faces = []
+    for s in range(n_seg):
+        faces.append((0, idx(0, s + 1), idx(0, s)))
+        faces.append((len(verts) - 1, idx(n_rings - 1, s), idx(n_rings - 1, s + 1)))
+    for r in range(n_rings - 1):
+        for s in range(n_seg):
+            faces.append((idx(r, s), idx(r, s + 1), idx(r + 1, s)))
+            faces.append((idx(r, s + 1), idx(r + 1, s + 1), idx(r + 1, s)))
+    return torch.from_numpy(verts), torch.tensor(faces, dtype=torch.int32)
+
+
+def body_lift_tables(device, view_type="4MV-Z_Vitru", image_size=(1024, 1024)):
+    """pixel_to_vertex_map_1024 / bary_coords_map_1024 of ``body_mesh`` under the four hcontact cameras, produced by
+    the HIP rasteriser (render.human_lift_tables) -> (vid i32 [4,H,W,3], bary f32 [4,H,W,3]) on the device."""
+    from . import render
+
+    v, f = body_mesh()
+    return render.human_lift_tables(v.to(device), f.to(device), view_type, image_size)

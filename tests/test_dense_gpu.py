@@ -51,6 +51,36 @@ def test_gemm_shapes(hip_lib, cuda, M, N, K, act):
     assert torch.allclose(got32.cpu(), ref, atol=3e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(330, 4096, 11008), (257, 1024, 4096), (257, 1024, 1024), (64, 256, 2048)])
+def test_gemm_splitk_matches_single_pass(hip_lib, cuda, M, N, K):
+    """Small-M shapes take the split-K path (ops._splitk_choice > 1): same numbers as the one-pass kernel up to fp32
+    summation order, and both within a bf16 ulp of the fp32 reference."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    assert ops._splitk_choice(M, N, K, "none", None) > 1
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(cuda)
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    b = _bf(torch.randn(N, generator=g) * 0.1).to(cuda)
+    r = _bf(torch.randn(M, N, generator=g)).to(cuda)
+    for act in ("none", "quick_gelu"):
+        split = ops.linear(x, w, b, act=act, residual=r, out_f32=True)
+        ops.SPLITK = False
+        try:
+            single = ops.linear(x, w, b, act=act, residual=r, out_f32=True)
+        finally:
+            ops.SPLITK = True
+        ref = _ref_act(x.float() @ w.float().T + b.float(), act) + r.float()
+        assert torch.allclose(split, single, atol=2e-5, rtol=1e-5)
+        assert torch.allclose(split, ref, atol=2e-4, rtol=1e-4)
+    out = torch.full((M, N + 8), 7.0, dtype=torch.bfloat16, device=cuda)  # strided output rows (ldc > N)
+    ops.linear(x, w, out=out[:, :N])
+    assert bool((out[:, N:] == 7.0).all())
+    assert torch.allclose(out[:, :N].float(), x.float() @ w.float().T, atol=2e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("tile", [64, 128, 256])
 def test_gemm_forced_tiles(hip_lib, cuda, tile):
     """Both block-tile configurations on a shape with ragged M/N edges and a K tail."""

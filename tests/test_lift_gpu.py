@@ -247,6 +247,34 @@ def test_postprocess_vs_oracle(hip_lib, cuda):
     np.testing.assert_allclose(s, 1 / (1 + np.exp(-cref.postprocess_masks(x, (1024, 1024), (1024, 1024)))), atol=1e-6)
 
 
+@pytest.mark.parametrize("ins,orig", [((1024, 1024), (1024, 1024)), ((1024, 683), (750, 500)), ((768, 1024), (600, 800))])
+def test_fused_lowres_lift_equals_two_step(hip_lib, cuda, ins, orig):
+    """ivlm_lift_mesh_plan_lowres == ivlm_postprocess_masks -> ivlm_lift_mesh_plan, bit for bit (same arithmetic),
+    and both match the oracle's postprocess + lift within TOL."""
+    import torch
+
+    from interactvlm_amd import ops, synth
+    from oracle import cref
+
+    V, NV, B = 4, 6890, 2
+    H, W = orig
+    vid, bary = synth.synth_mesh_tables(V, H, W, NV, fg=0.4, seed=3, patch=6)
+    plan = ops.LiftPlan(_t(vid, cuda, torch.int32), _t(bary, cuda), NV)
+    low = (np.random.default_rng(5).standard_normal((B, V, 256, 256)) * 6).astype(np.float32)
+    for dt in (torch.float32, torch.bfloat16):
+        low_t = _t(low, cuda).to(dt)
+        full = ops.postprocess_masks(low_t.reshape(B * V, 1, 256, 256), ins, orig).reshape(B, V, H, W)
+        for mode, param in ((0, 20.0), (1, 0.3)):
+            two = ops.lift_mesh_plan(full, plan, mode=mode, param=param)
+            one = ops.lift_mesh_plan_lowres(low_t, plan, ins, orig, 1024, mode=mode, param=param)
+            assert torch.equal(one, two)
+    exp, _ = cref.lift_mesh_soft(cref.postprocess_masks(low.reshape(B * V, 1, 256, 256), ins, orig).reshape(B, V, H, W),
+                                 vid, bary, NV)
+    got = ops.lift_mesh_plan_lowres(_t(low, cuda), plan, ins, orig, 1024).cpu().numpy()
+    np.testing.assert_allclose(got, exp, atol=1e-3, rtol=0)
+    _check_sets(got, exp, 1e-3)  # postprocess itself is only 3e-4-exact on non-identity second resizes
+
+
 def test_predictor_modules_match_reference_api(hip_lib, cuda, tmp_path):
     """The nn.Module mirrors: same constructor files / forward signatures as model/components.py."""
     import joblib

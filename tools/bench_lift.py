@@ -37,16 +37,33 @@ def main():
     dev = torch.device("cuda:0")
     V, H, W, NV, NP, B = 4, 1024, 1024, 6890, 2048, a.B
     res = {}
-    for name, patch in (("random", 0), ("clustered6", 6)):
-        vid, bary = synth.synth_mesh_tables(V, H, W, NV, fg=0.4, seed=0, patch=patch)
-        vid_t = torch.from_numpy(vid).to(dev, torch.int32)
-        bary_t = torch.from_numpy(bary).to(dev)
+    from interactvlm_amd import synthetic
+    for name, patch in (("random", 0), ("clustered6", 6), ("body_render", -1)):
+        if patch < 0:  # the bench.py tables: rasterised 6890-vertex body, coherent vertex numbering
+            vid_t, bary_t = synthetic.body_lift_tables(dev)
+            vid_t, bary_t = vid_t.contiguous(), bary_t.contiguous()
+        else:
+            vid, bary = synth.synth_mesh_tables(V, H, W, NV, fg=0.4, seed=0, patch=patch)
+            vid_t = torch.from_numpy(vid).to(dev, torch.int32)
+            bary_t = torch.from_numpy(bary).to(dev)
         lg = torch.randn(B, V, H, W, device=dev) * 4
         t0 = timeit(lambda: ops.LiftPlan(vid_t, bary_t, NV), iters=3, warm=1)
         plan = ops.LiftPlan(vid_t, bary_t, NV)
         t_plan = timeit(lambda: ops.lift_mesh_plan(lg, plan), a.iters)
         t_dense = timeit(lambda: ops.lift_mesh_dense(lg, vid_t, bary_t, NV), a.iters)
+        lowr = torch.randn(B, V, 256, 256, device=dev) * 4
+        t_fused = timeit(lambda: ops.lift_mesh_plan_lowres(lowr, plan, (1024, 1024), (1024, 1024)), a.iters)
+        t_post = timeit(lambda: ops.postprocess_masks(lowr.view(B * V, 1, 256, 256), (1024, 1024), (1024, 1024)), a.iters)
+        big = torch.empty(512 << 20, dtype=torch.uint8, device=dev)  # > 256 MB Infinity Cache: flush between launches
+        def cold():
+            big.zero_()
+            ops.lift_mesh_plan(lg, plan)
+        t_zero = timeit(lambda: big.zero_(), 10, 2)
+        t_cold = timeit(cold, 10, 2) - t_zero
         res[name] = {
+            "plan_cold_us": t_cold * 1e6, "plan_cold_alg_GBps": B * ALG_BYTES_MESH / t_cold / 1e9,
+            "fused_lowres_us": t_fused * 1e6, "fused_lowres_alg_GBps": B * ALG_BYTES_MESH / t_fused / 1e9,
+            "postprocess_us": t_post * 1e6,
             "plan_build_ms": t0 * 1e3, "nnz": plan.nnz, "plan_bytes": plan.bytes(),
             "plan_us": t_plan * 1e6, "plan_alg_GBps": B * ALG_BYTES_MESH / t_plan / 1e9,
             "plan_actual_GBps": (plan.bytes() + B * (plan.nnz * 4)) / t_plan / 1e9,
