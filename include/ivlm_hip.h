@@ -163,6 +163,30 @@ int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, co
 int ivlm_relpos_bias(const void *q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void *tab_h, const void *tab_w,
                      int B, int H, int SH, int SW, int D, float *rel_h, float *rel_w, ivlm_stream_t stream);
 
+/* Whole greedy generation after the prefill, in ONE persistent launch (HF GenerationMixin greedy search driven by
+ * InteractVLM.evaluate, model/InteractVLM.py:524-531; per token: LlamaModel.forward of one position with the KV
+ * cache, final RMSNorm, lm_head, argmax, embed_tokens of the chosen id).  One resident workgroup per CU streams
+ * contiguous row slabs of every weight matrix; phases are separated by a device-wide barrier; argmax, the EOS test
+ * and the optional forced ids run on the device.
+ *   layer_ptrs  device int64 [L][6]: addresses of input_layernorm.weight, q|k|v weight [3*hidden, hidden] (q, k, v
+ *               rows concatenated), o_proj.weight, post_attention_layernorm.weight, gate|up weight [2*inter, hidden]
+ *               (rows interleaved gate_0, up_0, gate_1, ...), down_proj.weight [hidden, inter]; all bf16, dense.
+ *   kcache/vcache bf16 [L, max_len, H, D] (cache_layer_stride elements per layer), holding positions < pos0.
+ *   hidden_out  bf16 [>= pos0 + n_max - 1, hidden]: row pos0-1 is the INPUT (final-normed hidden state of the last
+ *               prompt position); rows pos0.. receive the final-normed hidden state of each generated position.
+ *   forced      int32 [n_max] or NULL: ids fed back instead of the argmax (teacher forcing; argmax still computed).
+ *   new_ids / argmax_ids int32 [n_max]; generation stops after an id == eos or n_max ids.
+ *   workspace   >= ivlm_llama_generate_workspace_bytes, 256-byte aligned; after the stream has drained, its first two
+ *               int32 are {number of ids generated, error flag (1: a barrier wait exceeded 2 s - results invalid)}.
+ * hidden, inter >= 512 and % 8 == 0, H * D == hidden, D <= 128, H <= number of CUs. */
+size_t ivlm_llama_generate_workspace_bytes(int hidden, int inter);
+int ivlm_llama_generate(const int64_t *layer_ptrs, int L, int H, int D, int hidden, int inter, int vocab, float eps,
+                        float scale, const float *cos_tab, const float *sin_tab, void *kcache, void *vcache,
+                        int64_t cache_layer_stride, int max_len, const void *embed, const void *final_norm,
+                        const void *lm_head, void *hidden_out, int pos0, int n_max, int eos, const int32_t *forced,
+                        int32_t *new_ids, int32_t *argmax_ids, void *workspace, size_t workspace_bytes,
+                        ivlm_stream_t stream);
+
 /* One decode step of HF LlamaAttention with a KV cache, for the newest token only: rotate-half RoPE of q,k at
  * position pos, append k,v to kcache/vcache [Tmax,H,D], o = softmax(q.K[0..pos]^T * scale).V[0..pos].
  * qkv bf16 [3,H,D] (output of the fused q|k|v projection), o bf16 [H,D]; D <= 128, pos < 4096. */

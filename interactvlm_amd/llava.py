@@ -88,6 +88,12 @@ class Llama:
         self.kcache = torch.zeros(cfg.layers, max_len, H, hd, dtype=BF16, device=device)
         self.vcache = torch.zeros(cfg.layers, max_len, H, hd, dtype=BF16, device=device)
         self.rope = ops.rope_table(max_len, hd, cfg.theta, device)  # fp32 cos/sin, computed once
+        # device-side table of the per-layer weight addresses for the persistent generation kernel
+        self.layer_ptrs = torch.tensor(
+            [[L[k].data_ptr() for k in ("ln1", "qkv", "o", "ln2", "gu", "down")] for L in self.layers],
+            dtype=torch.int64, device=device)
+        self.can_fuse_generate = (cfg.hidden >= 512 and cfg.inter >= 512 and cfg.hidden % 8 == 0 and cfg.inter % 8 == 0
+                                  and hd <= 128 and hd % 16 == 0)
 
     def embed_ids(self, ids_i32, out=None):
         """embed_tokens gather: ids int32 [n] -> [n, hidden]."""
@@ -127,6 +133,17 @@ class Llama:
             h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))
             x = ops.linear(h, L["down"], residual=x)
         return ops.rmsnorm(x, self.norm, c.eps)
+
+    def generate_fused(self, hidden_all, pos0, n_max, eos, forced=None):
+        """All decode steps in one persistent launch (ops.llama_generate).  hidden_all [>= pos0+n_max-1, hidden]: row
+        pos0-1 must hold the final-normed hidden state of the last prompt position; rows pos0.. are filled in.
+        -> (new_ids, argmax_ids, status) int32 device tensors."""
+        c = self.cfg
+        H, hd = c.heads, c.hidden // c.heads
+        assert pos0 + n_max - 1 <= self.max_len
+        return ops.llama_generate(self.layer_ptrs, c.layers, H, hd, c.hidden, c.inter, self.lm_head.shape[0], c.eps,
+                                  hd ** -0.5, self.rope, self.kcache, self.vcache, self.max_len, self.embed, self.norm,
+                                  self.lm_head, hidden_all, pos0, n_max, eos, forced)
 
     def logits(self, hidden_rows):
         """lm_head on [n, hidden] -> f32 [n, vocab]."""

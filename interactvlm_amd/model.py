@@ -28,6 +28,10 @@ from .weights import IvlmCfg
 BF16 = torch.bfloat16
 
 
+def forced_dev_early(forced, device):
+    return None if forced is None else torch.tensor([int(t) for t in forced], dtype=torch.int32, device=device)
+
+
 class _CamPoseEncoder:
     """CamPoseEncoder / ViewIndexCamPoseEncoder / VIv1CamPoseEncoder (components.py:491-572).
     The 5-wide first layer is zero-padded to K=8 (16-byte rows) for the streaming GEMV."""
@@ -78,6 +82,10 @@ class InteractVLMForCausalLM:
         self.use_fusion = self.use_uncertainty = False  # off in every released config (scripts/run_train.sh:61-62)
         self.debug_taps = None  # set to a dict to record intermediate tensors (tests / diagnostics only)
         self.overlap_sam_encoder = True
+        # persistent one-launch greedy decode (csrc/generate.hip): correct and bit-reproducible, but measured SLOWER than the
+        # per-op path on MI355X (3.43 vs 2.93 ms/token for 7B: every phase boundary costs ~9 us of device-wide sync
+        # skew + store/load latency, more than a kernel boundary) - kept as an opt-in experiment
+        self.fused_generate = False
         self.fused_lowres_lift = False  # measured slower than lifting the (cache-resident) full-res masks
         self._side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
 
@@ -270,6 +278,18 @@ class InteractVLMForCausalLM:
         hidden_all = torch.empty(T0 + n_max, self.config.llama.hidden, dtype=BF16, device=self.device)
         h = self.llm.forward(x, 0)
         hidden_all[:T0].copy_(h)
+        if self.fused_generate and self.llm.can_fuse_generate:
+            if forced_new_tokens is not None:
+                assert all(0 <= int(t) < self.llm.embed.shape[0] for t in forced_new_tokens)
+            new_t, arg_t, status = self.llm.generate_fused(hidden_all, T0, n_max, eos_token_id, forced_dev_early(
+                forced_new_tokens, self.device))
+            st = status.cpu()  # the one host sync of the generation
+            if int(st[1]) != 0:
+                raise ops.IvlmError("llama_generate: device-wide barrier timed out (GPU oversubscribed?)")
+            n = int(st[0])
+            self.last_argmax = [arg_t[i: i + 1] for i in range(n)]
+            out_ids = torch.cat([ids.cpu(), new_t[:n].cpu().to(ids.dtype)])[None]
+            return out_ids, hidden_all[: T0 + n - 1]
         new_ids = []
         last = h[T0 - 1: T0]
         pos = T0

@@ -466,6 +466,33 @@ def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, ta
     return out
 
 
+def llama_generate(layer_ptrs, L, H, D, hidden, inter, vocab, eps, scale, rope, kcache, vcache, max_len, embed, final_norm,
+                   lm_head, hidden_out, pos0, n_max, eos, forced=None):
+    """Whole greedy generation after the prefill in one persistent launch (ivlm_llama_generate).
+    Returns (new_ids i32 [n_max], argmax_ids i32 [n_max], status i32 [2]) device tensors; status = (n generated, error)."""
+    lib = _lib.load()
+    dev = hidden_out.device
+    new_ids = torch.zeros(n_max, dtype=torch.int32, device=dev)
+    arg_ids = torch.zeros(n_max, dtype=torch.int32, device=dev)
+    nbytes = lib.ivlm_llama_generate_workspace_bytes(hidden, inter)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    assert kcache.is_contiguous() and vcache.is_contiguous() and hidden_out.is_contiguous()
+    if forced is not None:
+        assert forced.dtype == torch.int32 and forced.numel() >= n_max
+    call = lambda: check(lib.ivlm_llama_generate(
+        layer_ptrs.data_ptr(), L, H, D, hidden, inter, vocab, float(eps), float(scale), rope[0].data_ptr(),
+        rope[1].data_ptr(), kcache.data_ptr(), vcache.data_ptr(), kcache.stride(0), int(max_len), embed.data_ptr(),
+        final_norm.data_ptr(), lm_head.data_ptr(), hidden_out.data_ptr(), int(pos0), int(n_max), int(eos),
+        _p(forced), new_ids.data_ptr(), arg_ids.data_ptr(), ws.data_ptr(), nbytes, _stream()), "llama_generate")
+    if TIMER.enabled:  # work = upper bound of the weight bytes streamed (n_max tokens; fewer if EOS comes early)
+        per_tok = 2.0 * (L * (4.0 * hidden * hidden + 3.0 * hidden * inter) + float(vocab) * hidden)
+        TIMER.time("llama_generate", per_tok * n_max - 2.0 * L * (4.0 * hidden * hidden + 3.0 * hidden * inter), call)
+    else:
+        call()
+    llama_generate.last_workspace = ws  # debugging (IVLM_GEN_TRACE=1: timestamps behind the scratch vectors)
+    return new_ids, arg_ids, ws[:8].view(torch.int32)
+
+
 # --------------------------------------------------------------------------------------------
 # right after the path: metrics, SMPL -> SMPL-X transfer
 # --------------------------------------------------------------------------------------------

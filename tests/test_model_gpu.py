@@ -129,6 +129,69 @@ def test_clip_and_llama_vs_oracle(hip_lib, cuda):
     assert int(ops.argmax(llm.logits(full[-1:]))[0]) == int(lg.argmax())
 
 
+@pytest.mark.parametrize("hidden,heads,inter,vocab", [(1024, 8, 1376, 1003), (512, 4, 1024, 1000)])
+def test_persistent_generate_vs_per_op_and_oracle(hip_lib, cuda, hidden, heads, inter, vocab):
+    """ivlm_llama_generate (one persistent launch: all layers of all new tokens, device-side argmax / EOS) against
+    (a) the per-op decode path token by token and (b) the fp32 oracle run teacher-forced over the same ids.
+    inter = 1376 makes rows 172 chunks long: not a whole number of waves (the 'straddle' reduction, like 11008)."""
+    import torch
+
+    from interactvlm_amd import llava
+    from interactvlm_amd import weights as Wt
+    from oracle import nn as O
+
+    lc = Wt.LlamaCfg(hidden=hidden, layers=3, heads=heads, inter=inter, vocab=vocab)
+    w = _bf16_weights(Wt.llama_spec(lc))
+    g = torch.Generator().manual_seed(7)
+    T0, n_new = 37, 12
+    emb = (torch.randn(T0, hidden, generator=g) * 0.5).to(torch.bfloat16)
+
+    def prefill():
+        llm = llava.Llama(w, lc, cuda, max_len=64)
+        hid = torch.zeros(T0 + n_new, hidden, dtype=torch.bfloat16, device=cuda)
+        hid[:T0] = llm.forward(emb.to(cuda), 0)
+        return llm, hid
+
+    # (a) free-running greedy: per-op loop vs persistent kernel
+    llm_a, hid_a = prefill()
+    ids_a, last = [], hid_a[T0 - 1: T0]
+    from interactvlm_amd import ops
+    for step in range(n_new):
+        tok = int(ops.argmax(llm_a.logits(last))[0])
+        ids_a.append(tok)
+        if step == n_new - 1:
+            break
+        last = llm_a.forward(llm_a.embed_ids(torch.tensor([tok], dtype=torch.int32, device=cuda)), T0 + step)
+        hid_a[T0 + step] = last[0]
+    llm_b, hid_b = prefill()
+    new_ids, arg_ids, status = llm_b.generate_fused(hid_b, T0, n_new, eos=-1)
+    st = status.cpu().tolist()
+    assert st == [n_new, 0], st
+    assert new_ids.cpu().tolist() == ids_a and arg_ids.cpu().tolist() == ids_a
+    assert _rel_err(hid_b[: T0 + n_new - 1], hid_a[: T0 + n_new - 1].float().cpu()) < 2e-2
+    assert _rel_err(llm_b.kcache[:, : T0 + n_new - 1], llm_a.kcache[:, : T0 + n_new - 1].float().cpu()) < 2e-2
+    # run-to-run bit reproducibility (fixed summation order, no atomics on data)
+    llm_c, hid_c = prefill()
+    llm_c.generate_fused(hid_c, T0, n_new, eos=-1)
+    assert torch.equal(hid_c, hid_b)
+
+    # (b) teacher-forced ids + EOS stop, against the fp32 oracle over the whole sequence
+    forced = [5, 17, 900, 3, 44, 2, 8, 9]  # EOS (2) at index 5: generation must stop there
+    llm_d, hid_d = prefill()
+    f_t = torch.tensor(forced, dtype=torch.int32, device=cuda)
+    new_ids, arg_ids, status = llm_d.generate_fused(hid_d, T0, len(forced), eos=2, forced=f_t)
+    assert status.cpu().tolist() == [6, 0]
+    assert new_ids.cpu().tolist()[:6] == forced[:6]
+    seq = torch.cat([emb.float(), w["model.embed_tokens.weight"][forced[:5]].float()])
+    ref = O.llama(w, "model", seq[None], lc.layers, heads)[0]
+    assert _rel_err(hid_d[: T0 + 5], ref) < 4e-2
+    # the argmax the kernel reports at each step == argmax of lm_head over ITS OWN hidden state of that step
+    lg = hid_d[T0 - 1: T0 + 5].float().cpu() @ w["lm_head.weight"].float().T
+    top2 = lg.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-2
+    assert (arg_ids.cpu()[:6][clear] == lg.argmax(-1)[clear].to(torch.int32)).all()
+
+
 def _toy(golden_dir):
     import torch
 
@@ -206,3 +269,10 @@ def test_model_forward_vs_reference_golden(hip_lib, cuda, golden_dir):
     ev2 = m.evaluate(images_clip.to(bf).to(cuda), images.to(bf).to(cuda), ids[None, :L0], cams, [(1024, 1024)],
                      [(1024, 1024)], contact_type="hcontact", forced_new_tokens=ids[L0:].tolist(), image_embeddings=emb)
     assert torch.equal(ev2["pred_contact_3d"], ev["pred_contact_3d"])
+    if m.llm.can_fuse_generate:  # opt-in persistent decode kernel: same ids, same contacts up to GEMV summation order
+        m.fused_generate = True
+        ev3 = m.evaluate(images_clip.to(bf).to(cuda), images.to(bf).to(cuda), ids[None, :L0], cams, [(1024, 1024)],
+                         [(1024, 1024)], contact_type="hcontact", forced_new_tokens=ids[L0:].tolist())
+        m.fused_generate = False
+        assert torch.equal(ev3["output_ids"], ev["output_ids"])
+        assert float((ev3["pred_contact_3d"] - ev["pred_contact_3d"]).abs().max()) < 2e-3
