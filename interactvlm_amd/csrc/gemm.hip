@@ -172,19 +172,20 @@ using Cfg128x64 = TileCfg<2, 2, 4, 2>;  // 128 x 64 block: more tiles for skinny
 //   * 256^2 (+10 % on SAM qkv / mlp1) when it fills whole waves of the 256 CUs (quantisation efficiency >= 0.85);
 //   * 128^2 otherwise.
 inline int choose_tile(const GemmArgs& g) {
-    if (g.tile == 128 || g.tile == 256 || g.tile == 64) return g.tile;
+    if (g.tile == 128 || g.tile == 256 || g.tile == 64 || g.tile == 512) return g.tile;
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
     if (t128 < 400) return 64;
     const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
     const double q = (double)t256 / (double)(((t256 + 255) / 256) * 256);
     const double edge = (double)(((g.M + 255) / 256) * 256) * (((g.N + 255) / 256) * 256) / ((double)g.M * g.N);
-    if (t256 >= 512 && q >= 0.85 && edge < 1.1) return 256;
+    if (t256 >= 512 && q >= 0.85 && edge < 1.1) return 512;  // 256^2 tile, 8-phase ping-pong pipeline (gemm256.hip)
     return 128;
 }
 
 template <int ACT>
 int launch(const GemmArgs& g, hipStream_t st) {
     switch (choose_tile(g)) {
+        case 512: return gemm_bf16_256p(g, st);  // 256^2, 8-phase ping-pong pipeline (gemm256.hip)
         case 256: return g.out_f32 ? launch_cfg<ACT, true, Cfg256>(g, st) : launch_cfg<ACT, false, Cfg256>(g, st);
         case 64: return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64>(g, st) : launch_cfg<ACT, false, Cfg128x64>(g, st);
         default: return g.out_f32 ? launch_cfg<ACT, true, Cfg128>(g, st) : launch_cfg<ACT, false, Cfg128>(g, st);
@@ -286,7 +287,7 @@ static int g_tile_override = 0;
 
 extern "C" int ivlm_gemm_tile_override(int tile) {
     const int prev = g_tile_override;
-    if (tile == 0 || tile == 64 || tile == 128 || tile == 256) g_tile_override = tile;
+    if (tile == 0 || tile == 64 || tile == 128 || tile == 256 || tile == 512) g_tile_override = tile;
     return prev;
 }
 

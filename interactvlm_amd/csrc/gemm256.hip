@@ -1,0 +1,207 @@
+// 256x256x64 bf16 MFMA GEMM for gfx950 with an 8-phase, ping-pong K loop (the large-M GEMMs of the SAM ViT-H encoder:
+// qkv / proj / mlp of model/segment_anything/modeling/image_encoder.py:222-260, common.py:13-27).
+//
+// Same contract and epilogues as gemm_bf16_kernel (gemm.hip); different pipeline:
+//   * 512 threads = 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 of the output = 8 x 4 MFMA fragments (128 acc regs).
+//   * A K tile (BK = 64) is held as four 16-KiB HALF-TILES, cut to match how the waves consume it:
+//         A0 / A1 = the 64 rows that output quadrant mq = 0 / 1 of BOTH wave rows reads,
+//         B0 / B1 = the 32 columns that quadrant nq = 0 / 1 of ALL FOUR wave columns reads;
+//     two K tiles of buffering = 128 KiB of LDS, one block per CU, 2 waves per SIMD.
+//   * The K tile is computed in four phases, one output quadrant (16 MFMAs) each:
+//         phase 1: read A0 + B0 -> (mq0,nq0)   phase 2: read B1 -> (mq0,nq1)
+//         phase 3: read A1      -> (mq1,nq1)   phase 4: (no reads) -> (mq1,nq0)
+//     and every phase issues the direct-to-LDS DMA of ONE half-tile, five half-tiles ahead of its first use:
+//     half-tile s (issue order A0,B0,B1,A1 of tile 0, then tile 1, ...) is issued in global phase s-5 and first read in
+//     phase >= s.  `s_waitcnt vmcnt(8)` once per phase (never 0) therefore leaves four half-tiles in flight across the
+//     barriers, and a slot is only restaged >= 2 phases after its last read (reads retire after the mid-phase barrier).
+//   * The two wave rows run staggered by one barrier: while one row of waves executes its MFMA quadrant, the other
+//     issues its LDS reads and DMA - on every SIMD one wave of each row is resident, so the matrix pipe and the LDS /
+//     memory pipes overlap (s_setprio(1) around the MFMAs arbitrates in favour of the computing wave).
+//   * LDS image and swizzle as in gemm.hip: DMA destination is lane-linear, so 16-byte chunk c of local row r is fetched
+//     from source chunk c ^ ((r >> 1) & 7) and read back with the same XOR.
+#include "gemm_common.h"
+
+namespace ivlm {
+namespace {
+
+constexpr int kBK = 64;
+constexpr int kHalfBytes = 128 * kBK * 2;        // 16 KiB
+constexpr int kTileLds = 4 * kHalfBytes;         // 64 KiB per K tile
+constexpr int kLds256 = 2 * kTileLds;            // 128 KiB
+// slot order inside a tile buffer == kind index: 0 A0, 1 B0, 2 B1, 3 A1 (also the issue order)
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int m0, n0;
+    gemm_tile_origin(g, 256, 256, m0, n0);
+    const int bz = blockIdx.z;
+    const bf16_t* __restrict__ A = g.A + (int64_t)bz * g.strideA;
+    const bf16_t* __restrict__ W = g.W + (int64_t)bz * g.strideW;
+
+    // ---- DMA sources: this lane copies local rows lr0 and lr0 + 64 of every half-tile ----------------------------------
+    const int lr0 = wave * 8 + (lane >> 3);                 // 0..63
+    const int chunk = (lane & 7) ^ ((lr0 >> 1) & 7);        // source chunk landing in LDS chunk lane & 7 (same for lr0+64)
+    const int kcol = chunk * 8;
+    const bf16_t* src[4][2];  // [kind][piece]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int ra = m0 + i * 128 + q * 64 + lr0;            // A half q: local row i*64 + lr0 = wave row i, quadrant row lr0
+            ra = ra < g.M ? ra : g.M - 1;
+            src[q == 0 ? 0 : 3][i] = A + (int64_t)ra * g.lda + kcol;
+            int rn = n0 + (2 * i + (lr0 >> 5)) * 64 + q * 32 + (lr0 & 31);  // B half q: local row i*64+lr0 = wave col, col
+            rn = rn < g.N ? rn : g.N - 1;
+            src[q == 0 ? 1 : 2][i] = W + (int64_t)rn * g.ldw + kcol;
+        }
+    }
+    const int nt = (g.K + kBK - 1) / kBK;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(kGemmZeroChunk);
+    unsigned char* dma_base = smem + wave * 1024;  // piece i of a slot: + i * 8192
+
+    // half-tile `kind` of K tile `tile` -> its slot (tiles past the end stream the zero chunk: keeps vmcnt uniform)
+    auto stage = [&](int kind, int tile) {
+        unsigned char* dst = dma_base + (tile & 1) * kTileLds + kind * kHalfBytes;
+        const int koff = tile * kBK;
+        const bool ok = tile < nt && kcol + koff < g.K;
+        glds16(ok ? src[kind][0] + koff : zero, dst);
+        glds16(ok ? src[kind][1] + koff : zero, dst + 8192);
+    };
+
+    // ---- fragment read offsets (bytes inside a half-tile) --------------------------------------------------------------
+    const int sw = (((lane & 15) >> 1) & 7);
+    const int offA = (wr * 64 + (lane & 15)) * 128 + (((lane >> 4) ^ sw) << 4);  // + i * 2048, ^ (kk << 6)
+    const int offB = (wc * 32 + (lane & 15)) * 128 + (((lane >> 4) ^ sw) << 4);  // + j * 2048, ^ (kk << 6)
+
+    f32x4_t acc[4][8];  // [n fragment][m fragment]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa[4][2];      // A quadrant in use: [m frag][k step]
+    bf16x8_t fb[2][2][2];   // both B quadrants:  [nq][n frag][k step]
+
+    auto read_a = [&](const unsigned char* slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                fa[i][kk] = *reinterpret_cast<const bf16x8_t*>(slot + ((offA + i * 2048) ^ (kk << 6)));
+    };
+    auto read_b = [&](int nq, const unsigned char* slot) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                fb[nq][j][kk] = *reinterpret_cast<const bf16x8_t*>(slot + ((offB + j * 2048) ^ (kk << 6)));
+    };
+    auto mfma_quadrant = [&](int mq, int nq) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[nq * 2 + j][mq * 4 + i] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nq][j][kk], fa[i][kk], acc[nq * 2 + j][mq * 4 + i], 0, 0, 0);
+    };
+    // one phase: [LDS reads][DMA of one half-tile][counted wait] | barrier | retire reads, 16 MFMAs | barrier
+#define IVLM_PHASE(READS, KIND, TILE, MQ, NQ)                    \
+    do {                                                         \
+        READS;                                                   \
+        stage(KIND, TILE);                                       \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_setprio(1);                           \
+        mfma_quadrant(MQ, NQ);                                   \
+        __builtin_amdgcn_s_setprio(0);                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+    } while (0)
+#define IVLM_KTILE(T, BUF)                                                                                        \
+    do {                                                                                                          \
+        const unsigned char* tb = smem + (BUF) * kTileLds;                                                        \
+        IVLM_PHASE({ read_b(0, tb + 1 * kHalfBytes); read_a(tb + 0 * kHalfBytes); }, 2, (T) + 1, 0, 0);           \
+        IVLM_PHASE({ read_b(1, tb + 2 * kHalfBytes); }, 3, (T) + 1, 0, 1);                                         \
+        IVLM_PHASE({ read_a(tb + 3 * kHalfBytes); }, 0, (T) + 2, 1, 1);                                            \
+        IVLM_PHASE({}, 1, (T) + 2, 1, 0);                                                                          \
+    } while (0)
+
+    // ---- prologue: half-tiles 0..5 (tile 0 complete, A0/B0 of tile 1) --------------------------------------------------
+    stage(0, 0);
+    stage(1, 0);
+    stage(2, 0);
+    stage(3, 0);
+    stage(0, 1);
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A0, B0 of tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: wave row 1 runs half a phase behind wave row 0
+
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+        IVLM_KTILE(t, 0);
+        IVLM_KTILE(t + 1, 1);
+    }
+    if (t < nt) IVLM_KTILE(t, 0);
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave rows
+#undef IVLM_KTILE
+#undef IVLM_PHASE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-chunk DMAs must not outlive the block's LDS
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = lane & 15, n = (lane >> 4) * 4 --------------------------------------------
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = m0 + wr * 128 + mi * 16 + (lane & 15);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wc * 64 + ni * 16 + (lane >> 4) * 4;
+            gemm_epilogue4<ACT, OUT_F32>(g, bz, m, n, acc[ni][mi]);
+        }
+    }
+}
+
+template <int ACT>
+int launch256(const GemmArgs& g, hipStream_t st) {
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    dim3 grid(tiles, 1, g.batch);
+#define IVLM_GO(F32)                                                                                             \
+    do {                                                                                                         \
+        auto kfn = gemm256_kernel<ACT, F32>;                                                                     \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      kLds256);                                                                  \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        kfn<<<grid, 512, kLds256, st>>>(g);                                                                      \
+    } while (0)
+    if (g.out_f32) IVLM_GO(true); else IVLM_GO(false);
+#undef IVLM_GO
+    return ivlm_launch_status();
+}
+
+}  // namespace
+
+// tile-256 8-phase variant (arguments already validated by gemm_bf16)
+int gemm_bf16_256p(const GemmArgs& g, hipStream_t st) {
+    switch (g.act) {
+        case ACT_NONE: return launch256<ACT_NONE>(g, st);
+        case ACT_GELU: return launch256<ACT_GELU>(g, st);
+        case ACT_QUICK_GELU: return launch256<ACT_QUICK_GELU>(g, st);
+        case ACT_RELU: return launch256<ACT_RELU>(g, st);
+        case ACT_SILU: return launch256<ACT_SILU>(g, st);
+        case ACT_SWIGLU: return launch256<ACT_SWIGLU>(g, st);
+        case ACT_SIGMOID: return launch256<ACT_SIGMOID>(g, st);
+        default: return IVLM_ERR_INVALID_ARG;
+    }
+}
+
+}  // namespace ivlm

@@ -29,6 +29,8 @@ struct GemmArgs {
 
 // bf16 x bf16 -> fp32-accumulate MFMA GEMM with fused bias/activation/residual epilogue.
 int gemm_bf16(const GemmArgs& g, hipStream_t st);
+// 256x256 tile with the 8-phase ping-pong K loop (gemm256.hip); same contract as gemm_bf16
+int gemm_bf16_256p(const GemmArgs& g, hipStream_t st);
 // split-K variant for small M (fp32 partials in `workspace`, >= splits*M*N*4 bytes); act != SWIGLU
 int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st);
 // nn.Linear dispatch: GEMV (M <= 8) or the MFMA tile kernel

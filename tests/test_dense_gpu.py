@@ -81,7 +81,7 @@ def test_gemm_splitk_matches_single_pass(hip_lib, cuda, M, N, K):
     assert torch.allclose(out[:, :N].float(), x.float() @ w.float().T, atol=2e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("tile", [64, 128, 256])
+@pytest.mark.parametrize("tile", [64, 128, 256, 512])
 def test_gemm_forced_tiles(hip_lib, cuda, tile):
     """Both block-tile configurations on a shape with ragged M/N edges and a K tail."""
     import torch
@@ -101,6 +101,36 @@ def test_gemm_forced_tiles(hip_lib, cuda, tile):
     finally:
         _lib.load().ivlm_gemm_tile_override(prev)
     assert torch.allclose(got.cpu(), ref, atol=3e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (4096, 1280, 1280), (1000, 520, 200), (2048, 3840, 1288)])
+def test_gemm_8phase_matches_simple_kernel_bitwise(hip_lib, cuda, M, N, K):
+    """The 8-phase ping-pong 256^2 kernel (tile code 512) accumulates in the same order as the plain double-buffered
+    256^2 kernel, so the two must agree BIT FOR BIT; repeated launches screen for LDS races in the staggered pipeline
+    (a late DMA / early read shows up as a few wrong tiles in some runs)."""
+    import torch
+
+    from interactvlm_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(cuda)
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    b = _bf(torch.randn(N, generator=g) * 0.1).to(cuda)
+    prev = lib.ivlm_gemm_tile_override(256)
+    try:
+        base = ops.linear(x, w, b, act="gelu", out_f32=True)
+        lib.ivlm_gemm_tile_override(512)
+        filler = torch.randn(64 << 20, device=cuda)  # perturb memory timing between runs
+        for it in range(30):
+            got = ops.linear(x, w, b, act="gelu", out_f32=True)
+            if it % 3 == 0:
+                filler.mul_(1.0001)
+            assert torch.equal(got, base), f"run {it}: {(got != base).sum().item()} elements differ"
+    finally:
+        lib.ivlm_gemm_tile_override(prev)
+    ref = _ref_act(x.float() @ w.float().T + b.float(), "gelu")
+    assert torch.allclose(base, ref, atol=3e-3, rtol=1e-3)
 
 
 def test_gemm_transpose_detecting(hip_lib, cuda):
