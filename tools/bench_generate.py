@@ -43,11 +43,12 @@ def main():
         reps = 3
         for _ in range(reps):
             out = fn()
+        t_enq = (time.perf_counter() - t0) / reps  # host time to enqueue everything (no sync yet)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         per_tok_bytes = 2.0 * (c.layers * (4.0 * c.hidden ** 2 + 3.0 * c.hidden * c.inter) + c.vocab * c.hidden)
         res[name] = {"ms_total": dt * 1e3, "ms_per_token": dt * 1e3 / (n - 1 + 1e-9),
-                     "GBps": per_tok_bytes * (n - 1) / dt / 1e9}
+                     "GBps": per_tok_bytes * (n - 1) / dt / 1e9, "host_enqueue_ms_per_token": t_enq * 1e3 / (n - 1 + 1e-9)}
         if name == "fused":
             res[name]["status"] = out[2].cpu().tolist()
     print(json.dumps(res, indent=1))

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Timeline summary of the LAST evaluate() step in a rocprofv3 kernel-trace rocpd DB: per-stream busy time, overlap of the
+two streams, GPU idle time.  python tools/rocpd_timeline.py x_results.db"""
+import sqlite3
+import sys
+
+
+def union_len(iv):
+    iv = sorted(iv)
+    tot, cs, ce = 0, None, None
+    for s, e in iv:
+        if cs is None:
+            cs, ce = s, e
+        elif s <= ce:
+            ce = max(ce, e)
+        else:
+            tot += ce - cs
+            cs, ce = s, e
+    if cs is not None:
+        tot += ce - cs
+    return tot
+
+
+def main():
+    c = sqlite3.connect(sys.argv[1])
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    rows = c.execute(f"select name, start, end, {qcol or '0'} from kernels order by start").fetchall()
+    # steps are delimited by the lift kernel (last kernel of evaluate)
+    lifts = [i for i, r in enumerate(rows) if "lift_plan" in r[0]]
+    if len(lifts) < 3:
+        print("not enough steps")
+        return
+    for a, b in ((lifts[-3], lifts[-2]), (lifts[-2], lifts[-1])):
+        seg = rows[a + 1: b + 1]
+        t0, t1 = seg[0][1], max(r[2] for r in seg)
+        by = {}
+        for n, s, e, q in seg:
+            by.setdefault(q, []).append((s, e, n))
+        print(f"step: {len(seg)} kernels, span {(t1 - t0) / 1e6:.2f} ms, busy(union) {union_len([(s, e) for _, s, e, _ in seg]) / 1e6:.2f} ms, "
+              f"sum of kernel durations {sum(e - s for _, s, e, _ in seg) / 1e6:.2f} ms")
+        for q, lst in by.items():
+            s0, e1 = lst[0][0], max(x[1] for x in lst)
+            print(f"  queue {q}: {len(lst)} kernels, window {(s0 - t0) / 1e6:.2f} .. {(e1 - t0) / 1e6:.2f} ms, busy {union_len([(s, e) for s, e, _ in lst]) / 1e6:.2f} ms, "
+                  f"sum {sum(e - s for s, e, _ in lst) / 1e6:.2f} ms; first {lst[0][2][:40]} last {lst[-1][2][:40]}")
+        # decode-phase probe: time between consecutive llama_decode_attn kernels
+        da = [(s, e) for n, s, e, q in seg if "llama_decode_attn" in n]
+        if len(da) > 64:
+            import statistics
+            gaps = [da[i + 1][0] - da[i][0] for i in range(len(da) - 1)]
+            print(f"  decode: layer period median {statistics.median(gaps) / 1e3:.1f} us, mean {sum(gaps) / len(gaps) / 1e3:.1f} us over {len(gaps)} layers")
+
+
+if __name__ == "__main__":
+    main()
