@@ -133,6 +133,10 @@ int ivlm_gemm_bf16_splitk(const void *A, int64_t lda, const void *W, int64_t ldw
                           int act, int out_f32, int splits, void *workspace, size_t workspace_bytes,
                           ivlm_stream_t stream);
 
+/* Benchmark/test hook: M == 1 GEMVs use the wave-per-row kernel (0, default: faster as a stand-alone launch) or the flat
+ * slab-streaming kernel (1; the streaming code of ivlm_llama_generate). */
+int ivlm_gemv_slab_enable(int on);
+
 /* Benchmark/test hook: force the GEMM block tile (64 = 128x64, 128, 256; 0 = automatic choice). Returns the previous value. */
 int ivlm_gemm_tile_override(int tile);
 

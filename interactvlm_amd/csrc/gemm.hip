@@ -285,6 +285,11 @@ int linear_bf16(const GemmArgs& g, hipStream_t st) {
 
 static int g_tile_override = 0;
 
+extern "C" int ivlm_gemv_slab_enable(int on) {  // benchmark/test hook: 0 = wave-per-row GEMV kernel for M == 1 as well
+    ivlm::gemv_set_slab(on);
+    return 0;
+}
+
 extern "C" int ivlm_gemm_tile_override(int tile) {
     const int prev = g_tile_override;
     if (tile == 0 || tile == 64 || tile == 128 || tile == 256 || tile == 512) g_tile_override = tile;

@@ -262,10 +262,19 @@ static int launch_gemv(const GemmArgs& g, hipStream_t st) {
     return ivlm_launch_status();
 }
 
+// opt-in: measured slower than the wave-per-row kernel as a stand-alone launch (qkv 20.9 vs 18.7 us, o 18.6 vs 14.6 us):
+// one 512-thread block per CU cannot overlap its own prologue / epilogue with streaming the way 4 small blocks per CU do
+static int g_gemv_slab = 0;
+void gemv_set_slab(int on) { g_gemv_slab = on; }
+
 int gemv_bf16(const GemmArgs& g, hipStream_t st) {
     if (!g.A || !g.W || !g.C || g.M <= 0 || g.M > kMaxM || g.N <= 0 || g.K <= 0) return IVLM_ERR_INVALID_ARG;
     if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || g.batch != 1) return IVLM_ERR_UNSUPPORTED;
     if (g.act == ACT_SWIGLU && ((g.N & 1) || g.residual)) return IVLM_ERR_UNSUPPORTED;
+    if (g.M == 1 && g_gemv_slab && g.N >= 1024) {  // decode: flat slab streaming (gemv_slab.hip) when the shape qualifies
+        const int rc = gemv_slab_bf16(g, st);
+        if (rc != IVLM_ERR_UNSUPPORTED) return rc;
+    }
     switch (g.M) {
         case 1: return launch_gemv<1>(g, st);
         case 2: return launch_gemv<2>(g, st);

@@ -31,6 +31,9 @@ struct GemmArgs {
 int gemm_bf16(const GemmArgs& g, hipStream_t st);
 // 256x256 tile with the 8-phase ping-pong K loop (gemm256.hip); same contract as gemm_bf16
 int gemm_bf16_256p(const GemmArgs& g, hipStream_t st);
+// M == 1 decode GEMV as flat slab streaming (gemv_slab.hip); IVLM_ERR_UNSUPPORTED = shape does not qualify
+int gemv_slab_bf16(const GemmArgs& g, hipStream_t st);
+void gemv_set_slab(int on);
 // split-K variant for small M (fp32 partials in `workspace`, >= splits*M*N*4 bytes); act != SWIGLU
 int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st);
 // nn.Linear dispatch: GEMV (M <= 8) or the MFMA tile kernel

@@ -88,6 +88,8 @@ class InteractVLMForCausalLM:
         self.fused_generate = False
         self.fused_lowres_lift = False  # measured slower than lifting the (cache-resident) full-res masks
         self._side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._hi_stream = torch.cuda.Stream(device=dev, priority=-1) if dev.type == "cuda" else None
+        self.prioritise_llm = False  # measured: no gain (the two streams time-share the CUs either way)
 
         self.vision_tower = ClipTower(w, c.clip, dev)
         self.mm_projector = _Lin(w, "model.mm_projector", dev)
@@ -338,6 +340,27 @@ class InteractVLMForCausalLM:
                 image_embeddings = self.model.visual_model.image_encoder(images[0].to(self.device))
                 ev = torch.cuda.Event()
                 ev.record(side)
+        # ... and the language path (the critical path) on a HIGH-priority stream, so that whenever CU slots free up
+        # its workgroups are dispatched ahead of the encoder's
+        hi = self._hi_stream if (side is not None and self.prioritise_llm) else None
+        if hi is not None:
+            hi.wait_stream(main)
+            with torch.cuda.stream(hi):
+                out = self._evaluate_tail(images_clip, images, input_ids, cam_params, resize_list, original_size_list,
+                                          lift2d_dict_path, contact_type, max_new_tokens, forced_new_tokens,
+                                          eos_token_id, image_embeddings, side, ev)
+            main.wait_stream(hi)
+            for tns in list(out["pred_masks"]) + [out["pred_contact_3d"]]:
+                if tns is not None:
+                    tns.record_stream(main)
+            return out
+        return self._evaluate_tail(images_clip, images, input_ids, cam_params, resize_list, original_size_list,
+                                   lift2d_dict_path, contact_type, max_new_tokens, forced_new_tokens, eos_token_id,
+                                   image_embeddings, side, ev)
+
+    def _evaluate_tail(self, images_clip, images, input_ids, cam_params, resize_list, original_size_list,
+                       lift2d_dict_path, contact_type, max_new_tokens, forced_new_tokens, eos_token_id,
+                       image_embeddings, side, ev):
         output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, eos_token_id, forced_new_tokens)
         rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)
         if side is not None:

@@ -133,6 +133,47 @@ def test_gemm_8phase_matches_simple_kernel_bitwise(hip_lib, cuda, M, N, K):
     assert torch.allclose(base, ref, atol=3e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("N,K,act,rms,res,f32", [(12288, 4096, "none", True, False, False), (22016, 4096, "swiglu", True, False, False),
+                                                 (4096, 11008, "none", False, True, False), (4096, 4096, "none", False, True, False),
+                                                 (32003, 4096, "none", False, False, True), (1000, 1376, "quick_gelu", True, True, False),
+                                                 (5120, 512, "none", False, False, False)])
+def test_gemv_slab_streaming_vs_rowwave_and_fp32(hip_lib, cuda, N, K, act, rms, res, f32):
+    """M == 1 decode GEMVs: the opt-in flat slab-streaming kernel against the default wave-per-row kernel and fp32 torch;
+    K = 11008 / 1376 rows are not a whole number of waves long (two rows per wave step); repeated launches are bit-equal."""
+    import torch
+
+    from interactvlm_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N + K)
+    x = _bf(torch.randn(1, K, generator=g)).to(cuda)
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    gam = _bf(1 + 0.1 * torch.randn(K, generator=g)).to(cuda)
+    n_out = N // 2 if act == "swiglu" else N
+    r = _bf(torch.randn(1, n_out, generator=g)).to(cuda) if res else None
+    kw = dict(act=act, residual=r, rms=(gam, 1e-5) if rms else None, out_f32=f32)
+    roww = ops.linear(x, w, **kw)
+    lib.ivlm_gemv_slab_enable(1)
+    try:
+        slab = ops.linear(x, w, **kw)
+        assert torch.equal(slab, ops.linear(x, w, **kw))
+    finally:
+        lib.ivlm_gemv_slab_enable(0)
+    xf = x.float()
+    if rms:  # the fused path: bf16(x * gamma) . w, scaled by rstd afterwards
+        xf = (xf * gam.float()).to(torch.bfloat16).float() * torch.rsqrt(x.float().pow(2).mean() + 1e-5)
+    y = xf @ w.float().T
+    if act == "swiglu":
+        y = torch.nn.functional.silu(y[:, 0::2]) * y[:, 1::2]
+    else:
+        y = _ref_act(y, act)
+    if res:
+        y = y + r.float()
+    tol = dict(atol=2e-3, rtol=1e-3) if f32 else dict(atol=2e-2, rtol=1.6e-2)
+    assert torch.allclose(slab.float(), y, **tol)
+    assert torch.allclose(slab.float(), roww.float(), **tol)
+
+
 def test_gemm_transpose_detecting(hip_lib, cuda):
     """A = I (padded) with an ASYMMETRIC W catches row/col swaps in the MFMA C layout."""
     import torch
