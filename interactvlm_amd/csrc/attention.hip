@@ -387,6 +387,90 @@ __global__ __launch_bounds__(256) void relpos_kernel(const bf16_t* __restrict__ 
     }
 }
 
+// Same operator, restructured for throughput (the thread-per-output kernel above spent 5.6 ms per image): one thread per
+// QUERY keeps its q vector packed in registers and walks its SH + SW outputs; both rel-pos tables sit in LDS (row stride
+// D + 8 elements: the 16 lanes of a ds_read_b128 pass that read 16 consecutive rows hit distinct banks; lanes that share a
+// row broadcast); 8 x 8 bf16 products per v_dot2c_f32_bf16 quad; outputs leave as 16-byte stores, 64 contiguous bytes per
+// lane per 16 outputs (whole sectors).  NCH = D / 8.
+typedef __attribute__((ext_vector_type(2))) __bf16 rp_bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int rp_u32x4_t;
+
+template <int NCH>
+__global__ __launch_bounds__(256) void relpos_rows_kernel(const bf16_t* __restrict__ q, int64_t q_bs, int64_t q_hs,
+                                                          int64_t q_rs, const bf16_t* __restrict__ tab_h,
+                                                          const bf16_t* __restrict__ tab_w, int H, int SH, int SW,
+                                                          float* __restrict__ rel_h, float* __restrict__ rel_w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rp_smem[];
+    constexpr int D = NCH * 8, kStride = D + 8;  // elements
+    rp_u32x4_t* th = reinterpret_cast<rp_u32x4_t*>(rp_smem);                        // [2SH-1][kStride/8] chunks
+    rp_u32x4_t* tw = th + (2 * SH - 1) * (kStride / 8);
+    const int nh = (2 * SH - 1) * NCH, nw = (2 * SW - 1) * NCH;
+    for (int i = threadIdx.x; i < nh + nw; i += 256) {
+        const bool isw = i >= nh;
+        const int k = isw ? i - nh : i;
+        const int row = k / NCH, c = k - row * NCH;
+        const rp_u32x4_t v = *reinterpret_cast<const rp_u32x4_t*>((isw ? tab_w : tab_h) + (int64_t)row * D + c * 8);
+        (isw ? tw : th)[row * (kStride / 8) + c] = v;
+    }
+    __syncthreads();
+    const int S = SH * SW;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= S) return;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int qh = qi / SW, qw = qi - qh * SW;
+    const bf16_t* qv = q + b * q_bs + h * q_hs + (int64_t)qi * q_rs;
+    rp_u32x4_t qr[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) qr[c] = *reinterpret_cast<const rp_u32x4_t*>(qv + c * 8);
+    const int64_t bq = ((int64_t)b * H + h) * S + qi;
+    auto run = [&](const rp_u32x4_t* tab, int base_row, int n, float* out) {
+        // out[j] = q . tab[base_row - j], j = 0..n-1, in groups of 4 (16-byte stores; n % 4 tail scalar)
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {
+            float r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const rp_u32x4_t* row = tab + (base_row - (j + u)) * (kStride / 8);
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const rp_u32x4_t t4 = row[c];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t a = qr[c][e], w = t4[e];
+                        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2_t, a),
+                                                               __builtin_bit_cast(rp_bf16x2_t, w), acc, false);
+                    }
+                }
+                r[u] = bf16_to_f32(f32_to_bf16(acc));  // the reference materialises rel_h/rel_w in bf16
+            }
+            if ((((uintptr_t)(out + j)) & 15) == 0) {
+                *reinterpret_cast<float4*>(out + j) = make_float4(r[0], r[1], r[2], r[3]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) out[j + u] = r[u];
+            }
+        }
+        for (; j < n; ++j) {
+            const rp_u32x4_t* row = tab + (base_row - j) * (kStride / 8);
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const rp_u32x4_t t4 = row[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t a = qr[c][e], w = t4[e];
+                    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2_t, a),
+                                                           __builtin_bit_cast(rp_bf16x2_t, w), acc, false);
+                }
+            }
+            out[j] = bf16_to_f32(f32_to_bf16(acc));
+        }
+    };
+    run(th, qh + SH - 1, SH, rel_h + bq * SH);
+    run(tw, qw + SW - 1, SW, rel_w + bq * SW);
+}
+
 }  // namespace
 
 int attention_bf16(const AttnArgs& a, hipStream_t st) {
@@ -409,6 +493,14 @@ int attention_bf16(const AttnArgs& a, hipStream_t st) {
 int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const bf16_t* tab_h, const bf16_t* tab_w,
                 int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, hipStream_t st) {
     if (!q || !tab_h || !tab_w || !rel_h || !rel_w || (D & 7)) return IVLM_ERR_INVALID_ARG;
+    if ((D == 80 || D == 64) && SH <= 128 && SW <= 128 && H <= 65535 && B <= 65535 &&
+        ((q_bs | q_hs | q_rs) & 7) == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0) {
+        const size_t lds = (size_t)(2 * SH - 1 + 2 * SW - 1) * (D + 8) * 2;
+        dim3 grid((SH * SW + 255) / 256, H, B);
+        if (D == 80) relpos_rows_kernel<10><<<grid, 256, lds, st>>>(q, q_bs, q_hs, q_rs, tab_h, tab_w, H, SH, SW, rel_h, rel_w);
+        else relpos_rows_kernel<8><<<grid, 256, lds, st>>>(q, q_bs, q_hs, q_rs, tab_h, tab_w, H, SH, SW, rel_h, rel_w);
+        return ivlm_launch_status();
+    }
     const int64_t total = (int64_t)B * H * SH * SW * (SH + SW);
     const int grid = (int)((total + 255) / 256 < 65535 * 4 ? (total + 255) / 256 : 65535 * 4);
     relpos_kernel<<<grid, 256, 0, st>>>(q, q_bs, q_hs, q_rs, tab_h, tab_w, B, H, SH, SW, D, rel_h, rel_w);
