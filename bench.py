@@ -235,43 +235,47 @@ def main():
                   "note": "SAM ViT-H embeddings of the input-independent hcontact renders pre-computed (SURVEY 8f-1); "
                           "NOT the headline metric"}
 
-    roof = roof_lift = breakdown = roof_serial = None
+    roof = roof_lift = roof_serial = None
 
     def timed_pass(nsteps):
+        """per-launch HIP events (on the launch stream) around every GEMM / GEMV / lift launch of `nsteps` steps"""
         ops.TIMER.start()
         for _ in range(nsteps):
             step()
         ops.TIMER.stop()
         sm = ops.TIMER.summary()
-        g, l, gv = sm["gemm_bf16_mfma"], sm["lift_mesh_plan"], sm.get("gemv_bf16")
+        g, l, gv = sm["gemm_bf16_mfma"], sm["lift_mesh_plan"], sm["gemv_bf16"]
         ach = g["work"] / g["total_s"] / 1e12
-        r = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-             "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-             "launches_per_image": g["launches"] // nsteps, "avg_us": round(g["avg_us"], 2)}
+        rg = {"bound": "mfma", "kernel": "gemm_bf16_kernel + gemm256_kernel (all MFMA-path launches)",
+              "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+              "traffic": None, "launches_per_image": g["launches"] // nsteps, "avg_us": round(g["avg_us"], 2),
+              "ms_per_image": round(g["total_s"] / nsteps * 1e3, 2)}
         la = l["work"] / l["total_s"] / 1e9
         rl = {"bound": "hbm", "kernel": "lift_plan_kernel", "achieved": round(la, 1), "peak": PEAK_HBM_GBPS,
               "unit": "GB/s", "frac": round(la / PEAK_HBM_GBPS, 4), "traffic": None,
               "algorithmic_bytes": int(l["work"] / l["launches"]), "avg_us": round(l["avg_us"], 2)}
-        bd = None
-        if gv:
-            bd = {"gemv_weight_stream_GBps": round(gv["work"] / gv["total_s"] / 1e9, 1),
-                  "gemv_total_ms_per_image": round(gv["total_s"] / nsteps * 1e3, 2),
-                  "gemm_total_ms_per_image": round(g["total_s"] / nsteps * 1e3, 2)}
-        return r, rl, bd
+        va = gv["work"] / gv["total_s"] / 1e9
+        rv = {"bound": "hbm", "kernel": "gemv_kernel (decode linears: weight streaming)", "achieved": round(va, 1),
+              "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(va / PEAK_HBM_GBPS, 4), "traffic": None,
+              "algorithmic_bytes": int(gv["work"] / gv["launches"]), "launches_per_image": gv["launches"] // nsteps,
+              "avg_us": round(gv["avg_us"], 2), "ms_per_image": round(gv["total_s"] / nsteps * 1e3, 2)}
+        return rg, rl, rv
 
+    roof_gemv = None
     if not args.no_roofline:  # the same steps again with per-launch HIP events on the launch stream(s)
         ns = max(1, min(args.steps, 3))
-        roof, roof_lift, breakdown = timed_pass(ns)  # as timed: SAM encoder overlapped with the LLM on a 2nd stream
+        roof, roof_lift, roof_gemv = timed_pass(ns)  # as timed: SAM encoder overlapped with the LLM on a 2nd stream
         model.overlap_sam_encoder = False
-        rs, rls, bds = timed_pass(ns)                # kernels one at a time: isolates kernel quality from overlap
+        rs, rls, rvs = timed_pass(ns)                 # kernels one at a time: isolates kernel quality from overlap
         model.overlap_sam_encoder = True
         roof_serial = {"note": "same steps with the two-stream overlap disabled (kernels run alone)", "gemm": rs,
-                       "lift": rls, "breakdown": bds}
+                       "lift": rls, "gemv": rvs}
         pj = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pj):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
             pm = json.load(open(pj))
             roof["traffic"] = pm.get("gemm_bf16_kernel")
             roof_lift["traffic"] = pm.get("lift_plan_kernel")
+            roof_gemv["traffic"] = pm.get("gemv_kernel")
 
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -295,7 +299,10 @@ def main():
                        "images_per_gpu_per_step": 1, "parallelism": f"dp{world}",
                        "collective": "one all_gather of [1,6890] f32 contacts per step"},
             "algorithmic_tflop_per_image": round(fl["total"] / 1e12, 2),
-            "roofline": roof, "roofline_lift": roof_lift, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+            # `roofline` = the kernel family with the largest share of GPU time (decode GEMV: HBM-bound);
+            # the MFMA GEMMs and the mask-to-vertex lift (the two north-star targets) follow under their own keys
+            "roofline": (roof_gemv if (roof_gemv and roof and roof_gemv["ms_per_image"] >= roof["ms_per_image"]) else roof),
+            "roofline_mfma": roof, "roofline_gemv": roof_gemv, "roofline_lift": roof_lift, "cpu_baseline": cpu,
             "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "parity_vs_oracle": parity,
         }
         print(json.dumps(line))

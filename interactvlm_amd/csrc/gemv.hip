@@ -200,20 +200,34 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     }
 }
 
-// first index of the row maximum (torch.argmax tie rule), one block per row
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x, int cols, int32_t* __restrict__ out) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
+// first index of the row maximum (torch.argmax tie rule), one 1024-thread block per row, 16-byte loads
+// (the lm_head logits row is 128 KB: ~5 us instead of 38 us for the 256-thread scalar version)
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, int cols, int32_t* __restrict__ out) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
     const float* r = x + (int64_t)blockIdx.x * cols;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < cols; i += 256) {
-        const float v = r[i];
+    auto take = [&](float v, int i) {
         if (v > best || (v == best && i < bi)) {
             best = v;
             bi = i;
         }
+    };
+    const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 2);  // scalars up to the first 16-byte boundary
+    const int nhead = head < cols ? head : cols;
+    if ((int)threadIdx.x < nhead) take(r[threadIdx.x], threadIdx.x);
+    const int nvec = (cols - nhead) >> 2;
+    const float4* rv = reinterpret_cast<const float4*>(r + nhead);
+    for (int i = threadIdx.x; i < nvec; i += 1024) {
+        const float4 v = rv[i];
+        const int c = nhead + 4 * i;
+        take(v.x, c);
+        take(v.y, c + 1);
+        take(v.z, c + 2);
+        take(v.w, c + 3);
     }
+    for (int i = nhead + 4 * nvec + threadIdx.x; i < cols; i += 1024) take(r[i], i);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_xor(best, off, 64);
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < 16; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
                 best = sv[w];
                 bi = si[w];
@@ -289,7 +303,7 @@ int gemv_bf16(const GemmArgs& g, hipStream_t st) {
 
 int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st) {
     if (!x || !out || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
-    argmax_kernel<<<rows, 256, 0, st>>>(x, cols, out);
+    argmax_kernel<<<rows, 1024, 0, st>>>(x, cols, out);
     return ivlm_launch_status();
 }
 

@@ -82,6 +82,7 @@ class InteractVLMForCausalLM:
         self.use_fusion = self.use_uncertainty = False  # off in every released config (scripts/run_train.sh:61-62)
         self.debug_taps = None  # set to a dict to record intermediate tensors (tests / diagnostics only)
         self.overlap_sam_encoder = True
+        self.sam_after_prefill = False  # measured: 116.9 vs 115.3 ms - overlapping the decode instead of the prefill is not better
         # persistent one-launch greedy decode (csrc/generate.hip): correct and bit-reproducible, but measured SLOWER than the
         # per-op path on MI355X (3.43 vs 2.93 ms/token for 7B: every phase boundary costs ~9 us of device-wide sync
         # skew + store/load latency, more than a kernel boundary) - kept as an opt-in experiment
@@ -268,7 +269,8 @@ class InteractVLMForCausalLM:
         return result
 
     @torch.no_grad()
-    def generate(self, images_clip, input_ids, max_new_tokens=32, eos_token_id=2, forced_new_tokens=None):
+    def generate(self, images_clip, input_ids, max_new_tokens=32, eos_token_id=2, forced_new_tokens=None,
+                 after_prefill=None):
         """Greedy search with a KV cache for ONE sequence.  Returns (output_ids [1, L+n], hidden [L+n-1+255, H]).
         forced_new_tokens (extension for weight-free benchmarking): feed these ids instead of the argmax (the
         argmax/lm_head work is still done every step), like the reference's inference_type='forward'."""
@@ -280,6 +282,8 @@ class InteractVLMForCausalLM:
         hidden_all = torch.empty(T0 + n_max, self.config.llama.hidden, dtype=BF16, device=self.device)
         h = self.llm.forward(x, 0)
         hidden_all[:T0].copy_(h)
+        if after_prefill is not None:
+            after_prefill()  # evaluate(): the SAM encoder is enqueued here, between the prefill and the decode loop
         if self.fused_generate and self.llm.can_fuse_generate:
             if forced_new_tokens is not None:
                 assert all(0 <= int(t) < self.llm.embed.shape[0] for t in forced_new_tokens)
@@ -331,15 +335,24 @@ class InteractVLMForCausalLM:
         # The SAM ViT-H encoder (MFMA-bound, ~60 ms) does not depend on the language model (CLIP -> prefill -> decode:
         # HBM-bound weight streaming that leaves the matrix cores idle): run it on a second HIP stream and join
         # before the mask decoder.  The reference runs them back to back (InteractVLM.py:524-531, 578).
-        side = ev = None
-        if image_embeddings is None and self.overlap_sam_encoder:
-            main = torch.cuda.current_stream(self.device)
-            side = self._side_stream
+        side = None
+        box = {"emb": image_embeddings, "ev": None}
+        main = torch.cuda.current_stream(self.device)
+
+        def launch_sam():
             side.wait_stream(main)  # inputs were produced on the caller's stream
             with torch.cuda.stream(side):
-                image_embeddings = self.model.visual_model.image_encoder(images[0].to(self.device))
-                ev = torch.cuda.Event()
-                ev.record(side)
+                box["emb"] = self.model.visual_model.image_encoder(images[0].to(self.device))
+                box["ev"] = torch.cuda.Event()
+                box["ev"].record(side)
+
+        after_prefill = None
+        if image_embeddings is None and self.overlap_sam_encoder:
+            side = self._side_stream
+            if self.sam_after_prefill:
+                after_prefill = launch_sam  # MFMA-bound encoder overlaps the HBM-bound decode, not the MFMA-bound prefill
+            else:
+                launch_sam()
         # ... and the language path (the critical path) on a HIGH-priority stream, so that whenever CU slots free up
         # its workgroups are dispatched ahead of the encoder's
         hi = self._hi_stream if (side is not None and self.prioritise_llm) else None
@@ -348,7 +361,7 @@ class InteractVLMForCausalLM:
             with torch.cuda.stream(hi):
                 out = self._evaluate_tail(images_clip, images, input_ids, cam_params, resize_list, original_size_list,
                                           lift2d_dict_path, contact_type, max_new_tokens, forced_new_tokens,
-                                          eos_token_id, image_embeddings, side, ev)
+                                          eos_token_id, box, side, after_prefill)
             main.wait_stream(hi)
             for tns in list(out["pred_masks"]) + [out["pred_contact_3d"]]:
                 if tns is not None:
@@ -356,15 +369,17 @@ class InteractVLMForCausalLM:
             return out
         return self._evaluate_tail(images_clip, images, input_ids, cam_params, resize_list, original_size_list,
                                    lift2d_dict_path, contact_type, max_new_tokens, forced_new_tokens, eos_token_id,
-                                   image_embeddings, side, ev)
+                                   box, side, after_prefill)
 
     def _evaluate_tail(self, images_clip, images, input_ids, cam_params, resize_list, original_size_list,
                        lift2d_dict_path, contact_type, max_new_tokens, forced_new_tokens, eos_token_id,
-                       image_embeddings, side, ev):
-        output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, eos_token_id, forced_new_tokens)
+                       box, side, after_prefill):
+        output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, eos_token_id, forced_new_tokens,
+                                           after_prefill=after_prefill)
         rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)
+        image_embeddings = box["emb"]
         if side is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            torch.cuda.current_stream(self.device).wait_event(box["ev"])
             image_embeddings.record_stream(torch.cuda.current_stream(self.device))
         if image_embeddings is None:
             image_embeddings = self.model.visual_model.image_encoder(images[0].to(self.device))

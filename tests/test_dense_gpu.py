@@ -174,6 +174,22 @@ def test_gemv_slab_streaming_vs_rowwave_and_fp32(hip_lib, cuda, N, K, act, rms, 
     assert torch.allclose(slab.float(), roww.float(), **tol)
 
 
+def test_argmax_first_index_ties_and_unaligned_rows(hip_lib, cuda):
+    """torch.argmax semantics (first index of the maximum) on rows that do not start on 16-byte boundaries."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    for cols in (1, 3, 7, 255, 4099, 32003):
+        x = torch.randn(5, cols, generator=g)
+        x[1, cols // 2:] = x[1].max() + 1.0   # a run of equal maxima: the FIRST must win
+        x[2, -1] = 100.0                      # maximum in the scalar tail
+        x[3, 0] = 100.0                       # maximum in the scalar head
+        got = ops.argmax(x.to(cuda)).cpu()
+        assert got.tolist() == x.argmax(-1).tolist(), cols
+
+
 def test_gemm_transpose_detecting(hip_lib, cuda):
     """A = I (padded) with an ASYMMETRIC W catches row/col swaps in the MFMA C layout."""
     import torch
