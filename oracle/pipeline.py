@@ -75,3 +75,25 @@ def model_forward(w, cfg, images, images_clip, input_ids, cam_params, tables, in
     contact, nviews = L.lift_mesh_soft(masks.numpy()[None], vid, bary, 6890)
     return dict(clip_feat=feat, hidden=hidden, seg_emb=seg_emb, sam_emb=emb, low_res=low, pred_masks=masks,
                 pred_contact=torch.from_numpy(contact), nviews=nviews)
+
+
+def model_forward_oafford(w, cfg, images, images_clip, input_ids, cam_params, point_maps, valid_mask,
+                          input_size=None, original_size=None):
+    """One 'oafford' sample with an 'HM' object view type (InteractVLM.py:452-456, components.py:289-347):
+    pred masks get a sigmoid on the pixels whose gt mask is not IGNORE_LABEL (valid_mask [V,H,W] bool), then the
+    per-view pixel->point maps (int [V,H,W], -1 = none) vote onto the 2048 points.
+    -> dict(pred_masks [V,H,W], pred_afford [1, Np])."""
+    S = cfg.sam.img_size
+    input_size = input_size or (S, S)
+    original_size = original_size or (S, S)
+    feat = encode_images(w, cfg, images_clip)[0]
+    hidden = llm_hidden(w, cfg, input_ids, feat)
+    rows = O.seg_rows(input_ids, [cfg.seg_token_idx], cfg.img_emb_len, model_forward=True)
+    seg_emb = O.text_hidden_fcs(w, hidden)[rows]
+    k = int(rows.nonzero()[0]) - cfg.img_emb_len + 1
+    token = int(input_ids[k]) if k > 0 else None
+    emb = sam_embed(w, cfg, images)
+    masks, low, iou = decode_masks(w, cfg, seg_emb, token, cam_params, emb, input_size, original_size)
+    masks = torch.where(torch.as_tensor(valid_mask), torch.sigmoid(masks), masks)
+    afford, _ = L.lift_points(masks.numpy()[None], point_maps[None], 2048)
+    return dict(pred_masks=masks, pred_afford=torch.from_numpy(afford), low_res=low)

@@ -231,7 +231,9 @@ TOY = dict(hidden=128, layers=2, heads=4, inter=256, vocab=32003, clip_hidden=64
            clip_inter=128, clip_image=224, clip_patch=14)
 
 
-def gen_model_forward():
+def gen_model_forward(batch2=False):
+    """batch2: second scenario - an oafford sample with the object predictors enabled
+    (oC_loss_weight > 0, 'HM' view type: sigmoid on the valid pixels, per-view p2pmap files for the point lift)."""
     import json
     import torch
     _ref_shims.install(full_model=True)
@@ -268,7 +270,7 @@ def gen_model_forward():
                          mm_use_im_start_end=True, mm_vision_select_layer=-2, use_fusion=False, use_uncertainty=False,
                          img_emb_len=255, seg_token_idx=32000, hseg_token_idx=None, oseg_token_idx=None, token_type="Gen",
                          hC_sam_view_type="4MV-Z_Vitru", oC_sam_view_type="4MV-Z_HM", hC_loss_weight=1.0,
-                         oC_loss_weight=0.0, multiview_channels=4, multiview_cam_cond=True, cam_encoder_type="vi_v1",
+                         oC_loss_weight=1.0 if batch2 else 0.0, multiview_channels=4, multiview_cam_cond=True, cam_encoder_type="vi_v1",
                          train_mask_decoder=True, out_dim=256).items():
             setattr(cfg, k, v)
         os.chdir(td)
@@ -286,6 +288,45 @@ def gen_model_forward():
         # the openai/clip-vit-large-patch14 checkpoint have it, and so do our keys: re-pour under that name.
         if not any(k.startswith("vision_model.") for k in vt.vision_tower.state_dict()):
             synth.fill_state_dict(vt.vision_tower, 0, "model.vision_tower.vision_tower.vision_model.")
+        if batch2:
+            # NOTE: two conversation rows ([SEG] tokens) on ONE image is not a runnable scenario of the reference in
+            # multiview mode (mask_decoder.py:138 raises a shape error: 2 x V prompt rows vs V dense embeddings), so the
+            # object scenario is one oafford sample, like evaluate.py's batch-1 validation loop.
+            from interactvlm_amd.constants import OBJS_VIEW_DICT
+            from interactvlm_amd.synth import synth_point_maps
+            rng = np.random.default_rng(1)
+            ids2 = rng.integers(3, 31000, size=52)
+            ids2[10], ids2[11], ids2[12] = 32001, -200, 32002
+            ids2[44] = 32000
+            ids2[51] = 2
+            input_ids = torch.from_numpy(ids2)[None]
+            images_clip = torch.from_numpy(synth.synth_normal("mf2/images_clip", (1, 3, 224, 224), 1.0, 0))
+            images = torch.from_numpy(synth.synth_normal("mf2/images", (1, 4, 3, 1024, 1024), 1.0, 0))
+            cams = torch.stack([normalize_cam_params(c) for c in OBJS_VIEW_DICT["4MV-Z_HM"]["cam_params"].values()])[None]
+            pid = synth_point_maps(1, 4, 1024, 1024, 2048, fg=0.3, seed=5)[0]  # [V,H,W] int64, -1 = none
+            od = os.path.join(td, "obj")
+            os.makedirs(od)
+            mask_paths = []
+            for v in range(4):
+                mp = os.path.join(od, f"chair_mask_{v}.png")
+                np.savez(mp.replace("mask", "p2pmap")[:-4] + ".npz", mapping=pid[v])
+                mask_paths.append(mp)
+            gt1 = torch.zeros(4, 1, 1024, 1024)
+            gt1[:, :, :100] = -1.0  # IGNORE_LABEL (utils/utils.py:19) band: those pixels keep their logits (no sigmoid)
+            with torch.no_grad():
+                out = m.model_forward(images=images, images_clip=images_clip, input_ids=input_ids, labels=None,
+                                      attention_masks=torch.ones_like(input_ids), offset=torch.tensor([0, 1]),
+                                      masks_list=[gt1], label_list=[torch.zeros(1024, 1024)],
+                                      gt_contact_3d_list=None, cam_params=cams, resize_list=[(1024, 1024)],
+                                      ds_name_list=["oafford_piad"], mask_paths_list=[mask_paths], inference=True)
+            pm1 = out["pred_masks"][0].numpy()
+            _save("model_forward_oafford.npz", input_ids=ids2, cam_params=cams.numpy(), toy=json.dumps(TOY),
+                  point_maps_seed=np.int32(5), ignore_rows=np.int32(100),  # maps: synth_point_maps(1,4,1024,1024,2048,0.3,seed)
+                  pred_masks_sub=_sub(pm1), pred_masks_sum=np.float64(pm1.astype(np.float64).sum()),
+                  pred_human=out["pred_human_3d_contact"].numpy(),
+                  pred_afford=out["pred_object_3d_afford"].numpy(),
+                  pred_ocontact=out["pred_object_3d_contact"].numpy())
+            return
         # ids: 40 prompt ids with <im_start> <image> <im_end> at 10..12, then a 12-token answer with [SEG]
         rng = np.random.default_rng(0)
         ids = rng.integers(3, 31000, size=52)
@@ -330,7 +371,8 @@ def gen_model_forward():
 
 
 GENERATORS = {"lift": gen_lift, "lift_points": gen_lift_points, "sam_decoder": gen_sam_decoder, "cam": gen_cam,
-              "sam_encoder": gen_sam_encoder, "model_forward": gen_model_forward}
+              "sam_encoder": gen_sam_encoder, "model_forward": gen_model_forward,
+              "model_forward_oafford": lambda: gen_model_forward(batch2=True)}
 
 
 def main():

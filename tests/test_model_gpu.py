@@ -276,3 +276,55 @@ def test_model_forward_vs_reference_golden(hip_lib, cuda, golden_dir):
         m.fused_generate = False
         assert torch.equal(ev3["output_ids"], ev["output_ids"])
         assert float((ev3["pred_contact_3d"] - ev["pred_contact_3d"]).abs().max()) < 2e-3
+
+
+def test_model_forward_oafford_vs_reference_golden(hip_lib, cuda, golden_dir, tmp_path):
+    """Object-affordance branch end to end (configs[3]): an 'oafford' sample through HIP model_forward(inference=True) with
+    the object predictors enabled, vs the reference's own output: sigmoid only on the non-ignored pixels of the 'HM'
+    masks, point lift through the per-view p2pmap files named after the mask paths, the predictors that do not apply."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth
+    from interactvlm_amd import weights as Wt
+
+    d = np.load(os.path.join(golden_dir, "model_forward_oafford.npz"))
+    t = json.loads(str(d["toy"]))
+    cfg = Wt.IvlmCfg(
+        llama=Wt.LlamaCfg(hidden=t["hidden"], layers=t["layers"], heads=t["heads"], inter=t["inter"], vocab=t["vocab"]),
+        clip=Wt.ClipCfg(hidden=t["clip_hidden"], layers=t["clip_layers"], heads=t["clip_heads"], inter=t["clip_inter"]),
+        sam=Wt.SamEncCfg(embed_dim=160, depth=2, num_heads=2, global_attn_indexes=(1,)), oC_loss_weight=1.0)
+    ids = torch.from_numpy(d["input_ids"])
+    images_clip = torch.from_numpy(synth.synth_normal("mf2/images_clip", (1, 3, 224, 224), 1.0, 0))
+    images = torch.from_numpy(synth.synth_normal("mf2/images", (1, 4, 3, 1024, 1024), 1.0, 0))
+    cams = torch.from_numpy(d["cam_params"])
+    pid = synth.synth_point_maps(1, 4, 1024, 1024, 2048, fg=0.3, seed=int(d["point_maps_seed"]))[0]
+    mask_paths = []
+    for v in range(4):
+        mp = str(tmp_path / f"chair_mask_{v}.png")
+        np.savez(mp.replace("mask", "p2pmap")[:-4] + ".npz", mapping=pid[v])
+        mask_paths.append(mp)
+    gt = torch.zeros(4, 1, 1024, 1024)
+    gt[:, :, : int(d["ignore_rows"])] = -1.0
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    bf = torch.bfloat16
+    out = m.model_forward(images=images.to(bf).to(cuda), images_clip=images_clip.to(bf).to(cuda), input_ids=ids[None],
+                          labels=None, attention_masks=torch.ones(1, len(ids)), offset=torch.tensor([0, 1]),
+                          masks_list=[gt], label_list=[torch.zeros(1024, 1024)], gt_contact_3d_list=None,
+                          cam_params=cams, resize_list=[(1024, 1024)], ds_name_list=["oafford_piad"],
+                          mask_paths_list=[mask_paths], inference=True)
+    assert set(out) == {"gt_masks", "pred_masks", "pred_human_3d_contact", "pred_object_3d_contact", "pred_object_3d_afford"}
+    pm = out["pred_masks"][0].float().cpu()
+    ref_pm = torch.from_numpy(d["pred_masks_sub"])
+    sub = pm[..., ::16, ::16]
+    band = int(d["ignore_rows"]) // 16 + 1  # subsampled rows inside the IGNORE band keep raw logits
+    assert float((sub[:, band:] - ref_pm[:, band:]).abs().max()) < 2e-2          # probabilities
+    assert float((sub[:, :band] - ref_pm[:, :band]).abs().max()) < 0.08 * float(ref_pm[:, :band].abs().max())
+    aff = out["pred_object_3d_afford"].float().cpu()
+    e = float((aff - torch.from_numpy(d["pred_afford"])).abs().max())
+    print(f"\n[model_forward oafford] max|dp_afford| = {e:.2e}")
+    assert aff.shape == (1, 2048) and e < 5e-3
+    assert tuple(out["pred_object_3d_contact"].shape) == tuple(d["pred_ocontact"].shape)
+    assert float(out["pred_human_3d_contact"].abs().max()) == 0.0

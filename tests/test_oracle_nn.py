@@ -101,3 +101,25 @@ def test_model_forward_end_to_end(golden_dir):
     # [SEG] at id-index 47 selects hidden row 47 - 1 + 255 (InteractVLM.py:331-341)
     rows = O.seg_rows(ids, [32000], 255, model_forward=True)
     assert rows.nonzero().flatten().tolist() == [47 - 1 + 255]
+
+
+def test_model_forward_oafford_end_to_end(golden_dir):
+    """The object-affordance branch of the reference's model_forward(inference=True) ('oafford' sample, 'HM' view type:
+    sigmoid on the non-ignored pixels, per-view pixel->point maps, 2048-point lift) vs the oracle pipeline."""
+    d = _g(golden_dir, "model_forward_oafford.npz")
+    cfg = toy_cfg(json.loads(str(d["toy"])))
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    ids = torch.from_numpy(d["input_ids"])
+    images_clip = torch.from_numpy(synth.synth_normal("mf2/images_clip", (1, 3, 224, 224), 1.0, 0))
+    images = torch.from_numpy(synth.synth_normal("mf2/images", (1, 4, 3, 1024, 1024), 1.0, 0))[0]
+    cams = torch.from_numpy(d["cam_params"])[0]
+    pid = synth.synth_point_maps(1, 4, 1024, 1024, 2048, fg=0.3, seed=int(d["point_maps_seed"]))[0]
+    valid = np.ones((4, 1024, 1024), bool)
+    valid[:, : int(d["ignore_rows"])] = False
+    o = P.model_forward_oafford(w, cfg, images, images_clip, ids, cams, pid, valid)
+    pm = o["pred_masks"].numpy()
+    np.testing.assert_allclose(pm[..., ::16, ::16], d["pred_masks_sub"], atol=5e-5)
+    assert abs(float(pm.astype(np.float64).sum()) - float(d["pred_masks_sum"])) < 1e-6 * pm.size
+    np.testing.assert_allclose(o["pred_afford"].numpy(), d["pred_afford"], atol=1e-5)
+    # what the reference returns for the predictors that do not apply to an 'oafford' sample
+    assert d["pred_ocontact"].shape == (1, 0) and float(np.abs(d["pred_human"]).max()) == 0.0
