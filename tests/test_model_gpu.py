@@ -328,3 +328,32 @@ def test_model_forward_oafford_vs_reference_golden(hip_lib, cuda, golden_dir, tm
     assert aff.shape == (1, 2048) and e < 5e-3
     assert tuple(out["pred_object_3d_contact"].shape) == tuple(d["pred_ocontact"].shape)
     assert float(out["pred_human_3d_contact"].abs().max()) == 0.0
+
+
+def test_load_model_from_released_layout(hip_lib, cuda, tmp_path):
+    """checkpoint.load_model (HF sharded safetensors + CLIP folder) builds the same model as passing the
+    state dict directly: identical evaluate() outputs."""
+    import torch
+
+    from interactvlm_amd import checkpoint as C
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth, synthetic
+    from interactvlm_amd import weights as Wt
+    from _ckpt_util import _write_clip, _write_version
+
+    cfg = synthetic.config_tiny()
+    state = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    ver, clip = str(tmp_path / "ver"), str(tmp_path / "clip")
+    _write_version(ver, cfg, state, "sharded_st")
+    _write_clip(clip, state)
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    m1 = C.load_model(ver, clip, cuda, lift_tables=tables)
+    rounded = {k: (v if k.startswith(Wt.CLIP_PREFIX) else v.to(torch.bfloat16)) for k, v in state.items()}
+    m2 = M.InteractVLMForCausalLM(cfg, rounded, cuda, lift_tables=tables)
+    ids, forced = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=6)
+    cams = synthetic.human_cam_params()
+    ic, im = synthetic.images(cfg, cuda)
+    o1 = m1.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced)
+    o2 = m2.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced)
+    assert torch.equal(o1["pred_contact_3d"], o2["pred_contact_3d"])
+    assert m1.config.oC_loss_weight == 0.5  # picked up from pretrained_config.json
