@@ -357,3 +357,41 @@ def test_load_model_from_released_layout(hip_lib, cuda, tmp_path):
     o2 = m2.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced)
     assert torch.equal(o1["pred_contact_3d"], o2["pred_contact_3d"])
     assert m1.config.oC_loss_weight == 0.5  # picked up from pretrained_config.json
+
+
+def test_object_render_localize_lift_flow(hip_lib, cuda, tmp_path):
+    """run_demo's object path (utils/demo_utils.py:171-257 -> InteractVLM.py:620-632): normalise + rasterise a mesh under the
+    four object cameras on the GPU, write the lift2d_dict.pkl the reference's predictor reads, evaluate(contact_type=
+    'ocontact') -> per-vertex contacts == the C oracle's threshold lift of the same masks through the same tables."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import render, synthetic
+    from interactvlm_amd import weights as Wt
+    from oracle import cref
+    from oracle import raster as R
+
+    v, f = R.icosphere(3)
+    v = (v * np.array([1.0, 0.6, 0.8], np.float32)).astype(np.float32)
+    vid, bary, nv = render.object_lift_tables(torch.from_numpy(v).to(cuda), torch.from_numpy(f).to(cuda), "4MV-Z_HM_BM")
+    assert nv == v.shape[0] and vid.shape == (4, 1024, 1024, 3)
+    assert 0.05 < float((vid[..., 0] >= 0).float().mean()) < 0.8
+    path = str(tmp_path / "lift2d_dict.pkl")
+    render.save_lift2d_dict(path, vid, bary, nv)
+    cfg = synthetic.config_tiny()
+    cfg.oC_loss_weight, cfg.oC_sam_view_type = 1.0, "4MV-Z_HM_BM"
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    from interactvlm_amd import synth
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    ids, forced = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=6)
+    cams = synthetic.human_cam_params()
+    ic, im = synthetic.images(cfg, cuda)
+    out = m.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced,
+                     contact_type="ocontact", lift2d_dict_path=path)
+    pc = out["pred_contact_3d"].float().cpu().numpy()
+    assert pc.shape == (1, nv)
+    pm = out["pred_masks"][0].float().cpu().numpy()
+    exp, _ = cref.lift_mesh_thresh(pm, vid.cpu().numpy().astype(np.int32), bary.cpu().numpy(), nv)
+    np.testing.assert_allclose(pc, exp, atol=2e-6)
+    assert np.array_equal(pc > 0.3, exp > 0.3) or np.abs(pc - exp)[(pc > 0.3) != (exp > 0.3)].max() < 2e-6
