@@ -249,16 +249,22 @@ def main():
         rg = {"bound": "mfma", "kernel": "gemm_bf16_kernel + gemm256_kernel (all MFMA-path launches)",
               "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
               "traffic": None, "launches_per_image": g["launches"] // nsteps, "avg_us": round(g["avg_us"], 2),
+              "avg_us_events_raw": round(g["avg_us_events_raw"], 2),
+              "event_pair_overhead_us": round(g["event_pair_overhead_us"], 2),
               "ms_per_image": round(g["total_s"] / nsteps * 1e3, 2)}
         la = l["work"] / l["total_s"] / 1e9
         rl = {"bound": "hbm", "kernel": "lift_plan_kernel", "achieved": round(la, 1), "peak": PEAK_HBM_GBPS,
               "unit": "GB/s", "frac": round(la / PEAK_HBM_GBPS, 4), "traffic": None,
-              "algorithmic_bytes": int(l["work"] / l["launches"]), "avg_us": round(l["avg_us"], 2)}
+              "algorithmic_bytes": int(l["work"] / l["launches"]), "avg_us": round(l["avg_us"], 2),
+              "avg_us_events_raw": round(l["avg_us_events_raw"], 2),
+              "event_pair_overhead_us": round(l["event_pair_overhead_us"], 2)}
         va = gv["work"] / gv["total_s"] / 1e9
         rv = {"bound": "hbm", "kernel": "gemv_kernel (decode linears: weight streaming)", "achieved": round(va, 1),
               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(va / PEAK_HBM_GBPS, 4), "traffic": None,
               "algorithmic_bytes": int(gv["work"] / gv["launches"]), "launches_per_image": gv["launches"] // nsteps,
-              "avg_us": round(gv["avg_us"], 2), "ms_per_image": round(gv["total_s"] / nsteps * 1e3, 2)}
+              "avg_us": round(gv["avg_us"], 2), "avg_us_events_raw": round(gv["avg_us_events_raw"], 2),
+              "event_pair_overhead_us": round(gv["event_pair_overhead_us"], 2),
+              "ms_per_image": round(gv["total_s"] / nsteps * 1e3, 2)}
         return rg, rl, rv
 
     roof_gemv = None
@@ -301,7 +307,9 @@ def main():
             "algorithmic_tflop_per_image": round(fl["total"] / 1e12, 2),
             # `roofline` = the kernel family with the largest share of GPU time (decode GEMV: HBM-bound);
             # the MFMA GEMMs and the mask-to-vertex lift (the two north-star targets) follow under their own keys
-            "roofline": (roof_gemv if (roof_gemv and roof and roof_gemv["ms_per_image"] >= roof["ms_per_image"]) else roof),
+            # (dominance is decided on the pass where kernels run alone: overlap inflates whichever kernel shares the CUs)
+            "roofline": (roof_gemv if (roof_serial and roof_serial["gemv"]["ms_per_image"] >= roof_serial["gemm"]["ms_per_image"])
+                         else roof),
             "roofline_mfma": roof, "roofline_gemv": roof_gemv, "roofline_lift": roof_lift, "cpu_baseline": cpu,
             "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "parity_vs_oracle": parity,
         }

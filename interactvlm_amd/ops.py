@@ -52,12 +52,29 @@ class KernelTimer:
             d["work"] += w
         return out
 
-    def summary(self):
+    def event_pair_overhead_ms(self, n=64):
+        """Elapsed time an EMPTY event pair reports on the current stream (median): what two event records add to
+        whatever they bracket.  Subtracted from every bracketed launch (matters for the 10-30 us kernels)."""
         torch.cuda.synchronize()
+        pairs = []
+        for _ in range(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            b.record()
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        v = sorted(a.elapsed_time(b) for a, b in pairs)
+        return v[len(v) // 2]
+
+    def summary(self, subtract_event_overhead=True):
+        torch.cuda.synchronize()
+        ovh = self.event_pair_overhead_ms() if subtract_event_overhead else 0.0
         out = {}
         for name, rec in self.records.items():
-            ms = [a.elapsed_time(b) for a, b, _, _ in rec]
+            raw = [a.elapsed_time(b) for a, b, _, _ in rec]
+            ms = [max(x - ovh, 0.2 * x) for x in raw]
             out[name] = {"launches": len(rec), "total_s": sum(ms) * 1e-3, "avg_us": sum(ms) / len(ms) * 1e3,
+                         "avg_us_events_raw": sum(raw) / len(raw) * 1e3, "event_pair_overhead_us": ovh * 1e3,
                          "work": float(sum(r[2] for r in rec))}
         return out
 
