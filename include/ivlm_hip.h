@@ -197,6 +197,11 @@ int ivlm_llama_generate(const int64_t *layer_ptrs, int L, int H, int D, int hidd
 int ivlm_llama_decode_attn(const void *qkv, void *kcache, void *vcache, void *o, int H, int D, int pos,
                            float theta, float scale, const float *cos_tab, const float *sin_tab,
                            ivlm_stream_t stream);
+/* Same, with the position read from device memory (int32 *pos_dev; the caller keeps *pos_dev < Tmax and < 4096): one
+ * captured HIP graph of a decode step can then be replayed for every generated token. */
+int ivlm_llama_decode_attn_devpos(const void *qkv, void *kcache, void *vcache, void *o, int H, int D,
+                                  const int32_t *pos_dev, float theta, float scale, const float *cos_tab,
+                                  const float *sin_tab, ivlm_stream_t stream);
 
 /* torch.argmax(logits, -1) of HF greedy search (first maximal index); x f32 [rows, cols] -> out i32 [rows]. */
 int ivlm_argmax_f32(const float *x, int rows, int cols, int32_t *out, ivlm_stream_t stream);

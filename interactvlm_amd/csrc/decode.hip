@@ -18,9 +18,12 @@ constexpr int kDecThreads = 1024, kDecGroups = kDecThreads / 16;  // 64 key rows
 __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_kernel(const bf16_t* __restrict__ qkv /*[3,H,D]*/,
                                                                 bf16_t* __restrict__ kcache /*[Tmax,H,D]*/,
                                                                 bf16_t* __restrict__ vcache, bf16_t* __restrict__ o,
-                                                                int H, int D, int pos, float theta, float scale,
+                                                                int H, int D, int pos_arg, float theta, float scale,
                                                                 const float* __restrict__ ct,
-                                                                const float* __restrict__ stab) {
+                                                                const float* __restrict__ stab,
+                                                                const int32_t* __restrict__ pos_dev) {
+    // position from device memory when given: lets one captured HIP graph serve every decode step
+    const int pos = pos_dev ? __builtin_amdgcn_readfirstlane(*pos_dev) : pos_arg;
     __shared__ float q_s[kMaxD];
     __shared__ float knew_s[kMaxD];
     __shared__ float vnew_s[kMaxD];
@@ -151,10 +154,11 @@ __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_kernel(const bf
 }  // namespace
 
 int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
-                      float scale, hipStream_t st, const float* cos_tab, const float* sin_tab) {
-    if (!qkv || !kcache || !vcache || !o || H <= 0 || D <= 0 || D > kMaxD || (D & 15) || pos < 0 || pos >= kMaxT)
-        return IVLM_ERR_INVALID_ARG;
-    llama_decode_attn_kernel<<<H, kDecThreads, 0, st>>>(qkv, kcache, vcache, o, H, D, pos, theta, scale, cos_tab, sin_tab);
+                      float scale, hipStream_t st, const float* cos_tab, const float* sin_tab, const int32_t* pos_dev) {
+    if (!qkv || !kcache || !vcache || !o || H <= 0 || D <= 0 || D > kMaxD || (D & 15)) return IVLM_ERR_INVALID_ARG;
+    if (!pos_dev && (pos < 0 || pos >= kMaxT)) return IVLM_ERR_INVALID_ARG;
+    llama_decode_attn_kernel<<<H, kDecThreads, 0, st>>>(qkv, kcache, vcache, o, H, D, pos, theta, scale, cos_tab, sin_tab,
+                                                       pos_dev);
     return ivlm_launch_status();
 }
 
@@ -166,5 +170,15 @@ extern "C" int ivlm_llama_decode_attn(const void* qkv, void* kcache, void* vcach
     ivlm_enter();
     return ivlm::llama_decode_attn(static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(kcache),
                                    static_cast<bf16_t*>(vcache), static_cast<bf16_t*>(o), H, D, pos, theta, scale,
-                                   ivlm_stream(stream), cos_tab, sin_tab);
+                                   ivlm_stream(stream), cos_tab, sin_tab, nullptr);
+}
+
+extern "C" int ivlm_llama_decode_attn_devpos(const void* qkv, void* kcache, void* vcache, void* o, int H, int D,
+                                             const int32_t* pos_dev, float theta, float scale, const float* cos_tab,
+                                             const float* sin_tab, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!pos_dev) return IVLM_ERR_INVALID_ARG;
+    return ivlm::llama_decode_attn(static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(kcache),
+                                   static_cast<bf16_t*>(vcache), static_cast<bf16_t*>(o), H, D, 0, theta, scale,
+                                   ivlm_stream(stream), cos_tab, sin_tab, pos_dev);
 }

@@ -101,7 +101,7 @@ int rasterize_points(const float* pts, int np, const float* cam12_host, float fo
 
 // ---- single-token decode (decode.hip) ---------------------------------------------------------------
 int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
-                      float scale, hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr);
+                      float scale, hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr, const int32_t* pos_dev = nullptr);
 
 // ---- skinny GEMM (gemv.hip): M <= 8 rows of activations against streamed weights -------------------
 int gemv_bf16(const GemmArgs& g, hipStream_t st);

@@ -82,6 +82,7 @@ class InteractVLMForCausalLM:
         self.use_fusion = self.use_uncertainty = False  # off in every released config (scripts/run_train.sh:61-62)
         self.debug_taps = None  # set to a dict to record intermediate tensors (tests / diagnostics only)
         self.overlap_sam_encoder = True
+        self.graph_decode = True  # HIP-graph replay of the decode step (launch-bound on the host otherwise)
         self.sam_after_prefill = False  # measured: 116.9 vs 115.3 ms - overlapping the decode instead of the prefill is not better
         # persistent one-launch greedy decode (csrc/generate.hip): correct and bit-reproducible, but measured SLOWER than the
         # per-op path on MI355X (3.43 vs 2.93 ms/token for 7B: every phase boundary costs ~9 us of device-wide sync
@@ -303,6 +304,32 @@ class InteractVLMForCausalLM:
         if forced_new_tokens is not None:
             forced_dev = torch.tensor([int(t) for t in forced_new_tokens], dtype=torch.int32, device=self.device)
         self.last_argmax = []
+        use_graph = self.graph_decode and not ops.TIMER.enabled and not torch.cuda.is_current_stream_capturing()
+        if use_graph:
+            # one decode step = one replay of a captured HIP graph (embed -> 32 layers -> norm -> lm_head -> argmax, position
+            # read from device memory); the host issues 3 launches per token instead of ~165
+            dg = self.llm.decode_graph()
+            dg["pos"].fill_(T0)
+            dg["pos64"].fill_(T0)
+            nxt = ops.argmax(self.llm.logits(last))
+            for step in range(n_max):
+                self.last_argmax.append(nxt)
+                if forced_new_tokens is not None:
+                    tok = int(forced_new_tokens[step])
+                    tok_t = forced_dev[step: step + 1]
+                else:
+                    tok = int(nxt.item())
+                    tok_t = nxt
+                new_ids.append(tok)
+                if tok == eos_token_id or step == n_max - 1:
+                    break
+                dg["tok"].copy_(tok_t)
+                dg["graph"].replay()
+                hidden_all[pos: pos + 1].copy_(dg["hidden"])
+                nxt = dg["nxt"].clone()
+                pos += 1
+            out_ids = torch.cat([ids.cpu(), torch.tensor(new_ids, dtype=ids.dtype)])[None]
+            return out_ids, hidden_all[:pos]
         for step in range(n_max):
             nxt = ops.argmax(self.llm.logits(last))  # int32 [1] on device
             self.last_argmax.append(nxt)

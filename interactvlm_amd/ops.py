@@ -472,11 +472,19 @@ def mask_dot(up, hyper, B, gh, gw):
 
 
 def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, table=None):
-    """qkv bf16 [1, 3*H*D] of the newest token -> o bf16 [1, H*D]; RoPE + cache append fused."""
+    """qkv bf16 [1, 3*H*D] of the newest token -> o bf16 [1, H*D]; RoPE + cache append fused.
+    pos: python int, or an int32 device tensor [1] (read by the kernel: HIP-graph friendly)."""
     lib = _lib.load()
     assert qkv.dtype == BF16 and qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
     if out is None:
         out = torch.empty(1, H * D, dtype=BF16, device=qkv.device)
+    if isinstance(pos, torch.Tensor):
+        assert pos.dtype == torch.int32 and pos.is_cuda
+        check(lib.ivlm_llama_decode_attn_devpos(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), H, D,
+                                                pos.data_ptr(), float(theta), float(scale),
+                                                _p(table[0]) if table else 0, _p(table[1]) if table else 0, _stream()),
+              "llama_decode_attn_devpos")
+        return out
     check(lib.ivlm_llama_decode_attn(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), H, D,
                                      int(pos), float(theta), float(scale), _p(table[0]) if table else 0,
                                      _p(table[1]) if table else 0, _stream()), "llama_decode_attn")

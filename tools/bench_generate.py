@@ -36,7 +36,17 @@ def main():
                 break
             last = llm.forward(llm.embed_ids(forced[step: step + 1]), T0 + step)
 
-    for name, fn in (("fused", fused), ("per_op", per_op)):
+    def per_op_graph():
+        dg = llm.decode_graph()
+        dg["pos"].fill_(T0)
+        dg["pos64"].fill_(T0)
+        ops.argmax(llm.logits(hid[T0 - 1: T0]))
+        for step in range(n - 1):
+            dg["tok"].copy_(forced[step: step + 1])
+            dg["graph"].replay()
+            hid[T0 + step: T0 + step + 1].copy_(dg["hidden"])
+
+    for name, fn in (("fused", fused), ("per_op", per_op), ("per_op_graph", per_op_graph)):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
