@@ -230,6 +230,15 @@ int ivlm_dense_pe(const void *gauss, void *pe, int h, int w, int F, ivlm_stream_
  * positions pos0+t, and KV-cache append (kcache/vcache [Tmax,H,D], may be NULL). */
 int ivlm_rope_kv(void *qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void *kcache, void *vcache,
                  const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
+/* Decode attention (as ivlm_llama_decode_attn_devpos) and the o_proj GEMV + residual of the same layer in ONE launch:
+ * x_out[hidden] = x + W_o . attention(qkv).  The o_proj blocks stream their weight rows while the attention blocks run and
+ * wait for them on `counter` (int32, zeroed by the caller at the start of a generation; `step_dev` = tokens decoded so far,
+ * incremented by the caller after each token; target = H * (step + 1)).  attn_scratch: hidden bf16.  status[0] != 0 after the
+ * stream drained = a bounded wait expired (results invalid).  hidden = H*D in {512, 1024, 4096, 5120}. */
+int ivlm_llama_attn_oproj(const void *qkv, void *kcache, void *vcache, void *attn_scratch, const void *wo, const void *x,
+                          void *x_out, int H, int D, float theta, float scale, const float *cos_tab, const float *sin_tab,
+                          const int32_t *pos_dev, const int32_t *step_dev, int32_t *counter, int32_t *status,
+                          ivlm_stream_t stream);
 /* fp32 rotary tables cos/sin [T, D/2] (optional inputs of ivlm_rope_kv / ivlm_llama_decode_attn; NULL = compute) */
 int ivlm_rope_table(float *cos_tab, float *sin_tab, int T, int D, float theta, ivlm_stream_t stream);
 /* Caller-side image preprocessing (run_demo.py:65-79 `preprocess`: (x - mean)/std then zero-pad to the square model

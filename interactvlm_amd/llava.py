@@ -113,6 +113,8 @@ class Llama:
         self.vcache = torch.zeros(cfg.layers, max_len, H, hd, dtype=BF16, device=device)
         self.rope = ops.rope_table(max_len, hd, cfg.theta, device)  # fp32 cos/sin, computed once
         self._dgraph = None
+        self._fused = None
+        self.fuse_attn_oproj = True
         # device-side table of the per-layer weight addresses for the persistent generation kernel
         self.layer_ptrs = torch.tensor(
             [[L[k].data_ptr() for k in ("ln1", "qkv", "o", "ln2", "gu", "down")] for L in self.layers],
@@ -154,6 +156,14 @@ class Llama:
             dev = self.device
             st = dict(tok=torch.zeros(1, dtype=torch.int32, device=dev), pos=torch.zeros(1, dtype=torch.int32, device=dev),
                       pos64=torch.zeros(1, dtype=torch.int64, device=dev))
+            c = self.cfg
+            if self.fuse_attn_oproj and c.hidden in (512, 1024, 4096, 5120):
+                # fused attention + o_proj launches: per-layer arrival counters, tokens-decoded counter, status word
+                st["fused"] = dict(step=torch.zeros(1, dtype=torch.int32, device=dev),
+                                   counters=torch.zeros(c.layers, 32, dtype=torch.int32, device=dev),  # 128-B apart
+                                   status=torch.zeros(1, dtype=torch.int32, device=dev),
+                                   scratch=torch.zeros(c.layers, c.hidden, dtype=BF16, device=dev))
+            self._fused = st.get("fused")
 
             def body():
                 e = self.embed_ids(st["tok"])
@@ -162,6 +172,8 @@ class Llama:
                 st["nxt"] = ops.argmax(self.logits(h))
                 st["pos"].add_(1)
                 st["pos64"].add_(1)
+                if self._fused is not None:
+                    self._fused["step"].add_(1)
 
             saved = (self.kcache[:, :1].clone(), self.vcache[:, :1].clone())  # the warm-up / capture runs write row 0
             side = torch.cuda.Stream(device=dev)
@@ -171,6 +183,9 @@ class Llama:
             torch.cuda.current_stream(dev).wait_stream(side)
             st["pos"].zero_()
             st["pos64"].zero_()
+            if self._fused is not None:
+                self._fused["step"].zero_()
+                self._fused["counters"].zero_()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 body()
@@ -185,8 +200,15 @@ class Llama:
         fused into the attention kernel, residual adds and SwiGLU in the GEMV epilogues)."""
         c = self.cfg
         H, hd = c.heads, c.hidden // c.heads
+        fz = self._fused if isinstance(pos, torch.Tensor) else None
         for li, L in enumerate(self.layers):
             qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps))
+            if fz is not None:  # attention + o_proj + residual in one launch (W_o streams while the attention runs)
+                x = ops.llama_attn_oproj(qkv, self.kcache[li], self.vcache[li], L["o"], x, H, hd, pos, fz["step"],
+                                         fz["counters"][li], fz["status"], c.theta, hd ** -0.5, self.rope, fz["scratch"][li])
+                h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))
+                x = ops.linear(h, L["down"], residual=x)
+                continue
             a = ops.llama_decode_attn(qkv, self.kcache[li], self.vcache[li], H, hd, pos, c.theta, hd ** -0.5, table=self.rope)
             x = ops.linear(a, L["o"], residual=x)
             h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))

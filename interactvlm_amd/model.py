@@ -311,6 +311,11 @@ class InteractVLMForCausalLM:
             dg = self.llm.decode_graph()
             dg["pos"].fill_(T0)
             dg["pos64"].fill_(T0)
+            fz = dg.get("fused")
+            if fz is not None:
+                fz["step"].zero_()
+                fz["counters"].zero_()
+                fz["status"].zero_()
             nxt = ops.argmax(self.llm.logits(last))
             for step in range(n_max):
                 self.last_argmax.append(nxt)
@@ -328,6 +333,8 @@ class InteractVLMForCausalLM:
                 hidden_all[pos: pos + 1].copy_(dg["hidden"])
                 nxt = dg["nxt"].clone()
                 pos += 1
+            if fz is not None and int(fz["status"].item()) != 0:
+                raise ops.IvlmError("fused decode launch: a bounded device-side wait expired (results invalid)")
             out_ids = torch.cat([ids.cpu(), torch.tensor(new_ids, dtype=ids.dtype)])[None]
             return out_ids, hidden_all[:pos]
         for step in range(n_max):

@@ -491,6 +491,17 @@ def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, ta
     return out
 
 
+def llama_attn_oproj(qkv, kcache, vcache, wo, x, H, D, pos_dev, step_dev, counter, status, theta, scale, table, scratch):
+    """One launch: single-token attention of every head + o_proj GEMV + residual -> x_out bf16 [1, H*D]."""
+    lib = _lib.load()
+    out = torch.empty(1, H * D, dtype=BF16, device=qkv.device)
+    check(lib.ivlm_llama_attn_oproj(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), scratch.data_ptr(), wo.data_ptr(),
+                                    x.data_ptr(), out.data_ptr(), H, D, float(theta), float(scale), table[0].data_ptr(),
+                                    table[1].data_ptr(), pos_dev.data_ptr(), step_dev.data_ptr(), counter.data_ptr(),
+                                    status.data_ptr(), _stream()), "llama_attn_oproj")
+    return out
+
+
 def llama_generate(layer_ptrs, L, H, D, hidden, inter, vocab, eps, scale, rope, kcache, vcache, max_len, embed, final_norm,
                    lm_head, hidden_out, pos0, n_max, eos, forced=None):
     """Whole greedy generation after the prefill in one persistent launch (ivlm_llama_generate).

@@ -40,6 +40,9 @@ def main():
         dg = llm.decode_graph()
         dg["pos"].fill_(T0)
         dg["pos64"].fill_(T0)
+        if dg.get("fused") is not None:
+            dg["fused"]["step"].zero_()
+            dg["fused"]["counters"].zero_()
         ops.argmax(llm.logits(hid[T0 - 1: T0]))
         for step in range(n - 1):
             dg["tok"].copy_(forced[step: step + 1])
