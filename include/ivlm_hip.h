@@ -239,6 +239,20 @@ int ivlm_llama_attn_oproj(const void *qkv, void *kcache, void *vcache, void *att
                           void *x_out, int H, int D, float theta, float scale, const float *cos_tab, const float *sin_tab,
                           const int32_t *pos_dev, const int32_t *step_dev, int32_t *counter, int32_t *status,
                           ivlm_stream_t stream);
+/* ALL decoder layers of one generated token in ONE launch, as a dataflow of role-specialised workgroups (q|k|v rows ->
+ * attention heads -> o_proj rows -> gate|up pairs -> down rows, layer after layer): every block streams its weight rows first
+ * and then waits on a device counter for the blocks that produce its input, so no launch / barrier bubble stalls HBM.
+ *   layer_ptrs as for ivlm_llama_generate; kcache/vcache bf16 [L, Tmax, H, D]; x0 bf16 [hidden] = embedding of the token;
+ *   x_out bf16 [hidden] = residual stream after the last layer (before the final RMSNorm);
+ *   pos_dev / step_dev: int32 in device memory (position of the token; tokens decoded so far in this generation);
+ *   workspace: ivlm_llama_decode_layers_workspace_bytes, 256-byte aligned; its first L*5*32 int32 (counters) and the
+ *   following int32 (status) must be zeroed by the caller at the start of a generation; status != 0 afterwards = a bounded
+ *   wait expired, results invalid.  (hidden, inter) in {(4096,11008), (5120,13824), (1024,1376), (512,1024)}. */
+size_t ivlm_llama_decode_layers_workspace_bytes(int L, int hidden, int inter);
+int ivlm_llama_decode_layers(const int64_t *layer_ptrs, int L, int H, int D, int hidden, int inter, float eps, float theta,
+                             float scale, const float *cos_tab, const float *sin_tab, void *kcache, void *vcache,
+                             int64_t cache_layer_stride, const void *x0, void *x_out, const int32_t *pos_dev,
+                             const int32_t *step_dev, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
 /* fp32 rotary tables cos/sin [T, D/2] (optional inputs of ivlm_rope_kv / ivlm_llama_decode_attn; NULL = compute) */
 int ivlm_rope_table(float *cos_tab, float *sin_tab, int T, int D, float theta, ivlm_stream_t stream);
 /* Caller-side image preprocessing (run_demo.py:65-79 `preprocess`: (x - mean)/std then zero-pad to the square model

@@ -12,14 +12,21 @@ constexpr int kDecThreads = 1024, kDecGroups = kDecThreads / 16;  // 64 key rows
 
 // body shared by the stand-alone kernel below and the fused attention + o_proj kernel (decode_fused.hip).
 // COHERENT_OUT: the output row is written with agent-scope (sc1) stores, for consumers inside the same launch.
-template <bool COHERENT_OUT>
+// COHERENT_IN: qkv was produced by other blocks of the same launch: read it with agent-scope loads, after wait_fn()
+// (called once per thread, after the K/V rows are in flight; returns false => give up) has seen the producers arrive.
+struct NoWait {
+    __device__ __forceinline__ bool operator()() const { return true; }
+};
+template <bool COHERENT_OUT, bool COHERENT_IN = false, class WaitFn = NoWait, int THREADS = 1024>
 __device__ __forceinline__ void llama_decode_attn_body(const int h, const bf16_t* __restrict__ qkv /*[3,H,D]*/,
                                                                 bf16_t* __restrict__ kcache /*[Tmax,H,D]*/,
                                                                 bf16_t* __restrict__ vcache, bf16_t* __restrict__ o,
                                                                 int H, int D, int pos_arg, float theta, float scale,
                                                                 const float* __restrict__ ct,
                                                                 const float* __restrict__ stab,
-                                                                const int32_t* __restrict__ pos_dev) {
+                                                                const int32_t* __restrict__ pos_dev,
+                                                                WaitFn wait_fn = WaitFn()) {
+    constexpr int kDecThreads = THREADS, kDecGroups = THREADS / 16;  // (shadow the namespace defaults)
     // position from device memory when given: lets one captured HIP graph serve every decode step
     const int pos = pos_dev ? __builtin_amdgcn_readfirstlane(*pos_dev) : pos_arg;
     (void)theta;
@@ -34,7 +41,7 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const bf16_t
     // K and V rows of the first kTileKeys keys go in flight before anything else (they do not depend on q): the kernel is a
     // chain of dependent memory round trips otherwise (one per 64 keys).  16 lanes share a key row; group g owns keys
     // g, g + 64, ...
-    constexpr int kU = 6;  // rows per group and tile: 384 keys per tile, 6 K + 6 V chunks (48 VGPRs) per lane
+    constexpr int kU = 384 / kDecGroups;  // rows per group and tile: 384 keys per tile (6 K + 6 V chunks per lane at 1024 threads)
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     const int sub = t & 15, grp = t >> 4;  // 64 groups of 16 lanes
     const int nch = D >> 3;                // 16-byte chunks per row (<= 16)
@@ -50,6 +57,11 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const bf16_t
         kr[i] = *reinterpret_cast<const u32x4_t*>(kb + j * rstride);
         vr[i] = *reinterpret_cast<const u32x4_t*>(vb + j * rstride);
     }
+    if (!wait_fn()) return;
+    auto ld = [](const bf16_t* p) -> bf16_t {
+        if (COHERENT_IN) return __hip_atomic_load(const_cast<bf16_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return *p;
+    };
     // ---- RoPE on q and the new k; append k, v to the cache -------------------------------------
     if (t < half) {
         const bf16_t* q = qkv + h * D;
@@ -63,8 +75,8 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const bf16_t
             c = cosf(ang);
             s = sinf(ang);
         }
-        const float q0 = bf16_to_f32(q[t]), q1 = bf16_to_f32(q[t + half]);
-        const float k0 = bf16_to_f32(k[t]), k1 = bf16_to_f32(k[t + half]);
+        const float q0 = bf16_to_f32(ld(q + t)), q1 = bf16_to_f32(ld(q + t + half));
+        const float k0 = bf16_to_f32(ld(k + t)), k1 = bf16_to_f32(ld(k + t + half));
         // round q, k to bf16 exactly like the prefill path (rope_kv_kernel) so both paths see the same values
         const bf16_t qa = f32_to_bf16(q0 * c - q1 * s), qb = f32_to_bf16(q1 * c + q0 * s);
         const bf16_t ka = f32_to_bf16(k0 * c - k1 * s), kb = f32_to_bf16(k1 * c + k0 * s);
@@ -77,7 +89,7 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const bf16_t
         kc[t + half] = kb;
     } else if (t >= 128 && t < 128 + D) {
         const int d = t - 128;
-        const bf16_t v = qkv[2 * (int64_t)H * D + h * D + d];
+        const bf16_t v = ld(qkv + 2 * (int64_t)H * D + h * D + d);
         vnew_s[d] = bf16_to_f32(v);
         vcache[((int64_t)pos * H + h) * D + d] = v;
     }

@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .sam import _LN, _Lin, _dev
 from .weights import CLIP_PREFIX, ClipCfg, LlamaCfg
 
@@ -114,7 +114,12 @@ class Llama:
         self.rope = ops.rope_table(max_len, hd, cfg.theta, device)  # fp32 cos/sin, computed once
         self._dgraph = None
         self._fused = None
+        self._dataflow = None
         self.fuse_attn_oproj = True
+        # all layers in one dataflow launch (csrc/decode_layers.hip): correct, but 3.25-3.5 ms/token vs 2.72 for the per-layer
+        # launches: every role is an all-to-all dependency, and one resident block per CU cannot both stream its role with all
+        # CUs and keep the next role's rows prefetched - opt-in experiment
+        self.dataflow_layers = False
         # device-side table of the per-layer weight addresses for the persistent generation kernel
         self.layer_ptrs = torch.tensor(
             [[L[k].data_ptr() for k in ("ln1", "qkv", "o", "ln2", "gu", "down")] for L in self.layers],
@@ -164,6 +169,11 @@ class Llama:
                                    status=torch.zeros(1, dtype=torch.int32, device=dev),
                                    scratch=torch.zeros(c.layers, c.hidden, dtype=BF16, device=dev))
             self._fused = st.get("fused")
+            if self.dataflow_layers and (c.hidden, c.inter) in ((4096, 11008), (5120, 13824), (1024, 1376), (512, 1024)):
+                nbytes = _lib.load().ivlm_llama_decode_layers_workspace_bytes(c.layers, c.hidden, c.inter)
+                st["dataflow"] = dict(ws=torch.zeros(nbytes, dtype=torch.uint8, device=dev),
+                                      step=torch.zeros(1, dtype=torch.int32, device=dev), zero_bytes=c.layers * 5 * 32 * 4 + 256)
+            self._dataflow = st.get("dataflow")
 
             def body():
                 e = self.embed_ids(st["tok"])
@@ -174,6 +184,8 @@ class Llama:
                 st["pos64"].add_(1)
                 if self._fused is not None:
                     self._fused["step"].add_(1)
+                if self._dataflow is not None:
+                    self._dataflow["step"].add_(1)
 
             saved = (self.kcache[:, :1].clone(), self.vcache[:, :1].clone())  # the warm-up / capture runs write row 0
             side = torch.cuda.Stream(device=dev)
@@ -186,6 +198,8 @@ class Llama:
             if self._fused is not None:
                 self._fused["step"].zero_()
                 self._fused["counters"].zero_()
+            if self._dataflow is not None:
+                self.reset_dataflow()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 body()
@@ -195,11 +209,26 @@ class Llama:
             self._dgraph = st
         return self._dgraph
 
+    def reset_dataflow(self):
+        """start of a generation: arrival counters, status word and the tokens-decoded counter back to zero"""
+        df = self._dataflow
+        df["ws"][: df["zero_bytes"]].zero_()
+        df["step"].zero_()
+
+    def dataflow_status(self):
+        df = self._dataflow
+        return int(df["ws"][df["zero_bytes"] - 256: df["zero_bytes"] - 252].view(torch.int32)[0])
+
     def _decode_step(self, x, pos):
         """One new token: 5 launches per layer (RMSNorm fused into the q|k|v and gate|up GEMVs, RoPE + cache append
         fused into the attention kernel, residual adds and SwiGLU in the GEMV epilogues)."""
         c = self.cfg
         H, hd = c.heads, c.hidden // c.heads
+        if self._dataflow is not None and isinstance(pos, torch.Tensor):  # all layers in one dataflow launch
+            df = self._dataflow
+            x = ops.llama_decode_layers(self.layer_ptrs, c.layers, H, hd, c.hidden, c.inter, c.eps, c.theta, self.rope,
+                                        self.kcache, self.vcache, x, pos, df["step"], df["ws"])
+            return ops.rmsnorm(x, self.norm, c.eps)
         fz = self._fused if isinstance(pos, torch.Tensor) else None
         for li, L in enumerate(self.layers):
             qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps))

@@ -316,6 +316,8 @@ class InteractVLMForCausalLM:
                 fz["step"].zero_()
                 fz["counters"].zero_()
                 fz["status"].zero_()
+            if dg.get("dataflow") is not None:
+                self.llm.reset_dataflow()
             nxt = ops.argmax(self.llm.logits(last))
             for step in range(n_max):
                 self.last_argmax.append(nxt)
@@ -335,6 +337,8 @@ class InteractVLMForCausalLM:
                 pos += 1
             if fz is not None and int(fz["status"].item()) != 0:
                 raise ops.IvlmError("fused decode launch: a bounded device-side wait expired (results invalid)")
+            if dg.get("dataflow") is not None and self.llm.dataflow_status() != 0:
+                raise ops.IvlmError("dataflow decode launch: a bounded device-side wait expired (results invalid)")
             out_ids = torch.cat([ids.cpu(), torch.tensor(new_ids, dtype=ids.dtype)])[None]
             return out_ids, hidden_all[:pos]
         for step in range(n_max):

@@ -502,6 +502,17 @@ def llama_attn_oproj(qkv, kcache, vcache, wo, x, H, D, pos_dev, step_dev, counte
     return out
 
 
+def llama_decode_layers(layer_ptrs, L, H, D, hidden, inter, eps, theta, rope, kcache, vcache, x0, pos_dev, step_dev, ws):
+    """All decoder layers of one token in one dataflow launch -> residual stream after the last layer, bf16 [1, hidden]."""
+    lib = _lib.load()
+    out = torch.empty(1, hidden, dtype=BF16, device=x0.device)
+    check(lib.ivlm_llama_decode_layers(layer_ptrs.data_ptr(), L, H, D, hidden, inter, float(eps), float(theta), float(D) ** -0.5,
+                                       rope[0].data_ptr(), rope[1].data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
+                                       kcache.stride(0), x0.data_ptr(), out.data_ptr(), pos_dev.data_ptr(), step_dev.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _stream()), "llama_decode_layers")
+    return out
+
+
 def llama_generate(layer_ptrs, L, H, D, hidden, inter, vocab, eps, scale, rope, kcache, vcache, max_len, embed, final_norm,
                    lm_head, hidden_out, pos0, n_max, eos, forced=None):
     """Whole greedy generation after the prefill in one persistent launch (ivlm_llama_generate).

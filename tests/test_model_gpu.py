@@ -192,8 +192,9 @@ def test_persistent_generate_vs_per_op_and_oracle(hip_lib, cuda, hidden, heads, 
     assert (arg_ids.cpu()[:6][clear] == lg.argmax(-1)[clear].to(torch.int32)).all()
 
 
-@pytest.mark.parametrize("hidden,heads", [(1024, 8), (512, 4)])
-def test_graph_decode_with_fused_attn_oproj_matches_eager(hip_lib, cuda, hidden, heads):
+@pytest.mark.parametrize("dataflow", [True, False])
+@pytest.mark.parametrize("hidden,heads,inter", [(1024, 8, 1376), (512, 4, 1024)])
+def test_graph_decode_with_fused_attn_oproj_matches_eager(hip_lib, cuda, hidden, heads, inter, dataflow):
     """The replayed HIP graph of a decode step (position from device memory; attention + o_proj fused into one launch whose
     GEMV blocks wait on a device counter) against the eager per-op steps: same argmax ids, hidden states and KV cache."""
     import torch
@@ -201,7 +202,7 @@ def test_graph_decode_with_fused_attn_oproj_matches_eager(hip_lib, cuda, hidden,
     from interactvlm_amd import llava, ops
     from interactvlm_amd import weights as Wt
 
-    lc = Wt.LlamaCfg(hidden=hidden, layers=3, heads=heads, inter=1376, vocab=1003)
+    lc = Wt.LlamaCfg(hidden=hidden, layers=3, heads=heads, inter=inter, vocab=1003)
     w = _bf16_weights(Wt.llama_spec(lc))
     g = torch.Generator().manual_seed(11)
     T0, n_new = 29, 14
@@ -216,21 +217,24 @@ def test_graph_decode_with_fused_attn_oproj_matches_eager(hip_lib, cuda, hidden,
         hid_a.append(h)
         arg_a.append(int(ops.argmax(llm_a.logits(h))[0]))
     llm_b = llava.Llama(w, lc, cuda, max_len=64)
+    llm_b.dataflow_layers = dataflow  # True: all layers in ONE dataflow launch; False: attention + o_proj fused per layer
     llm_b.forward(emb, 0)
     dg = llm_b.decode_graph()
-    assert dg.get("fused") is not None
+    assert dg.get("fused") is not None and (dg.get("dataflow") is not None) == dataflow
     for rep in range(2):  # a second generation re-uses the graph: counters / step / position are reset by the caller
         dg["pos"].fill_(T0)
         dg["pos64"].fill_(T0)
         for k in ("step", "counters", "status"):
             dg["fused"][k].zero_()
+        if dataflow:
+            llm_b.reset_dataflow()
         hid_b, arg_b = [], []
         for s in range(n_new):
             dg["tok"].copy_(toks[s: s + 1])
             dg["graph"].replay()
             hid_b.append(dg["hidden"].clone())
             arg_b.append(int(dg["nxt"][0]))
-        assert int(dg["fused"]["status"][0]) == 0
+        assert int(dg["fused"]["status"][0]) == 0 and (not dataflow or llm_b.dataflow_status() == 0)
         assert int(dg["pos"][0]) == T0 + n_new and int(dg["fused"]["step"][0]) == n_new
         assert _rel_err(torch.cat(hid_b), torch.cat(hid_a).float().cpu()) < 2e-2
         assert _rel_err(llm_b.kcache[:, : T0 + n_new], llm_a.kcache[:, : T0 + n_new].float().cpu()) < 2e-2

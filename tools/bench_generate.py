@@ -43,6 +43,8 @@ def main():
         if dg.get("fused") is not None:
             dg["fused"]["step"].zero_()
             dg["fused"]["counters"].zero_()
+        if dg.get("dataflow") is not None:
+            llm.reset_dataflow()
         ops.argmax(llm.logits(hid[T0 - 1: T0]))
         for step in range(n - 1):
             dg["tok"].copy_(forced[step: step + 1])
