@@ -179,6 +179,7 @@ inline int choose_tile(const GemmArgs& g) {
     const double q = (double)t256 / (double)(((t256 + 255) / 256) * 256);
     const double edge = (double)(((g.M + 255) / 256) * 256) * (((g.N + 255) / 256) * 256) / ((double)g.M * g.N);
     if (t256 >= 512 && q >= 0.85 && edge < 1.1) return 512;  // 256^2 tile, 8-phase ping-pong pipeline (gemm256.hip)
+    if (t256 >= 256 && g.K >= 2048 && edge < 1.1) return 512;     // long K amortises its prologue/epilogue even at 1-2 waves of tiles (SAM mlp2: 911 vs 837 TF)
     return 128;
 }
 
