@@ -1,0 +1,68 @@
+"""run_demo-equivalent plumbing: prompt assembly, image-token splicing, and one sample end to
+end on the GPU with the reference's output files."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from interactvlm_amd import demo
+
+
+class _Tok:
+    """minimal stand-in for the HF tokenizer interface used by tokenizer_image_token: BOS + one id per word"""
+    bos_token_id = 1
+
+    def __init__(self, bos=True):
+        self.bos = bos
+        self.vocab = {}
+
+    def __call__(self, text):
+        ids = [self.vocab.setdefault(w, 10 + len(self.vocab)) for w in text.split()]
+
+        class R:
+            input_ids = ([1] if self.bos else []) + ids
+        return R
+
+
+def test_prompt_and_image_token_splicing():
+    p = demo.build_prompt(demo.HCONTACT_PROMPT.format(object="chair"))
+    assert p.startswith("A chat between a curious human") and p.endswith("Segment these contact areas. ASSISTANT:")
+    assert "USER: <im_start><image><im_end>\nWhich body parts" in p
+    tok = _Tok(bos=True)
+    ids = demo.tokenizer_image_token("a b <image> c d <image> e", tok).tolist()
+    a, b, c, d, e = (tok.vocab[w] for w in "abcde")
+    assert ids == [1, a, b, -200, c, d, -200, e]          # one BOS, one placeholder per <image> (mm_utils.py:16-44)
+    tok2 = _Tok(bos=False)
+    ids2 = demo.tokenizer_image_token("a <image> b", tok2).tolist()
+    assert ids2 == [tok2.vocab["a"], -200, tok2.vocab["b"]]
+    cams = demo.cam_params_for("hcontact", "4MV-Z_Vitru")
+    assert cams.shape == (1, 4, 5) and abs(float(cams[0, 0, 0]) - 0.2) < 1e-6   # d / 10 (base_contact_dataset.py:37-50)
+
+
+@pytest.mark.gpu
+def test_run_sample_writes_reference_outputs(hip_lib, cuda, tmp_path):
+    from interactvlm_amd import model as M
+    from interactvlm_amd import ops, synth, synthetic
+    from interactvlm_amd import weights as Wt
+
+    cfg = synthetic.config_tiny()
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    rng = np.random.default_rng(0)
+    photo = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)                    # any size: CLIP resize + crop
+    renders = [rng.integers(0, 256, size=(1024, 1024, 3), dtype=np.uint8) for _ in range(4)]
+    ids, forced = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=6)
+    mapping = torch.zeros(10475, 6890)
+    r = torch.arange(10475)
+    for k in range(3):  # 3 non-zeros per row like the SMPL -> SMPL-X barycentric transfer
+        mapping[r, (r * 7 + k * 13) % 6890] += [0.5, 0.3, 0.2][k]
+    out = demo.run_sample(m, photo, renders, ids[0], "hcontact", out_dir=str(tmp_path), name="chair__img",
+                          smpl_to_smplx=ops.SparseRows(mapping, cuda), forced_new_tokens=forced)
+    z = np.load(os.path.join(tmp_path, "chair__img_hcontact_vertices.npz"))
+    assert z["pred_contact_3d_smplh"].shape == (1, 6890) and z["pred_contact_3d_smplx"].shape == (10475,)
+    pc = out["pred_contact_3d"].float().cpu()
+    assert np.array_equal(z["pred_contact_3d_smplh"], pc.numpy())
+    np.testing.assert_allclose(z["pred_contact_3d_smplx"], (mapping @ pc[0]).numpy(), atol=1e-5)
+    assert out["pred_masks"][0].shape == (4, 1024, 1024)
