@@ -62,7 +62,7 @@ class ClipTower:
                 self._forward(static_in)
             torch.cuda.current_stream(images.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (an RCCL watchdog thread may be polling events)
                 static_out = self._forward(static_in)
             ent = self._graphs[B] = (g, static_in, static_out)
         g, static_in, static_out = ent
@@ -201,7 +201,7 @@ class Llama:
             if self._dataflow is not None:
                 self.reset_dataflow()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 body()
             self.kcache[:, :1].copy_(saved[0])
             self.vcache[:, :1].copy_(saved[1])
