@@ -7,8 +7,9 @@ shipped.  ``interactvlm_amd`` never imports this package.
 
 Pinning status:
   * lift (K14/K15/K16), SAM prompt-encoder / mask-decoder / postprocess, SAM ViT blocks,
-    cam-pose encoders, [SEG] selection and the model_forward(inference=True) wiring are
-    PINNED against golden vectors produced by importing the reference itself
+    cam-pose encoders, [SEG] selection and the model_forward(inference=True) wiring (an hcontact sample and an
+    oafford sample with the object predictors enabled) are PINNED against golden vectors produced by importing
+    the reference itself
     (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``).
   * LLaMA / CLIP arithmetic lives in un-vendored ``transformers==4.31.0`` (absent here).
     The stand-in used to produce goldens is transformers 5.15 (same published architecture);
