@@ -136,6 +136,12 @@ int llama_attn_oproj(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* 
     a.H = H; a.D = D; a.theta = theta; a.scale = scale; a.cos_tab = cos_tab; a.sin_tab = sin_tab;
     a.pos_dev = pos_dev; a.step_dev = step_dev; a.counter = counter; a.status = status;
     const int grid = H + (hidden + kRowsPerBlock - 1) / kRowsPerBlock;
+    {  // consumers wait for producers inside the launch: the whole grid must be resident (one block per CU)
+        int dev = 0, cus = 0;
+        IVLM_HIP_TRY(hipGetDevice(&dev));
+        IVLM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (grid > cus) return IVLM_ERR_UNSUPPORTED;
+    }
     switch (hidden / 512) {
         case 8: attn_oproj_kernel<8><<<grid, kDecThreads, 0, st>>>(a); break;    // 4096 (LLaMA-2 7B)
         case 10: attn_oproj_kernel<10><<<grid, kDecThreads, 0, st>>>(a); break;  // 5120 (13B)

@@ -162,7 +162,9 @@ class Llama:
             st = dict(tok=torch.zeros(1, dtype=torch.int32, device=dev), pos=torch.zeros(1, dtype=torch.int32, device=dev),
                       pos64=torch.zeros(1, dtype=torch.int64, device=dev))
             c = self.cfg
-            if self.fuse_attn_oproj and c.hidden in (512, 1024, 4096, 5120):
+            n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            # (every block of the fused launch must be resident at once: one 1024-thread block per CU)
+            if self.fuse_attn_oproj and c.hidden in (512, 1024, 4096, 5120) and c.heads + c.hidden // 32 <= n_cu:
                 # fused attention + o_proj launches: per-layer arrival counters, tokens-decoded counter, status word
                 st["fused"] = dict(step=torch.zeros(1, dtype=torch.int32, device=dev),
                                    counters=torch.zeros(c.layers, 32, dtype=torch.int32, device=dev),  # 128-B apart
