@@ -137,9 +137,12 @@ int llama_attn_oproj(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* 
     a.pos_dev = pos_dev; a.step_dev = step_dev; a.counter = counter; a.status = status;
     const int grid = H + (hidden + kRowsPerBlock - 1) / kRowsPerBlock;
     {  // consumers wait for producers inside the launch: the whole grid must be resident (one block per CU)
-        int dev = 0, cus = 0;
-        IVLM_HIP_TRY(hipGetDevice(&dev));
-        IVLM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        static int cus = 0;  // queried once (never during a stream capture: the graph path warms up first)
+        if (cus == 0) {
+            int dev = 0;
+            IVLM_HIP_TRY(hipGetDevice(&dev));
+            IVLM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        }
         if (grid > cus) return IVLM_ERR_UNSUPPORTED;
     }
     switch (hidden / 512) {
