@@ -68,7 +68,7 @@ class _CamPoseEncoder:
 
 class InteractVLMForCausalLM:
     def __init__(self, config: IvlmCfg, weights: dict, device="cuda:0", lift_tables=None, metadata_root="./data",
-                 max_len=640):
+                 max_len=1024):
         c = self.config = config
         self.device = dev = torch.device(device)
         w = weights
@@ -280,6 +280,13 @@ class InteractVLMForCausalLM:
         x = self._input_embeds(ids, feats)
         T0 = x.shape[0]
         n_max = len(forced_new_tokens) if forced_new_tokens is not None else max_new_tokens
+        # KV-cache capacity (constructor argument max_len, default 1024 = 330 prompt positions + run_demo's 512 new tokens
+        # with room to spare): never generate past it
+        n_max = min(n_max, self.llm.max_len - T0)
+        if n_max <= 0:
+            raise ops.IvlmError(f"prompt of {T0} positions does not fit the KV cache (max_len={self.llm.max_len})")
+        if forced_new_tokens is not None:
+            forced_new_tokens = list(forced_new_tokens)[:n_max]
         hidden_all = torch.empty(T0 + n_max, self.config.llama.hidden, dtype=BF16, device=self.device)
         h = self.llm.forward(x, 0)
         hidden_all[:T0].copy_(h)
