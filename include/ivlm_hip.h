@@ -253,6 +253,13 @@ int ivlm_llama_decode_layers(const int64_t *layer_ptrs, int L, int H, int D, int
                              float scale, const float *cos_tab, const float *sin_tab, void *kcache, void *vcache,
                              int64_t cache_layer_stride, const void *x0, void *x_out, const int32_t *pos_dev,
                              const int32_t *step_dev, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* The MLP of a decode layer (HF LlamaMLP + post_attention_layernorm + residual) in ONE launch:
+ * x_out = x2 + W_down . (SiLU(g) * u), (g_j, u_j) = rows (2j, 2j+1) of wgu . RMSNorm(x2).  The down_proj blocks stream their
+ * first weight rows while the gate|up blocks run and wait for them on `counter` (zeroed at the start of a generation;
+ * target = number of gate|up blocks * (*step_dev + 1)); h_scratch bf16 [inter]; status as for ivlm_llama_attn_oproj. */
+int ivlm_llama_gateup_down(const void *x2, const void *ln_w, float eps, const void *wgu, const void *wdown, void *h_scratch,
+                           void *x_out, int hidden, int inter, const int32_t *step_dev, int32_t *counter, int32_t *status,
+                           ivlm_stream_t stream);
 /* fp32 rotary tables cos/sin [T, D/2] (optional inputs of ivlm_rope_kv / ivlm_llama_decode_attn; NULL = compute) */
 int ivlm_rope_table(float *cos_tab, float *sin_tab, int T, int D, float theta, ivlm_stream_t stream);
 /* Caller-side image preprocessing (run_demo.py:65-79 `preprocess`: (x - mean)/std then zero-pad to the square model

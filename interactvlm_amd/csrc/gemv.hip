@@ -6,6 +6,10 @@
 // them with non-temporal 16-byte loads (8 in flight per lane), dots them against the L1-resident
 // activation rows and reduces with a wave butterfly.  Two rows per wave also lets the SwiGLU epilogue
 // (row-interleaved gate/up weights) complete inside the wave.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace ivlm {
@@ -38,8 +42,19 @@ __device__ __forceinline__ float act_apply(float x, int act) {
 // ROWS weight rows per wave (2: enables the SwiGLU epilogue and doubles the loads in flight; 1: small N, more
 // waves).  XLDS: the activation rows (optionally RMS-normalised: x * gamma, bf16) are staged ONCE per block in LDS
 // together with their row scale, instead of every wave re-deriving them from global memory for every weight row.
-template <int M, int ROWS, bool RMS, bool XLDS>
-__global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
+// Intra-launch producer / consumer hooks (gemv_pair_kernel below): a consumer block issues its first weight loads, then
+// waits until *wait_ctr >= wait_target before it reads its input vector (with agent-scope loads); a producer block
+// writes its outputs with agent-scope stores and bumps *arrive_ctr once when done.
+struct GemvSync {
+    const int32_t* wait_ctr = nullptr;
+    int wait_target = 0;
+    int32_t* arrive_ctr = nullptr;
+    int32_t* status = nullptr;
+};
+constexpr long long kGemvWaitTicks = 100000000LL;  // 1 s of the 100 MHz wall clock
+
+template <int M, int ROWS, bool RMS, bool XLDS, bool COH_X = false, bool COH_OUT = false>
+__device__ __forceinline__ void gemv_body(const GemmArgs& g, const int vblock, const int vgrid, const GemvSync sy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float s_red[4][M];
     __shared__ float s_rstd[M];
@@ -48,8 +63,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);  // [M][nchunk] when XLDS
 
     constexpr int U = ROWS == 2 ? 4 : 8;  // 8 x 16-byte weight loads in flight per lane per step
-    const int wave_global = blockIdx.x * 4 + wave;
-    const int nwaves = gridDim.x * 4;
+    const int wave_global = vblock * 4 + wave;
+    const int nwaves = vgrid * 4;
     const int ngroups = (g.N + ROWS - 1) / ROWS;
     const int nbatch = (nchunk + 64 * U - 1) / (64 * U);
     const int my_groups = wave_global < ngroups ? (ngroups - wave_global + nwaves - 1) / nwaves : 0;
@@ -75,6 +90,31 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
         float ssq[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) ssq[m] = 0.0f;
+        if (COH_X) {
+            // x was produced by other blocks of this launch: agent-scope loads.  ALL of this thread's loads are issued
+            // before the first is used (a load-use-per-iteration loop costs one memory round trip per iteration: 5-6
+            // round trips for the 22 KB vector of down_proj).  XLDS, M == 1, no RMS fusion on this path.
+            constexpr int kMaxDw = 48;  // <= 48 KB of x / (256 threads x 4 B); lane-consecutive dwords: fully coalesced
+            uint32_t v[kMaxDw];
+            const uint32_t* xp = reinterpret_cast<const uint32_t*>(g.A);
+            uint32_t* xs32 = reinterpret_cast<uint32_t*>(xs);
+            const int ndw = g.K >> 1;
+            const int nper = (ndw + 255) >> 8;  // dwords per thread (22 for K = 11008)
+#pragma unroll
+            for (int i = 0; i < kMaxDw; ++i)
+                if (i < nper) {
+                    const int d = min((int)threadIdx.x + 256 * i, ndw - 1);
+                    v[i] = __hip_atomic_load(const_cast<uint32_t*>(xp) + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+            for (int i = 0; i < kMaxDw; ++i)
+                if (i < nper) {
+                    const int d = threadIdx.x + 256 * i;
+                    if (d < ndw) xs32[d] = v[i];
+                }
+            __syncthreads();
+            return;
+        }
         for (int c = threadIdx.x; c < nchunk; c += 256) {
             u32x4_t gv;
             if (RMS) gv = *(reinterpret_cast<const u32x4_t*>(g.rms_w) + c);
@@ -160,6 +200,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
                     const float o = (v0 / (1.0f + __expf(-v0))) * v1;
                     const int64_t idx = (int64_t)m * g.ldc + pr;
                     if (g.out_f32) static_cast<float*>(g.C)[idx] = o;
+                    else if (COH_OUT) __hip_atomic_store(static_cast<bf16_t*>(g.C) + idx, f32_to_bf16(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else static_cast<bf16_t*>(g.C)[idx] = f32_to_bf16(o);
                     continue;
                 }
@@ -189,6 +230,24 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     //      step s is consumed, including across row groups and across the block prologue ---------------------
     u32x4_t wa0[U], wb0[U], wa1[U], wb1[U];
     if (nsteps > 0) issue(wa0, wb0, 0);
+    if (sy.wait_ctr) {  // consumer: the first weight loads are in flight; now wait for the producers of the input vector
+        __shared__ int s_ok;
+        if (threadIdx.x == 0) {
+            int ok = 1;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(const_cast<int32_t*>(sy.wait_ctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.wait_target) {
+                __builtin_amdgcn_s_sleep(100);  // ~2.7 us: up to ~1000 blocks poll this one line; the wait itself is 20+ us
+                if (wall_clock64() - t0 > kGemvWaitTicks) {
+                    __hip_atomic_store(sy.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) return;
+    }
     if (XLDS || RMS) prologue();
     for (int s2 = 0; s2 < nsteps; s2 += 2) {
         if (s2 + 1 < nsteps) issue(wa1, wb1, s2 + 1);
@@ -197,6 +256,42 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
             if (s2 + 2 < nsteps) issue(wa0, wb0, s2 + 2);
             consume(wa1, wb1, s2 + 1);
         }
+    }
+    if (sy.arrive_ctr) {  // producer: outputs performed, one arrival per block
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(sy.arrive_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int M, int ROWS, bool RMS, bool XLDS>
+__global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
+    gemv_body<M, ROWS, RMS, XLDS>(g, blockIdx.x, gridDim.x, GemvSync());
+}
+
+// (opt-in; measured SLOWER than two launches on MI355X: 80-90 us vs 51 us - each half alone runs at its stand-alone speed
+// inside this kernel, 37 + 21 us, but the two streaming patterns sharing one grid cost another 22 us)
+// gate|up (RMSNorm + SwiGLU fused) and down (+ residual) of one decoder layer in ONE launch: blocks [0, na) are the gate|up
+// GEMV; blocks [na, na + nb) are the down GEMV - they stream their first weight rows immediately and wait on `counter`
+// for the na producers before staging h.  Counter monotonic over the tokens of a generation (target = na * (step + 1)).
+struct GemvPairArgs {
+    GemmArgs ga, gb;
+    int na, nb;
+    const int32_t* step_dev;
+    int32_t* counter;
+    int32_t* status;
+};
+__global__ __launch_bounds__(256) void gemv_pair_kernel(GemvPairArgs p) {
+    if ((int)blockIdx.x < p.na) {
+        GemvSync sy;
+        sy.arrive_ctr = p.counter;
+        gemv_body<1, 2, true, true, false, true>(p.ga, blockIdx.x, p.na, sy);
+    } else {
+        GemvSync sy;
+        sy.wait_ctr = p.counter;
+        sy.wait_target = p.na * (*p.step_dev + 1);
+        sy.status = p.status;
+        gemv_body<1, 1, false, true, true, false>(p.gb, (int)blockIdx.x - p.na, p.nb, sy);
     }
 }
 
@@ -278,6 +373,28 @@ static int launch_gemv(const GemmArgs& g, hipStream_t st) {
 
 // opt-in: measured slower than the wave-per-row kernel as a stand-alone launch (qkv 20.9 vs 18.7 us, o 18.6 vs 14.6 us):
 // one 512-thread block per CU cannot overlap its own prologue / epilogue with streaming the way 4 small blocks per CU do
+// h = SwiGLU(W_gu . RMSNorm(x2)), x_out = x2 + W_down . h in one launch (decode, M == 1)
+int gemv_gu_down(const bf16_t* x2, const bf16_t* ln_w, float eps, const bf16_t* wgu, const bf16_t* wdown, bf16_t* h_scratch,
+                 bf16_t* x_out, int hidden, int inter, const int32_t* step_dev, int32_t* counter, int32_t* status,
+                 hipStream_t st) {
+    if (!x2 || !ln_w || !wgu || !wdown || !h_scratch || !x_out || !step_dev || !counter || !status) return IVLM_ERR_INVALID_ARG;
+    if ((hidden & 7) || (inter & 7) || (size_t)inter * 2 > 48 * 1024 || (size_t)hidden * 2 > 48 * 1024) return IVLM_ERR_UNSUPPORTED;
+    GemvPairArgs p;
+    p.ga = GemmArgs();
+    p.ga.A = x2; p.ga.lda = hidden; p.ga.W = wgu; p.ga.ldw = hidden; p.ga.C = h_scratch; p.ga.ldc = inter;
+    p.ga.M = 1; p.ga.N = 2 * inter; p.ga.K = hidden; p.ga.act = ACT_SWIGLU; p.ga.rms_w = ln_w; p.ga.rms_eps = eps;
+    p.gb = GemmArgs();
+    p.gb.A = h_scratch; p.gb.lda = inter; p.gb.W = wdown; p.gb.ldw = inter; p.gb.C = x_out; p.gb.ldc = hidden;
+    p.gb.M = 1; p.gb.N = hidden; p.gb.K = inter; p.gb.act = ACT_NONE; p.gb.residual = x2; p.gb.ldr = hidden;
+    auto blocks_of = [](int ngroups) { int b = (ngroups + 3) / 4; return b > 1024 ? 1024 : b; };
+    p.na = blocks_of(inter);   // 2 rows (one gate/up pair) per wave
+    p.nb = blocks_of(hidden);  // 1 row per wave
+    p.step_dev = step_dev; p.counter = counter; p.status = status;
+    const size_t lds = (size_t)std::max(hidden, inter) * 2;
+    gemv_pair_kernel<<<p.na + p.nb, 256, lds, st>>>(p);
+    return ivlm_launch_status();
+}
+
 static int g_gemv_slab = 0;
 void gemv_set_slab(int on) { g_gemv_slab = on; }
 
@@ -312,4 +429,14 @@ int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st)
 extern "C" int ivlm_argmax_f32(const float* x, int rows, int cols, int32_t* out, ivlm_stream_t stream) {
     ivlm_enter();
     return ivlm::argmax_f32(x, rows, cols, out, ivlm_stream(stream));
+}
+
+extern "C" int ivlm_llama_gateup_down(const void* x2, const void* ln_w, float eps, const void* wgu, const void* wdown,
+                                      void* h_scratch, void* x_out, int hidden, int inter, const int32_t* step_dev,
+                                      int32_t* counter, int32_t* status, ivlm_stream_t stream) {
+    ivlm_enter();
+    return ivlm::gemv_gu_down(static_cast<const bf16_t*>(x2), static_cast<const bf16_t*>(ln_w), eps,
+                              static_cast<const bf16_t*>(wgu), static_cast<const bf16_t*>(wdown),
+                              static_cast<bf16_t*>(h_scratch), static_cast<bf16_t*>(x_out), hidden, inter, step_dev, counter,
+                              status, ivlm_stream(stream));
 }

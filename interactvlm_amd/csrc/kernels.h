@@ -31,6 +31,10 @@ struct GemmArgs {
 int gemm_bf16(const GemmArgs& g, hipStream_t st);
 // 256x256 tile with the 8-phase ping-pong K loop (gemm256.hip); same contract as gemm_bf16
 int gemm_bf16_256p(const GemmArgs& g, hipStream_t st);
+// decode MLP in one launch: h = SwiGLU(W_gu . RMSNorm(x2)), x_out = x2 + W_down . h (down blocks wait on a device counter)
+int gemv_gu_down(const bf16_t* x2, const bf16_t* ln_w, float eps, const bf16_t* wgu, const bf16_t* wdown, bf16_t* h_scratch,
+                 bf16_t* x_out, int hidden, int inter, const int32_t* step_dev, int32_t* counter, int32_t* status,
+                 hipStream_t st);
 // M == 1 decode GEMV as flat slab streaming (gemv_slab.hip); IVLM_ERR_UNSUPPORTED = shape does not qualify
 int gemv_slab_bf16(const GemmArgs& g, hipStream_t st);
 void gemv_set_slab(int on);

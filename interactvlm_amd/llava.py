@@ -116,6 +116,7 @@ class Llama:
         self._fused = None
         self._dataflow = None
         self.fuse_attn_oproj = True
+        self.fuse_gateup_down = False  # one launch for gate|up + down: measured slower (88 vs 51 us), see csrc/gemv.hip
         # all layers in one dataflow launch (csrc/decode_layers.hip): correct, but 3.25-3.5 ms/token vs 2.72 for the per-layer
         # launches: every role is an all-to-all dependency, and one resident block per CU cannot both stream its role with all
         # CUs and keep the next role's rows prefetched - opt-in experiment
@@ -167,9 +168,10 @@ class Llama:
             if self.fuse_attn_oproj and c.hidden in (512, 1024, 4096, 5120) and c.heads + c.hidden // 32 <= n_cu:
                 # fused attention + o_proj launches: per-layer arrival counters, tokens-decoded counter, status word
                 st["fused"] = dict(step=torch.zeros(1, dtype=torch.int32, device=dev),
-                                   counters=torch.zeros(c.layers, 32, dtype=torch.int32, device=dev),  # 128-B apart
+                                   counters=torch.zeros(2 * c.layers, 32, dtype=torch.int32, device=dev),  # 128-B apart
                                    status=torch.zeros(1, dtype=torch.int32, device=dev),
-                                   scratch=torch.zeros(c.layers, c.hidden, dtype=BF16, device=dev))
+                                   scratch=torch.zeros(c.layers, c.hidden, dtype=BF16, device=dev),
+                                   hscratch=torch.zeros(c.inter, dtype=BF16, device=dev))
             self._fused = st.get("fused")
             if self.dataflow_layers and (c.hidden, c.inter) in ((4096, 11008), (5120, 13824), (1024, 1376), (512, 1024)):
                 nbytes = _lib.load().ivlm_llama_decode_layers_workspace_bytes(c.layers, c.hidden, c.inter)
@@ -237,8 +239,12 @@ class Llama:
             if fz is not None:  # attention + o_proj + residual in one launch (W_o streams while the attention runs)
                 x = ops.llama_attn_oproj(qkv, self.kcache[li], self.vcache[li], L["o"], x, H, hd, pos, fz["step"],
                                          fz["counters"][li], fz["status"], c.theta, hd ** -0.5, self.rope, fz["scratch"][li])
-                h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))
-                x = ops.linear(h, L["down"], residual=x)
+                if self.fuse_gateup_down:  # gate|up + down + residual in one launch (down streams while gate|up runs)
+                    x = ops.llama_gateup_down(x, L["ln2"], c.eps, L["gu"], L["down"], fz["step"],
+                                              fz["counters"][c.layers + li], fz["status"], fz["hscratch"])
+                else:
+                    h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))
+                    x = ops.linear(h, L["down"], residual=x)
                 continue
             a = ops.llama_decode_attn(qkv, self.kcache[li], self.vcache[li], H, hd, pos, c.theta, hd ** -0.5, table=self.rope)
             x = ops.linear(a, L["o"], residual=x)

@@ -503,6 +503,17 @@ def llama_attn_oproj(qkv, kcache, vcache, wo, x, H, D, pos_dev, step_dev, counte
     return out
 
 
+def llama_gateup_down(x2, ln_w, eps, wgu, wdown, step_dev, counter, status, scratch):
+    """One launch: x_out = x2 + W_down . SwiGLU(W_gu . RMSNorm(x2)) for one decode token, bf16 [1, hidden]."""
+    lib = _lib.load()
+    hidden, inter = wdown.shape[0], wdown.shape[1]
+    out = torch.empty(1, hidden, dtype=BF16, device=x2.device)
+    check(lib.ivlm_llama_gateup_down(x2.data_ptr(), ln_w.data_ptr(), float(eps), wgu.data_ptr(), wdown.data_ptr(),
+                                     scratch.data_ptr(), out.data_ptr(), hidden, inter, step_dev.data_ptr(), counter.data_ptr(),
+                                     status.data_ptr(), _stream()), "llama_gateup_down")
+    return out
+
+
 def llama_decode_layers(layer_ptrs, L, H, D, hidden, inter, eps, theta, rope, kcache, vcache, x0, pos_dev, step_dev, ws):
     """All decoder layers of one token in one dataflow launch -> residual stream after the last layer, bf16 [1, hidden]."""
     lib = _lib.load()

@@ -174,6 +174,32 @@ def test_gemv_slab_streaming_vs_rowwave_and_fp32(hip_lib, cuda, N, K, act, rms, 
     assert torch.allclose(slab.float(), roww.float(), **tol)
 
 
+def test_fused_gateup_down_matches_two_launches(hip_lib, cuda):
+    """ivlm_llama_gateup_down (opt-in: gate|up + SwiGLU + down + residual in one launch, the down blocks waiting on a device
+    counter) == the two GEMV launches, over consecutive 'tokens' (monotonic counter)."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    H, I = 1024, 1376
+    x = _bf(torch.randn(1, H, generator=g)).to(cuda)
+    gam = _bf(1 + 0.1 * torch.randn(H, generator=g)).to(cuda)
+    wgu = _bf(torch.randn(2 * I, H, generator=g) / H ** 0.5).to(cuda)
+    wd = _bf(torch.randn(H, I, generator=g) / I ** 0.5).to(cuda)
+    step = torch.zeros(1, dtype=torch.int32, device=cuda)
+    ctr = torch.zeros(32, dtype=torch.int32, device=cuda)
+    status = torch.zeros(1, dtype=torch.int32, device=cuda)
+    hs = torch.zeros(I, dtype=torch.bfloat16, device=cuda)
+    for tok in range(4):
+        xi = _bf(x.float() * (1 + 0.1 * tok))
+        ref = ops.linear(ops.linear(xi, wgu, act="swiglu", rms=(gam, 1e-5)), wd, residual=xi)
+        got = ops.llama_gateup_down(xi, gam, 1e-5, wgu, wd, step, ctr, status, hs)
+        step.add_(1)
+        assert torch.equal(got, ref), tok
+    assert int(status[0]) == 0
+
+
 def test_argmax_first_index_ties_and_unaligned_rows(hip_lib, cuda):
     """torch.argmax semantics (first index of the maximum) on rows that do not start on 16-byte boundaries."""
     import torch
