@@ -224,6 +224,28 @@ def gen_sam_encoder():
     _save("sam_encoder_small.npz", out=y.numpy())
 
 
+def gen_sam_encoder_full():
+    """F6: the real ViT-H dimensions (1280 wide, 16 heads of 80, MLP 5120, 1024^2 -> 64x64 tokens, one windowed (14) + one
+    global block with 127-row rel-pos tables), depth 2, one view.  Output subsampled for the fixture."""
+    from functools import partial
+    import torch
+    _ref_shims.install()
+    from model.segment_anything.modeling import ImageEncoderViT
+    from interactvlm_amd.weights import SAM_PREFIX
+
+    enc = ImageEncoderViT(depth=2, embed_dim=1280, img_size=1024, mlp_ratio=4,
+                          norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=16, patch_size=16, qkv_bias=True,
+                          use_rel_pos=True, global_attn_indexes=(1,), window_size=14, out_chans=256)
+    synth.fill_state_dict(enc, 0, SAM_PREFIX + ".image_encoder.")
+    enc.eval()
+    x = torch.from_numpy(synth.synth_normal("samenc_full/x", (1, 3, 1024, 1024), 1.0, 0))
+    with torch.no_grad():
+        y = enc(x)  # [1, 256, 64, 64]
+    y = y.numpy()
+    _save("sam_encoder_vith_dims.npz", out_sub=y[:, ::4, ::2, ::2].copy(), out_sum=np.float64(y.astype(np.float64).sum()),
+          out_abs_mean=np.float64(np.abs(y).mean()))
+
+
 # ------------------------------------------------------------------------------------------
 # F7/F8: the facade — InteractVLMForCausalLM.model_forward(inference=True) on a toy LLaMA/CLIP
 # ------------------------------------------------------------------------------------------
@@ -371,7 +393,7 @@ def gen_model_forward(batch2=False):
 
 
 GENERATORS = {"lift": gen_lift, "lift_points": gen_lift_points, "sam_decoder": gen_sam_decoder, "cam": gen_cam,
-              "sam_encoder": gen_sam_encoder, "model_forward": gen_model_forward,
+              "sam_encoder": gen_sam_encoder, "sam_encoder_full": gen_sam_encoder_full, "model_forward": gen_model_forward,
               "model_forward_oafford": lambda: gen_model_forward(batch2=True)}
 
 

@@ -72,6 +72,27 @@ def test_sam_encoder_small_vs_reference_golden(hip_lib, cuda, golden_dir):
     assert _rel_err(y, ref) < 5e-2, _rel_err(y, ref)
 
 
+def test_sam_encoder_vith_dimensions_vs_reference_golden(hip_lib, cuda, golden_dir):
+    """HIP SAM encoder at the real ViT-H layer dimensions (head dim 80 padded to 96 in the MFMA attention, 14x14 windows with
+    padding 64 -> 70, the global block with 127-row rel-pos tables, neck) against the reference's own output (depth 2)."""
+    import torch
+
+    from interactvlm_amd import sam, synth
+    from interactvlm_amd import weights as Wt
+
+    d = np.load(os.path.join(golden_dir, "sam_encoder_vith_dims.npz"))
+    c = Wt.SamEncCfg(depth=2, global_attn_indexes=(1,))
+    w = Wt.synth_weights(Wt.sam_encoder_spec(c))
+    enc = sam.SamImageEncoder(w, c, cuda)
+    x = torch.from_numpy(synth.synth_normal("samenc_full/x", (1, 3, 1024, 1024), 1.0, 0)).to(torch.bfloat16).to(cuda)
+    y = enc(x).float().cpu().view(1, 64, 64, 256).permute(0, 3, 1, 2)  # -> [1,256,64,64]
+    ref = torch.from_numpy(d["out_sub"])
+    got = y[:, ::4, ::2, ::2]
+    rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"\n[SAM ViT-H dims, depth 2] rel rms err vs reference = {rel:.4f}, max abs = {float((got - ref).abs().max()):.4f}")
+    assert rel < 3e-2 and float((got - ref).abs().max()) < 0.1 * float(ref.abs().max())
+
+
 def test_sam_block_full_dims_vs_oracle(hip_lib, cuda):
     """One windowed + one global block at ViT-H width (1280 / 16 heads / head dim 80) on a 64x64 grid."""
     import torch

@@ -123,3 +123,15 @@ def test_model_forward_oafford_end_to_end(golden_dir):
     np.testing.assert_allclose(o["pred_afford"].numpy(), d["pred_afford"], atol=1e-5)
     # what the reference returns for the predictors that do not apply to an 'oafford' sample
     assert d["pred_ocontact"].shape == (1, 0) and float(np.abs(d["pred_human"]).max()) == 0.0
+
+
+def test_sam_image_encoder_vith_dimensions(golden_dir):
+    """The real ViT-H layer dimensions (1280 / 16 heads of 80 / MLP 5120 / 64x64 grid / window 14 + one global block) against
+    the reference's ImageEncoderViT (image_encoder.py:110-125), depth 2."""
+    d = _g(golden_dir, "sam_encoder_vith_dims.npz")
+    c = Wt.SamEncCfg(depth=2, global_attn_indexes=(1,))
+    w = Wt.synth_weights(Wt.sam_encoder_spec(c))
+    x = torch.from_numpy(synth.synth_normal("samenc_full/x", (1, 3, 1024, 1024), 1.0, 0))
+    y = O.sam_image_encoder(w, SAM_PREFIX + ".image_encoder", x, 2, 16, (1,)).numpy()
+    np.testing.assert_allclose(y[:, ::4, ::2, ::2], d["out_sub"], atol=2e-5)
+    assert abs(float(y.astype(np.float64).sum()) - float(d["out_sum"])) < 1e-5 * y.size
