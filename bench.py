@@ -277,8 +277,13 @@ def main():
         roof_serial = {"note": "same steps with the two-stream overlap disabled (kernels run alone)", "gemm": rs,
                        "lift": rls, "gemv": rvs}
         pj = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        pm = {}
         if os.path.exists(pj):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
-            pm = json.load(open(pj))
+            try:
+                pm = json.load(open(pj))
+            except ValueError:
+                pm = {}
+        if pm:
             roof["traffic"] = pm.get("gemm_bf16_kernel")
             roof_lift["traffic"] = pm.get("lift_plan_kernel")
             roof_gemv["traffic"] = pm.get("gemv_kernel")

@@ -13,6 +13,7 @@ MI355X-first restructuring that leaves results unchanged:
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import List, Optional
 
@@ -82,7 +83,9 @@ class InteractVLMForCausalLM:
         self.use_fusion = self.use_uncertainty = False  # off in every released config (scripts/run_train.sh:61-62)
         self.debug_taps = None  # set to a dict to record intermediate tensors (tests / diagnostics only)
         self.overlap_sam_encoder = True
-        self.graph_decode = True  # HIP-graph replay of the decode step (launch-bound on the host otherwise)
+        # HIP-graph replay of the decode step / CLIP tower (launch-bound on the host otherwise); IVLM_NO_GRAPHS=1 turns both
+        # off (rocprofv3 --pmc passes crash on replayed graphs)
+        self.graph_decode = not os.environ.get("IVLM_NO_GRAPHS")
         self.sam_after_prefill = False  # measured: 116.9 vs 115.3 ms - overlapping the decode instead of the prefill is not better
         # persistent one-launch greedy decode (csrc/generate.hip): correct and bit-reproducible, but measured SLOWER than the
         # per-op path on MI355X (3.43 vs 2.93 ms/token for 7B: every phase boundary costs ~9 us of device-wide sync
@@ -94,6 +97,8 @@ class InteractVLMForCausalLM:
         self.prioritise_llm = False  # measured: no gain (the two streams time-share the CUs either way)
 
         self.vision_tower = ClipTower(w, c.clip, dev)
+        if os.environ.get("IVLM_NO_GRAPHS"):
+            self.vision_tower.use_graph = False
         self.mm_projector = _Lin(w, "model.mm_projector", dev)
         self.llm = Llama(w, c.llama, dev, max_len=max_len)
         self.text_hidden_fcs = (_Lin(w, "model.text_hidden_fcs.0.0", dev), _Lin(w, "model.text_hidden_fcs.0.2", dev))
