@@ -292,6 +292,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del model
         torch.cuda.empty_cache()
+        # the CPU leg: the oracle is used here only - as the timed baseline and as the checker of the "F1 vs ref" half of the metric
         parity = parity_vs_oracle(dev)
         cpu = cpu_baseline(cfg, T0, len(forced), V, (vid, bary))
 
