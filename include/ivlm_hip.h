@@ -136,6 +136,9 @@ int ivlm_gemm_bf16_splitk(const void *A, int64_t lda, const void *W, int64_t ldw
 /* Benchmark/test hook: M == 1 GEMVs use the wave-per-row kernel (0, default: faster as a stand-alone launch) or the flat
  * slab-streaming kernel (1; the streaming code of ivlm_llama_generate). */
 int ivlm_gemv_slab_enable(int on);
+/* Benchmark/test hook for the skinny-M dispatch: rows M in [min_m, 16] against matrices with K, N >= 1024 go to the
+ * split-K MFMA kernel (csrc/gemv_mfma.hip) instead of the wave-per-row GEMV / tile GEMM; 0 restores the automatic choice. */
+int ivlm_gemv_mfma_min_m(int min_m);
 
 /* Benchmark/test hook: force the GEMM block tile (64 = 128x64, 128, 256; 0 = automatic choice). Returns the previous value. */
 int ivlm_gemm_tile_override(int tile);
@@ -202,6 +205,13 @@ int ivlm_llama_decode_attn(const void *qkv, void *kcache, void *vcache, void *o,
 int ivlm_llama_decode_attn_devpos(const void *qkv, void *kcache, void *vcache, void *o, int H, int D,
                                   const int32_t *pos_dev, float theta, float scale, const float *cos_tab,
                                   const float *sin_tab, ivlm_stream_t stream);
+
+/* B sequences in one launch (grid H x B): sequence b reads qkv + b*ldq, appends to kcache/vcache + b*cache_stride
+ * ([Tmax,H,D] each), writes o + b*ldo and sits at position pos_dev[b] (strides in elements, multiples of 8).  The
+ * batched counterpart of the reference's padded-batch generate (model/InteractVLM.py:524-531 with B > 1 prompts). */
+int ivlm_llama_decode_attn_batch(const void *qkv, int64_t ldq, void *kcache, void *vcache, int64_t cache_stride,
+                                 void *o, int64_t ldo, int B, int H, int D, const int32_t *pos_dev, float theta,
+                                 float scale, const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
 
 /* torch.argmax(logits, -1) of HF greedy search (first maximal index); x f32 [rows, cols] -> out i32 [rows]. */
 int ivlm_argmax_f32(const float *x, int rows, int cols, int32_t *out, ivlm_stream_t stream);

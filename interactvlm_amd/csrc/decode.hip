@@ -21,7 +21,30 @@ __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_kernel(const bf
     llama_decode_attn_body<false>(blockIdx.x, qkv, kcache, vcache, o, H, D, pos_arg, theta, scale, ct, stab, pos_dev);
 }
 
+// B sequences of one decode step: blockIdx.y picks the sequence; each has its own cache slab, qkv row, output row and
+// position (the sequences of a batch sit at different lengths: prompts differ, model/InteractVLM.py:524-531 pads them).
+__global__ __launch_bounds__(kDecThreads) void llama_decode_attn_batch_kernel(
+    const bf16_t* __restrict__ qkv, int64_t ldq, bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache, int64_t cache_stride,
+    bf16_t* __restrict__ o, int64_t ldo, int H, int D, float theta, float scale, const float* __restrict__ ct,
+    const float* __restrict__ stab, const int32_t* __restrict__ pos_dev) {
+    const int b = blockIdx.y;
+    llama_decode_attn_body<false>(blockIdx.x, qkv + b * ldq, kcache + b * cache_stride, vcache + b * cache_stride, o + b * ldo, H,
+                                  D, 0, theta, scale, ct, stab, pos_dev + b);
+}
+
 }  // namespace
+
+int llama_decode_attn_batch(const bf16_t* qkv, int64_t ldq, bf16_t* kcache, bf16_t* vcache, int64_t cache_stride, bf16_t* o,
+                            int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta, float scale,
+                            const float* cos_tab, const float* sin_tab, hipStream_t st) {
+    if (!qkv || !kcache || !vcache || !o || !pos_dev) return IVLM_ERR_INVALID_ARG;
+    if (B <= 0 || B > 65535 || H <= 0 || D <= 0 || D > kMaxD || (D & 15)) return IVLM_ERR_INVALID_ARG;
+    if (ldq < 3LL * H * D || ldo < (int64_t)H * D || cache_stride < (int64_t)H * D || ((ldq | ldo | cache_stride) & 7))
+        return IVLM_ERR_INVALID_ARG;  // 16-byte rows
+    llama_decode_attn_batch_kernel<<<dim3(H, B), kDecThreads, 0, st>>>(qkv, ldq, kcache, vcache, cache_stride, o, ldo, H, D,
+                                                                        theta, scale, cos_tab, sin_tab, pos_dev);
+    return ivlm_launch_status();
+}
 
 int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
                       float scale, hipStream_t st, const float* cos_tab, const float* sin_tab, const int32_t* pos_dev) {
@@ -51,4 +74,13 @@ extern "C" int ivlm_llama_decode_attn_devpos(const void* qkv, void* kcache, void
     return ivlm::llama_decode_attn(static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(kcache),
                                    static_cast<bf16_t*>(vcache), static_cast<bf16_t*>(o), H, D, 0, theta, scale,
                                    ivlm_stream(stream), cos_tab, sin_tab, pos_dev);
+}
+
+extern "C" int ivlm_llama_decode_attn_batch(const void* qkv, int64_t ldq, void* kcache, void* vcache, int64_t cache_stride,
+                                            void* o, int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta,
+                                            float scale, const float* cos_tab, const float* sin_tab, ivlm_stream_t stream) {
+    ivlm_enter();
+    return ivlm::llama_decode_attn_batch(static_cast<const bf16_t*>(qkv), ldq, static_cast<bf16_t*>(kcache),
+                                         static_cast<bf16_t*>(vcache), cache_stride, static_cast<bf16_t*>(o), ldo, B, H, D,
+                                         pos_dev, theta, scale, cos_tab, sin_tab, ivlm_stream(stream));
 }

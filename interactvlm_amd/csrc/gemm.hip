@@ -275,8 +275,21 @@ int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_
     return ivlm_launch_status();
 }
 
-// dispatch: weight-streaming GEMV for M <= 8, MFMA tile kernel otherwise
+// dispatch: weight-streaming GEMV for M <= 8 (wave per row while the activation rows fit LDS, the split-K MFMA skinny
+// kernel of gemv_mfma.hip for the batched decode step: M up to 16 rows against big matrices), MFMA tile kernel otherwise
+static int g_skinny_min_m = 0;  // 0: automatic; > 0: every M in [min_m, 16] with K, N >= 1024 (benchmark hook)
+void gemv_mfma_set_min_m(int m) { g_skinny_min_m = m; }
+
 int linear_bf16(const GemmArgs& g, hipStream_t st) {
+    if (g.batch == 1 && g.M <= 16 && g.K >= 1024 && g.N >= 1024 && !(g.K & 7) && !(g.lda & 7) && !(g.ldw & 7) &&
+        !(g.act == ACT_SWIGLU && ((g.N & 1) || g.residual))) {
+        const bool skinny = g_skinny_min_m > 0 ? g.M >= g_skinny_min_m
+                                               : (g.M >= 5 || (g.M >= 3 && (size_t)g.M * g.K * 2 > 48 * 1024));
+        // (measured on the LLaMA-7B shapes, tools/bench_skinny.py: the wave-per-row GEMV wins for M <= 4 while its
+        //  activation rows fit LDS - 5.0-5.7 TB/s at M = 1 - and falls to 0.9-2.5 TB/s at M = 8; this kernel holds
+        //  3.4-4.4 TB/s for every M <= 8 and 2.9-3.4 TB/s at M = 16, where the 128x64 tile GEMM reaches 0.7-1.8 TB/s)
+        if (skinny) return gemv_mfma_bf16(g, st);
+    }
     if (g.M <= 8 && g.batch == 1) return gemv_bf16(g, st);
     if (g.rms_w) return IVLM_ERR_UNSUPPORTED;  // the RMSNorm fusion exists on the decode (GEMV) path only
     return gemm_bf16(g, st);
@@ -288,6 +301,11 @@ static int g_tile_override = 0;
 
 extern "C" int ivlm_gemv_slab_enable(int on) {  // benchmark/test hook: 0 = wave-per-row GEMV kernel for M == 1 as well
     ivlm::gemv_set_slab(on);
+    return 0;
+}
+
+extern "C" int ivlm_gemv_mfma_min_m(int min_m) {  // benchmark/test hook: 0 = automatic choice
+    ivlm::gemv_mfma_set_min_m(min_m);
     return 0;
 }
 

@@ -1,0 +1,137 @@
+// Skinny GEMM on the matrix cores for gfx950: out[M <= 16, N] = act(x[M,K] . W[N,K]^T + bias) + residual.
+//
+// The batched decode step (B sequences per GPU, BASELINE.json configs[2]; model/InteractVLM.py:524-531 with B prompts)
+// is still pure weight streaming - every weight byte is read once per step - but each 16-byte weight chunk now meets
+// B activation rows.  The wave-per-row GEMV (gemv.hip) keeps the activations in LDS (B x K x 2 bytes: 176 KB for the
+// down projection at B = 8 - more than a CU has) and spends B x 8 dot instructions per chunk; here one
+// v_mfma_f32_16x16x32_bf16 consumes 16 weight rows x 32 k against up to 16 activation rows, and nothing is staged:
+//
+//   * one block = 16 weight rows, 8 waves; wave w owns the k-steps [w*per, (w+1)*per) of those rows (split-K inside the
+//     block), so N/16 blocks x 8 waves stream the matrix (256 blocks for N = 4096: every CU busy, 16 waves per CU);
+//   * W fragment: lane (n = l & 15, kg = l >> 4) loads 16 bytes of row n at k = 32*step + 8*kg straight from HBM
+//     (non-temporal; 4 lanes cover 64 contiguous bytes, consecutive steps continue the row), 8 steps in flight per lane;
+//   * x fragment: lane (m = l & 15, kg) loads the same k of activation row m (L2 resident: M x K x 2 bytes), zero for
+//     m >= M; the optional RMSNorm prologue of the decode path (x * gamma rounded to bf16, row scale applied to the
+//     accumulator) is fused exactly as in gemv.hip;
+//   * the 8 partial 16x16 tiles are summed through LDS in a fixed order (deterministic), then bias / activation /
+//     SwiGLU over interleaved gate-up rows / residual and the store.
+#include "gemm_common.h"
+
+namespace ivlm {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+constexpr int kWaves = 8, kThreads = kWaves * 64, kU = 8;
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    switch (act) {
+        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case ACT_RELU: return fmaxf(x, 0.0f);
+        case ACT_SILU: return x / (1.0f + __expf(-x));
+        case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
+        default: return x;
+    }
+}
+
+template <bool RMS>
+__global__ __launch_bounds__(kThreads, 2) void skinny_mfma_kernel(GemmArgs g) {
+    __shared__ float s_part[kWaves][16][17];  // [wave][m][n]
+    __shared__ float s_ssq[kWaves][16];
+    __shared__ float s_fin[16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nchunk = g.K >> 3;           // 16-byte chunks per row
+    const int nsteps = (nchunk + 3) >> 2;  // MFMA k-steps (32 elements)
+    const int per = (nsteps + kWaves - 1) / kWaves;
+    const int s0 = wave * per, s1 = min(s0 + per, nsteps);
+    const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(g.W + (int64_t)min(n0 + r, g.N - 1) * g.ldw);
+    const bool xrow = r < g.M;
+    const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(g.A + (int64_t)(xrow ? r : 0) * g.lda);
+    const u32x4_t* gp = reinterpret_cast<const u32x4_t*>(g.rms_w);
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+    f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    float ssq = 0.0f;
+    for (int s = s0; s < s1; s += kU) {
+        u32x4_t w[kU], x[kU], gm[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int c = (s + u) * 4 + kg;
+            const bool ok = (s + u) < s1 && c < nchunk;
+            const int cc = ok ? c : 0;  // clamped (unconditional) weight loads keep the buffers in registers
+            w[u] = __builtin_nontemporal_load(wp + cc);
+            x[u] = (ok && xrow) ? xp[cc] : zero;
+            if (RMS) gm[u] = gp[cc];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            u32x4_t xv = x[u];
+            if (RMS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = __uint_as_float(xv[j] << 16), hi = __uint_as_float(xv[j] & 0xffff0000u);
+                    ssq += lo * lo + hi * hi;
+                    xv[j] = pack_bf16x2(lo * __uint_as_float(gm[u][j] << 16), hi * __uint_as_float(gm[u][j] & 0xffff0000u));
+                }
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[u]), __builtin_bit_cast(bf16x8_t, xv),
+                                                          acc, 0, 0, 0);
+        }
+    }
+    // lane holds C[m = r][n = 4*kg + i] of this wave's K slice
+    if (RMS) {
+        ssq += __shfl_xor(ssq, 16);
+        ssq += __shfl_xor(ssq, 32);
+        if (kg == 0) s_ssq[wave][r] = ssq;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_part[wave][r][kg * 4 + i] = acc[i];
+    __syncthreads();
+    const int m = threadIdx.x >> 4, n = threadIdx.x & 15;
+    if (threadIdx.x < 256) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) v += s_part[w][m][n];
+        if (RMS) {
+            float q = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) q += s_ssq[w][m];
+            v *= rsqrtf(q / (float)g.K + g.rms_eps);
+        }
+        const int nn = min(n0 + n, g.N - 1);
+        s_fin[m][n] = v + (g.bias ? bf16_to_f32(g.bias[nn]) : 0.0f);
+    }
+    __syncthreads();
+    if (threadIdx.x >= 256 || m >= g.M || n0 + n >= g.N) return;
+    float v = s_fin[m][n];
+    int64_t col = n0 + n;
+    if (g.act == ACT_SWIGLU) {  // rows (gate_j, up_j) interleaved: even n pairs with n + 1
+        if (n & 1) return;
+        const float up = s_fin[m][n + 1];
+        v = (v / (1.0f + __expf(-v))) * up;
+        col >>= 1;
+    } else {
+        v = act_apply(v, g.act);
+        if (g.residual) {
+            const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
+            v += bf16_to_f32(g.residual[rrow * g.ldr + col]);
+        }
+    }
+    if (g.out_f32) static_cast<float*>(g.C)[(int64_t)m * g.ldc + col] = v;
+    else static_cast<bf16_t*>(g.C)[(int64_t)m * g.ldc + col] = f32_to_bf16(v);
+}
+
+}  // namespace
+
+int gemv_mfma_bf16(const GemmArgs& g, hipStream_t st) {
+    if (!g.A || !g.W || !g.C || g.M <= 0 || g.M > 16 || g.N <= 0 || g.K <= 0) return IVLM_ERR_INVALID_ARG;
+    if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || g.batch != 1) return IVLM_ERR_UNSUPPORTED;
+    if (g.act == ACT_SWIGLU && ((g.N & 1) || g.residual)) return IVLM_ERR_UNSUPPORTED;
+    const int blocks = (g.N + 15) / 16;
+    if (g.rms_w) skinny_mfma_kernel<true><<<blocks, kThreads, 0, st>>>(g);
+    else skinny_mfma_kernel<false><<<blocks, kThreads, 0, st>>>(g);
+    return ivlm_launch_status();
+}
+
+}  // namespace ivlm

@@ -107,8 +107,14 @@ int rasterize_points(const float* pts, int np, const float* cam12_host, float fo
 int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
                       float scale, hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr, const int32_t* pos_dev = nullptr);
 
+int llama_decode_attn_batch(const bf16_t* qkv, int64_t ldq, bf16_t* kcache, bf16_t* vcache, int64_t cache_stride, bf16_t* o,
+                            int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta, float scale,
+                            const float* cos_tab, const float* sin_tab, hipStream_t st);
+
 // ---- skinny GEMM (gemv.hip): M <= 8 rows of activations against streamed weights -------------------
 int gemv_bf16(const GemmArgs& g, hipStream_t st);
+// skinny GEMM on MFMA (gemv_mfma.hip): M <= 16 activation rows, split-K inside the block, RMSNorm prologue optional
+int gemv_mfma_bf16(const GemmArgs& g, hipStream_t st);
 int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st);
 
 }  // namespace ivlm

@@ -132,22 +132,24 @@ class Llama:
         """embed_tokens gather: ids int32 [n] -> [n, hidden]."""
         return ops.gather_rows(self.embed, ids_i32, out=out)
 
-    def forward(self, x, pos0):
+    def forward(self, x, pos0, cache=None):
         """x [T, hidden] input embeddings at positions pos0..pos0+T-1 -> final-norm hidden [T, hidden];
-        appends to the KV cache (prefill: T = prompt, decode: T = 1)."""
+        appends to the KV cache (prefill: T = prompt, decode: T = 1).  cache = (k, v) [layers, Tmax, H, hd] views of
+        another sequence's slab (batched generation); default: this instance's single-sequence cache."""
         c = self.cfg
         T = x.shape[0]
         H, hd = c.heads, c.hidden // c.heads
         assert pos0 + T <= self.max_len
-        if T == 1:
+        if T == 1 and cache is None:
             return self._decode_step(x, pos0)
+        kc, vc = cache if cache is not None else (self.kcache, self.vcache)
         for li, L in enumerate(self.layers):
             y = ops.rmsnorm(x, L["ln1"], c.eps)
             qkv = ops.linear(y, L["qkv"])  # [T, 3*hidden] == [T, 3, H, hd]
-            ops.rope_kv(qkv, H, hd, pos0, c.theta, self.kcache[li], self.vcache[li], table=self.rope)
+            ops.rope_kv(qkv, H, hd, pos0, c.theta, kc[li], vc[li], table=self.rope)
             q = qkv.view(T, 3, H, hd)[:, 0].permute(1, 0, 2).unsqueeze(0)  # [1,H,T,hd]
-            k = self.kcache[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
-            v = self.vcache[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
+            k = kc[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
+            v = vc[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
             a = ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=pos0)
             x = ops.linear(a.permute(0, 2, 1, 3).reshape(T, c.hidden), L["o"], residual=x)
             h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps), L["gu"], act="swiglu")
@@ -212,6 +214,68 @@ class Llama:
             st["graph"] = g
             self._dgraph = st
         return self._dgraph
+
+    # ---- B sequences per decode step (configs[2]: 8 images per GPU) ---------------------------------------------------
+    # The weights are streamed once per step for all B tokens (GEMV rows M = B <= 8 share every weight load), so a step of
+    # 8 sequences costs little more than a step of one.  Each sequence owns a cache slab [Tmax, H, hd] per layer.
+    def batch_cache(self, B):
+        bc = getattr(self, "_bcache", None)
+        if bc is None or bc[0].shape[1] < B:
+            c = self.cfg
+            H, hd = c.heads, c.hidden // c.heads
+            bc = self._bcache = tuple(torch.zeros(c.layers, B, self.max_len, H, hd, dtype=BF16, device=self.device)
+                                      for _ in range(2))
+            self._bgraphs = {}
+        return bc[0][:, :B], bc[1][:, :B]
+
+    def decode_step_batch(self, x, pos_dev, kc, vc):
+        """x bf16 [B, hidden] (one new token per sequence), pos_dev int32 [B], kc/vc [layers, B, Tmax, H, hd] ->
+        final-norm hidden [B, hidden]; same arithmetic per row as ``_decode_step``."""
+        c = self.cfg
+        H, hd = c.heads, c.hidden // c.heads
+        # the skinny-GEMM kernels fuse the RMSNorm prologue: wave-per-row GEMV for M <= 8, split-K MFMA up to 16 rows
+        fuse = x.shape[0] <= 8 or (x.shape[0] <= 16 and c.hidden >= 1024)
+        for li, L in enumerate(self.layers):
+            qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps)) if fuse else ops.linear(ops.rmsnorm(x, L["ln1"], c.eps), L["qkv"])
+            a = ops.llama_decode_attn_batch(qkv, kc[li], vc[li], H, hd, pos_dev, c.theta, hd ** -0.5, table=self.rope)
+            x = ops.linear(a, L["o"], residual=x)
+            if fuse:
+                h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))
+            else:
+                h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps), L["gu"], act="swiglu")
+            x = ops.linear(h, L["down"], residual=x)
+        return ops.rmsnorm(x, self.norm, c.eps)
+
+    def decode_graph_batch(self, B):
+        """One batched decode step (embed -> layers -> norm -> lm_head -> argmax, positions += 1) as a HIP graph."""
+        kc, vc = self.batch_cache(B)
+        st = self._bgraphs.get(B)
+        if st is None:
+            dev = self.device
+            st = dict(tok=torch.zeros(B, dtype=torch.int32, device=dev), pos=torch.zeros(B, dtype=torch.int32, device=dev))
+
+            def body():
+                h = self.decode_step_batch(self.embed_ids(st["tok"]), st["pos"], kc, vc)
+                st["hidden"] = h
+                st["nxt"] = ops.argmax(self.logits(h))
+                st["pos"].add_(1)
+
+            saved = (kc[:, :, :1].clone(), vc[:, :, :1].clone())  # the warm-up / capture runs write row 0 of every slab
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            st["pos"].zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                body()
+            kc[:, :, :1].copy_(saved[0])
+            vc[:, :, :1].copy_(saved[1])
+            st["pos"].zero_()
+            st["graph"] = g
+            self._bgraphs[B] = st
+        return st
 
     def reset_dataflow(self):
         """start of a generation: arrival counters, status word and the tokens-decoded counter back to zero"""

@@ -373,6 +373,126 @@ class InteractVLMForCausalLM:
         return out_ids, hidden_all[:pos]
 
     @torch.no_grad()
+    # ---- B images per call (BASELINE.json configs[2]: 8 images per GPU) -----------------------------------------------
+    def generate_batch(self, images_clip, input_ids_list, max_new_tokens=32, eos_token_id=2, forced_new_tokens=None):
+        """Greedy search for B sequences at once (extension: the reference's evaluate() is batch 1, evaluate.py:479).
+        The prompts are prefilled one by one into their own KV-cache slab, then every decode step streams the weights ONCE
+        for all B new tokens.  Per sequence the arithmetic is that of ``generate`` (same kernels, row-independent), so the
+        outputs equal B separate calls.  forced_new_tokens: one list per sequence (or one shared list).
+        -> [(output_ids [1, L+n], hidden [L+n-1+255, H])] * B."""
+        B = len(input_ids_list)
+        dev = self.device
+        feats = self.encode_images(images_clip)
+        kc, vc = self.llm.batch_cache(B)
+        xs = [self._input_embeds(input_ids_list[b].reshape(-1), feats[b]) for b in range(B)]
+        T0 = [int(x.shape[0]) for x in xs]
+        if forced_new_tokens is not None:
+            if not isinstance(forced_new_tokens[0], (list, tuple)):
+                forced_new_tokens = [list(forced_new_tokens)] * B
+            n_seq = [len(f) for f in forced_new_tokens]
+        else:
+            n_seq = [max_new_tokens] * B
+        n_seq = [min(n, self.llm.max_len - t) for n, t in zip(n_seq, T0)]
+        if min(n_seq) <= 0:
+            raise ops.IvlmError(f"a prompt of {max(T0)} positions does not fit the KV cache (max_len={self.llm.max_len})")
+        n_max = max(n_seq)
+        hidden_all = torch.empty(B, max(T0) + n_max, self.config.llama.hidden, dtype=BF16, device=dev)
+        last = torch.empty(B, self.config.llama.hidden, dtype=BF16, device=dev)
+        for b in range(B):
+            h = self.llm.forward(xs[b], 0, cache=(kc[:, b], vc[:, b]))
+            hidden_all[b, : T0[b]].copy_(h)
+            last[b].copy_(h[T0[b] - 1])
+        forced_dev = None
+        if forced_new_tokens is not None:
+            pad = [list(map(int, f[:n])) + [eos_token_id] * (n_max - n) for f, n in zip(forced_new_tokens, n_seq)]
+            forced_dev = torch.tensor(pad, dtype=torch.int32, device=dev).t().contiguous()  # [n_max, B]
+        use_graph = self.graph_decode and not ops.TIMER.enabled and not torch.cuda.is_current_stream_capturing()
+        pos_t = torch.tensor(T0, dtype=torch.int32, device=dev)
+        if use_graph:
+            dg = self.llm.decode_graph_batch(B)
+            dg["pos"].copy_(pos_t)
+        rows = torch.arange(B, device=dev)
+        nxt = ops.argmax(self.llm.logits(last))
+        new_ids = [[] for _ in range(B)]
+        done = [False] * B
+        for step in range(n_max):
+            if forced_dev is not None:
+                tok_t = forced_dev[step]
+                toks = [pad[b][step] for b in range(B)]
+            else:
+                tok_t = nxt
+                toks = nxt.tolist()  # host sync per step, as in generate()
+            for b in range(B):
+                if not done[b]:
+                    new_ids[b].append(int(toks[b]))
+                    if toks[b] == eos_token_id or len(new_ids[b]) >= n_seq[b]:
+                        done[b] = True
+            if all(done):
+                break
+            # (finished sequences keep stepping - their rows are ignored; n_max keeps every position inside the cache)
+            if use_graph:
+                dg["tok"].copy_(tok_t)
+                idx = dg["pos"].to(torch.int64)  # positions BEFORE the step's += 1
+                dg["graph"].replay()
+                h, nxt = dg["hidden"], dg["nxt"].clone()
+            else:
+                h = self.llm.decode_step_batch(self.llm.embed_ids(tok_t.contiguous()), pos_t, kc, vc)
+                idx = pos_t.to(torch.int64)
+                nxt = ops.argmax(self.llm.logits(h))
+                pos_t = pos_t + 1
+            hidden_all[rows, idx] = h
+        out = []
+        for b in range(B):
+            ids = input_ids_list[b].reshape(-1).cpu()
+            out_ids = torch.cat([ids, torch.tensor(new_ids[b], dtype=ids.dtype)])[None]
+            out.append((out_ids, hidden_all[b, : T0[b] + len(new_ids[b]) - 1]))
+        return out
+
+    def evaluate_batch(self, images_clip, images, input_ids_list, cam_params, resize_list, original_size_list,
+                       contact_type="hcontact", max_new_tokens=32, forced_new_tokens=None, eos_token_id=2,
+                       lift2d_dict_path=None):
+        """``evaluate`` for B images in one call: images_clip [B,3,h,w], images [B,V,3,S,S], one prompt per image.
+        The SAM encoder of every image runs on the side stream while the B sequences decode together; the masks of all
+        images are lifted in one launch.  -> [{'output_ids','pred_masks','pred_contact_3d'}] * B, each equal to what
+        ``evaluate`` returns for that image alone."""
+        B = len(input_ids_list)
+        main = torch.cuda.current_stream(self.device)
+        side = self._side_stream if self.overlap_sam_encoder else main
+        embs = []
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for b in range(B):  # one image's V views per encoder pass: the same launches as the batch-1 path
+                embs.append(self.model.visual_model.image_encoder(images[b].to(self.device)))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        gens = self.generate_batch(images_clip, input_ids_list, max_new_tokens, eos_token_id, forced_new_tokens)
+        if side is not main:
+            main.wait_event(ev)
+            for e in embs:
+                e.record_stream(main)
+        outs, lows = [], []
+        for b, (output_ids, hidden) in enumerate(gens):
+            rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)
+            pm, _ = self._decode_sample(hidden, rows, output_ids[0], cam_params[b], embs[b], resize_list[b],
+                                        original_size_list[b])
+            outs.append({"output_ids": output_ids, "pred_masks": [pm], "pred_contact_3d": None})
+            lows.append(pm)
+        have = [b for b in range(B) if lows[b].shape[0] > 0]
+        if have:
+            masks = [lows[b] for b in have]
+            if self.hC_loss_weight > 0 and "hcontact" in contact_type:
+                pc = self.human_3d_contact_predictor(masks)
+                for i, b in enumerate(have):
+                    outs[b]["pred_contact_3d"] = pc[i: i + 1]
+            elif (self.oC_loss_weight > 0 and "ocontact" in contact_type) or "oafford" in contact_type:
+                # every object has its own mesh and tables (components.py:463: batch size 1): one lift per image
+                paths = lift2d_dict_path if isinstance(lift2d_dict_path, (list, tuple)) else [lift2d_dict_path] * B
+                for b in have:
+                    outs[b]["pred_contact_3d"] = self.object_3d_contact_predictor(
+                        [lows[b]], ds_names=["ocontact"], lift2d_dict_path=paths[b])
+        return outs
+
     def evaluate(self, images_clip, images, input_ids, cam_params, resize_list, original_size_list,
                  lift2d_dict_path=None, contact_type="hcontact", max_new_tokens=32, tokenizer=None,
                  forced_new_tokens=None, eos_token_id=2, image_embeddings=None):

@@ -258,6 +258,8 @@ def _splitk_choice(M, N, K, act, rms):
     """number of K slices (1 = plain kernel): only where the 128x64 tiling leaves most of the 256 CUs idle."""
     if not SPLITK or M <= 8 or M > 1024 or act == "swiglu" or rms is not None or N % 4 or K % 64:
         return 1
+    if M <= 16 and N >= 1024 and K >= 1024:
+        return 1  # the skinny split-K MFMA kernel (csrc/gemv_mfma.hip) takes these
     tiles = ((M + 127) // 128) * ((N + 63) // 64)
     if tiles >= 256:
         return 1
@@ -489,6 +491,23 @@ def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, ta
     check(lib.ivlm_llama_decode_attn(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), H, D,
                                      int(pos), float(theta), float(scale), _p(table[0]) if table else 0,
                                      _p(table[1]) if table else 0, _stream()), "llama_decode_attn")
+    return out
+
+
+def llama_decode_attn_batch(qkv, kcache, vcache, H, D, pos_dev, theta, scale, table=None, out=None):
+    """One decode step of B sequences: qkv bf16 [B, 3*H*D], kcache/vcache bf16 [B, Tmax, H, D] (one slab per sequence),
+    pos_dev int32 [B] on the device -> o bf16 [B, H*D]."""
+    lib = _lib.load()
+    B = qkv.shape[0]
+    assert qkv.dtype == BF16 and qkv.stride(1) == 1 and kcache.dim() == 4 and kcache.shape[0] == B
+    assert kcache[0].is_contiguous() and vcache[0].is_contiguous() and kcache.stride(0) == vcache.stride(0)
+    assert pos_dev.dtype == torch.int32 and pos_dev.is_cuda and pos_dev.numel() == B and pos_dev.is_contiguous()
+    if out is None:
+        out = torch.empty(B, H * D, dtype=BF16, device=qkv.device)
+    check(lib.ivlm_llama_decode_attn_batch(qkv.data_ptr(), qkv.stride(0), kcache.data_ptr(), vcache.data_ptr(),
+                                           kcache.stride(0), out.data_ptr(), out.stride(0), B, H, D, pos_dev.data_ptr(),
+                                           float(theta), float(scale), _p(table[0]) if table else 0,
+                                           _p(table[1]) if table else 0, _stream()), "llama_decode_attn_batch")
     return out
 
 

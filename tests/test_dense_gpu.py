@@ -300,3 +300,55 @@ def test_layernorm_rmsnorm(hip_lib, cuda, cols, eps):
     ref_r = (w * n).float()  # HF LlamaRMSNorm: bf16 weight * bf16 normalised
     got_r = ops.rmsnorm(x.to(cuda), w.to(cuda), eps).float().cpu()
     assert torch.allclose(got_r, ref_r, atol=2e-2, rtol=2 ** -7)
+
+
+@pytest.mark.parametrize("M", [3, 5, 8, 13, 16])
+@pytest.mark.parametrize("N,K,act,rms,res,f32,bias", [
+    (4096, 4096, "none", False, True, False, False),    # o_proj
+    (2752, 1024, "swiglu", True, False, False, False),  # gate|up with the fused RMSNorm
+    (1032, 1096, "gelu", False, False, True, True),     # N not a multiple of 16, K not a multiple of 32 x 8 waves
+    (1024, 11008, "none", True, True, False, False),    # down-projection length (43 k-steps per wave)
+])
+def test_skinny_mfma_gemm_vs_fp32(hip_lib, cuda, M, N, K, act, rms, res, f32, bias):
+    """gemv_mfma.hip (batched decode: up to 16 activation rows, split-K inside the block, MFMA) against fp32 torch and,
+    where it applies (M <= 8), the wave-per-row GEMV; deterministic across launches."""
+    import torch
+
+    from interactvlm_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(cuda)
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    gam = _bf(1 + 0.1 * torch.randn(K, generator=g)).to(cuda)
+    b = _bf(0.1 * torch.randn(N, generator=g)).to(cuda) if bias else None
+    n_out = N // 2 if act == "swiglu" else N
+    r = _bf(torch.randn(M, n_out, generator=g)).to(cuda) if res else None
+    kw = dict(act=act, residual=r, rms=(gam, 1e-5) if rms else None, out_f32=f32, bias=b)
+    lib.ivlm_gemv_mfma_min_m(1)
+    try:
+        got = ops.linear(x, w, **kw)
+        assert torch.equal(got, ops.linear(x, w, **kw))
+    finally:
+        lib.ivlm_gemv_mfma_min_m(0)
+    xf = x.float()
+    if rms:
+        xf = (xf * gam.float()).to(torch.bfloat16).float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5)
+    y = xf @ w.float().T
+    if bias:
+        y = y + b.float()
+    if act == "swiglu":
+        y = torch.nn.functional.silu(y[:, 0::2]) * y[:, 1::2]
+    else:
+        y = _ref_act(y, act)
+    if res:
+        y = y + r.float()
+    tol = dict(atol=2e-3, rtol=1e-3) if f32 else dict(atol=2e-2, rtol=1.6e-2)
+    assert got.shape == (M, n_out) and torch.allclose(got.float(), y, **tol)
+    if M <= 8:
+        lib.ivlm_gemv_mfma_min_m(17)  # never: the wave-per-row kernel
+        try:
+            roww = ops.linear(x, w, **kw)
+        finally:
+            lib.ivlm_gemv_mfma_min_m(0)
+        assert torch.allclose(got.float(), roww.float(), **tol)

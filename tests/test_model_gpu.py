@@ -468,3 +468,79 @@ def test_object_render_localize_lift_flow(hip_lib, cuda, tmp_path):
     exp, _ = cref.lift_mesh_thresh(pm, vid.cpu().numpy().astype(np.int32), bary.cpu().numpy(), nv)
     np.testing.assert_allclose(pc, exp, atol=2e-6)
     assert np.array_equal(pc > 0.3, exp > 0.3) or np.abs(pc - exp)[(pc > 0.3) != (exp > 0.3)].max() < 2e-6
+
+
+def test_decode_attn_batch_equals_per_sequence(hip_lib, cuda):
+    """ivlm_llama_decode_attn_batch (grid heads x sequences, one cache slab and one position per sequence) is bit-identical
+    to B separate single-sequence launches, including the appended cache rows."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    B, H, D, Tmax = 5, 8, 128, 96
+    g = torch.Generator().manual_seed(3)
+    qkv = (torch.randn(B, 3 * H * D, generator=g)).to(torch.bfloat16).to(cuda)
+    kc = (torch.randn(B, Tmax, H, D, generator=g)).to(torch.bfloat16).to(cuda)
+    vc = (torch.randn(B, Tmax, H, D, generator=g)).to(torch.bfloat16).to(cuda)
+    pos = torch.tensor([0, 17, 63, 64, 95], dtype=torch.int32, device=cuda)
+    tab = ops.rope_table(Tmax, D, 10000.0, cuda)
+    kc1, vc1 = kc.clone(), vc.clone()
+    exp = torch.cat([ops.llama_decode_attn(qkv[b: b + 1].contiguous(), kc1[b], vc1[b], H, D, int(pos[b]), 10000.0,
+                                           D ** -0.5, table=tab) for b in range(B)])
+    got = ops.llama_decode_attn_batch(qkv, kc, vc, H, D, pos, 10000.0, D ** -0.5, table=tab)
+    assert torch.equal(got, exp) and torch.equal(kc, kc1) and torch.equal(vc, vc1)
+    with pytest.raises(AssertionError):
+        ops.llama_decode_attn_batch(qkv, kc, vc, H, D, pos[:3], 10000.0, D ** -0.5, table=tab)
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_evaluate_batch_equals_per_image_evaluate(hip_lib, cuda, golden_dir, graph):
+    """evaluate_batch (BASELINE.json configs[2]: several images per GPU - prompts of different lengths, one decode step
+    streaming the weights once for all sequences) returns, image by image, what evaluate() returns for that image alone:
+    same ids bit for bit, contacts within the GEMV-row tolerance (M = B vs M = 1 kernels share the summation order)."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth
+    from interactvlm_amd import weights as Wt
+
+    d, cfg, ids, images_clip, images, cams, tables = _toy(golden_dir)
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    m.graph_decode = graph
+    bf = torch.bfloat16
+    B = 3
+    ic = torch.from_numpy(synth.synth_normal("eb/images_clip", (B, 3, 224, 224), 1.0, 0)).to(bf).to(cuda)
+    im = torch.from_numpy(synth.synth_normal("eb/images", (B, 4, 3, 1024, 1024), 1.0, 0)).to(bf).to(cuda)
+    L0 = [40, 36, 40]  # prompt lengths differ: the sequences sit at different positions in every step
+    prompts, forced = [], []
+    for b in range(B):
+        p = ids[: L0[b]].clone()
+        if b == 1:
+            p = torch.cat([ids[:30], ids[34:40]])
+        prompts.append(p)
+        forced.append(ids[40:].tolist() if b != 2 else ids[40: len(ids) - 2].tolist() + [int(ids[-1])])
+    cam_b = [cams[0]] * B
+    sizes = [(1024, 1024)] * B
+    single = [m.evaluate(ic[b: b + 1], im[b: b + 1], prompts[b][None], cams, [(1024, 1024)], [(1024, 1024)],
+                         forced_new_tokens=forced[b]) for b in range(B)]
+    outs = m.evaluate_batch(ic, im, prompts, cam_b, sizes, sizes, forced_new_tokens=forced)
+    assert len(outs) == B
+    for b in range(B):
+        assert torch.equal(outs[b]["output_ids"], single[b]["output_ids"])
+        e = float((outs[b]["pred_contact_3d"] - single[b]["pred_contact_3d"]).abs().max())
+        em = float((outs[b]["pred_masks"][0] - single[b]["pred_masks"][0]).abs().max())
+        print(f"\n[evaluate_batch graph={graph}] image {b}: max|dp| = {e:.2e}, max|dmask| = {em:.3e}")
+        assert outs[b]["pred_contact_3d"].shape == (1, 6890)
+        assert e < 2e-3
+    # free-running greedy search: every sequence stops at its own EOS / length, ids equal the per-image runs
+    free1 = [m.evaluate(ic[b: b + 1], im[b: b + 1], prompts[b][None], cams, [(1024, 1024)], [(1024, 1024)],
+                        max_new_tokens=6 + b, eos_token_id=-1)["output_ids"] for b in range(B)]
+    free = m.generate_batch(ic, prompts, max_new_tokens=8, eos_token_id=-1)
+    for b in range(B):
+        n = min(free1[b].shape[1], free[b][0].shape[1])
+        assert torch.equal(free1[b][0, :n], free[b][0][0, :n])
+    # a second call re-uses the captured graph and the cache slabs
+    outs2 = m.evaluate_batch(ic, im, prompts, cam_b, sizes, sizes, forced_new_tokens=forced)
+    for b in range(B):
+        assert torch.equal(outs2[b]["pred_contact_3d"], outs[b]["pred_contact_3d"])
