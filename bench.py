@@ -256,7 +256,12 @@ def main():
         sync()
         tb = time.perf_counter() - t1
         assert rb.shape == (Bv, 6890)
+        # the same images one at a time through evaluate(): the batched step (split-K MFMA skinny GEMM, M = 8) against the
+        # batch-1 step (wave-per-row GEMV) - same arithmetic, different summation order
+        one = torch.cat([model.evaluate(icb[b: b + 1], imb[b: b + 1], ids, cams, [(S, S)], [(S, S)], contact_type="hcontact",
+                                        forced_new_tokens=forced)["pred_contact_3d"] for b in range(2)]).cpu()
         batch8 = {"images_per_s": round(Bv * nb / tb, 4), "batch": Bv, "ms_per_batch": round(1e3 * tb / nb, 2),
+                  "max_abs_dp_vs_batch1": float((rb[:2] - one).abs().max()),
                   "note": "evaluate_batch: 8 images per call on one GPU (configs[2] per-GPU share); NOT the headline metric"}
         del icb, imb
 

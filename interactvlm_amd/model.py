@@ -105,6 +105,8 @@ class InteractVLMForCausalLM:
         vm = SimpleNamespace()
         vm.image_encoder = SamImageEncoder(w, c.sam, dev)
         vm.mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid)
+        if os.environ.get("IVLM_NO_GRAPHS"):
+            vm.mask_decoder.use_graph = False
         vm.prompt_encoder = vm.mask_decoder  # text path of the prompt encoder is folded into the decoder object
         vm.postprocess_masks = lambda m, input_size, original_size: postprocess_masks(
             m, input_size, original_size, c.sam.img_size)
@@ -384,7 +386,9 @@ class InteractVLMForCausalLM:
         dev = self.device
         feats = self.encode_images(images_clip)
         kc, vc = self.llm.batch_cache(B)
-        xs = [self._input_embeds(input_ids_list[b].reshape(-1), feats[b]) for b in range(B)]
+        # one image for all prompts (configs[4]: a human-contact and an object prompt about the same picture): ONE CLIP pass
+        shared = feats.shape[0] == 1 and B > 1
+        xs = [self._input_embeds(input_ids_list[b].reshape(-1), feats[0 if shared else b]) for b in range(B)]
         T0 = [int(x.shape[0]) for x in xs]
         if forced_new_tokens is not None:
             if not isinstance(forced_new_tokens[0], (list, tuple)):
@@ -454,7 +458,10 @@ class InteractVLMForCausalLM:
         """``evaluate`` for B images in one call: images_clip [B,3,h,w], images [B,V,3,S,S], one prompt per image.
         The SAM encoder of every image runs on the side stream while the B sequences decode together; the masks of all
         images are lifted in one launch.  -> [{'output_ids','pred_masks','pred_contact_3d'}] * B, each equal to what
-        ``evaluate`` returns for that image alone."""
+        ``evaluate`` returns for that image alone.
+        images_clip [1,3,h,w] with B > 1 prompts = B questions about ONE picture (one CLIP pass; configs[4]: a human-contact
+        prompt over the body renders and an object prompt over the object renders); contact_type and lift2d_dict_path
+        may then be lists, one entry per prompt."""
         B = len(input_ids_list)
         main = torch.cuda.current_stream(self.device)
         side = self._side_stream if self.overlap_sam_encoder else main
@@ -478,19 +485,21 @@ class InteractVLMForCausalLM:
                                         original_size_list[b])
             outs.append({"output_ids": output_ids, "pred_masks": [pm], "pred_contact_3d": None})
             lows.append(pm)
+        ctypes = [contact_type] * B if isinstance(contact_type, str) else list(contact_type)
+        paths = lift2d_dict_path if isinstance(lift2d_dict_path, (list, tuple)) else [lift2d_dict_path] * B
         have = [b for b in range(B) if lows[b].shape[0] > 0]
-        if have:
-            masks = [lows[b] for b in have]
-            if self.hC_loss_weight > 0 and "hcontact" in contact_type:
-                pc = self.human_3d_contact_predictor(masks)
-                for i, b in enumerate(have):
-                    outs[b]["pred_contact_3d"] = pc[i: i + 1]
-            elif (self.oC_loss_weight > 0 and "ocontact" in contact_type) or "oafford" in contact_type:
+        hum = [b for b in have if self.hC_loss_weight > 0 and "hcontact" in ctypes[b]]
+        if hum:  # all body lifts in one launch (same tables)
+            pc = self.human_3d_contact_predictor([lows[b] for b in hum])
+            for i, b in enumerate(hum):
+                outs[b]["pred_contact_3d"] = pc[i: i + 1]
+        for b in have:
+            if b in hum:
+                continue
+            if (self.oC_loss_weight > 0 and "ocontact" in ctypes[b]) or "oafford" in ctypes[b]:
                 # every object has its own mesh and tables (components.py:463: batch size 1): one lift per image
-                paths = lift2d_dict_path if isinstance(lift2d_dict_path, (list, tuple)) else [lift2d_dict_path] * B
-                for b in have:
-                    outs[b]["pred_contact_3d"] = self.object_3d_contact_predictor(
-                        [lows[b]], ds_names=["ocontact"], lift2d_dict_path=paths[b])
+                outs[b]["pred_contact_3d"] = self.object_3d_contact_predictor(
+                    [lows[b]], ds_names=["ocontact"], lift2d_dict_path=paths[b])
         return outs
 
     def evaluate(self, images_clip, images, input_ids, cam_params, resize_list, original_size_list,

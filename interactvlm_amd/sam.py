@@ -185,7 +185,38 @@ class SamMaskDecoder:
         o = ops.attention(q4, k4, v4, 1.0 / math.sqrt(d))
         return o.permute(0, 2, 1, 3).reshape(B * Sq, inner)
 
+    # The decoder chain (prompt tokens -> two-way transformer -> upscaler -> hypernetwork dot -> IoU head) is ~150 launches of
+    # 3-30 us kernels with no host decision inside: replayed as ONE HIP graph per (views, tokens) shape (BASELINE.json
+    # configs[4]: "fused SAM decoder in one hipGraph").  Same kernels, same order: bit-identical to the eager chain.
+    use_graph = True
+
     def __call__(self, image_embeddings, text_embeds):
+        if (not (self.use_graph and image_embeddings.is_cuda) or torch.cuda.is_current_stream_capturing()
+                or ops.TIMER.enabled):
+            return self._forward(image_embeddings, text_embeds)
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        key = (tuple(image_embeddings.shape), tuple(text_embeds.shape), text_embeds.dtype)
+        ent = self._graphs.get(key)
+        dev = image_embeddings.device
+        if ent is None:
+            s_emb, s_txt = image_embeddings.contiguous().clone(), text_embeds.contiguous().clone()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):  # warm-up outside capture (allocator pools, lazy module loads)
+                self._forward(s_emb, s_txt)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                s_out = self._forward(s_emb, s_txt)
+            ent = self._graphs[key] = (g, s_emb, s_txt, s_out)
+        g, s_emb, s_txt, s_out = ent
+        s_emb.copy_(image_embeddings)
+        s_txt.copy_(text_embeds)
+        g.replay()
+        return s_out[0].clone(), s_out[1].clone()
+
+    def _forward(self, image_embeddings, text_embeds):
         """image_embeddings [V, g*g, C] bf16 (channels last); text_embeds [1, T, C] (the views as TOKENS)
         -> low_res_masks f32 [V,1,4g,4g], iou f32 [V,1].
 

@@ -47,6 +47,13 @@ def test_sam_decoder_vs_reference_golden(hip_lib, cuda, golden_dir):
         emb_cl = emb.permute(0, 2, 3, 1).reshape(V, 4096, 256).to(torch.bfloat16).to(cuda)
         low, iou = dec(emb_cl, text.to(torch.bfloat16).to(cuda))
         assert low.shape == (V, 1, 256, 256) and low.dtype == torch.float32 and iou.shape == (V, 1)
+        # the call above replayed the chain as one HIP graph (configs[4]); the eager chain and a second replay with other
+        # inputs in between give the same bits
+        assert dec.use_graph and len(dec._graphs) >= 1
+        low_e, iou_e = dec._forward(emb_cl, text.to(torch.bfloat16).to(cuda))
+        dec(emb_cl.flip(0).contiguous(), text.to(torch.bfloat16).to(cuda) * 0.5)
+        low_r, iou_r = dec(emb_cl, text.to(torch.bfloat16).to(cuda))
+        assert torch.equal(low, low_e) and torch.equal(iou, iou_e) and torch.equal(low_r, low) and torch.equal(iou_r, iou)
         ref = torch.from_numpy(d["low_res"])
         assert _rel_err(low, ref) < 4e-2, _rel_err(low, ref)
         assert float((iou.cpu() - torch.from_numpy(d["iou"])).abs().max()) < 5e-2
@@ -468,6 +475,36 @@ def test_object_render_localize_lift_flow(hip_lib, cuda, tmp_path):
     exp, _ = cref.lift_mesh_thresh(pm, vid.cpu().numpy().astype(np.int32), bary.cpu().numpy(), nv)
     np.testing.assert_allclose(pc, exp, atol=2e-6)
     assert np.array_equal(pc > 0.3, exp > 0.3) or np.abs(pc - exp)[(pc > 0.3) != (exp > 0.3)].max() < 2e-6
+
+    # BASELINE.json configs[4], joint case: a human-contact prompt over the body renders AND an object prompt over the
+    # object renders about ONE picture, in one call (one CLIP pass, both answers decoded together, one SAM encoder pass per
+    # render set) == the two separate evaluate() calls
+    m.hC_loss_weight = 1.0
+    ids_o, forced_o = synthetic.prompt_ids(cfg, n_prompt=44, n_answer=8, seed=1)
+    _, im_o = synthetic.images(cfg, cuda, seed=3)
+    h1 = m.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced, contact_type="hcontact")
+    o1 = m.evaluate(ic, im_o, ids_o, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced_o,
+                    contact_type="ocontact", lift2d_dict_path=path)
+    calls = {"n": 0}
+    tower = m.vision_tower.__class__.__call__
+
+    def counting(self_, x):
+        calls["n"] += 1
+        return tower(self_, x)
+
+    m.vision_tower.__class__.__call__ = counting
+    try:
+        both = m.evaluate_batch(ic, torch.cat([im, im_o]), [ids[0], ids_o[0]], [cams[0], cams[0]], [(1024, 1024)] * 2,
+                                [(1024, 1024)] * 2, contact_type=["hcontact", "ocontact"],
+                                forced_new_tokens=[forced, forced_o], lift2d_dict_path=[None, path])
+    finally:
+        m.vision_tower.__class__.__call__ = tower
+    assert calls["n"] == 1  # one CLIP encode for both prompts
+    assert both[0]["pred_contact_3d"].shape == (1, 6890) and both[1]["pred_contact_3d"].shape == (1, nv)
+    for got, ref in ((both[0], h1), (both[1], o1)):
+        assert torch.equal(got["output_ids"], ref["output_ids"])
+        assert float((got["pred_contact_3d"] - ref["pred_contact_3d"]).abs().max()) < 2e-3
+        assert float((got["pred_masks"][0] - ref["pred_masks"][0]).abs().max()) < 0.05
 
 
 def test_decode_attn_batch_equals_per_sequence(hip_lib, cuda):
