@@ -14,8 +14,14 @@
 //     (two xor-shuffles across the four 16-lane groups), and P never leaves registers: the four
 //     scores a lane holds per 16-key tile are exactly the K-slots it must feed to the next MFMA
 //     once the key order inside each 32-key step is permuted consistently for P and V.
-//   * V is stored transposed in LDS ([d][key], +8 pad) so that permuted slot order is two 8-byte
-//     reads; K rows are padded (+8) => conflict-free ds_read_b128.  Head dim 80 pads to 96 for QK^T.
+//   * LDS images are built for the hardware's lane groups (a ds_read_b128 is served 16 lanes at a time: {0-3,12-15,
+//     20-27}, {4-11,16-19,28-31}, ...; bank = dword address mod 64):
+//       K  [k-step][key][32 elements]: 64-byte rows, 16-byte chunk g of key r stored at chunk g ^ ((r >> 3 & 1) << 1) -
+//          every lane group then covers 16 distinct 16-byte bank slots (a padded row-major image is 2-way conflicted);
+//       V  [16-wide d tile][key][16 elements], row-major as it arrives from HBM (16-byte stores, no scatter): the
+//          V^T fragments of the second MFMA come from ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group, lane i
+//          receives column i), two reads per fragment in the permuted key order.
+//     Both are double-buffered: one barrier per key tile.  Head dim 80 pads to 96 for QK^T (zero chunks).
 //   * the S x S score matrix is never materialised (the reference materialises [B*16,4096,4096]).
 #include "kernels.h"
 
@@ -41,13 +47,13 @@ template <int DQK, int DV, bool CAUSAL, int REL>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     constexpr int KS = DQK / 32;        // MFMA k-steps over the head dim
     constexpr int DT = DV / 16;         // 16-wide output tiles over the head dim
-    constexpr int KROW = DQK + 8;       // padded K row (elements)
-    constexpr int VROW = kKV + 8;       // padded V^T row (elements)
     constexpr int DCH = DV / 8;         // 16-byte chunks per K/V row actually present in memory
     constexpr int NCH = kKV * DCH;      // chunks per K (or V) tile
     constexpr int CPT = (NCH + 255) / 256;
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[kKV * KROW];
-    __shared__ __attribute__((aligned(16))) bf16_t Vt[DV * VROW];
+    constexpr int KBUF = KS * kKV * 32;  // elements: [ks][key][32]
+    constexpr int VBUF = DT * kKV * 16;  // elements: [dt][key][16]
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KBUF];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[2][VBUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -59,10 +65,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     const bf16_t* __restrict__ K = a.k + bkv * a.k_bs + h * a.k_hs;
     const bf16_t* __restrict__ V = a.v + bkv * a.v_bs + h * a.v_hs;
 
-    // ---- zero the pad columns of K once (head dim < DQK, and the +8 row pad) -------------------
-    if (DV < KROW) {
-        constexpr int PADW = KROW - DV;
-        for (int i = tid; i < kKV * PADW; i += 256) Ks[(i / PADW) * KROW + DV + (i % PADW)] = 0;
+    // ---- zero the pad chunks of K once (head dim < DQK), both buffers ------------------------------
+    if (DCH < KS * 4) {
+        constexpr int NPAD = KS * 4 - DCH;
+        for (int i = tid; i < 2 * kKV * NPAD; i += 256) {
+            const int buf = i / (kKV * NPAD), r = i % (kKV * NPAD);
+            const int key = r / NPAD, ch = DCH + r % NPAD;
+            const int phys = (ch & 3) ^ (((key >> 3) & 1) << 1);
+            *reinterpret_cast<u32x4_t*>(&Ks[buf][(ch >> 2) * (kKV * 32) + key * 32 + phys * 8]) = u32x4_t{0u, 0u, 0u, 0u};
+        }
     }
 
     // ---- Q fragments (B operand): lane holds Q[q0 + qt*16 + l15][(s*4+g)*8 .. +8] ---------------
@@ -117,22 +128,20 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
             vreg[i] = *reinterpret_cast<const u32x4_t*>(V + (int64_t)key * a.v_rs + dch * 8);
         }
     };
-    auto lds_store = [&]() __attribute__((always_inline)) {
+    auto lds_store = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = tid + i * 256;
             if (c < NCH) {
                 const int key = c / DCH, dch = c % DCH;
-                *reinterpret_cast<u32x4_t*>(&Ks[key * KROW + dch * 8]) = kreg[i];
-                const uint32_t vw[4] = {vreg[i][0], vreg[i][1], vreg[i][2], vreg[i][3]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    Vt[(dch * 8 + 2 * e) * VROW + key] = (bf16_t)(vw[e] & 0xffffu);
-                    Vt[(dch * 8 + 2 * e + 1) * VROW + key] = (bf16_t)(vw[e] >> 16);
-                }
+                const int phys = (dch & 3) ^ (((key >> 3) & 1) << 1);
+                *reinterpret_cast<u32x4_t*>(&Ks[buf][(dch >> 2) * (kKV * 32) + key * 32 + phys * 8]) = kreg[i];
+                *reinterpret_cast<u32x4_t*>(&Vs[buf][(dch >> 1) * (kKV * 16) + key * 16 + (dch & 1) * 8]) = vreg[i];
             }
         }
     };
+    const int kswz = (g ^ ((l15 >> 3) << 1)) * 8;                       // this lane's K chunk inside a 64-byte row
+    const int voff = (g * 4 + (l15 >> 2)) * 16 + (l15 & 3) * 4;         // tr-read address: key g*4 + i/4, d-quad i%4
 
     // ---- rel-pos operands of this lane's two queries -------------------------------------------
     bf16x8_t qrel[2];       // REL 1: [rel_h(KH) | rel_w(KW) | 0] features g*8 .. g*8+7
@@ -174,11 +183,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     const float sc2 = a.prescale_q ? kLog2e : a.scale * kLog2e;
 
     gload(0);
+    lds_store(0);
     for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();  // all waves done reading the previous tile
-        lds_store();
-        __syncthreads();
+        __syncthreads();  // tile t is in buffer t & 1; every wave is done with tile t - 1 (the other buffer)
         if (t + 1 < ntiles) gload(t + 1);
+        const bf16_t* Kb = Ks[t & 1];
+        const bf16_t* Vb = Vs[t & 1];
+        int nkt = (a.Sk - t * kKV + 15) >> 4;  // 16-key sub-tiles that hold real keys (wave-uniform)
+        nkt = nkt < 4 ? nkt : 4;
 
         // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query l15 ------------------
         f32x4_t s[2][4];
@@ -188,10 +200,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
             for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
+            if (kt >= nkt) continue;  // keys past Sk: their scores are masked below
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8_t kf =
-                    *reinterpret_cast<const bf16x8_t*>(&Ks[(kt * 16 + l15) * KROW + (ks * 4 + g) * 8]);
+                    *reinterpret_cast<const bf16x8_t*>(&Kb[ks * (kKV * 32) + (kt * 16 + l15) * 32 + kswz]);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
@@ -216,69 +229,88 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         }
 
         // ---- scale, bias, mask, online softmax (log2 domain) -----------------------------------
+        // The softmax, not the MFMAs, bounds this kernel (32 scores per lane per tile on the VALU): ~8 VALU slots per score
+        // (bias add, one fma into the log2 domain, max, subtract, raw v_exp_f32, sum; bf16 packing by v_cvt_pk_bf16_f32
+        // below), and the accumulators are rescaled only when some running maximum moved.  Edge tiles (keys past Sk, the
+        // causal diagonal) first overwrite their invalid raw scores with -1e30 in a pre-pass under one wave-uniform
+        // branch; exp2 of those is exactly 0 because every query has a valid key in its first tile (key 0).
         const int kv0 = t * kKV;
+        bool edge = kv0 + kKV > a.Sk;
+        if (CAUSAL) edge = edge || (kv0 + kKV - 1 > q0 + a.q_pos0);
+        if (REL == 3 || edge) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int qi = q0 + qt * 16 + l15;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int kb = kv0 + kt * 16 + g * 4;
+                    int gkh = 0, gkw = 0;
+                    if (REL == 3) {
+                        gkh = kb / a.rel_kw;
+                        gkw = kb - gkh * a.rel_kw;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kb + r;
+                        bool ok = key < a.Sk;
+                        if (REL == 3) {
+                            if (ok) s[qt][kt][r] += rhp[qt][gkh] + rwg[qt][gkw];
+                            if (++gkw == a.rel_kw) {
+                                gkw = 0;
+                                ++gkh;
+                            }
+                        }
+                        if (CAUSAL) ok = ok && (key <= qi + a.q_pos0);
+                        s[qt][kt][r] = ok ? s[qt][kt][r] : kNegBig;
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const int qi = q0 + qt * 16 + l15;
             float mx = kNegBig;
-            float rh_t = 0.0f;
-            if (REL == 2) rh_t = rhp[qt][t < a.rel_kh ? t : a.rel_kh - 1];
+            float bias2 = 0.0f;
+            if (REL == 2) bias2 = rhp[qt][t < a.rel_kh ? t : a.rel_kh - 1] * sc2;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const int kb = kv0 + kt * 16 + g * 4;
-                int gkh = 0, gkw = 0;
-                if (REL == 3) {
-                    gkh = kb / a.rel_kw;
-                    gkw = kb - gkh * a.rel_kw;
-                }
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kb + r;
                     float x = s[qt][kt][r];
-                    if (REL == 3) {
-                        if (key < a.Sk) x += rhp[qt][gkh] + rwg[qt][gkw];
-                        if (++gkw == a.rel_kw) {
-                            gkw = 0;
-                            ++gkh;
-                        }
-                    }
                     if (REL == 2) {
                         const uint32_t pw = rwp[qt][2 * kt + (r >> 1)];
-                        x += rh_t + __uint_as_float((r & 1) ? (pw & 0xffff0000u) : (pw << 16));
+                        x += __uint_as_float((r & 1) ? (pw & 0xffff0000u) : (pw << 16));
                     }
-                    x *= sc2;
-                    bool ok = key < a.Sk;
-                    if (CAUSAL) ok = ok && (key <= qi + a.q_pos0);
-                    x = ok ? x : kNegBig;
+                    x = __builtin_fmaf(x, sc2, bias2);
                     s[qt][kt][r] = x;
                     mx = fmaxf(mx, x);
                 }
-            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[qt], mx);
-            const float alpha = exp2f(m_run[qt] - m_new);
+            if (__any(m_new > m_run[qt])) {  // wave-uniform: some query's running maximum moved
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    o[qt][dt][0] *= alpha;
+                    o[qt][dt][1] *= alpha;
+                    o[qt][dt][2] *= alpha;
+                    o[qt][dt][3] *= alpha;
+                }
+                m_run[qt] = m_new;
+            }
             float rs = 0.0f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // fully masked entries: exp2(-1e30 - m) == 0 unless the whole row is masked so far
-                    const float p = s[qt][kt][r] <= kNegBig ? 0.0f : exp2f(s[qt][kt][r] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(s[qt][kt][r] - m_new);
                     s[qt][kt][r] = p;
                     rs += p;
                 }
             rs += __shfl_xor(rs, 16, 64);
             rs += __shfl_xor(rs, 32, 64);
-            l_run[qt] = l_run[qt] * alpha + rs;
-            m_run[qt] = m_new;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                o[qt][dt][0] *= alpha;
-                o[qt][dt][1] *= alpha;
-                o[qt][dt][2] *= alpha;
-                o[qt][dt][3] *= alpha;
-            }
+            l_run[qt] += rs;
         }
 
         // ---- P^T fragments straight from the score registers (key order permuted per 32-step) --
@@ -287,11 +319,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                uint4 u;
-                u.x = pack_bf16x2(s[qt][2 * s2][0], s[qt][2 * s2][1]);
-                u.y = pack_bf16x2(s[qt][2 * s2][2], s[qt][2 * s2][3]);
-                u.z = pack_bf16x2(s[qt][2 * s2 + 1][0], s[qt][2 * s2 + 1][1]);
-                u.w = pack_bf16x2(s[qt][2 * s2 + 1][2], s[qt][2 * s2 + 1][3]);
+                uint4 u;  // round-to-nearest-even pairs in one instruction each (probabilities: finite, no NaN handling needed)
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.x) : "v"(s[qt][2 * s2][0]), "v"(s[qt][2 * s2][1]));
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.y) : "v"(s[qt][2 * s2][2]), "v"(s[qt][2 * s2][3]));
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.z) : "v"(s[qt][2 * s2 + 1][0]), "v"(s[qt][2 * s2 + 1][1]));
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.w) : "v"(s[qt][2 * s2 + 1][2]), "v"(s[qt][2 * s2 + 1][3]));
                 pf[qt][s2] = *reinterpret_cast<bf16x8_t*>(&u);
             }
 
@@ -300,17 +332,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16_t* vrow = &Vt[(dt * 16 + l15) * VROW + g * 4];
-                uint4 u;
-                const uint2 lo = *reinterpret_cast<const uint2*>(vrow + (2 * s2) * 16);
-                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (2 * s2 + 1) * 16);
-                u.x = lo.x; u.y = lo.y; u.z = hi.x; u.w = hi.y;
-                const bf16x8_t vf = *reinterpret_cast<bf16x8_t*>(&u);
+                if (2 * s2 >= nkt) continue;  // all 32 keys of this step are past Sk (their P is 0)
+                typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+                typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+                const bf16_t* vp = Vb + dt * (kKV * 16) + (2 * s2) * 16 * 16 + voff;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vp));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vp + 16 * 16));
+                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                const s16x8_t v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, v8);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                     o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s2], o[qt][dt], 0, 0, 0);
             }
         }
+        if (t + 1 < ntiles) lds_store((t + 1) & 1);  // the other buffer: last read in iteration t - 1, before this barrier round
     }
 
     // ---- normalise and store: lane holds O[query l15][d = dt*16 + g*4 + r] ---------------------

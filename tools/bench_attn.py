@@ -1,62 +1,63 @@
-#!/usr/bin/env python3
-"""TFLOP/s of the fused attention kernel on the hot-path shapes."""
+"""Attention kernel micro-benchmark on the path's shapes (+ fp32 torch check on a slice): SAM ViT-H global (4 views x 16 heads,
+4096 tokens, d 80, rel-pos), SAM window (100 windows, 196 tokens), CLIP (257, d 64), LLaMA prefill (330, d 128, causal)."""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from interactvlm_amd import ops  # noqa: E402
 
-SHAPES = [("sam_global", 4, 16, 4096, 4096, 80, False, True), ("sam_window", 100, 16, 196, 196, 80, False, True),
-          ("sam_global_norel", 4, 16, 4096, 4096, 80, False, False),
-          ("clip", 1, 16, 257, 257, 64, False, False), ("llm_prefill", 1, 32, 330, 330, 128, True, False),
-          ("llm_decode", 1, 32, 1, 354, 128, True, False), ("dec_t2i", 4, 8, 9, 4096, 16, False, False),
-          ("dec_i2t", 4, 8, 4096, 9, 16, False, False)]
+
+def ref_attn(q, k, v, scale, causal, rel, side):
+    qf, kf, vf = q.float(), k.float(), v.float()
+    if rel is not None:  # prescaled q rounded to bf16 first, like the kernel / SAM
+        qf = (qf * scale).to(torch.bfloat16).float()
+        s = qf @ kf.transpose(-1, -2)
+        B, H, S, _ = q.shape
+        rh, rw = rel
+        bias = rh.view(B, H, S, side, 1) + rw.view(B, H, S, 1, side)
+        s = s + bias.reshape(B, H, S, side * side)
+    else:
+        s = (qf @ kf.transpose(-1, -2)) * scale
+    if causal:
+        Sq, Sk = s.shape[-2:]
+        s = s.masked_fill(torch.ones(Sq, Sk, dtype=torch.bool, device=s.device).triu(1), float("-inf"))
+    return torch.softmax(s, -1) @ vf
 
 
 def main():
+    from interactvlm_amd import ops
+
     dev = torch.device("cuda:0")
-    for name, B, H, Sq, Sk, D, causal, rel in SHAPES:
-        q = torch.randn(B, H, Sq, D, device=dev).to(torch.bfloat16)
-        k = torch.randn(B, H, Sk, D, device=dev).to(torch.bfloat16)
-        v = torch.randn(B, H, Sk, D, device=dev).to(torch.bfloat16)
-        r = None
-        if rel:
-            side = int(Sk ** 0.5)
-            r = (torch.randn(B * H, Sq, side, device=dev), torch.randn(B * H, Sq, side, device=dev))
-        out = ops.attention(q, k, v, D ** -0.5, causal=causal, q_pos0=Sk - Sq, rel=r)
+    bf = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(0)
+    cases = [("sam_global", 4, 16, 4096, 80, False, 64), ("sam_window", 100, 16, 196, 80, False, 14),
+             ("clip", 1, 16, 257, 64, False, 0), ("llama_prefill", 1, 32, 330, 128, True, 0)]
+    for name, B, H, S, D, causal, side in cases:
+        qkv = torch.randn(B, S, 3, H, D, generator=g, device=dev).to(bf)
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        rel = None
+        if side:
+            rel = (0.5 * torch.randn(B * H, S, side, generator=g, device=dev), 0.5 * torch.randn(B * H, S, side, generator=g, device=dev))
+        scale = D ** -0.5
+        o = ops.attention(q, k, v, scale, causal=causal, rel=rel)
+        nb = min(B, 2)
+        r = ref_attn(q[:nb], k[:nb], v[:nb], scale, causal, None if rel is None else (rel[0][: nb * H], rel[1][: nb * H]), side)
+        err = float((o[:nb].float() - r).abs().max())
         for _ in range(3):
-            ops.attention(q, k, v, D ** -0.5, causal=causal, q_pos0=Sk - Sq, rel=r, out=out)
+            ops.attention(q, k, v, scale, causal=causal, rel=rel)
         torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 20
-        s.record()
-        for _ in range(iters):
-            ops.attention(q, k, v, D ** -0.5, causal=causal, q_pos0=Sk - Sq, rel=r, out=out)
-        e.record()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        a.record()
+        for _ in range(reps):
+            ops.attention(q, k, v, scale, causal=causal, rel=rel)
+        b.record()
         torch.cuda.synchronize()
-        t = s.elapsed_time(e) / iters * 1e-3
-        fl = 4.0 * B * H * Sq * Sk * D * (0.5 if causal and Sq > 1 else 1.0)
-        print(name, f"{t*1e6:.1f} us", f"{fl/t/1e12:.1f} TFLOP/s", flush=True)
-
-
-def bench_relpos():
-    dev = torch.device("cuda:0")
-    for name, B, H, SH in (("relpos_global", 4, 16, 64), ("relpos_window", 100, 16, 14)):
-        q = torch.randn(B, H, SH * SH, 80, device=dev).to(torch.bfloat16)
-        th = torch.randn(2 * SH - 1, 80, device=dev).to(torch.bfloat16)
-        ops.relpos_bias(q, th, th, SH, SH)
-        torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(10):
-            ops.relpos_bias(q, th, th, SH, SH)
-        e.record()
-        torch.cuda.synchronize()
-        print(name, f"{s.elapsed_time(e) / 10 * 1e3:.1f} us", flush=True)
+        us = a.elapsed_time(b) * 1e3 / reps
+        flops = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
+        print(f"{name:14s} B={B:3d} H={H} S={S} D={D}: {us:8.1f} us  {flops / us * 1e-6:7.1f} TFLOP/s  max|err| {err:.3e}", flush=True)
 
 
 if __name__ == "__main__":
-    bench_relpos()
     main()
