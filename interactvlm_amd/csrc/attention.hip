@@ -39,6 +39,21 @@ constexpr int kQPerWave = 32, kWaves = 4, kQPerBlock = kQPerWave * kWaves, kKV =
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kNegBig = -1.0e30f;
 
+// max / sum over the four 16-lane groups (lanes l, l^16, l^32, l^48) with gfx950's row-swap permutes: no LDS round trip
+// (ds_bpermute costs ~100 cycles of latency per step, eight dependent steps per key tile)
+__device__ __forceinline__ float groups_max(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float groups_sum(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // REL: 0 no bias; 1 rel-pos folded into the QK^T MFMA (KH + KW <= 32: one extra k-step whose Q' operand is
 // [rel_h | rel_w] and whose K' operand is the one-hot (kh, KH + kw) code of the key: exact, no VALU);
 // 2 rel_kw == 64 == key-tile: rel_w is tile-invariant (held as packed bf16 in registers), rel_h is one
@@ -114,21 +129,28 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     }
 
     // ---- register staging of one K/V tile ------------------------------------------------------
-    u32x4_t kreg[CPT], vreg[CPT];
-    auto gload = [&](int t) __attribute__((always_inline)) {
+    // two register sets: the loads of tile t + 2 are issued while tile t is computed (HBM/L2 latency is longer than one
+    // tile of compute), tile t + 1 - loaded one step earlier - is written to the free LDS buffer at the end of the step
+    u32x4_t kregA[CPT], vregA[CPT], kregB[CPT], vregB[CPT];
+    int ld_key[CPT], ld_d[CPT];  // this thread's chunks of a tile: key inside the tile, element offset inside the row
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        int c = tid + i * 256;
+        c = c < NCH ? c : NCH - 1;  // unconditional (clamped) loads keep the staging registers in registers across the loop
+        ld_key[i] = c / DCH;
+        ld_d[i] = (c % DCH) * 8;
+    }
+    const int last_key = a.Sk - 1;
+    auto gload = [&](u32x4_t (&kreg)[CPT], u32x4_t (&vreg)[CPT], int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            // unconditional (clamped) loads keep kreg/vreg in registers across the loop
-            int c = tid + i * 256;
-            c = c < NCH ? c : NCH - 1;
-            int key = t * kKV + c / DCH;
-            key = key < a.Sk ? key : a.Sk - 1;
-            const int dch = c % DCH;
-            kreg[i] = *reinterpret_cast<const u32x4_t*>(K + (int64_t)key * a.k_rs + dch * 8);
-            vreg[i] = *reinterpret_cast<const u32x4_t*>(V + (int64_t)key * a.v_rs + dch * 8);
+            int key = t * kKV + ld_key[i];
+            key = key < last_key ? key : last_key;
+            kreg[i] = *reinterpret_cast<const u32x4_t*>(K + (int64_t)key * a.k_rs + ld_d[i]);
+            vreg[i] = *reinterpret_cast<const u32x4_t*>(V + (int64_t)key * a.v_rs + ld_d[i]);
         }
     };
-    auto lds_store = [&](int buf) __attribute__((always_inline)) {
+    auto lds_store = [&](const u32x4_t (&kreg)[CPT], const u32x4_t (&vreg)[CPT], int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = tid + i * 256;
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 
     // ---- rel-pos operands of this lane's two queries -------------------------------------------
     bf16x8_t qrel[2];       // REL 1: [rel_h(KH) | rel_w(KW) | 0] features g*8 .. g*8+7
-    uint32_t rwp[2][8];     // REL 2: rel_w[q][kt*16 + g*4 + r] as packed bf16 pairs
+    f32x4_t rwf[2][4];      // REL 2: rel_w[q][kt*16 + g*4 + r]: tile-invariant, SEEDS the score accumulators (no add later)
     const float* rhp[2] = {nullptr, nullptr};
     const float* rwg[2] = {nullptr, nullptr};  // REL 3
     if (REL != 0) {
@@ -174,19 +196,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
                     const float4 w4 = *reinterpret_cast<const float4*>(rw + kt * 16 + g * 4);
-                    rwp[qt][2 * kt] = pack_bf16x2(w4.x, w4.y);
-                    rwp[qt][2 * kt + 1] = pack_bf16x2(w4.z, w4.w);
+                    rwf[qt][kt] = f32x4_t{w4.x, w4.y, w4.z, w4.w};
                 }
             }
         }
     }
     const float sc2 = a.prescale_q ? kLog2e : a.scale * kLog2e;
 
-    gload(0);
-    lds_store(0);
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile = [&](const int t, u32x4_t (&kld)[CPT], u32x4_t (&vld)[CPT], const u32x4_t (&kst)[CPT],
+                    const u32x4_t (&vst)[CPT]) __attribute__((always_inline)) {
         __syncthreads();  // tile t is in buffer t & 1; every wave is done with tile t - 1 (the other buffer)
-        if (t + 1 < ntiles) gload(t + 1);
+        if (t + 2 < ntiles) gload(kld, vld, t + 2);
         const bf16_t* Kb = Ks[t & 1];
         const bf16_t* Vb = Vs[t & 1];
         int nkt = (a.Sk - t * kKV + 15) >> 4;  // 16-key sub-tiles that hold real keys (wave-uniform)
@@ -197,10 +217,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = REL == 2 ? rwf[qt][kt] : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (kt >= nkt) continue;  // keys past Sk: their scores are masked below
+            if (REL != 2 && kt >= nkt) continue;  // keys past Sk: their scores are masked below (REL 2: Sk % 64 == 0)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8_t kf =
@@ -235,9 +255,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         // causal diagonal) first overwrite their invalid raw scores with -1e30 in a pre-pass under one wave-uniform
         // branch; exp2 of those is exactly 0 because every query has a valid key in its first tile (key 0).
         const int kv0 = t * kKV;
-        bool edge = kv0 + kKV > a.Sk;
+        bool edge = REL != 2 && kv0 + kKV > a.Sk;  // (REL 2 is dispatched only when Sk is a whole number of tiles)
         if (CAUSAL) edge = edge || (kv0 + kKV - 1 > q0 + a.q_pos0);
         if (REL == 3 || edge) {
+            asm volatile("" ::: "memory");  // keep this a real branch (if-converted it costs 2 VALU per score on EVERY tile)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int qi = q0 + qt * 16 + l15;
@@ -268,24 +289,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = kNegBig;
+            // log2-domain score y = x * sc2 + bias2 (monotonic in x): the maximum is taken on the raw scores, and the
+            // subtraction of the running maximum rides in the same fma as the scaling: p = exp2(x * sc2 + (bias2 - m))
             float bias2 = 0.0f;
             if (REL == 2) bias2 = rhp[qt][t < a.rel_kh ? t : a.rel_kh - 1] * sc2;
+            float mx = kNegBig;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = s[qt][kt][r];
-                    if (REL == 2) {
-                        const uint32_t pw = rwp[qt][2 * kt + (r >> 1)];
-                        x += __uint_as_float((r & 1) ? (pw & 0xffff0000u) : (pw << 16));
-                    }
-                    x = __builtin_fmaf(x, sc2, bias2);
-                    s[qt][kt][r] = x;
-                    mx = fmaxf(mx, x);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
+            mx = __builtin_fmaf(groups_max(mx), sc2, bias2);
             const float m_new = fmaxf(m_run[qt], mx);
             if (__any(m_new > m_run[qt])) {  // wave-uniform: some query's running maximum moved
                 const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
@@ -299,18 +312,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
                 }
                 m_run[qt] = m_new;
             }
+            const float c2 = bias2 - m_new;
             float rs = 0.0f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[qt][kt][r] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][kt][r], sc2, c2));
                     s[qt][kt][r] = p;
                     rs += p;
                 }
-            rs += __shfl_xor(rs, 16, 64);
-            rs += __shfl_xor(rs, 32, 64);
-            l_run[qt] += rs;
+            l_run[qt] += groups_sum(rs);
         }
 
         // ---- P^T fragments straight from the score registers (key order permuted per 32-step) --
@@ -327,12 +339,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
                 pf[qt][s2] = *reinterpret_cast<bf16x8_t*>(&u);
             }
 
-        // ---- O^T += V^T . P^T -------------------------------------------------------------------
+        // ---- O^T += V^T . P^T  (key step outer: one uniform skip test per 32 keys, DT independent accumulators inner) ---
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (REL != 2 && 2 * s2 >= nkt) continue;  // all 32 keys of this step are past Sk (their P is 0)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                if (2 * s2 >= nkt) continue;  // all 32 keys of this step are past Sk (their P is 0)
+            for (int dt = 0; dt < DT; ++dt) {
                 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
                 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
                 const bf16_t* vp = Vb + dt * (kKV * 16) + (2 * s2) * 16 * 16 + voff;
@@ -346,7 +358,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
                     o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s2], o[qt][dt], 0, 0, 0);
             }
         }
-        if (t + 1 < ntiles) lds_store((t + 1) & 1);  // the other buffer: last read in iteration t - 1, before this barrier round
+        if (t + 1 < ntiles) lds_store(kst, vst, (t + 1) & 1);  // the other buffer: last read in step t - 1, before this barrier round
+    };
+    gload(kregA, vregA, 0);
+    if (ntiles > 1) gload(kregB, vregB, 1);
+    lds_store(kregA, vregA, 0);
+    for (int t = 0; t < ntiles; t += 2) {
+        tile(t, kregA, vregA, kregB, vregB);                           // loads tile t + 2 -> A, stores tile t + 1 <- B
+        if (t + 1 < ntiles) tile(t + 1, kregB, vregB, kregA, vregA);   // loads tile t + 3 -> B, stores tile t + 2 <- A
     }
 
     // ---- normalise and store: lane holds O[query l15][d = dt*16 + g*4 + r] ---------------------

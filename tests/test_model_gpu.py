@@ -473,8 +473,9 @@ def test_object_render_localize_lift_flow(hip_lib, cuda, tmp_path):
     assert pc.shape == (1, nv)
     pm = out["pred_masks"][0].float().cpu().numpy()
     exp, _ = cref.lift_mesh_thresh(pm, vid.cpu().numpy().astype(np.int32), bary.cpu().numpy(), nv)
-    np.testing.assert_allclose(pc, exp, atol=2e-6)
-    assert np.array_equal(pc > 0.3, exp > 0.3) or np.abs(pc - exp)[(pc > 0.3) != (exp > 0.3)].max() < 2e-6
+    # fp32 vote sums of up to a few thousand pixels per vertex, accumulated in a different order than the C oracle's
+    np.testing.assert_allclose(pc, exp, atol=5e-6)
+    assert np.array_equal(pc > 0.3, exp > 0.3) or np.abs(pc - exp)[(pc > 0.3) != (exp > 0.3)].max() < 5e-6
 
     # BASELINE.json configs[4], joint case: a human-contact prompt over the body renders AND an object prompt over the
     # object renders about ONE picture, in one call (one CLIP pass, both answers decoded together, one SAM encoder pass per
