@@ -163,6 +163,9 @@ int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, co
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float *rel_h,
                         const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q,
                         ivlm_stream_t stream);
+/* Benchmark/test hook: -1 (default) picks per shape; 0 forces the 4-wave / 128-query block, 1 the 8-wave ping-pong block
+ * (256 queries; one wave group on the matrix unit while the other does its softmax on the VALU). */
+int ivlm_attention_pingpong(int mode);
 
 /* add_decomposed_rel_pos operands (image_encoder.py:354-392), q_size == k_size == (SH,SW):
  *   rel_h[bh,q,kh] = q . rel_pos_h[qh-kh+SH-1],  rel_w[bh,q,kw] = q . rel_pos_w[qw-kw+SW-1]  (rounded to bf16

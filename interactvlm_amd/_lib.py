@@ -9,7 +9,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libivlm_hip.so")
+# (IVLM_LIB_PATH: load another build of the same library - kernel experiments; the default is the in-tree build)
+LIB_PATH = os.environ.get("IVLM_LIB_PATH") or os.path.join(_HERE, "libivlm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ivlm_hip.h")
 
 _lib = None

@@ -54,26 +54,45 @@ __device__ __forceinline__ float groups_sum(float x) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Block barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait at EVERY key tile for the
+// global loads of the next tiles that were issued precisely so that they stay in flight across the barrier.
+__device__ __forceinline__ void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // REL: 0 no bias; 1 rel-pos folded into the QK^T MFMA (KH + KW <= 32: one extra k-step whose Q' operand is
 // [rel_h | rel_w] and whose K' operand is the one-hot (kh, KH + kw) code of the key: exact, no VALU);
 // 2 rel_kw == 64 == key-tile: rel_w is tile-invariant (held as packed bf16 in registers), rel_h is one
 // value per (query, tile); 3 any other grid: per-score table lookups (slow, non-SAM-H sizes only).
-template <int DQK, int DV, bool CAUSAL, int REL>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
+// PP (ping-pong): 8 waves = two groups of four that share the K/V tiles of a 256-query block and run half a tile apart -
+// while one group issues its MFMAs (P.V of the previous tile, then Q.K^T of the next), the other does its softmax on the
+// VALU, and they swap at every barrier.  Waves w and w + 4 share a SIMD, so the matrix unit and the VALU are both busy
+// instead of both groups queueing for the same unit (without PP the two co-resident blocks drift into the same phase:
+// measured time = MFMA time + VALU time).
+template <int DQK, int DV, bool CAUSAL, int REL, bool PP>
+__global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnArgs a) {
+    constexpr int NT = PP ? 512 : 256;  // threads per block
+    constexpr int kQBlk = PP ? 2 * kQPerBlock : kQPerBlock;
     constexpr int KS = DQK / 32;        // MFMA k-steps over the head dim
     constexpr int DT = DV / 16;         // 16-wide output tiles over the head dim
     constexpr int DCH = DV / 8;         // 16-byte chunks per K/V row actually present in memory
     constexpr int NCH = kKV * DCH;      // chunks per K (or V) tile
-    constexpr int CPT = (NCH + 255) / 256;
-    constexpr int KBUF = KS * kKV * 32;  // elements: [ks][key][32]
-    constexpr int VBUF = DT * kKV * 16;  // elements: [dt][key][16]
+    constexpr int CPT = (NCH + NT - 1) / NT;
+    // plane strides carry one extra row: the staging stores (8 consecutive lanes of a ds_write_b128 = 8 consecutive 16-byte
+    // chunks of a key) then walk 8 distinct 16-byte bank slots instead of hitting one slot 2x (K) / 4x (V); the fragment
+    // reads of one plane are only rotated by it
+    constexpr int KPL = kKV * 32 + 32;   // elements per k-step plane  [key][32] (+ 64 B)
+    constexpr int VPL = kKV * 16 + 16;   // elements per d-tile plane  [key][16] (+ 32 B)
+    constexpr int KBUF = KS * KPL;
+    constexpr int VBUF = DT * VPL;
     __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KBUF];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[2][VBUF];
+    // REL 2: rel_h[query][key row] of the block's queries, one value per (query, key tile).  Read from global at its point of use it is a dependent load in every tile, and the s_waitcnt the
+    // compiler puts in front of it also drains the K/V prefetches of the following tiles.
+    __shared__ __attribute__((aligned(16))) float Rh[REL == 2 ? kQBlk * kKV : 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q_blk0 = blockIdx.x * kQPerBlock;
+    const int q_blk0 = blockIdx.x * kQBlk;
     const int q0 = q_blk0 + wave * kQPerWave;
     const int bkv = b / a.kv_batch_div;
     const bf16_t* __restrict__ Q = a.q + b * a.q_bs + h * a.q_hs;
@@ -83,11 +102,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     // ---- zero the pad chunks of K once (head dim < DQK), both buffers ------------------------------
     if (DCH < KS * 4) {
         constexpr int NPAD = KS * 4 - DCH;
-        for (int i = tid; i < 2 * kKV * NPAD; i += 256) {
+        for (int i = tid; i < 2 * kKV * NPAD; i += NT) {
             const int buf = i / (kKV * NPAD), r = i % (kKV * NPAD);
             const int key = r / NPAD, ch = DCH + r % NPAD;
             const int phys = (ch & 3) ^ (((key >> 3) & 1) << 1);
-            *reinterpret_cast<u32x4_t*>(&Ks[buf][(ch >> 2) * (kKV * 32) + key * 32 + phys * 8]) = u32x4_t{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4_t*>(&Ks[buf][(ch >> 2) * KPL + key * 32 + phys * 8]) = u32x4_t{0u, 0u, 0u, 0u};
+        }
+    }
+
+    if (REL == 2) {  // rel_kh == 64 key rows (dispatch); rows of queries past Sq are clamped like the Q loads
+        const int64_t bh = (int64_t)b * a.H + h;
+        for (int i = tid; i < kQBlk * (kKV / 4); i += NT) {
+            const int ql = i / (kKV / 4), c4 = i % (kKV / 4);
+            int qi = q_blk0 + ql;
+            qi = qi < a.Sq ? qi : a.Sq - 1;
+            const float4 v4 = *reinterpret_cast<const float4*>(a.rel_h + (bh * a.Sq + qi) * a.rel_kh + c4 * 4);
+            *reinterpret_cast<float4*>(&Rh[ql * kKV + c4 * 4]) = v4;
         }
     }
 
@@ -121,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 
     int ntiles = (a.Sk + kKV - 1) / kKV;
     if (CAUSAL) {
-        int last_q = q_blk0 + kQPerBlock - 1;
+        int last_q = q_blk0 + kQBlk - 1;
         last_q = last_q < a.Sq ? last_q : a.Sq - 1;
         const int last_key = last_q + a.q_pos0;  // inclusive
         const int lim = last_key / kKV + 1;
@@ -129,36 +159,49 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     }
 
     // ---- register staging of one K/V tile ------------------------------------------------------
-    // two register sets: the loads of tile t + 2 are issued while tile t is computed (HBM/L2 latency is longer than one
-    // tile of compute), tile t + 1 - loaded one step earlier - is written to the free LDS buffer at the end of the step
-    u32x4_t kregA[CPT], vregA[CPT], kregB[CPT], vregB[CPT];
     int ld_key[CPT], ld_d[CPT];  // this thread's chunks of a tile: key inside the tile, element offset inside the row
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-        int c = tid + i * 256;
+        int c = tid + i * NT;
         c = c < NCH ? c : NCH - 1;  // unconditional (clamped) loads keep the staging registers in registers across the loop
         ld_key[i] = c / DCH;
         ld_d[i] = (c % DCH) * 8;
     }
     const int last_key = a.Sk - 1;
-    auto gload = [&](u32x4_t (&kreg)[CPT], u32x4_t (&vreg)[CPT], int t) __attribute__((always_inline)) {
+    auto gload_k = [&](u32x4_t (&kreg)[CPT], int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             int key = t * kKV + ld_key[i];
             key = key < last_key ? key : last_key;
             kreg[i] = *reinterpret_cast<const u32x4_t*>(K + (int64_t)key * a.k_rs + ld_d[i]);
+        }
+    };
+    auto gload_v = [&](u32x4_t (&vreg)[CPT], int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            int key = t * kKV + ld_key[i];
+            key = key < last_key ? key : last_key;
             vreg[i] = *reinterpret_cast<const u32x4_t*>(V + (int64_t)key * a.v_rs + ld_d[i]);
         }
     };
-    auto lds_store = [&](const u32x4_t (&kreg)[CPT], const u32x4_t (&vreg)[CPT], int buf) __attribute__((always_inline)) {
+    auto store_k = [&](const u32x4_t (&kreg)[CPT], int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NT;
             if (c < NCH) {
                 const int key = c / DCH, dch = c % DCH;
                 const int phys = (dch & 3) ^ (((key >> 3) & 1) << 1);
-                *reinterpret_cast<u32x4_t*>(&Ks[buf][(dch >> 2) * (kKV * 32) + key * 32 + phys * 8]) = kreg[i];
-                *reinterpret_cast<u32x4_t*>(&Vs[buf][(dch >> 1) * (kKV * 16) + key * 16 + (dch & 1) * 8]) = vreg[i];
+                *reinterpret_cast<u32x4_t*>(&Ks[buf][(dch >> 2) * KPL + key * 32 + phys * 8]) = kreg[i];
+            }
+        }
+    };
+    auto store_v = [&](const u32x4_t (&vreg)[CPT], int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * NT;
+            if (c < NCH) {
+                const int key = c / DCH, dch = c % DCH;
+                *reinterpret_cast<u32x4_t*>(&Vs[buf][(dch >> 1) * VPL + key * 16 + (dch & 1) * 8]) = vreg[i];
             }
         }
     };
@@ -203,17 +246,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     }
     const float sc2 = a.prescale_q ? kLog2e : a.scale * kLog2e;
 
-    auto tile = [&](const int t, u32x4_t (&kld)[CPT], u32x4_t (&vld)[CPT], const u32x4_t (&kst)[CPT],
-                    const u32x4_t (&vst)[CPT]) __attribute__((always_inline)) {
-        __syncthreads();  // tile t is in buffer t & 1; every wave is done with tile t - 1 (the other buffer)
-        if (t + 2 < ntiles) gload(kld, vld, t + 2);
-        const bf16_t* Kb = Ks[t & 1];
-        const bf16_t* Vb = Vs[t & 1];
+    // ---- the three phases of a key tile (state: s = scores then probabilities, pf = packed P^T fragments) ------------
+    f32x4_t s[2][4];
+    bf16x8_t pf[2][2];
+    auto nkt_of = [&](int t) __attribute__((always_inline)) {
         int nkt = (a.Sk - t * kKV + 15) >> 4;  // 16-key sub-tiles that hold real keys (wave-uniform)
-        nkt = nkt < 4 ? nkt : 4;
-
+        return nkt < 4 ? nkt : 4;
+    };
+    auto phase_qk = [&](const int t) __attribute__((always_inline)) {
+        const bf16_t* Kb = Ks[t & 1];
+        const int nkt = nkt_of(t);
         // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query l15 ------------------
-        f32x4_t s[2][4];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -224,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8_t kf =
-                    *reinterpret_cast<const bf16x8_t*>(&Kb[ks * (kKV * 32) + (kt * 16 + l15) * 32 + kswz]);
+                    *reinterpret_cast<const bf16x8_t*>(&Kb[ks * KPL + (kt * 16 + l15) * 32 + kswz]);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
@@ -248,6 +291,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
             }
         }
 
+    };
+    auto phase_softmax = [&](const int t) __attribute__((always_inline)) {
         // ---- scale, bias, mask, online softmax (log2 domain) -----------------------------------
         // The softmax, not the MFMAs, bounds this kernel (32 scores per lane per tile on the VALU): ~8 VALU slots per score
         // (bias add, one fma into the log2 domain, max, subtract, raw v_exp_f32, sum; bf16 packing by v_cvt_pk_bf16_f32
@@ -292,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
             // log2-domain score y = x * sc2 + bias2 (monotonic in x): the maximum is taken on the raw scores, and the
             // subtraction of the running maximum rides in the same fma as the scaling: p = exp2(x * sc2 + (bias2 - m))
             float bias2 = 0.0f;
-            if (REL == 2) bias2 = rhp[qt][t < a.rel_kh ? t : a.rel_kh - 1] * sc2;
+            if (REL == 2) bias2 = Rh[(wave * kQPerWave + qt * 16 + l15) * kKV + t] * sc2;
             float mx = kNegBig;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -326,7 +371,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         }
 
         // ---- P^T fragments straight from the score registers (key order permuted per 32-step) --
-        bf16x8_t pf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -339,6 +383,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
                 pf[qt][s2] = *reinterpret_cast<bf16x8_t*>(&u);
             }
 
+    };
+    auto phase_pv = [&](const int t) __attribute__((always_inline)) {
+        const bf16_t* Vb = Vs[t & 1];
+        const int nkt = nkt_of(t);
         // ---- O^T += V^T . P^T  (key step outer: one uniform skip test per 32 keys, DT independent accumulators inner) ---
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -347,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
             for (int dt = 0; dt < DT; ++dt) {
                 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
                 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
-                const bf16_t* vp = Vb + dt * (kKV * 16) + (2 * s2) * 16 * 16 + voff;
+                const bf16_t* vp = Vb + dt * VPL + (2 * s2) * 16 * 16 + voff;
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vp));
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vp + 16 * 16));
                 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -358,14 +406,69 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
                     o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s2], o[qt][dt], 0, 0, 0);
             }
         }
-        if (t + 1 < ntiles) lds_store(kst, vst, (t + 1) & 1);  // the other buffer: last read in step t - 1, before this barrier round
     };
-    gload(kregA, vregA, 0);
-    if (ntiles > 1) gload(kregB, vregB, 1);
-    lds_store(kregA, vregA, 0);
-    for (int t = 0; t < ntiles; t += 2) {
-        tile(t, kregA, vregA, kregB, vregB);                           // loads tile t + 2 -> A, stores tile t + 1 <- B
-        if (t + 1 < ntiles) tile(t + 1, kregB, vregB, kregA, vregA);   // loads tile t + 3 -> B, stores tile t + 2 <- A
+
+    if (!PP) {
+        // two register sets: the loads of tile t + 2 are issued while tile t is computed, tile t + 1 - loaded one step
+        // earlier - is written to the free LDS buffer at the end of the step; one barrier per tile
+        u32x4_t kregA[CPT], vregA[CPT], kregB[CPT], vregB[CPT];
+        auto tile = [&](const int t, u32x4_t (&kld)[CPT], u32x4_t (&vld)[CPT], const u32x4_t (&kst)[CPT],
+                        const u32x4_t (&vst)[CPT]) __attribute__((always_inline)) {
+            sync_lds();  // tile t is in buffer t & 1; every wave is done with tile t - 1 (the other buffer)
+            if (t + 2 < ntiles) {
+                gload_k(kld, t + 2);
+                gload_v(vld, t + 2);
+            }
+            phase_qk(t);
+            phase_softmax(t);
+            phase_pv(t);
+            if (t + 1 < ntiles) {  // the other buffer: last read in step t - 1, before this barrier round
+                store_k(kst, (t + 1) & 1);
+                store_v(vst, (t + 1) & 1);
+            }
+        };
+        gload_k(kregA, 0);
+        gload_v(vregA, 0);
+        if (ntiles > 1) {
+            gload_k(kregB, 1);
+            gload_v(vregB, 1);
+        }
+        store_k(kregA, 0);
+        store_v(vregA, 0);
+        for (int t = 0; t < ntiles; t += 2) {
+            tile(t, kregA, vregA, kregB, vregB);                           // loads tile t + 2 -> A, stores tile t + 1 <- B
+            if (t + 1 < ntiles) tile(t + 1, kregB, vregB, kregA, vregA);   // loads tile t + 3 -> B, stores tile t + 2 <- A
+        }
+    } else {
+        // Ping-pong.  Per wave the order is M(0) X(0) M(1) X(1) ... M(n) with M(t) = P.V(t-1) then Q.K^T(t) [matrix unit] and
+        // X(t) = softmax(t) [VALU]; group 1 runs one barrier interval behind group 0.  Interval 2t: group 0 in M(t), group 1
+        // in X(t-1); interval 2t+1: group 0 in X(t), group 1 in M(t).  Both intervals of a pair read K(t) and V(t-1), so
+        // K(t+1) and V(t) are loaded at the start of interval 2t and written to the other buffers at the end of interval
+        // 2t+1 (their previous contents, K(t-1) / V(t-2), were last read in interval 2t-1).
+        const int grp = wave >> 2;
+        u32x4_t kreg[CPT], vreg[CPT];
+        gload_k(kreg, 0);
+        store_k(kreg, 0);
+        for (int t = 0; t <= ntiles; ++t) {
+            sync_lds();  // ---- interval 2t
+            if (t + 1 < ntiles) gload_k(kreg, t + 1);
+            if (t < ntiles) gload_v(vreg, t);
+            if (grp == 0) {
+                if (t > 0) phase_pv(t - 1);
+                if (t < ntiles) phase_qk(t);
+            } else if (t > 0) {
+                phase_softmax(t - 1);
+            }
+            sync_lds();  // ---- interval 2t + 1
+            if (grp == 0) {
+                if (t < ntiles) phase_softmax(t);
+            } else {
+                if (t > 0) phase_pv(t - 1);
+                if (t < ntiles) phase_qk(t);
+            }
+            if (t + 1 < ntiles) store_k(kreg, (t + 1) & 1);
+            if (t < ntiles) store_v(vreg, t & 1);
+        }
     }
 
     // ---- normalise and store: lane holds O[query l15][d = dt*16 + g*4 + r] ---------------------
@@ -384,26 +487,39 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     }
 }
 
-template <int DQK, int DV>
-int launch_d(const AttnArgs& a, hipStream_t st) {
-    dim3 grid((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B);
+static int g_attn_pp = -1;  // -1 automatic; 0 / 1 force the 4-wave / 8-wave ping-pong kernel (benchmark hook)
+void attn_set_pingpong(int mode) { g_attn_pp = mode; }
+
+template <int DQK, int DV, bool PP>
+int launch_dp(const AttnArgs& a, hipStream_t st) {
+    constexpr int NT = PP ? 512 : 256, QB = PP ? 2 * kQPerBlock : kQPerBlock;
+    dim3 grid((a.Sq + QB - 1) / QB, a.H, a.B);
     const bool rel = a.rel_h != nullptr;
     if (a.causal) {
         if (rel) return IVLM_ERR_UNSUPPORTED;
-        attn_kernel<DQK, DV, true, 0><<<grid, 256, 0, st>>>(a);
+        attn_kernel<DQK, DV, true, 0, PP><<<grid, NT, 0, st>>>(a);
     } else if (rel) {
         if (DV != 80) return IVLM_ERR_UNSUPPORTED;  // only SAM's ViT uses rel-pos; keeps the build small
         if (!a.prescale_q) return IVLM_ERR_UNSUPPORTED;
         if (a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw)
-            attn_kernel<DQK, DV, false, DV == 80 ? 2 : 0><<<grid, 256, 0, st>>>(a);
+            attn_kernel<DQK, DV, false, DV == 80 ? 2 : 0, PP><<<grid, NT, 0, st>>>(a);
         else if (a.rel_kh + a.rel_kw <= 32)
-            attn_kernel<DQK, DV, false, DV == 80 ? 1 : 0><<<grid, 256, 0, st>>>(a);
+            attn_kernel<DQK, DV, false, DV == 80 ? 1 : 0, PP><<<grid, NT, 0, st>>>(a);
         else
-            attn_kernel<DQK, DV, false, DV == 80 ? 3 : 0><<<grid, 256, 0, st>>>(a);
+            attn_kernel<DQK, DV, false, DV == 80 ? 3 : 0, false><<<dim3((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B), 256, 0, st>>>(a);
     } else {
-        attn_kernel<DQK, DV, false, 0><<<grid, 256, 0, st>>>(a);
+        attn_kernel<DQK, DV, false, 0, PP><<<grid, NT, 0, st>>>(a);
     }
     return ivlm_launch_status();
+}
+
+template <int DQK, int DV>
+int launch_d(const AttnArgs& a, hipStream_t st) {
+    // the 8-wave ping-pong block (256 queries) is opt-in: measured 5-15 % SLOWER than two independent 4-wave blocks per CU on
+    // every shape of the path (SAM global 634 vs 604 us, windows 151 vs 132 us) - the loop is bound by the issue latency of
+    // the dependent softmax chain, not by the two waves of a SIMD contending for the same unit
+    const bool pp = g_attn_pp > 0;
+    return pp ? launch_dp<DQK, DV, true>(a, st) : launch_dp<DQK, DV, false>(a, st);
 }
 
 // rel_h[bh,q,kh] = q_vec . rel_pos_h[qh - kh + KH - 1],  rel_w[bh,q,kw] = q_vec . rel_pos_w[qw - kw + KW - 1]
@@ -565,6 +681,11 @@ int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
 }  // namespace ivlm
 
 extern "C" {
+
+int ivlm_attention_pingpong(int mode) {  // benchmark/test hook: -1 automatic, 0 four-wave kernel, 1 eight-wave ping-pong
+    ivlm::attn_set_pingpong(mode);
+    return 0;
+}
 
 int ivlm_attention_bf16(const void* q, const void* k, const void* v, void* o, const int64_t* strides /*[12]*/, int B,
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float* rel_h,

@@ -7,6 +7,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["4-wave", "ping-pong"])
+def attn_block_shape(request, hip_lib):
+    """Every case runs through both block shapes: 4 waves / 128 queries, and the 8-wave ping-pong block (256 queries, the
+    two wave groups half a tile apart: edge tiles, causal diagonals and the drain of the trailing group differ)."""
+    from interactvlm_amd import _lib
+
+    lib = _lib.load()
+    lib.ivlm_attention_pingpong(0 if request.param == "4-wave" else 1)
+    yield request.param
+    lib.ivlm_attention_pingpong(-1)
+
+
 def _ref(q, k, v, scale, causal=False, q_pos0=0, bias=None):
     import torch
 

@@ -44,20 +44,30 @@ def main():
         nb = min(B, 2)
         r = ref_attn(q[:nb], k[:nb], v[:nb], scale, causal, None if rel is None else (rel[0][: nb * H], rel[1][: nb * H]), side)
         err = float((o[:nb].float() - r).abs().max())
-        for _ in range(3):
-            ops.attention(q, k, v, scale, causal=causal, rel=rel)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        a.record()
-        for _ in range(reps):
-            ops.attention(q, k, v, scale, causal=causal, rel=rel)
-        b.record()
-        torch.cuda.synchronize()
-        us = a.elapsed_time(b) * 1e3 / reps
         flops = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
-        print(f"{name:14s} B={B:3d} H={H} S={S} D={D}: {us:8.1f} us  {flops / us * 1e-6:7.1f} TFLOP/s  max|err| {err:.3e}", flush=True)
-
+        row = [f"{name:14s} B={B:3d} H={H} S={S} D={D}: max|err| {err:.3e}"]
+        from interactvlm_amd import _lib
+        lib = _lib.load()
+        for mode, label in ((0, "4-wave"), (1, "ping-pong")):
+            lib.ivlm_attention_pingpong(mode)
+            try:
+                o2 = ops.attention(q, k, v, scale, causal=causal, rel=rel)
+                e2 = float((o2[:nb].float() - r).abs().max())
+                for _ in range(3):
+                    ops.attention(q, k, v, scale, causal=causal, rel=rel)
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 20
+                a.record()
+                for _ in range(reps):
+                    ops.attention(q, k, v, scale, causal=causal, rel=rel)
+                b.record()
+                torch.cuda.synchronize()
+                us = a.elapsed_time(b) * 1e3 / reps
+                row.append(f"{label}: {us:8.1f} us {flops / us * 1e-6:7.1f} TFLOP/s (err {e2:.1e})")
+            finally:
+                lib.ivlm_attention_pingpong(-1)
+        print("  ".join(row), flush=True)
 
 if __name__ == "__main__":
     main()
