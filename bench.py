@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the cached-SAM and batch-8 variant legs (profiling runs)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -217,7 +218,7 @@ def main():
 
     # ---- variant (reported separately, never the headline): SAM embeddings of the 4 canonical body renders cached
     cached = None
-    if not args.no_roofline:
+    if not args.no_roofline and not args.no_variants:
         emb = model.precompute_visual_embs(images[0])
 
         def step_cached():
@@ -238,7 +239,7 @@ def main():
     # ---- variant (reported separately, never the headline): BASELINE.json configs[2]'s per-GPU share, 8 images per call.
     # One decode step streams the LLaMA weights once for all 8 sequences; the 8 x 4 SAM views run on the side stream.
     batch8 = None
-    if not args.no_roofline and world == 1:
+    if not args.no_roofline and not args.no_variants and world == 1:
         Bv = 8
         icb, imb = synthetic.images(cfg, dev, seed=100 + rank, batch=Bv)
         prompts = [ids[0]] * Bv
