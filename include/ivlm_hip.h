@@ -314,6 +314,15 @@ int ivlm_rasterize_mesh(const float *verts, int nv, const int32_t *faces, int nf
 /* pts f32 [Np,3], disc radius in NDC units -> map i32 [H,W] = index of the nearest covering point, -1 none */
 int ivlm_rasterize_points(const float *pts, int np, const float *cam12_host, float fov_deg, float radius, int H,
                           int W, int32_t *map, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* Hard Phong shading of a rasterised mesh = the colour renders fed to SAM for object meshes (utils/demo_utils.py:146-168:
+ * MeshRenderer + HardPhongShader + one PointLights over TexturesVertex colours; same in render_mesh_utils.py:177-198).
+ * p2v i32 [npix,3] / bary f32 [npix,3] from ivlm_rasterize_mesh; verts / normals / colors f32 [Nv,3] (world space, unit
+ * vertex normals, vertex colours); light3 / cam3 / bg3: HOST pointers to 3 floats (light location, camera centre, background
+ * colour); ambient / diffuse / specular: the light's grey levels (0.5 / 0.3 / 0.2 in the reference), shininess 64.
+ * out_rgb u8 [npix,3] = trunc(colour * 255). */
+int ivlm_phong_shade(const int32_t *p2v, const float *bary, const float *verts, const float *normals, const float *colors,
+                     int npix, const float *light3_host, const float *cam3_host, float ambient, float diffuse,
+                     float specular, float shininess, const float *bg3_host, uint8_t *out_rgb, ivlm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,11 @@ int rasterize_mesh(const float* verts, int nv, const int32_t* faces, int nf, con
 int rasterize_points(const float* pts, int np, const float* cam12_host, float fov_deg, float radius, int H, int W,
                      int32_t* map, void* ws, size_t ws_bytes, hipStream_t st);
 
+// ---- shaded colour renders (shade.hip) --------------------------------------------------------------
+int phong_shade(const int32_t* p2v, const float* bary, const float* verts, const float* normals, const float* colors, int npix,
+                const float* light3_host, const float* cam3_host, float ambient, float diffuse, float specular, float shininess,
+                const float* bg3_host, uint8_t* out, hipStream_t st);
+
 // ---- single-token decode (decode.hip) ---------------------------------------------------------------
 int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
                       float scale, hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr, const int32_t* pos_dev = nullptr);

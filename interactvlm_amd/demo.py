@@ -55,6 +55,20 @@ def cam_params_for(contact_type: str, view_type: str) -> torch.Tensor:
 
 
 @torch.no_grad()
+def generate_sam_inp_objs(verts, faces, out_dir: str, view_type: str = "4MV-Z_HM_BM", colored: bool = True,
+                          image_size=(1024, 1024)):
+    """generate_sam_inp_objs (utils/demo_utils.py:171-257) on the GPU: normalise the object mesh, rasterise + Phong-shade
+    the four object views, write ``lift2d_dict.pkl`` (the file ObjectMeshContact3DPredictor reads) into ``out_dir``.
+    verts f32 [Nv,3] / faces i32 [Nf,3] GPU tensors -> (sam_views: 4 uint8 [H,W,3] arrays, lift2d_dict_path)."""
+    from . import render
+
+    imgs, vid, bary, nv = render.object_renders(verts, faces, view_type, colored=colored, image_size=image_size)
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "lift2d_dict.pkl")
+    render.save_lift2d_dict(path, vid, bary, nv)
+    return [im.cpu().numpy() for im in imgs], path
+
+
 def run_sample(model, image_rgb: np.ndarray, sam_views: Sequence[np.ndarray], input_ids: torch.Tensor, contact_type="hcontact",
                out_dir: Optional[str] = None, name: str = "sample", lift2d_dict_path: Optional[str] = None,
                smpl_to_smplx: Optional[ops.SparseRows] = None, max_new_tokens: int = 512, forced_new_tokens=None,

@@ -3,7 +3,8 @@
 Mirrors utils/demo_utils.py:128-257 (normalize_mesh, 4 cameras, rasterise -> lift2d_dict) and
 preprocess_data/render_mesh_utils.py:115-174 / utils_obj_pc.py:28-113, with the pytorch3d rasteriser replaced by
 ``ivlm_rasterize_mesh`` / ``ivlm_rasterize_points``.  Camera matrices are 12 floats of host math.
-(Phong-shaded colour renders of demo_utils.py are visualisation inputs and are not produced here.)
+The Phong-shaded colour renders that demo_utils.py feeds to SAM for object meshes are produced by ``object_renders``
+(``ivlm_phong_shade`` on the rasteriser's own outputs).
 """
 from __future__ import annotations
 
@@ -114,3 +115,64 @@ def save_lift2d_dict(path, vid, bary, num_vertices):
 
     joblib.dump({"pixel_to_vertices_map": [v.cpu().numpy().astype(np.int64) for v in vid],
                  "bary_coords_map": [b.cpu().numpy() for b in bary], "num_vertices": int(num_vertices)}, path)
+
+
+# ---- shaded colour renders (the SAM inputs of the object path) ------------------------------------------------------------
+LIGHT_LOCATIONS = [[0, 0, 3], [0, 0, 3], [0, 0, -3], [0, 0, -3]]  # utils/demo_utils.py:23, one per object view
+YELLOW_VERTEX_COLOR = [1.00, 0.90, 0.30]                          # utils/demo_utils.py:25 ('grey' renders)
+
+
+def vertex_normals(verts, faces):
+    """pytorch3d Meshes.verts_normals_packed: face cross products accumulated on their vertices, normalised (eps 1e-6)."""
+    f = faces.long()
+    v0, v1, v2 = verts[f[:, 0]], verts[f[:, 1]], verts[f[:, 2]]
+    fn = torch.cross(v1 - v0, v2 - v0, dim=1)
+    vn = torch.zeros_like(verts)
+    for k in range(3):
+        vn.index_add_(0, f[:, k], fn)
+    return (vn / vn.norm(dim=1, keepdim=True).clamp_min(1e-6)).contiguous()
+
+
+def shade_mesh(verts, faces, colors, cam_params, light_location, image_size=(1024, 1024), fov_deg=60.0, normals=None,
+               raster=None, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, background=(1.0, 1.0, 1.0)):
+    """render_mesh (utils/demo_utils.py:146-168): HardPhongShader with one point light over vertex colours.
+    verts f32 [Nv,3], faces i32 [Nf,3], colors f32 [Nv,3] on the GPU -> uint8 [H,W,3] RGB on the GPU.
+    raster = (p2v, bary) of the same camera re-uses an existing rasterisation."""
+    lib = _lib.load()
+    verts = verts.float().contiguous()
+    H, W = image_size
+    p2v, bary = raster if raster is not None else rasterize_mesh(verts, faces, cam_params, image_size, fov_deg)
+    normals = vertex_normals(verts, faces) if normals is None else normals
+    colors = colors.to(device=verts.device, dtype=torch.float32).contiguous()
+    R, T = look_at_view_transform(*cam_params)
+    cam = (-(T @ R.T)).astype(F)
+    f3 = lambda x: (ctypes.c_float * 3)(*[float(t) for t in x])
+    out = torch.empty(H, W, 3, dtype=torch.uint8, device=verts.device)
+    check(lib.ivlm_phong_shade(p2v.data_ptr(), bary.data_ptr(), verts.data_ptr(), normals.data_ptr(), colors.data_ptr(),
+                               H * W, f3(light_location), f3(cam), float(ambient), float(diffuse), float(specular),
+                               float(shininess), f3(background), out.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream), "phong_shade")
+    return out
+
+
+def object_renders(verts, faces, view_type="4MV-Z_HM_BM", colored=True, image_size=(1024, 1024)):
+    """generate_sam_inp_objs (utils/demo_utils.py:171-257), all of it: normalise the mesh, colour it (xyz position colours
+    for the 'color' renders, flat yellow for the 'grey' ones, both * 0.8 + 0.1), and for each of the four object cameras
+    rasterise once and shade -> (renders uint8 [4,H,W,3], vid i32 [4,H,W,3], bary f32 [4,H,W,3], num_vertices)."""
+    cams = OBJS_VIEW_DICT[view_type].get("mesh_cam_params") or OBJS_VIEW_DICT[view_type]["cam_params"]
+    v = normalize_mesh(verts.float()).contiguous()
+    if colored:
+        lo, hi = v.min(0).values, v.max(0).values
+        col = (v - lo) / (hi - lo)
+    else:
+        col = torch.tensor(YELLOW_VERTEX_COLOR, device=v.device).expand(v.shape[0], 3)
+    col = (col * 0.8 + 0.1).contiguous()
+    vn = vertex_normals(v, faces)
+    imgs, vids, barys = [], [], []
+    for i, name in enumerate(cams):
+        p2v, bary = rasterize_mesh(v, faces, cams[name], image_size)
+        imgs.append(shade_mesh(v, faces, col, cams[name], LIGHT_LOCATIONS[i % len(LIGHT_LOCATIONS)], image_size, normals=vn,
+                               raster=(p2v, bary)))
+        vids.append(p2v)
+        barys.append(bary)
+    return torch.stack(imgs), torch.stack(vids), torch.stack(barys), int(verts.shape[0])

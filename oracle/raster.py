@@ -145,3 +145,48 @@ def icosphere(subdiv=3):
             nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
         f = nf
     return np.array(v, dtype=F), np.array(f, dtype=np.int32)
+
+
+# ---- shaded renders (utils/demo_utils.py:146-168, 196-216: HardPhongShader + PointLights + TexturesVertex) -------------
+# Restates pytorch3d's published shading path: Meshes.verts_normals_packed (face cross products accumulated on the three
+# vertices, F.normalize eps 1e-6), interpolate_face_attributes with the rasteriser's barycentrics, lighting.PointLights
+# .diffuse / .specular, shading.phong_shading, blending.hard_rgb_blend (white background).  Parity unpinned (see header).
+def camera_center(R, T):
+    """World position of the camera of X_view = X_world @ R + T."""
+    return (-(T.astype(F) @ R.T.astype(F))).astype(F)
+
+
+def vertex_normals(verts, faces):
+    v = verts.astype(F)
+    f = np.asarray(faces, dtype=np.int64)
+    fn = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]).astype(F)
+    vn = np.zeros_like(v)
+    for k in range(3):
+        np.add.at(vn, f[:, k], fn)
+    return (vn / np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), F(1e-6))).astype(F)
+
+
+def _unit(x):
+    return x / np.maximum(np.linalg.norm(x, axis=-1, keepdims=True), F(1e-6))
+
+
+def phong_shade(p2v, bary, verts, normals, colors, light, cam, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0,
+                bg=(1.0, 1.0, 1.0)):
+    """p2v int [H,W,3] (-1 background), bary f32 [H,W,3] -> uint8 [H,W,3] = (image * 255).astype(uint8)."""
+    ids = np.asarray(p2v, dtype=np.int64)
+    fg = ids[..., 0] >= 0
+    idc = np.where(fg[..., None], ids, 0)
+    b = bary.astype(F)[..., None]
+    n = (b * normals.astype(F)[idc]).sum(-2)
+    q = (b * verts.astype(F)[idc]).sum(-2)
+    t = (b * colors.astype(F)[idc]).sum(-2)
+    n = _unit(n)
+    l = _unit(np.asarray(light, F) - q)
+    v = _unit(np.asarray(cam, F) - q)
+    cosang = (n * l).sum(-1)
+    refl = -l + F(2.0) * cosang[..., None] * n
+    alpha = np.maximum((v * refl).sum(-1), 0) * (cosang > 0)
+    spec = F(specular) * np.power(alpha.astype(F), F(shininess))
+    col = (F(ambient) + F(diffuse) * np.maximum(cosang, 0))[..., None] * t + spec[..., None]
+    img = np.where(fg[..., None], col, np.asarray(bg, F)).astype(F)
+    return (np.clip(img * F(255.0), 0, 255)).astype(np.uint8)

@@ -66,3 +66,33 @@ def test_run_sample_writes_reference_outputs(hip_lib, cuda, tmp_path):
     assert np.array_equal(z["pred_contact_3d_smplh"], pc.numpy())
     np.testing.assert_allclose(z["pred_contact_3d_smplx"], (mapping @ pc[0]).numpy(), atol=1e-5)
     assert out["pred_masks"][0].shape == (4, 1024, 1024)
+
+
+@pytest.mark.gpu
+def test_object_sample_from_a_mesh_end_to_end(hip_lib, cuda, tmp_path):
+    """run_demo's object branch from nothing but a mesh (utils/demo_utils.py:171-257 then run_demo.py:325-392): normalise,
+    rasterise and Phong-shade the four object views on the GPU, write lift2d_dict.pkl, run evaluate('ocontact') on the
+    renders and write ``*_oafford_vertices.npz`` - one contact value per mesh vertex."""
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth, synthetic
+    from interactvlm_amd import weights as Wt
+    from oracle import raster as R
+
+    v, f = R.icosphere(3)
+    v = (v * np.array([1.0, 0.5, 0.7], np.float32)).astype(np.float32)
+    vt, ft = torch.from_numpy(v).to(cuda), torch.from_numpy(f.astype(np.int32)).to(cuda)
+    views, path = demo.generate_sam_inp_objs(vt, ft, str(tmp_path / "sam_inp_objs"))
+    assert len(views) == 4 and views[0].shape == (1024, 1024, 3) and views[0].dtype == np.uint8 and os.path.exists(path)
+    assert (views[0][0, 0] == 255).all() and len(np.unique(views[0].reshape(-1, 3), axis=0)) > 50  # white bg, shaded object
+    cfg = synthetic.config_tiny()
+    cfg.oC_loss_weight, cfg.oC_sam_view_type = 1.0, "4MV-Z_HM_BM"
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    photo = np.random.default_rng(1).integers(0, 256, size=(600, 400, 3), dtype=np.uint8)
+    ids, forced = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=6)
+    out = demo.run_sample(m, photo, views, ids[0], "ocontact", out_dir=str(tmp_path), name="mug__img", lift2d_dict_path=path,
+                          forced_new_tokens=forced)
+    z = np.load(os.path.join(tmp_path, "mug__img_oafford_vertices.npz"))
+    assert z["pred_contact_3d"].shape == (1, v.shape[0]) and np.isfinite(z["pred_contact_3d"]).all()
+    assert np.array_equal(z["pred_contact_3d"], out["pred_contact_3d"].float().cpu().numpy())

@@ -88,3 +88,67 @@ def test_gpu_point_raster_and_tables_feed_the_lift(hip_lib, cuda):
     seen = nv > 0
     assert seen.float().mean() > 0.8  # four views see most of a sphere
     assert torch.allclose(out[seen], torch.full_like(out[seen], 1 / (1 + np.exp(-1.5))), atol=1e-5)
+
+
+def test_oracle_phong_shading_properties():
+    """CPU: the restated HardPhongShader on a sphere lit from the camera side - white background, ambient floor on every
+    covered pixel, brightest where the normal points at the light, specular highlight confined to a small spot."""
+    v, f = R.icosphere(3)
+    v = (v * 0.5).astype(np.float32)
+    Rm, T = R.look_at_view_transform(1.5, 0.0, 0.0)
+    p2v, bary, p2f = R.rasterize_mesh(v, f, Rm, T, 64, 64)
+    vn = R.vertex_normals(v, f)
+    assert np.allclose(vn, v / np.linalg.norm(v, axis=1, keepdims=True), atol=2e-2)  # sphere: normal = radial direction
+    col = np.full_like(v, 0.5)
+    img = R.phong_shade(p2v, bary, v, vn, col, light=[0, 0, 3], cam=R.camera_center(Rm, T))
+    hit = p2f >= 0
+    assert img.dtype == np.uint8 and (img[~hit] == 255).all()
+    lum = img[..., 0].astype(int)
+    assert lum[hit].min() >= int(0.5 * 0.5 * 255) - 1                # ambient 0.5 * texel 0.5
+    cy, cx = np.unravel_index(np.argmax(np.where(hit, lum, 0)), lum.shape)
+    assert abs(cy - 31.5) < 3 and abs(cx - 31.5) < 3                  # brightest at the centre (normal -> light & camera)
+    assert lum[hit].max() >= int(((0.5 + 0.3) * 0.5 + 0.2) * 255) - 12  # ambient + diffuse + most of the specular lobe
+    rim = hit & (np.hypot(*np.meshgrid(np.arange(64) - 31.5, np.arange(64) - 31.5)) > 0.8 * np.sqrt(hit.sum() / np.pi))
+    assert lum[rim].max() < int(((0.5 + 0.3 * 0.75) * 0.5) * 255) + 4   # no specular, reduced diffuse near the rim
+    # a light behind the object leaves the ambient term only
+    dark = R.phong_shade(p2v, bary, v, vn, col, light=[0, 0, -3], cam=R.camera_center(Rm, T))
+    assert set(np.unique(dark[hit])) <= {int(0.25 * 255), int(0.25 * 255) + 1, int(0.25 * 255) - 1}
+
+
+@pytest.mark.gpu
+def test_gpu_phong_renders_vs_oracle(hip_lib, cuda):
+    """ivlm_phong_shade + render.object_renders (the 'color' and 'grey' SAM inputs of generate_sam_inp_objs,
+    utils/demo_utils.py:171-257) against the numpy restatement on the GPU rasteriser's own tables."""
+    import torch
+
+    from interactvlm_amd import render
+    from interactvlm_amd.constants import OBJS_VIEW_DICT
+
+    v, f = R.icosphere(3)
+    v = (v * np.array([1.0, 0.6, 0.8], np.float32) + np.array([0.3, -0.2, 0.1], np.float32)).astype(np.float32)
+    vt, ft = torch.from_numpy(v).to(cuda), torch.from_numpy(f.astype(np.int32)).to(cuda)
+    S = 256
+    for colored in (True, False):
+        imgs, vid, bary, nv = render.object_renders(vt, ft, "4MV-Z_HM_BM", colored=colored, image_size=(S, S))
+        assert imgs.shape == (4, S, S, 3) and imgs.dtype == torch.uint8 and nv == v.shape[0]
+        vn_t = render.normalize_mesh(vt.float())
+        vn = vn_t.cpu().numpy()
+        normals = R.vertex_normals(vn, f)
+        assert np.allclose(render.vertex_normals(vn_t.contiguous(), ft).cpu().numpy(), normals, atol=1e-5)
+        if colored:
+            col = (vn - vn.min(0)) / (vn.max(0) - vn.min(0))
+        else:
+            col = np.tile(np.array(render.YELLOW_VERTEX_COLOR, np.float32), (vn.shape[0], 1))
+        col = (col * 0.8 + 0.1).astype(np.float32)
+        cams = OBJS_VIEW_DICT["4MV-Z_HM_BM"].get("mesh_cam_params") or OBJS_VIEW_DICT["4MV-Z_HM_BM"]["cam_params"]
+        for i, name in enumerate(cams):
+            Rm, T = R.look_at_view_transform(*cams[name])
+            exp = R.phong_shade(vid[i].cpu().numpy(), bary[i].cpu().numpy(), vn, normals, col, render.LIGHT_LOCATIONS[i],
+                                R.camera_center(Rm, T))
+            got = imgs[i].cpu().numpy()
+            hit = vid[i, ..., 0].cpu().numpy() >= 0
+            assert 0.05 < hit.mean() < 0.8 and (got[~hit] == 255).all()
+            d = np.abs(got.astype(int) - exp.astype(int))
+            assert d.max() <= 1 and (d > 0).mean() < 0.02, (colored, name, d.max(), (d > 0).mean())
+        # the colour renders differ between views and carry position colours; the grey ones are shades of one hue
+        assert float((imgs[0].float() - imgs[2].float()).abs().mean()) > 1.0
