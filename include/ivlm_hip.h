@@ -291,6 +291,13 @@ int ivlm_mask_dot(const void *up, const void *hyper, float *low, int B, int gh, 
  * ------------------------------------------------------------------------------------------- */
 /* get_h_contact_metrics (utils/eval_utils.py:63-94): per sample F1 / precision / recall of (pred >= thr) against
  * (gt > 0); gt, pred f32 [B,n] -> out f32 [B,3] = (f1, precision, recall). */
+/* get_h_geo_metric (utils/eval_utils.py:129-151): dist f32 [n,n] geodesic matrix, pred / gt f32 [B,n] -> out f32 [B,2] =
+ * (false-positive distance, false-negative distance) per sample: rows = {pred >= 0.5} (all rows if empty), columns =
+ * {gt == 1} (all if empty), fp = mean over rows of the min over columns, fn = mean over columns of the min over rows.
+ * n <= 8192.  The caller averages over the batch like the reference does. */
+size_t ivlm_h_geo_workspace_bytes(int n);
+int ivlm_h_geo_metric(const float *dist, const float *pred, const float *gt, int B, int n, float *out, void *workspace,
+                      size_t workspace_bytes, ivlm_stream_t stream);
 int ivlm_contact_prf(const float *gt, const float *pred, int B, int n, float thr, float *out, ivlm_stream_t stream);
 /* convert_contacts (utils/utils.py:428-443): y[b] = M . x[b] with the SMPL->SMPL-X matrix M [rows,cols] held in CSR
  * (row_ptr i32 [rows+1], col i32 [nnz], val f32 [nnz]) instead of the reference's dense 10475x6890 bmm. */

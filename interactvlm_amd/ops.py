@@ -586,6 +586,24 @@ def contact_prf(gt, pred, threshold=0.5):
     return out
 
 
+def h_geo_metric(pred, gt, dist):
+    """get_h_geo_metric (utils/eval_utils.py:129-151) on the device: pred / gt f32 [B,n], dist f32 [n,n] ->
+    (fp_dist_avg, fn_dist_avg) python floats (batch means) and the per-sample f32 [B,2] tensor."""
+    lib = _lib.load()
+    pred = _req(pred, torch.float32, "pred")
+    gt = _req(gt, torch.float32, "gt")
+    dist = _req(dist, torch.float32, "dist")
+    B, n = pred.shape
+    assert gt.shape == pred.shape and dist.shape == (n, n)
+    nbytes = lib.ivlm_h_geo_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
+    out = torch.empty(B, 2, dtype=torch.float32, device=pred.device)
+    check(lib.ivlm_h_geo_metric(dist.data_ptr(), pred.data_ptr(), gt.data_ptr(), B, n, out.data_ptr(), ws.data_ptr(), nbytes,
+                                _stream()), "h_geo_metric")
+    m = out.mean(0)
+    return float(m[0]), float(m[1]), out
+
+
 class SparseRows:
     """CSR copy of a (mostly empty) dense matrix, e.g. the SMPL->SMPL-X transfer matrix [10475, 6890]."""
 

@@ -392,9 +392,50 @@ def gen_model_forward(batch2=False):
           pred_contact=out["pred_human_3d_contact"].numpy())
 
 
+# ------------------------------------------------------------------------------------------
+# metrics right after the path (utils/eval_utils.py:63-151): get_h_contact_metrics, get_h_geo_metric
+# ------------------------------------------------------------------------------------------
+def gen_metrics():
+    import torch
+
+    _ref_shims.install()
+    n = 211  # synthetic "mesh" size: the distance matrix is an input (the real one is a 190 MB data file we do not have)
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(n, 3)).astype(np.float32)
+    dist = np.linalg.norm(pts[:, None] - pts[None], axis=-1).astype(np.float32)
+    dist = dist + 0.05 * rng.random((n, n)).astype(np.float32) * (1 - np.eye(n, dtype=np.float32))  # NOT symmetric
+    real_load = np.load
+
+    def fake_load(path, *a, **k):  # eval_utils.py:15 loads the geodesic matrix at import time
+        return dist if "geodesic" in str(path) else real_load(path, *a, **k)
+
+    np.load = fake_load
+    try:
+        import utils.eval_utils as E
+    finally:
+        np.load = real_load
+    E.DIST_MATRIX = torch.from_numpy(dist)
+    B = 5
+    pred = rng.random((B, n)).astype(np.float32)
+    gt = (rng.random((B, n)) < 0.3).astype(np.float32)
+    pred[1] = 0.1          # no vertex predicted in contact: every row is used (eval_utils.py:141)
+    gt[2] = 0.0            # no ground-truth contact: every column is used (:140)
+    pred[3, :5] = 0.5      # the >= 0.5 boundary
+    gt[4] = gt[4] * 0.7    # gt values other than exactly 1 are not contact columns for the geodesic metric, but are > 0 for F1
+    gt[4, :3] = 1.0
+    pt, gtt = torch.from_numpy(pred), torch.from_numpy(gt)
+    geo = [E.get_h_geo_metric(pt[b: b + 1], gtt[b: b + 1]) for b in range(B)]
+    geo_all = E.get_h_geo_metric(pt, gtt)
+    prf = [E.get_h_contact_metrics(gtt[b: b + 1], pt[b: b + 1]) for b in range(B)]
+    prf_o = [E.get_o_contact_metrics(gtt[b: b + 1], pt[b: b + 1]) for b in range(B)]
+    _save("metrics.npz", dist=dist, pred=pred, gt=gt, geo_per_sample=np.asarray(geo, np.float64),
+          geo_batch=np.asarray(geo_all, np.float64), prf_per_sample=np.asarray(prf, np.float64),
+          prf_o_per_sample=np.asarray(prf_o, np.float64))
+
+
 GENERATORS = {"lift": gen_lift, "lift_points": gen_lift_points, "sam_decoder": gen_sam_decoder, "cam": gen_cam,
               "sam_encoder": gen_sam_encoder, "sam_encoder_full": gen_sam_encoder_full, "model_forward": gen_model_forward,
-              "model_forward_oafford": lambda: gen_model_forward(batch2=True)}
+              "model_forward_oafford": lambda: gen_model_forward(batch2=True), "metrics": gen_metrics}
 
 
 def main():

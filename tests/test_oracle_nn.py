@@ -135,3 +135,20 @@ def test_sam_image_encoder_vith_dimensions(golden_dir):
     y = O.sam_image_encoder(w, SAM_PREFIX + ".image_encoder", x, 2, 16, (1,)).numpy()
     np.testing.assert_allclose(y[:, ::4, ::2, ::2], d["out_sub"], atol=2e-5)
     assert abs(float(y.astype(np.float64).sum()) - float(d["out_sum"])) < 1e-5 * y.size
+
+
+def test_metrics_oracle_vs_reference_golden(golden_dir):
+    """oracle/metrics.py against the reference's own get_h_contact_metrics / get_h_geo_metric outputs."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from oracle import metrics as OM
+
+    d = np.load(os.path.join(golden_dir, "metrics.npz"))
+    pred, gt, dist = (torch.from_numpy(d[k]) for k in ("pred", "gt", "dist"))
+    fp, fn, per = OM.h_geo_metric(pred, gt, dist)
+    np.testing.assert_allclose(per.numpy(), d["geo_per_sample"], rtol=1e-6)
+    np.testing.assert_allclose([fp, fn], d["geo_batch"], rtol=1e-6)
+    np.testing.assert_allclose(OM.h_contact_metrics(gt, pred).numpy(), d["prf_per_sample"], atol=1e-7)
