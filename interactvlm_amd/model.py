@@ -107,6 +107,7 @@ class InteractVLMForCausalLM:
         vm.mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid)
         if os.environ.get("IVLM_NO_GRAPHS"):
             vm.mask_decoder.use_graph = False
+            vm.image_encoder.use_graph = False
         vm.prompt_encoder = vm.mask_decoder  # text path of the prompt encoder is folded into the decoder object
         vm.postprocess_masks = lambda m, input_size, original_size: postprocess_masks(
             m, input_size, original_size, c.sam.img_size)

@@ -43,6 +43,18 @@ def main():
             s0, e1 = lst[0][0], max(x[1] for x in lst)
             print(f"  queue {q}: {len(lst)} kernels, window {(s0 - t0) / 1e6:.2f} .. {(e1 - t0) / 1e6:.2f} ms, busy {union_len([(s, e) for s, e, _ in lst]) / 1e6:.2f} ms, "
                   f"sum {sum(e - s for s, e, _ in lst) / 1e6:.2f} ms; first {lst[0][2][:40]} last {lst[-1][2][:40]}")
+        for q, lst in by.items():  # the first operations of each queue (start-up ordering of the two streams)
+            for s_, e_, n_ in sorted(lst)[:6]:
+                print(f"      q{q} {(s_ - t0) / 1e6:8.3f} .. {(e_ - t0) / 1e6:8.3f} ms  {n_[:60]}")
+        # idle gaps on each queue (host-induced bubbles on the critical path show up here)
+        for q, lst in by.items():
+            lst = sorted(lst)
+            gaps = [(lst[i + 1][0] - lst[i][1], lst[i][2][:36], lst[i + 1][2][:36], (lst[i][1] - t0) / 1e6) for i in range(len(lst) - 1)]
+            big = sorted([g for g in gaps if g[0] > 30000], reverse=True)
+            print(f"  queue {q}: idle between its kernels {sum(max(g[0], 0) for g in gaps) / 1e6:.2f} ms total; gaps > 30 us: "
+                  f"{len(big)} ({sum(g[0] for g in big) / 1e6:.2f} ms)")
+            for g in big[:12]:
+                print(f"      {g[0] / 1e3:8.1f} us at {g[3]:7.2f} ms after {g[1]} before {g[2]}")
         # decode-phase probe: time between consecutive llama_decode_attn kernels
         da = [(s, e) for n, s, e, q in seg if "llama_decode_attn" in n]
         if len(da) > 64:
