@@ -168,9 +168,6 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    if os.environ.get("IVLM_GEMV_XLDS_KB"):  # experiments only: KiB limit of the GEMV's x-in-LDS staging (0 = never)
-        from interactvlm_amd import _lib
-        _lib.load().ivlm_gemv_slab_enable(100 + int(os.environ["IVLM_GEMV_XLDS_KB"]))
     if os.environ.get("IVLM_TILE"):  # experiments only: force the GEMM block tile (64/128/256/512)
         from interactvlm_amd import _lib
         _lib.load().ivlm_gemm_tile_override(int(os.environ["IVLM_TILE"]))

@@ -349,12 +349,12 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 
 }  // namespace
 
-static int g_gemv_xlds_limit = 48 * 1024;  // experiments: 0 = never stage x in LDS (co-residency with LDS-heavy GEMM blocks)
-
 template <int M>
 static int launch_gemv(const GemmArgs& g, hipStream_t st) {
     const size_t xbytes = (size_t)M * g.K * 2;
-    const bool xlds = xbytes <= (size_t)g_gemv_xlds_limit;
+    // (x staged in LDS also when the GEMV shares the CUs with the encoder's 128-KB-LDS GEMM blocks: never staging it costs
+    //  12 ms end to end, staging only K = 4096 vectors 1 ms - LDS room is not what slows the decode next to the encoder)
+    const bool xlds = xbytes <= 48 * 1024;
     const bool rows2 = g.act == ACT_SWIGLU || g.N > 8192;  // small N: one row per wave = twice the waves
     const int ngroups = rows2 ? (g.N + 1) / 2 : g.N;
     int blocks = (ngroups + 3) / 4;
@@ -398,10 +398,7 @@ int gemv_gu_down(const bf16_t* x2, const bf16_t* ln_w, float eps, const bf16_t* 
 }
 
 static int g_gemv_slab = 0;
-void gemv_set_slab(int on) {
-    if (on >= 100) g_gemv_xlds_limit = (on - 100) * 1024;  // experiment channel: 100 + KiB limit of the x-in-LDS path
-    else g_gemv_slab = on;
-}
+void gemv_set_slab(int on) { g_gemv_slab = on; }
 
 int gemv_bf16(const GemmArgs& g, hipStream_t st) {
     if (!g.A || !g.W || !g.C || g.M <= 0 || g.M > kMaxM || g.N <= 0 || g.K <= 0) return IVLM_ERR_INVALID_ARG;

@@ -18,6 +18,8 @@ def main():
     vid, bary = synthetic.body_lift_tables(dev)
     m = M.InteractVLMForCausalLM(cfg, w, dev, lift_tables=(vid, bary))
     del w
+    if os.environ.get("IVLM_NO_FUSE_ATTN_OPROJ"):
+        m.llm.fuse_attn_oproj = False
     ids, forced = synthetic.prompt_ids(cfg)
     cams = synthetic.human_cam_params()
     ic, im = synthetic.images(cfg, dev)
