@@ -455,30 +455,36 @@ class InteractVLMForCausalLM:
 
     def evaluate_batch(self, images_clip, images, input_ids_list, cam_params, resize_list, original_size_list,
                        contact_type="hcontact", max_new_tokens=32, forced_new_tokens=None, eos_token_id=2,
-                       lift2d_dict_path=None):
+                       lift2d_dict_path=None, image_embeddings=None):
         """``evaluate`` for B images in one call: images_clip [B,3,h,w], images [B,V,3,S,S], one prompt per image.
         The SAM encoder of every image runs on the side stream while the B sequences decode together; the masks of all
         images are lifted in one launch.  -> [{'output_ids','pred_masks','pred_contact_3d'}] * B, each equal to what
         ``evaluate`` returns for that image alone.
         images_clip [1,3,h,w] with B > 1 prompts = B questions about ONE picture (one CLIP pass; configs[4]: a human-contact
         prompt over the body renders and an object prompt over the object renders); contact_type and lift2d_dict_path
-        may then be lists, one entry per prompt."""
+        may then be lists, one entry per prompt.
+        image_embeddings: pre-computed SAM embeddings, one [V, g*g, 256] tensor for all samples (the four
+        canonical body renders of hcontact are the same for every image) or a list of B; ``images`` is then not encoded."""
         B = len(input_ids_list)
         main = torch.cuda.current_stream(self.device)
-        side = self._side_stream if self.overlap_sam_encoder else main
-        embs = []
-        if side is not main:
-            side.wait_stream(main)
-        with torch.cuda.stream(side):
-            for b in range(B):  # one image's V views per encoder pass: the same launches as the batch-1 path
-                embs.append(self.model.visual_model.image_encoder(images[b].to(self.device)))
-            ev = torch.cuda.Event()
-            ev.record(side)
-        gens = self.generate_batch(images_clip, input_ids_list, max_new_tokens, eos_token_id, forced_new_tokens)
-        if side is not main:
-            main.wait_event(ev)
-            for e in embs:
-                e.record_stream(main)
+        if image_embeddings is not None:
+            embs = list(image_embeddings) if isinstance(image_embeddings, (list, tuple)) else [image_embeddings] * B
+            gens = self.generate_batch(images_clip, input_ids_list, max_new_tokens, eos_token_id, forced_new_tokens)
+        else:
+            side = self._side_stream if self.overlap_sam_encoder else main
+            embs = []
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for b in range(B):  # one image's V views per encoder pass: the same launches as the batch-1 path
+                    embs.append(self.model.visual_model.image_encoder(images[b].to(self.device)))
+                ev = torch.cuda.Event()
+                ev.record(side)
+            gens = self.generate_batch(images_clip, input_ids_list, max_new_tokens, eos_token_id, forced_new_tokens)
+            if side is not main:
+                main.wait_event(ev)
+                for e in embs:
+                    e.record_stream(main)
         outs, lows = [], []
         for b, (output_ids, hidden) in enumerate(gens):
             rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)

@@ -582,3 +582,8 @@ def test_evaluate_batch_equals_per_image_evaluate(hip_lib, cuda, golden_dir, gra
     outs2 = m.evaluate_batch(ic, im, prompts, cam_b, sizes, sizes, forced_new_tokens=forced)
     for b in range(B):
         assert torch.equal(outs2[b]["pred_contact_3d"], outs[b]["pred_contact_3d"])
+    # pre-computed SAM embeddings (8f-1), one tensor per image: same results without running the encoder
+    embs = [m.precompute_visual_embs(im[b]) for b in range(B)]
+    outs3 = m.evaluate_batch(ic, None, prompts, cam_b, sizes, sizes, forced_new_tokens=forced, image_embeddings=embs)
+    for b in range(B):
+        assert torch.equal(outs3[b]["pred_contact_3d"], outs[b]["pred_contact_3d"])
