@@ -156,6 +156,36 @@ class Llama:
             x = ops.linear(h, L["down"], residual=x)
         return ops.rmsnorm(x, self.norm, c.eps)
 
+    def forward_packed(self, xs, kc, vc):
+        """Prefill of B sequences in ONE pass over the weights: xs = [x_b [T_b, hidden]] (lengths may differ), kc / vc
+        [layers, B, Tmax, H, hd] cache slabs -> [final-norm hidden [T_b, hidden]].  The four projections of a layer run
+        on the packed rows (M = sum T_b: one efficient GEMM instead of B skinny ones, weights streamed once); RoPE + cache
+        append and the causal attention stay per sequence.  Row-wise identical arithmetic to ``forward``."""
+        c = self.cfg
+        H, hd = c.heads, c.hidden // c.heads
+        lens = [int(x.shape[0]) for x in xs]
+        assert max(lens) <= self.max_len
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        x = torch.cat(xs, 0)
+        for li, L in enumerate(self.layers):
+            qkv = ops.linear(ops.rmsnorm(x, L["ln1"], c.eps), L["qkv"])
+            a = torch.empty(offs[-1], c.hidden, dtype=BF16, device=x.device)
+            for b, T in enumerate(lens):
+                qb = qkv[offs[b]: offs[b + 1]]
+                ops.rope_kv(qb, H, hd, 0, c.theta, kc[li, b], vc[li, b], table=self.rope)
+                q = qb.view(T, 3, H, hd)[:, 0].permute(1, 0, 2).unsqueeze(0)
+                k = kc[li, b, :T].permute(1, 0, 2).unsqueeze(0)
+                v = vc[li, b, :T].permute(1, 0, 2).unsqueeze(0)
+                ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=0,
+                              out=a[offs[b]: offs[b + 1]].view(1, T, H, hd).permute(0, 2, 1, 3))
+            x = ops.linear(a, L["o"], residual=x)
+            h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps), L["gu"], act="swiglu")
+            x = ops.linear(h, L["down"], residual=x)
+        x = ops.rmsnorm(x, self.norm, c.eps)
+        return [x[offs[b]: offs[b + 1]] for b in range(len(lens))]
+
     # ---- one decode step as a replayable HIP graph ------------------------------------------------------------------
     # Static buffers: token id in, position (device int32, read by the attention kernel), hidden out, argmax out.
     # Per generated token the host then issues 1 graph launch instead of ~165 kernel launches (2.4 ms of Python).

@@ -86,7 +86,8 @@ class InteractVLMForCausalLM:
         # HIP-graph replay of the decode step / CLIP tower (launch-bound on the host otherwise); IVLM_NO_GRAPHS=1 turns both
         # off (rocprofv3 --pmc passes crash on replayed graphs)
         self.graph_decode = not os.environ.get("IVLM_NO_GRAPHS")
-        self.sam_after_prefill = False  # measured: 116.9 vs 115.3 ms - overlapping the decode instead of the prefill is not better
+        self.sam_after_prefill = False  # measured: 107.6 vs 106.6 ms - overlapping the decode instead of the prefill is not better
+        self.packed_prefill = True  # generate_batch: prefill all prompts of a batch as one packed pass (rows independent)
         # persistent one-launch greedy decode (csrc/generate.hip): correct and bit-reproducible, but measured SLOWER than the
         # per-op path on MI355X (3.43 vs 2.93 ms/token for 7B: every phase boundary costs ~9 us of device-wide sync
         # skew + store/load latency, more than a kernel boundary) - kept as an opt-in experiment
@@ -403,8 +404,11 @@ class InteractVLMForCausalLM:
         n_max = max(n_seq)
         hidden_all = torch.empty(B, max(T0) + n_max, self.config.llama.hidden, dtype=BF16, device=dev)
         last = torch.empty(B, self.config.llama.hidden, dtype=BF16, device=dev)
-        for b in range(B):
-            h = self.llm.forward(xs[b], 0, cache=(kc[:, b], vc[:, b]))
+        if self.packed_prefill and B > 1:  # the B prompts in one pass over the weights
+            hs = self.llm.forward_packed(xs, kc, vc)
+        else:
+            hs = [self.llm.forward(xs[b], 0, cache=(kc[:, b], vc[:, b])) for b in range(B)]
+        for b, h in enumerate(hs):
             hidden_all[b, : T0[b]].copy_(h)
             last[b].copy_(h[T0[b] - 1])
         forced_dev = None
