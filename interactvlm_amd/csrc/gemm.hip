@@ -165,6 +165,7 @@ int launch_cfg(const GemmArgs& g, hipStream_t st) {
 }
 
 using Cfg128x64 = TileCfg<2, 2, 4, 2>;  // 128 x 64 block: more tiles for skinny problems (LLM prefill o/down)
+using Cfg128x96 = TileCfg<2, 2, 4, 3>;  // 128 x 96 block: M ~ 330 prefill against wide N (3 tile rows: see choose_tile)
 
 // Pick the block tile from the tile counts (measured with tools/bench_gemm.py):
 //   * fewer than ~400 tiles of 128^2 (under one resident wave at 2 blocks/CU): halve the tile (128x64) to
@@ -172,8 +173,11 @@ using Cfg128x64 = TileCfg<2, 2, 4, 2>;  // 128 x 64 block: more tiles for skinny
 //   * 256^2 (+10 % on SAM qkv / mlp1) when it fills whole waves of the 256 CUs (quantisation efficiency >= 0.85);
 //   * 128^2 otherwise.
 inline int choose_tile(const GemmArgs& g) {
-    if (g.tile == 128 || g.tile == 256 || g.tile == 64 || g.tile == 512) return g.tile;
+    if (g.tile == 128 || g.tile == 256 || g.tile == 64 || g.tile == 96 || g.tile == 512) return g.tile;
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
+    // LLaMA prefill (M ~ 330 = 3 tile rows) against the wide projections: 128x96 tiles quantise better over 256 CUs than
+    // 128x128 (288 / 516 tiles: 2 / 3 rounds) or 128x64 - qkv 58.6 -> 54.6 us, gate|up 105.5 -> 93.2 us (tools/bench_gemm.py)
+    if (g.batch == 1 && g.M > 256 && g.M <= 384 && g.N >= 8192) return 96;
     if (t128 < 400) return 64;
     const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
     const double q = (double)t256 / (double)(((t256 + 255) / 256) * 256);
@@ -189,6 +193,7 @@ int launch(const GemmArgs& g, hipStream_t st) {
         case 512: return gemm_bf16_256p(g, st);  // 256^2, 8-phase ping-pong pipeline (gemm256.hip)
         case 256: return g.out_f32 ? launch_cfg<ACT, true, Cfg256>(g, st) : launch_cfg<ACT, false, Cfg256>(g, st);
         case 64: return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64>(g, st) : launch_cfg<ACT, false, Cfg128x64>(g, st);
+        case 96: return g.out_f32 ? launch_cfg<ACT, true, Cfg128x96>(g, st) : launch_cfg<ACT, false, Cfg128x96>(g, st);
         default: return g.out_f32 ? launch_cfg<ACT, true, Cfg128>(g, st) : launch_cfg<ACT, false, Cfg128>(g, st);
     }
 }
@@ -311,7 +316,7 @@ extern "C" int ivlm_gemv_mfma_min_m(int min_m) {  // benchmark/test hook: 0 = au
 
 extern "C" int ivlm_gemm_tile_override(int tile) {
     const int prev = g_tile_override;
-    if (tile == 0 || tile == 64 || tile == 128 || tile == 256 || tile == 512) g_tile_override = tile;
+    if (tile == 0 || tile == 64 || tile == 96 || tile == 128 || tile == 256 || tile == 512) g_tile_override = tile;
     return prev;
 }
 

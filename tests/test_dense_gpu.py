@@ -81,7 +81,7 @@ def test_gemm_splitk_matches_single_pass(hip_lib, cuda, M, N, K):
     assert torch.allclose(out[:, :N].float(), x.float() @ w.float().T, atol=2e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("tile", [64, 128, 256, 512])
+@pytest.mark.parametrize("tile", [64, 96, 128, 256, 512])
 def test_gemm_forced_tiles(hip_lib, cuda, tile):
     """Both block-tile configurations on a shape with ragged M/N edges and a K tail."""
     import torch
