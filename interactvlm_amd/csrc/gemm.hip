@@ -175,9 +175,9 @@ using Cfg128x96 = TileCfg<2, 2, 4, 3>;  // 128 x 96 block: M ~ 330 prefill again
 inline int choose_tile(const GemmArgs& g) {
     if (g.tile == 128 || g.tile == 256 || g.tile == 64 || g.tile == 96 || g.tile == 512) return g.tile;
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
-    // LLaMA prefill (M ~ 330 = 3 tile rows) against the wide projections: 128x96 tiles quantise better over 256 CUs than
-    // 128x128 (288 / 516 tiles: 2 / 3 rounds) or 128x64 - qkv 58.6 -> 54.6 us, gate|up 105.5 -> 93.2 us (tools/bench_gemm.py)
-    if (g.batch == 1 && g.M > 256 && g.M <= 384 && g.N >= 8192) return 96;
+    // (128x96 tiles for the LLaMA prefill's wide projections, M ~ 330 = 3 tile rows: faster in the warm micro-benchmark -
+    //  qkv 58.6 -> 54.6 us, gate|up 105.5 -> 93.2 us - but SLOWER in the pipeline, where the 100-180 MB of weights come cold
+    //  from HBM and the encoder shares the CUs: 67.5 -> 73.4 us and 114 -> 133 us by rocprofv3; available as tile 96 only)
     if (t128 < 400) return 64;
     const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch;
     const double q = (double)t256 / (double)(((t256 + 255) / 256) * 256);
