@@ -172,6 +172,11 @@ int ivlm_attention_pingpong(int mode);
  *   like the reference's model-dtype einsum, stored f32).  tab_h bf16 [2*SH-1,D], tab_w bf16 [2*SW-1,D]. */
 int ivlm_relpos_bias(const void *q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void *tab_h, const void *tab_w,
                      int B, int H, int SH, int SW, int D, float *rel_h, float *rel_w, ivlm_stream_t stream);
+/* Second half of the GEMM formulation of the same operands: G bf16 [H][B*S][npad] = q . [rel_pos_h ; rel_pos_w]^T (one
+ * batched ivlm_gemm_bf16 over the heads, K = head dim), g_head_stride = elements between heads; this gathers the Toeplitz
+ * shifts rel_h[bh,s,kh] = G[qh-kh+SH-1], rel_w[bh,s,kw] = G[(2SH-1) + qw-kw+SW-1] into f32 [B*H,S,SH] / [B*H,S,SW]. */
+int ivlm_relpos_gather(const void *G, int64_t g_head_stride, int npad, int B, int H, int SH, int SW, float *rel_h,
+                       float *rel_w, ivlm_stream_t stream);
 
 /* Whole greedy generation after the prefill, in ONE persistent launch (HF GenerationMixin greedy search driven by
  * InteractVLM.evaluate, model/InteractVLM.py:524-531; per token: LlamaModel.forward of one position with the KV

@@ -23,6 +23,8 @@
 //          receives column i), two reads per fragment in the permuted key order.
 //     Both are double-buffered: one barrier per key tile.  Head dim 80 pads to 96 for QK^T (zero chunks).
 //   * the S x S score matrix is never materialised (the reference materialises [B*16,4096,4096]).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace ivlm {
@@ -642,7 +644,40 @@ __global__ __launch_bounds__(256) void relpos_rows_kernel(const bf16_t* __restri
     run(tw, qw + SW - 1, SW, rel_w + bq * SW);
 }
 
+// rel-pos operands from ONE batched MFMA GEMM: G[h][b*S + s][:] = q[b,h,s,:] . [rel_pos_h ; rel_pos_w]^T (bf16, the model
+// dtype the reference's einsum produces), then the Toeplitz shift is a pure gather:
+//   rel_h[bh,s,kh] = G[..][qh - kh + SH - 1],   rel_w[bh,s,kw] = G[..][(2 SH - 1) + qw - kw + SW - 1].
+// The dot products (2 x (2S-1) x D MACs per query: 5.6 GFLOP per global block) leave the VALU / LDS for the matrix cores;
+// this kernel only moves data: one thread per 4 consecutive outputs (16-byte stores).
+__global__ __launch_bounds__(256) void relpos_gather_kernel(const bf16_t* __restrict__ G, int64_t g_hs /*head stride*/, int npad,
+                                                            int H, int SH, int SW, float* __restrict__ rel_h,
+                                                            float* __restrict__ rel_w) {
+    // threadIdx.x = output slot of a query (kh for x < SH, then kw), threadIdx.y = query inside the block: the loads of a query
+    // are two reversed contiguous runs of its G row, the stores two contiguous runs - no integer division per output
+    const int S = SH * SW;
+    const int s_ = blockIdx.x * blockDim.y + threadIdx.y;
+    const int j = threadIdx.x;
+    if (s_ >= S || j >= SH + SW) return;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int qh = s_ / SW, qw = s_ - qh * SW;
+    const bf16_t* row = G + h * g_hs + ((int64_t)b * S + s_) * npad;
+    const int64_t bq = ((int64_t)b * H + h) * S + s_;
+    if (j < SH) rel_h[bq * SH + j] = bf16_to_f32(row[qh - j + SH - 1]);
+    else rel_w[bq * SW + (j - SH)] = bf16_to_f32(row[(2 * SH - 1) + qw - (j - SH) + SW - 1]);
+}
+
 }  // namespace
+
+int relpos_gather(const bf16_t* G, int64_t g_hs, int npad, int B, int H, int SH, int SW, float* rel_h, float* rel_w,
+                  hipStream_t st) {
+    if (!G || !rel_h || !rel_w || B <= 0 || H <= 0 || SH <= 0 || SW <= 0 || npad < 2 * SH - 1 + 2 * SW - 1) return IVLM_ERR_INVALID_ARG;
+    if (SH + SW > 256 || H > 65535 || B > 65535) return IVLM_ERR_UNSUPPORTED;
+    int bx = 32;
+    while (bx < SH + SW) bx <<= 1;
+    const int by = 256 / bx;
+    relpos_gather_kernel<<<dim3((SH * SW + by - 1) / by, H, B), dim3(bx, by), 0, st>>>(G, g_hs, npad, H, SH, SW, rel_h, rel_w);
+    return ivlm_launch_status();
+}
 
 int attention_bf16(const AttnArgs& a, hipStream_t st) {
     if (!a.q || !a.k || !a.v || !a.o || a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return IVLM_ERR_INVALID_ARG;
@@ -681,6 +716,13 @@ int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
 }  // namespace ivlm
 
 extern "C" {
+
+int ivlm_relpos_gather(const void* G, int64_t g_head_stride, int npad, int B, int H, int SH, int SW, float* rel_h, float* rel_w,
+                       ivlm_stream_t stream) {
+    ivlm_enter();
+    return ivlm::relpos_gather(static_cast<const bf16_t*>(G), g_head_stride, npad, B, H, SH, SW, rel_h, rel_w,
+                               ivlm_stream(stream));
+}
 
 int ivlm_attention_pingpong(int mode) {  // benchmark/test hook: -1 automatic, 0 four-wave kernel, 1 eight-wave ping-pong
     ivlm::attn_set_pingpong(mode);

@@ -363,13 +363,42 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, presca
     return out
 
 
-def relpos_bias(q, tab_h, tab_w, SH, SW):
-    """q [B,H,S=SH*SW,D] -> (rel_h f32 [B*H,S,SH], rel_w f32 [B*H,S,SW])."""
+def relpos_tables_cat(tab_h, tab_w):
+    """[rel_pos_h ; rel_pos_w] padded with zero rows to a multiple of 8: the weight matrix of the GEMM formulation."""
+    n = tab_h.shape[0] + tab_w.shape[0]
+    cat = torch.zeros((n + 7) // 8 * 8, tab_h.shape[1], dtype=BF16, device=tab_h.device)
+    cat[: tab_h.shape[0]] = tab_h
+    cat[tab_h.shape[0]: n] = tab_w
+    return cat
+
+
+RELPOS_GEMM = True  # rel-pos operands through one batched MFMA GEMM + gather instead of the VALU dot-product kernel
+
+
+def relpos_bias(q, tab_h, tab_w, SH, SW, cat=None):
+    """q [B,H,S=SH*SW,D] -> (rel_h f32 [B*H,S,SH], rel_w f32 [B*H,S,SW]).  cat = relpos_tables_cat(tab_h, tab_w)
+    (pre-built once per block) selects the GEMM formulation when the q rows of all (b, s) are uniformly strided."""
     lib = _lib.load()
     B, H, S, D = q.shape
     assert S == SH * SW and q.stride(3) == 1 and tab_h.is_contiguous() and tab_w.is_contiguous()
     rel_h = torch.empty(B * H, S, SH, dtype=torch.float32, device=q.device)
     rel_w = torch.empty(B * H, S, SW, dtype=torch.float32, device=q.device)
+    # (measured, SAM ViT-H: global 64x64 grid 242 -> 139 us; 14x14 windows 54 -> 62 us - the GEMM's N = 54 wastes half a tile and
+    #  the gather moves as many bytes as the dot kernel writes - so only grids of 32x32 and up take this path)
+    if (RELPOS_GEMM and cat is not None and min(SH, SW) >= 32 and q.dtype == BF16 and q.stride(0) == S * q.stride(2) and q.stride(2) % 8 == 0
+            and q.stride(1) % 8 == 0 and D % 8 == 0 and q.data_ptr() % 16 == 0):
+        npad, M = cat.shape[0], B * S
+        G = torch.empty(H, M, npad, dtype=BF16, device=q.device)
+        call = lambda: check(lib.ivlm_gemm_bf16(q.data_ptr(), q.stride(2), cat.data_ptr(), D, G.data_ptr(), npad, 0, 0, 0, 0,
+                                                M, npad, D, 0, 0, H, q.stride(1), 0, M * npad, 0, 0, 0.0, _stream()),
+                             "relpos gemm")
+        if TIMER.enabled:
+            TIMER.time("gemm_bf16_mfma", 2.0 * H * M * npad * D, call, tag=("relpos", M, npad, D))
+        else:
+            call()
+        check(lib.ivlm_relpos_gather(G.data_ptr(), M * npad, npad, B, H, SH, SW, rel_h.data_ptr(), rel_w.data_ptr(),
+                                     _stream()), "relpos_gather")
+        return rel_h, rel_w
     check(lib.ivlm_relpos_bias(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), tab_h.data_ptr(), tab_w.data_ptr(),
                                B, H, SH, SW, D, rel_h.data_ptr(), rel_w.data_ptr(), _stream()), "relpos_bias")
     return rel_h, rel_w

@@ -98,7 +98,9 @@ class SamImageEncoder:
         qkv = blk["qkv"](xn)  # [nwin*S, 3*D] == [nwin, S, 3, H, hd]
         qkv5 = qkv.view(nwin, S, 3, H, hd)
         q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side)
+        if "rel_cat" not in blk:
+            blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
+        rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat"])
         o = ops.attention(q, k, v, hd ** -0.5, rel=rel)  # view of a [nwin, S, H, hd] buffer
         return o.permute(0, 2, 1, 3).reshape(nwin * S, H * hd)
 

@@ -128,3 +128,49 @@ def test_attention_rescale_branch_forced(hip_lib, cuda):
     ref = _ref(q, k, v, 0.125)
     got = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), 0.125)
     assert (got.float().cpu() - ref).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("SH,SW,B,H", [(14, 14, 5, 4), (64, 64, 2, 3), (6, 10, 2, 2)])
+def test_relpos_gemm_formulation_matches_dot_kernel(hip_lib, cuda, SH, SW, B, H):
+    """rel-pos operands through one batched MFMA GEMM (q . [rel_pos_h ; rel_pos_w]^T, bf16 out) + the Toeplitz gather
+    against the VALU dot-product kernel, on q read in place from a fused qkv buffer (SAM layout)."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(SH * 100 + SW)
+    D, S = 80, SH * SW
+    bf = torch.bfloat16
+    qkv = torch.randn(B, S, 3, H, D, generator=g).to(bf).to(cuda)
+    q = qkv[:, :, 0].permute(0, 2, 1, 3)
+    tab_h = (torch.randn(2 * SH - 1, D, generator=g) * 0.2).to(bf).to(cuda)
+    tab_w = (torch.randn(2 * SW - 1, D, generator=g) * 0.2).to(bf).to(cuda)
+    eh, ew = ops.relpos_bias(q, tab_h, tab_w, SH, SW)                       # dot-product kernel
+    cat = ops.relpos_tables_cat(tab_h, tab_w)
+    assert cat.shape[0] % 8 == 0 and cat.shape[0] >= 2 * SH - 1 + 2 * SW - 1
+    G = torch.empty(H, B * S, cat.shape[0], dtype=bf, device=cuda)          # the two steps by hand: every grid size
+    from interactvlm_amd import _lib
+    lib = _lib.load()
+    ops.check(lib.ivlm_gemm_bf16(q.data_ptr(), q.stride(2), cat.data_ptr(), D, G.data_ptr(), cat.shape[0], 0, 0, 0, 0, B * S,
+                                 cat.shape[0], D, 0, 0, H, q.stride(1), 0, B * S * cat.shape[0], 0, 0, 0.0,
+                                 torch.cuda.current_stream().cuda_stream), "gemm")
+    gh, gw = torch.empty_like(eh), torch.empty_like(ew)
+    ops.check(lib.ivlm_relpos_gather(G.data_ptr(), B * S * cat.shape[0], cat.shape[0], B, H, SH, SW, gh.data_ptr(), gw.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), "gather")
+    if min(SH, SW) >= 32:  # the path ops.relpos_bias takes by itself for large grids
+        g2h, g2w = ops.relpos_bias(q, tab_h, tab_w, SH, SW, cat=cat)
+        assert torch.equal(g2h, gh) and torch.equal(g2w, gw)
+    assert gh.shape == eh.shape and gw.shape == ew.shape
+    # both round an fp32 dot product of 80 terms to bf16: equal up to one bf16 ulp where the summation order flips a rounding
+    for a, e in ((gh, eh), (gw, ew)):
+        d = (a - e).abs()
+        assert float(d.max()) <= 2.0 ** -7 * float(e.abs().max()) + 1e-6
+        assert float((d > 0).float().mean()) < 0.05
+    # and against fp32 torch
+    rq = q.float().reshape(B * H, SH, SW, D)
+    idx_h = torch.arange(SH)[:, None] - torch.arange(SH)[None, :] + (SH - 1)
+    idx_w = torch.arange(SW)[:, None] - torch.arange(SW)[None, :] + (SW - 1)
+    Rh, Rw = tab_h.float()[idx_h.to(cuda)], tab_w.float()[idx_w.to(cuda)]
+    ref_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh).reshape(B * H, S, SH)
+    ref_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw).reshape(B * H, S, SW)
+    assert torch.allclose(gh, ref_h, atol=2e-2, rtol=1e-2) and torch.allclose(gw, ref_w, atol=2e-2, rtol=1e-2)
