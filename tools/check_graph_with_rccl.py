@@ -34,6 +34,12 @@ def main():
         outs.append(gather_contacts(o["pred_contact_3d"]).cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     assert m.llm._dgraph is not None, "decode graph was not used"
+    assert len(m.model.visual_model.image_encoder._graphs) == 1 and len(m.model.visual_model.mask_decoder._graphs) >= 1
+    B = 3  # batched path: packed prefill + batched decode graph, next to the communicator as well
+    icb, imb = synthetic.images(cfg, dev, seed=2, batch=B)
+    ob = m.evaluate_batch(icb, imb, [ids[0]] * B, [cams[0]] * B, [(1024, 1024)] * B, [(1024, 1024)] * B, forced_new_tokens=forced)
+    allc = gather_contacts(torch.cat([o["pred_contact_3d"] for o in ob])).cpu()
+    assert allc.shape == (B, 6890)
     dist.barrier()
     dist.destroy_process_group()
     print("graphs + RCCL communicator: ok", tuple(outs[0].shape))
