@@ -55,6 +55,21 @@ def main():
                   f"{len(big)} ({sum(g[0] for g in big) / 1e6:.2f} ms)")
             for g in big[:12]:
                 print(f"      {g[0] / 1e3:8.1f} us at {g[3]:7.2f} ms after {g[1]} before {g[2]}")
+        # the same kernels while the other queue is busy vs after it went idle (what the two-stream overlap costs per kernel)
+        if len(by) == 2:
+            qs = sorted(by, key=lambda q_: len(by[q_]))
+            side_end = max(e_ for _, e_, _ in by[qs[0]])
+            agg = {}
+            for s_, e_, n_ in by[qs[1]]:
+                k = (n_.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:], e_ <= side_end)
+                a_ = agg.setdefault(k, [0, 0])
+                a_[0] += 1
+                a_[1] += e_ - s_
+            names = sorted({k[0] for k in agg}, key=lambda n_: -sum(agg.get((n_, f), [0, 0])[1] for f in (True, False)))
+            print(f"  main-queue kernels while the side queue is busy (until {(side_end - t0) / 1e6:.1f} ms) vs after:")
+            for n_ in names[:14]:
+                a_, b_ = agg.get((n_, True), [0, 0]), agg.get((n_, False), [0, 0])
+                print(f"      {n_[-52:]:<52} during: {a_[0]:5d} x {a_[1] / max(a_[0], 1) / 1e3:7.1f} us   after: {b_[0]:5d} x {b_[1] / max(b_[0], 1) / 1e3:7.1f} us")
         # decode-phase probe: time between consecutive llama_decode_attn kernels
         da = [(s, e) for n, s, e, q in seg if "llama_decode_attn" in n]
         if len(da) > 64:
