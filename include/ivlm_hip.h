@@ -132,6 +132,15 @@ int ivlm_gemm_bf16_splitk(const void *A, int64_t lda, const void *W, int64_t ldw
                           const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
                           int act, int out_f32, int splits, void *workspace, size_t workspace_bytes,
                           ivlm_stream_t stream);
+/* Tail-split variant for large GEMMs whose 256 x 256 tile count is just over a multiple of the 256 CUs (SAM mlp2:
+ * 16384 x 1280 -> 320 tiles = one full round + a quarter-filled one): the full rounds run as usual, the last tiles % 256
+ * tiles run as `splits` K slices on the otherwise idle CUs (tail * splits <= 256, K % (64*splits) == 0; fp32 partials in
+ * workspace [splits, M, N]) and are reduced with the bias / activation / residual epilogue by a second small kernel.
+ * Same result contract as ivlm_gemm_bf16 (batch 1, act != SwiGLU); IVLM_ERR_UNSUPPORTED when the shape does not qualify. */
+int ivlm_gemm_bf16_tailsplit(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
+                             const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
+                             int act, int out_f32, int splits, void *workspace, size_t workspace_bytes,
+                             ivlm_stream_t stream);
 
 /* Benchmark/test hook: M == 1 GEMVs use the wave-per-row kernel (0, default: faster as a stand-alone launch) or the flat
  * slab-streaming kernel (1; the streaming code of ivlm_llama_generate). */

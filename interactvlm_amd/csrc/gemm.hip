@@ -367,3 +367,22 @@ extern "C" int ivlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     g.out_f32 = out_f32;
     return ivlm::gemm_bf16_splitk(g, splits, static_cast<float*>(workspace), workspace_bytes, ivlm_stream(stream));
 }
+
+extern "C" int ivlm_gemm_bf16_tailsplit(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                        const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N,
+                                        int K, int act, int out_f32, int splits, void* workspace, size_t workspace_bytes,
+                                        ivlm_stream_t stream) {
+    ivlm_enter();
+    ivlm::GemmArgs g;
+    g.A = static_cast<const bf16_t*>(A);
+    g.W = static_cast<const bf16_t*>(W);
+    g.C = C;
+    g.bias = static_cast<const bf16_t*>(bias);
+    g.residual = static_cast<const bf16_t*>(residual);
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+    g.res_mod = res_mod;
+    g.M = M; g.N = N; g.K = K;
+    g.act = act;
+    g.out_f32 = out_f32;
+    return ivlm::gemm_bf16_tailsplit(g, splits, static_cast<float*>(workspace), workspace_bytes, ivlm_stream(stream));
+}

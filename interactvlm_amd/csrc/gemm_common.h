@@ -46,7 +46,8 @@ __device__ __forceinline__ void gemm_tile_origin(const GemmArgs& g, int BM, int 
     const int tiles_m = (g.M + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
     constexpr int kXcd = 8, kGroupM = 8;
-    const int xcd = blockIdx.x % kXcd, loc = blockIdx.x / kXcd;
+    const int bid = blockIdx.x + g.tile_offset;  // (tile_offset is a multiple of 8: the XCD of a block stays bid % 8)
+    const int xcd = bid % kXcd, loc = bid / kXcd;
     const int q = nwg / kXcd, r = nwg % kXcd;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     const int per_group = kGroupM * tiles_n;

@@ -22,6 +22,9 @@ struct GemmArgs {
     int batch = 1;
     int64_t strideA = 0, strideW = 0, strideC = 0, strideR = 0;
     int tile = 0;  // 0: choose, 128 / 256: force the block tile (benchmarks, tests)
+    // a launch may cover only the tiles [tile_offset, tile_offset + tile_count) of the raster (tile_count 0 = all): the tail
+    // round of a GEMM whose tile count is not a multiple of the CU count runs separately, K split over the idle CUs
+    int tile_offset = 0, tile_count = 0;
     // GEMV path only: fuse the preceding RMSNorm, out = W . (x * rsqrt(mean(x^2)+eps) * rms_w)
     const bf16_t* rms_w = nullptr;
     float rms_eps = 0.0f;
@@ -31,6 +34,9 @@ struct GemmArgs {
 int gemm_bf16(const GemmArgs& g, hipStream_t st);
 // 256x256 tile with the 8-phase ping-pong K loop (gemm256.hip); same contract as gemm_bf16
 int gemm_bf16_256p(const GemmArgs& g, hipStream_t st);
+// the same kernel with the last (tiles % 256) tiles - the under-filled final round - computed as `splits` K slices over the
+// otherwise idle CUs (fp32 partials in `workspace` [splits, M, N]) and reduced with the epilogue by a small second kernel
+int gemm_bf16_tailsplit(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st);
 // decode MLP in one launch: h = SwiGLU(W_gu . RMSNorm(x2)), x_out = x2 + W_down . h (down blocks wait on a device counter)
 int gemv_gu_down(const bf16_t* x2, const bf16_t* ln_w, float eps, const bf16_t* wgu, const bf16_t* wdown, bf16_t* h_scratch,
                  bf16_t* x_out, int hidden, int inter, const int32_t* step_dev, int32_t* counter, int32_t* status,

@@ -270,6 +270,27 @@ def _splitk_choice(M, N, K, act, rms):
     return best
 
 
+# opt-in: +12 % on SAM mlp2 in the warm micro-benchmark (244 -> 216 us), but 2 ms SLOWER end to end - three launches and
+# 67 MB of fp32 partials per GEMM next to a second stream that wants the same caches
+TAILSPLIT = False
+
+
+def _tail_choice(M, N, K, act, rms):
+    """K slices for the under-filled last round of a big GEMM on 256 x 256 tiles (0 = not applicable): the tile count is
+    above one round of the 256 CUs, the remainder at most half a round, and K long enough to be worth slicing."""
+    if not TAILSPLIT or act == "swiglu" or rms is not None or M < 4096 or N % 4 or K < 2048 or K % 64:
+        return 0
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    tail = tiles % 256
+    if tiles <= 256 or tail == 0 or tail > 128:
+        return 0
+    k64 = K // 64
+    for sp in range(min(256 // tail, 8), 1, -1):
+        if k64 % sp == 0:
+            return sp
+    return 0
+
+
 def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False, rms=None):
     """act(x @ weight.T + bias) + residual.  x [..., K] bf16 (last dim contiguous, uniform row stride),
     weight [N, K] bf16."""
@@ -304,6 +325,13 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
             x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
             _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out_f32 else 0, splits, ws.data_ptr(),
             ws.numel() * 4, _stream()), "gemm_bf16_splitk")
+    tsp = _tail_choice(M, N, K, act, rms) if splits <= 1 else 0
+    if tsp > 1 and o2.stride(0) % 4 == 0:
+        ws = torch.empty(tsp * M * N, dtype=torch.float32, device=x.device)  # only the tail tiles' region is touched
+        call = lambda: check(lib.ivlm_gemm_bf16_tailsplit(
+            x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
+            _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out_f32 else 0, tsp, ws.data_ptr(),
+            ws.numel() * 4, _stream()), "gemm_bf16_tailsplit")
     if TIMER.enabled:  # work = algorithmic FLOPs (MFMA path) or weight bytes (GEMV path)
         if M > 8:
             TIMER.time("gemm_bf16_mfma", 2.0 * M * N * K, call, tag=(M, N, K, act))

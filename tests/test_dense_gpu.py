@@ -352,3 +352,43 @@ def test_skinny_mfma_gemm_vs_fp32(hip_lib, cuda, M, N, K, act, rms, res, f32, bi
         finally:
             lib.ivlm_gemv_mfma_min_m(0)
         assert torch.allclose(got.float(), roww.float(), **tol)
+
+
+@pytest.mark.parametrize("M,N,K,act,res,f32,bias", [
+    (16384, 1280, 5120, "none", True, False, True),    # SAM mlp2: 320 tiles = one full round + 64 -> 4 K slices
+    (4352, 4096, 2048, "gelu", False, False, True),    # 272 tiles: tail 16 -> 8 K slices of 256
+    (4400, 4096, 2048, "none", True, True, False),     # ragged M (18 tile rows, last one partial): tail 32
+])
+def test_gemm_tailsplit_matches_single_pass(hip_lib, cuda, M, N, K, act, res, f32, bias):
+    """ivlm_gemm_bf16_tailsplit (the under-filled last round of 256 x 256 tiles runs as K slices on the idle CUs, fp32 partials
+    + a reduce kernel with the epilogue) against the single-pass kernel and fp32 torch."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(cuda)
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    b = _bf(0.1 * torch.randn(N, generator=g)).to(cuda) if bias else None
+    r = _bf(torch.randn(M, N, generator=g)).to(cuda) if res else None
+    kw = dict(bias=b, act=act, residual=r, out_f32=f32)
+    one = ops.linear(x, w, **kw)
+    ops.TAILSPLIT = True  # opt-in path
+    try:
+        assert ops._tail_choice(M, N, K, act, None) > 1
+        got = ops.linear(x, w, **kw)
+        assert torch.equal(got, ops.linear(x, w, **kw))  # deterministic (slice-ordered reduction)
+    finally:
+        ops.TAILSPLIT = False
+    y = x.float() @ w.float().T
+    if bias:
+        y = y + b.float()
+    y = _ref_act(y, act)
+    if res:
+        y = y + r.float()
+    tol = dict(atol=2e-3, rtol=1e-3) if f32 else dict(atol=3e-2, rtol=1.6e-2)
+    assert torch.allclose(got.float(), y, **tol) and torch.allclose(one.float(), y, **tol)
+    d = (got.float() - one.float()).abs()
+    frac = float((d > 0).float().mean())
+    assert frac < 0.3  # only the tail tiles can differ (and there only by the summation order)
+    print(f"\\n[tailsplit {M}x{N}x{K}] elements differing from the single-pass kernel: {100 * frac:.2f} %")
