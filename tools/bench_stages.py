@@ -13,6 +13,9 @@ def main():
     from interactvlm_amd import synthetic
 
     dev = torch.device("cuda:0")
+    if os.environ.get("IVLM_TILE"):  # force the GEMM block tile (64 / 96 / 128 / 256 / 512)
+        from interactvlm_amd import _lib
+        _lib.load().ivlm_gemm_tile_override(int(os.environ["IVLM_TILE"]))
     cfg = synthetic.config_7b()
     w = synthetic.device_weights(cfg, dev, seed=0)
     vid, bary = synthetic.body_lift_tables(dev)
