@@ -12,7 +12,11 @@
  *   - return value: 0 = IVLM_OK, negative = error (ivlm_error_string()); nothing throws
  *   - row-major contiguous tensors; shapes in comments use the reference's names:
  *       B images, V views, HW = H*W pixels, Nv mesh vertices, Np points
- *   - dtype codes: IVLM_F32 = 0, IVLM_BF16 = 1
+ *   - dtype codes: IVLM_F32 = 0, IVLM_BF16 = 1; IVLM_BF16_SPLIT = 2 (outputs of the row kernels only): a row of
+ *     `cols` fp32 values written as [hi(cols) | lo(cols)] bf16 with x = hi + lo to 2^-17 - the A operand of an
+ *     fp32-activation GEMM on the bf16 matrix cores (K' = 2K against [W | W])
+ *   - precision policy: weights bf16 (the checkpoint's own dtype); residual streams fp32; MFMA operands
+ *     bf16; the weight-streaming decode kernels (M <= 16) take fp32 activations with exact products.
  */
 #ifndef IVLM_HIP_H
 #define IVLM_HIP_H
@@ -32,6 +36,11 @@ extern "C" {
 
 #define IVLM_F32 0
 #define IVLM_BF16 1
+#define IVLM_BF16_SPLIT 2
+
+/* flags of ivlm_gemm_bf16 / ivlm_gemm_bf16_splitk */
+#define IVLM_GEMM_A_F32 1   /* A is fp32 [M,K] (M <= 16 weight-streaming paths only; lda % 4 == 0) */
+#define IVLM_GEMM_RES_F32 2 /* residual is fp32 (fp32 residual stream) */
 
 typedef void *ivlm_stream_t;
 
@@ -118,11 +127,17 @@ int ivlm_postprocess_masks(const void *low, int dtype, int n, int h, int w, int 
  * bf16 A/W/bias/residual, K % 8 == 0, lda/ldw % 8 == 0; C bf16 or f32 (out_f32).  batch > 1 runs a
  * strided batch (strides in elements).  M <= 8 takes the weight-streaming GEMV path (batch-1 decode:
  * HF greedy search under InteractVLM.evaluate, model/InteractVLM.py:524-531), K % 8 == 0 suffices there.
- * rms_w != NULL (M <= 8 only) fuses the preceding HF LlamaRMSNorm: C = act((A * rsqrt(mean(A^2)+rms_eps) * rms_w) . W^T). */
+ * rms_w != NULL (M <= 16 only) fuses the preceding HF LlamaRMSNorm: C = act((A * rsqrt(mean(A^2)+rms_eps) * rms_w) . W^T).
+ * flags: IVLM_GEMM_A_F32 (M <= 16: fp32 activations, exact bf16 x fp32 products in the GEMV, hi + lo bf16 operand split on the
+ * skinny MFMA kernel), IVLM_GEMM_RES_F32 (fp32 residual).
+ * out_rows != NULL (tile GEMM path, M > 16): scatter epilogue - row m of the product is written to row out_rows[m] of C and
+ * takes its residual from that row; rows with out_rows[m] < 0 are dropped (SAM window_unpartition + shortcut,
+ * image_encoder.py:186-190, folded into the proj GEMM; C may alias the residual). */
 int ivlm_gemm_bf16(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
                    const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
                    int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
-                   int64_t strideR, const void *rms_w, float rms_eps, ivlm_stream_t stream);
+                   int64_t strideR, const void *rms_w, float rms_eps, int flags, const int32_t *out_rows,
+                   ivlm_stream_t stream);
 
 /* Split-K variant for small-M GEMMs (LLaMA prefill, CLIP: too few output tiles for 256 CUs): same result contract as
  * ivlm_gemm_bf16 (batch 1, act != SwiGLU, no RMS fusion); K % (8*splits) == 0, N % 4 == 0.  fp32 partial sums of the
@@ -130,21 +145,8 @@ int ivlm_gemm_bf16(const void *A, int64_t lda, const void *W, int64_t ldw, void 
 size_t ivlm_gemm_splitk_workspace_bytes(int M, int N, int splits);
 int ivlm_gemm_bf16_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
                           const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
-                          int act, int out_f32, int splits, void *workspace, size_t workspace_bytes,
+                          int act, int out_f32, int splits, void *workspace, size_t workspace_bytes, int flags,
                           ivlm_stream_t stream);
-/* Tail-split variant for large GEMMs whose 256 x 256 tile count is just over a multiple of the 256 CUs (SAM mlp2:
- * 16384 x 1280 -> 320 tiles = one full round + a quarter-filled one): the full rounds run as usual, the last tiles % 256
- * tiles run as `splits` K slices on the otherwise idle CUs (tail * splits <= 256, K % (64*splits) == 0; fp32 partials in
- * workspace [splits, M, N]) and are reduced with the bias / activation / residual epilogue by a second small kernel.
- * Same result contract as ivlm_gemm_bf16 (batch 1, act != SwiGLU); IVLM_ERR_UNSUPPORTED when the shape does not qualify. */
-int ivlm_gemm_bf16_tailsplit(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
-                             const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
-                             int act, int out_f32, int splits, void *workspace, size_t workspace_bytes,
-                             ivlm_stream_t stream);
-
-/* Benchmark/test hook: M == 1 GEMVs use the wave-per-row kernel (0, default: faster as a stand-alone launch) or the flat
- * slab-streaming kernel (1; the streaming code of ivlm_llama_generate). */
-int ivlm_gemv_slab_enable(int on);
 /* Benchmark/test hook for the skinny-M dispatch: rows M in [min_m, 16] against matrices with K, N >= 1024 go to the
  * split-K MFMA kernel (csrc/gemv_mfma.hip) instead of the wave-per-row GEMV / tile GEMM; 0 restores the automatic choice. */
 int ivlm_gemv_mfma_min_m(int min_m);
@@ -153,13 +155,16 @@ int ivlm_gemv_mfma_min_m(int min_m);
 int ivlm_gemm_tile_override(int tile);
 
 /* nn.LayerNorm over the last dim (also SAM LayerNorm2d with NHWC activations, common.py:32-42);
- * bf16 in/out, fp32 statistics, cols % 8 == 0, cols <= 8192.  gelu_after != 0 fuses the exact-erf GELU that
- * follows LayerNorm2d in the mask decoder's upscaler (mask_decoder.py:53-63). */
-int ivlm_layernorm_bf16(const void *x, const void *w, const void *b, void *y, int64_t rows, int cols,
-                        float eps, int gelu_after, ivlm_stream_t stream);
-/* HF LlamaRMSNorm: y = w * bf16(x * rsqrt(mean(x^2) + eps)). */
-int ivlm_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t rows, int cols, float eps,
-                      ivlm_stream_t stream);
+ * x / y bf16 or fp32 (dtype codes), fp32 statistics, cols % 8 == 0, cols <= 8192.  gelu_after != 0 fuses the exact-erf GELU
+ * that follows LayerNorm2d in the mask decoder's upscaler (mask_decoder.py:53-63).  out_rows != NULL: row r is written to
+ * row out_rows[r] of y (SAM window_partition, image_encoder.py:263-288, folded into norm1; the caller keeps the padded rows
+ * of y zero). */
+int ivlm_layernorm(const void *x, int x_dtype, const void *w, const void *b, void *y, int y_dtype, int64_t rows, int cols,
+                   float eps, int gelu_after, const int32_t *out_rows, ivlm_stream_t stream);
+/* HF LlamaRMSNorm: y = w * (x * rsqrt(mean(x^2) + eps)); a bf16 x is cast back to bf16 before the weight multiply as HF
+ * does, an fp32 x (fp32 residual stream) is not. */
+int ivlm_rmsnorm(const void *x, int x_dtype, const void *w, void *y, int y_dtype, int64_t rows, int cols, float eps,
+                 ivlm_stream_t stream);
 
 /* Fused multi-head attention: o = softmax(scale * q.k^T + bias + mask) . v, never materialising
  * the score matrix (SAM image_encoder.py:235-260, transformer.py:220-242; HF CLIP / LLaMA attention).
@@ -172,6 +177,12 @@ int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, co
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float *rel_h,
                         const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q,
                         ivlm_stream_t stream);
+/* The same operator with fp32 q / k / v / o and no operand rounding, for the SAM mask decoder's small attentions
+ * (transformer.py:220-242: head dim 16 or 32; 9 tokens x 4096 image positions or the reverse) and the AttentionSplitter
+ * (components.py:155-193: one head of 128 over V keys): scores = (q.k) * scale, fp32 softmax, fp32 P.V on the VALU.
+ * D % 4 == 0, D <= 256 (16 / 32 take the fast kernels).  Strides as above but multiples of 4. */
+int ivlm_attention_f32(const float *q, const float *k, const float *v, float *o, const int64_t *strides_host, int B, int H,
+                       int Sq, int Sk, int D, float scale, int kv_batch_div, ivlm_stream_t stream);
 /* Benchmark/test hook: -1 (default) picks per shape; 0 forces the 4-wave / 128-query block, 1 the 8-wave ping-pong block
  * (256 queries; one wave group on the matrix unit while the other does its softmax on the VALU). */
 int ivlm_attention_pingpong(int mode);
@@ -187,47 +198,21 @@ int ivlm_relpos_bias(const void *q, int64_t q_bs, int64_t q_hs, int64_t q_rs, co
 int ivlm_relpos_gather(const void *G, int64_t g_head_stride, int npad, int B, int H, int SH, int SW, float *rel_h,
                        float *rel_w, ivlm_stream_t stream);
 
-/* Whole greedy generation after the prefill, in ONE persistent launch (HF GenerationMixin greedy search driven by
- * InteractVLM.evaluate, model/InteractVLM.py:524-531; per token: LlamaModel.forward of one position with the KV
- * cache, final RMSNorm, lm_head, argmax, embed_tokens of the chosen id).  One resident workgroup per CU streams
- * contiguous row slabs of every weight matrix; phases are separated by a device-wide barrier; argmax, the EOS test
- * and the optional forced ids run on the device.
- *   layer_ptrs  device int64 [L][6]: addresses of input_layernorm.weight, q|k|v weight [3*hidden, hidden] (q, k, v
- *               rows concatenated), o_proj.weight, post_attention_layernorm.weight, gate|up weight [2*inter, hidden]
- *               (rows interleaved gate_0, up_0, gate_1, ...), down_proj.weight [hidden, inter]; all bf16, dense.
- *   kcache/vcache bf16 [L, max_len, H, D] (cache_layer_stride elements per layer), holding positions < pos0.
- *   hidden_out  bf16 [>= pos0 + n_max - 1, hidden]: row pos0-1 is the INPUT (final-normed hidden state of the last
- *               prompt position); rows pos0.. receive the final-normed hidden state of each generated position.
- *   forced      int32 [n_max] or NULL: ids fed back instead of the argmax (teacher forcing; argmax still computed).
- *   new_ids / argmax_ids int32 [n_max]; generation stops after an id == eos or n_max ids.
- *   workspace   >= ivlm_llama_generate_workspace_bytes, 256-byte aligned; after the stream has drained, its first two
- *               int32 are {number of ids generated, error flag (1: a barrier wait exceeded 2 s - results invalid)}.
- * hidden, inter >= 512 and % 8 == 0, H * D == hidden, D <= 128, H <= number of CUs. */
-size_t ivlm_llama_generate_workspace_bytes(int hidden, int inter);
-int ivlm_llama_generate(const int64_t *layer_ptrs, int L, int H, int D, int hidden, int inter, int vocab, float eps,
-                        float scale, const float *cos_tab, const float *sin_tab, void *kcache, void *vcache,
-                        int64_t cache_layer_stride, int max_len, const void *embed, const void *final_norm,
-                        const void *lm_head, void *hidden_out, int pos0, int n_max, int eos, const int32_t *forced,
-                        int32_t *new_ids, int32_t *argmax_ids, void *workspace, size_t workspace_bytes,
-                        ivlm_stream_t stream);
-
 /* One decode step of HF LlamaAttention with a KV cache, for the newest token only: rotate-half RoPE of q,k at
- * position pos, append k,v to kcache/vcache [Tmax,H,D], o = softmax(q.K[0..pos]^T * scale).V[0..pos].
- * qkv bf16 [3,H,D] (output of the fused q|k|v projection), o bf16 [H,D]; D <= 128, pos < 4096. */
-int ivlm_llama_decode_attn(const void *qkv, void *kcache, void *vcache, void *o, int H, int D, int pos,
-                           float theta, float scale, const float *cos_tab, const float *sin_tab,
+ * position pos, append k,v (rounded to bf16) to kcache/vcache [tmax,H,D], o = softmax(q.K[0..pos]^T * scale).V[0..pos].
+ * qkv [3,H,D] (output of the fused q|k|v projection) and o [H,D] are bf16 or fp32 (io_dtype): with fp32 I/O q and the softmax
+ * weights are not rounded (the decode path keeps fp32 activations), with bf16 they are rounded like the MFMA prefill path.
+ * pos_dev != NULL: the position is read from device memory (one captured HIP graph then serves every decode step).
+ * A position >= tmax (or >= 4096) is skipped: nothing is appended, o is left untouched.  D <= 128. */
+int ivlm_llama_decode_attn(const void *qkv, int io_dtype, void *kcache, void *vcache, int tmax, void *o, int H, int D, int pos,
+                           const int32_t *pos_dev, float theta, float scale, const float *cos_tab, const float *sin_tab,
                            ivlm_stream_t stream);
-/* Same, with the position read from device memory (int32 *pos_dev; the caller keeps *pos_dev < Tmax and < 4096): one
- * captured HIP graph of a decode step can then be replayed for every generated token. */
-int ivlm_llama_decode_attn_devpos(const void *qkv, void *kcache, void *vcache, void *o, int H, int D,
-                                  const int32_t *pos_dev, float theta, float scale, const float *cos_tab,
-                                  const float *sin_tab, ivlm_stream_t stream);
 
 /* B sequences in one launch (grid H x B): sequence b reads qkv + b*ldq, appends to kcache/vcache + b*cache_stride
- * ([Tmax,H,D] each), writes o + b*ldo and sits at position pos_dev[b] (strides in elements, multiples of 8).  The
+ * ([tmax,H,D] each), writes o + b*ldo and sits at position pos_dev[b] (strides in elements, multiples of 8).  The
  * batched counterpart of the reference's padded-batch generate (model/InteractVLM.py:524-531 with B > 1 prompts). */
-int ivlm_llama_decode_attn_batch(const void *qkv, int64_t ldq, void *kcache, void *vcache, int64_t cache_stride,
-                                 void *o, int64_t ldo, int B, int H, int D, const int32_t *pos_dev, float theta,
+int ivlm_llama_decode_attn_batch(const void *qkv, int io_dtype, int64_t ldq, void *kcache, void *vcache, int64_t cache_stride,
+                                 int tmax, void *o, int64_t ldo, int B, int H, int D, const int32_t *pos_dev, float theta,
                                  float scale, const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
 
 /* torch.argmax(logits, -1) of HF greedy search (first maximal index); x f32 [rows, cols] -> out i32 [rows]. */
@@ -242,51 +227,33 @@ int ivlm_im2col_nchw(const void *x, void *out, int B, int C, int H, int W, int k
                      ivlm_stream_t stream);
 /* 3x3 / pad 1 conv operand from channels-last x [B,H,W,C] -> [(b,y,x), (ky,kx,c)] (SAM neck, image_encoder.py:92-108) */
 int ivlm_im2col3x3_nhwc(const void *x, void *out, int B, int H, int W, int C, ivlm_stream_t stream);
-/* dst[r] = (idx[r] >= 0 ? src[idx[r]] : 0) + (add ? add[r] : 0): window_partition / window_unpartition + shortcut
- * (image_encoder.py:263-318, 177-193), embed_tokens gather (llava_arch.py:185-208). */
-int ivlm_gather_rows(void *dst, int64_t ldd, const void *src, int64_t lds, const int32_t *idx, const void *add,
-                     int64_t lda, int64_t rows, int cols, ivlm_stream_t stream);
+/* dst[r] = (idx ? (idx[r] >= 0 ? src[idx[r]] : 0) : src[r]) + (add ? add[r] : 0): window_partition / window_unpartition +
+ * shortcut (image_encoder.py:263-318, 177-193), embed_tokens gather (llava_arch.py:185-208), dtype conversion.  src / add
+ * bf16 or fp32, dst bf16, fp32 or IVLM_BF16_SPLIT (row stride ldd >= 2*cols). */
+int ivlm_gather_rows(void *dst, int dst_kind, int64_t ldd, const void *src, int src_dtype, int64_t lds, const int32_t *idx,
+                     const void *add, int add_dtype, int64_t lda, int64_t rows, int cols, ivlm_stream_t stream);
 /* out[r] = a[r] (op 0: +, op 1: *) b[r % b_rows]  (queries + query_pe, keys + key_pe: transformer.py:160-176;
- * [SEG] embedding * view encoding: InteractVLM.py:275-282) */
-int ivlm_add_rows(void *out, const void *a, const void *b, int64_t rows, int cols, int64_t b_rows, int op,
-                  ivlm_stream_t stream);
-/* PositionEmbeddingRandom.forward (prompt_encoder.py:219-229): gauss f32 [2,F] -> pe bf16 [h*w, 2F]
+ * [SEG] embedding * view encoding: InteractVLM.py:275-282); a / b bf16 or fp32, out bf16, fp32 or IVLM_BF16_SPLIT
+ * (dense rows of 2*cols). */
+int ivlm_add_rows(void *out, int out_kind, const void *a, int a_dtype, const void *b, int b_dtype, int64_t rows, int cols,
+                  int64_t b_rows, int op, ivlm_stream_t stream);
+/* PositionEmbeddingRandom.forward (prompt_encoder.py:219-229): gauss f32 [2,F] -> pe bf16 | fp32 [h*w, 2F]
  * (the table is a constant of the weights: computed once at load, in fp32) */
-int ivlm_dense_pe(const void *gauss, void *pe, int h, int w, int F, ivlm_stream_t stream);
+int ivlm_dense_pe(const void *gauss, void *pe, int pe_dtype, int h, int w, int F, ivlm_stream_t stream);
 /* HF LlamaAttention rotary (rotate-half, base theta) applied in place to q,k of qkv [T,3,H,D] (row stride ld) at
  * positions pos0+t, and KV-cache append (kcache/vcache [Tmax,H,D], may be NULL). */
 int ivlm_rope_kv(void *qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void *kcache, void *vcache,
                  const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
-/* Decode attention (as ivlm_llama_decode_attn_devpos) and the o_proj GEMV + residual of the same layer in ONE launch:
- * x_out[hidden] = x + W_o . attention(qkv).  The o_proj blocks stream their weight rows while the attention blocks run and
- * wait for them on `counter` (int32, zeroed by the caller at the start of a generation; `step_dev` = tokens decoded so far,
- * incremented by the caller after each token; target = H * (step + 1)).  attn_scratch: hidden bf16.  status[0] != 0 after the
- * stream drained = a bounded wait expired (results invalid).  hidden = H*D in {512, 1024, 4096, 5120}. */
-int ivlm_llama_attn_oproj(const void *qkv, void *kcache, void *vcache, void *attn_scratch, const void *wo, const void *x,
-                          void *x_out, int H, int D, float theta, float scale, const float *cos_tab, const float *sin_tab,
-                          const int32_t *pos_dev, const int32_t *step_dev, int32_t *counter, int32_t *status,
-                          ivlm_stream_t stream);
-/* ALL decoder layers of one generated token in ONE launch, as a dataflow of role-specialised workgroups (q|k|v rows ->
- * attention heads -> o_proj rows -> gate|up pairs -> down rows, layer after layer): every block streams its weight rows first
- * and then waits on a device counter for the blocks that produce its input, so no launch / barrier bubble stalls HBM.
- *   layer_ptrs as for ivlm_llama_generate; kcache/vcache bf16 [L, Tmax, H, D]; x0 bf16 [hidden] = embedding of the token;
- *   x_out bf16 [hidden] = residual stream after the last layer (before the final RMSNorm);
- *   pos_dev / step_dev: int32 in device memory (position of the token; tokens decoded so far in this generation);
- *   workspace: ivlm_llama_decode_layers_workspace_bytes, 256-byte aligned; its first L*5*32 int32 (counters) and the
- *   following int32 (status) must be zeroed by the caller at the start of a generation; status != 0 afterwards = a bounded
- *   wait expired, results invalid.  (hidden, inter) in {(4096,11008), (5120,13824), (1024,1376), (512,1024)}. */
-size_t ivlm_llama_decode_layers_workspace_bytes(int L, int hidden, int inter);
-int ivlm_llama_decode_layers(const int64_t *layer_ptrs, int L, int H, int D, int hidden, int inter, float eps, float theta,
-                             float scale, const float *cos_tab, const float *sin_tab, void *kcache, void *vcache,
-                             int64_t cache_layer_stride, const void *x0, void *x_out, const int32_t *pos_dev,
-                             const int32_t *step_dev, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
-/* The MLP of a decode layer (HF LlamaMLP + post_attention_layernorm + residual) in ONE launch:
- * x_out = x2 + W_down . (SiLU(g) * u), (g_j, u_j) = rows (2j, 2j+1) of wgu . RMSNorm(x2).  The down_proj blocks stream their
- * first weight rows while the gate|up blocks run and wait for them on `counter` (zeroed at the start of a generation;
- * target = number of gate|up blocks * (*step_dev + 1)); h_scratch bf16 [inter]; status as for ivlm_llama_attn_oproj. */
-int ivlm_llama_gateup_down(const void *x2, const void *ln_w, float eps, const void *wgu, const void *wdown, void *h_scratch,
-                           void *x_out, int hidden, int inter, const int32_t *step_dev, int32_t *counter, int32_t *status,
-                           ivlm_stream_t stream);
+/* Decode attention (as ivlm_llama_decode_attn with fp32 I/O and a device position) and the o_proj GEMV + residual of the same
+ * layer in ONE launch: x_out[hidden] = x + W_o . attention(qkv), qkv / x / x_out fp32 (fp32 residual stream), W_o bf16.  The
+ * o_proj blocks stream their weight rows while the attention blocks run and wait for them on `counter` (int32, zeroed by the
+ * caller at the start of a generation; `step_dev` = tokens decoded so far, incremented by the caller after each token;
+ * target = H * (step + 1)).  attn_scratch: hidden fp32.  status[0] != 0 after the stream drained = a bounded wait expired
+ * (results invalid).  hidden = H*D in {512, 1024, 4096, 5120}; the grid (H + hidden/32 blocks) must fit the CUs. */
+int ivlm_llama_attn_oproj(const float *qkv, void *kcache, void *vcache, int tmax, float *attn_scratch, const void *wo,
+                          const float *x, float *x_out, int H, int D, float theta, float scale, const float *cos_tab,
+                          const float *sin_tab, const int32_t *pos_dev, const int32_t *step_dev, int32_t *counter,
+                          int32_t *status, ivlm_stream_t stream);
 /* fp32 rotary tables cos/sin [T, D/2] (optional inputs of ivlm_rope_kv / ivlm_llama_decode_attn; NULL = compute) */
 int ivlm_rope_table(float *cos_tab, float *sin_tab, int T, int D, float theta, ivlm_stream_t stream);
 /* Caller-side image preprocessing (run_demo.py:65-79 `preprocess`: (x - mean)/std then zero-pad to the square model
@@ -294,10 +261,10 @@ int ivlm_rope_table(float *cos_tab, float *sin_tab, int T, int D, float theta, i
  * (y0,x0,ch,cw) -> out bf16|f32 [3,OH,OW].  mean3/std3 are HOST pointers in 0..255 units. */
 int ivlm_normalize_pad_u8(const uint8_t *src, int H, int W, int y0, int x0, int ch, int cw, const float *mean3_host,
                           const float *std3_host, void *out, int out_bf16, int OH, int OW, ivlm_stream_t stream);
-/* masks = hyper_in @ upscaled_embedding (mask_decoder.py:150-153) for one mask token: up bf16
- * [B,gh,gw,2,2,2,2,C] (output of the two k2s2 transposed convs, channels last), hyper bf16 [B,C]
+/* masks = hyper_in @ upscaled_embedding (mask_decoder.py:150-153) for one mask token: up
+ * [B,gh,gw,2,2,2,2,C] (output of the two k2s2 transposed convs, channels last), hyper [B,C], both bf16 or both fp32 (dtype)
  * -> low f32 [B,4gh,4gw] */
-int ivlm_mask_dot(const void *up, const void *hyper, float *low, int B, int gh, int gw, int C,
+int ivlm_mask_dot(const void *up, const void *hyper, int dtype, float *low, int B, int gh, int gw, int C,
                   ivlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ void ivlm_set_last_hip_error(int code, const char* where) {
 
 const char* ivlm_last_hip_error(void) { return g_last_hip_error; }
 
-int ivlm_abi_version(void) { return 1; }
+int ivlm_abi_version(void) { return 2; }  // 2: fp32 residual streams / fp32 activation flags (round 2)
 
 const char* ivlm_build_arch(void) { return "gfx950"; }
 

@@ -12,75 +12,79 @@ namespace {
 
 using namespace decattn;
 
-__global__ __launch_bounds__(kDecThreads) void llama_decode_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kcache,
-                                                                        bf16_t* __restrict__ vcache, bf16_t* __restrict__ o, int H,
+template <bool F32IO>
+__global__ __launch_bounds__(kDecThreads) void llama_decode_attn_kernel(const void* __restrict__ qkv, bf16_t* __restrict__ kcache,
+                                                                        bf16_t* __restrict__ vcache, void* __restrict__ o, int H,
                                                                         int D, int pos_arg, float theta, float scale,
                                                                         const float* __restrict__ ct,
                                                                         const float* __restrict__ stab,
-                                                                        const int32_t* __restrict__ pos_dev) {
-    llama_decode_attn_body<false>(blockIdx.x, qkv, kcache, vcache, o, H, D, pos_arg, theta, scale, ct, stab, pos_dev);
+                                                                        const int32_t* __restrict__ pos_dev, int tmax) {
+    llama_decode_attn_body<false, F32IO>(blockIdx.x, qkv, kcache, vcache, o, H, D, pos_arg, theta, scale, ct, stab, pos_dev, tmax);
 }
 
 // B sequences of one decode step: blockIdx.y picks the sequence; each has its own cache slab, qkv row, output row and
 // position (the sequences of a batch sit at different lengths: prompts differ, model/InteractVLM.py:524-531 pads them).
+template <bool F32IO>
 __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_batch_kernel(
-    const bf16_t* __restrict__ qkv, int64_t ldq, bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache, int64_t cache_stride,
-    bf16_t* __restrict__ o, int64_t ldo, int H, int D, float theta, float scale, const float* __restrict__ ct,
-    const float* __restrict__ stab, const int32_t* __restrict__ pos_dev) {
+    const void* __restrict__ qkv, int64_t ldq, bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache, int64_t cache_stride,
+    void* __restrict__ o, int64_t ldo, int H, int D, float theta, float scale, const float* __restrict__ ct,
+    const float* __restrict__ stab, const int32_t* __restrict__ pos_dev, int tmax) {
     const int b = blockIdx.y;
-    llama_decode_attn_body<false>(blockIdx.x, qkv + b * ldq, kcache + b * cache_stride, vcache + b * cache_stride, o + b * ldo, H,
-                                  D, 0, theta, scale, ct, stab, pos_dev + b);
+    constexpr int esz = F32IO ? 4 : 2;
+    llama_decode_attn_body<false, F32IO>(blockIdx.x, static_cast<const char*>(qkv) + b * ldq * esz, kcache + b * cache_stride,
+                                         vcache + b * cache_stride, static_cast<char*>(o) + b * ldo * esz, H, D, 0, theta, scale,
+                                         ct, stab, pos_dev + b, tmax);
 }
 
 }  // namespace
 
-int llama_decode_attn_batch(const bf16_t* qkv, int64_t ldq, bf16_t* kcache, bf16_t* vcache, int64_t cache_stride, bf16_t* o,
-                            int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta, float scale,
+int llama_decode_attn_batch(const void* qkv, int io_f32, int64_t ldq, bf16_t* kcache, bf16_t* vcache, int64_t cache_stride,
+                            int tmax, void* o, int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta, float scale,
                             const float* cos_tab, const float* sin_tab, hipStream_t st) {
     if (!qkv || !kcache || !vcache || !o || !pos_dev) return IVLM_ERR_INVALID_ARG;
     if (B <= 0 || B > 65535 || H <= 0 || D <= 0 || D > kMaxD || (D & 15)) return IVLM_ERR_INVALID_ARG;
     if (ldq < 3LL * H * D || ldo < (int64_t)H * D || cache_stride < (int64_t)H * D || ((ldq | ldo | cache_stride) & 7))
         return IVLM_ERR_INVALID_ARG;  // 16-byte rows
-    llama_decode_attn_batch_kernel<<<dim3(H, B), kDecThreads, 0, st>>>(qkv, ldq, kcache, vcache, cache_stride, o, ldo, H, D,
-                                                                        theta, scale, cos_tab, sin_tab, pos_dev);
+    if (tmax <= 0 || (int64_t)tmax * H * D > cache_stride) return IVLM_ERR_INVALID_ARG;
+    if (io_f32)
+        llama_decode_attn_batch_kernel<true><<<dim3(H, B), kDecThreads, 0, st>>>(qkv, ldq, kcache, vcache, cache_stride, o, ldo, H,
+                                                                                  D, theta, scale, cos_tab, sin_tab, pos_dev, tmax);
+    else
+        llama_decode_attn_batch_kernel<false><<<dim3(H, B), kDecThreads, 0, st>>>(qkv, ldq, kcache, vcache, cache_stride, o, ldo, H,
+                                                                                   D, theta, scale, cos_tab, sin_tab, pos_dev, tmax);
     return ivlm_launch_status();
 }
 
-int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
-                      float scale, hipStream_t st, const float* cos_tab, const float* sin_tab, const int32_t* pos_dev) {
-    if (!qkv || !kcache || !vcache || !o || H <= 0 || D <= 0 || D > kMaxD || (D & 15)) return IVLM_ERR_INVALID_ARG;
-    if (!pos_dev && (pos < 0 || pos >= kMaxT)) return IVLM_ERR_INVALID_ARG;
-    llama_decode_attn_kernel<<<H, kDecThreads, 0, st>>>(qkv, kcache, vcache, o, H, D, pos, theta, scale, cos_tab, sin_tab,
-                                                       pos_dev);
+int llama_decode_attn(const void* qkv, int io_f32, bf16_t* kcache, bf16_t* vcache, int tmax, void* o, int H, int D, int pos,
+                      float theta, float scale, hipStream_t st, const float* cos_tab, const float* sin_tab,
+                      const int32_t* pos_dev) {
+    if (!qkv || !kcache || !vcache || !o || H <= 0 || D <= 0 || D > kMaxD || (D & 15) || tmax <= 0) return IVLM_ERR_INVALID_ARG;
+    if (!pos_dev && (pos < 0 || pos >= kMaxT || pos >= tmax)) return IVLM_ERR_INVALID_ARG;
+    if (io_f32)
+        llama_decode_attn_kernel<true><<<H, kDecThreads, 0, st>>>(qkv, kcache, vcache, o, H, D, pos, theta, scale, cos_tab, sin_tab,
+                                                                  pos_dev, tmax);
+    else
+        llama_decode_attn_kernel<false><<<H, kDecThreads, 0, st>>>(qkv, kcache, vcache, o, H, D, pos, theta, scale, cos_tab,
+                                                                   sin_tab, pos_dev, tmax);
     return ivlm_launch_status();
 }
 
 }  // namespace ivlm
 
-extern "C" int ivlm_llama_decode_attn(const void* qkv, void* kcache, void* vcache, void* o, int H, int D, int pos,
-                                      float theta, float scale, const float* cos_tab, const float* sin_tab,
-                                      ivlm_stream_t stream) {
+extern "C" int ivlm_llama_decode_attn(const void* qkv, int io_dtype, void* kcache, void* vcache, int tmax, void* o, int H, int D,
+                                      int pos, const int32_t* pos_dev, float theta, float scale, const float* cos_tab,
+                                      const float* sin_tab, ivlm_stream_t stream) {
     ivlm_enter();
-    return ivlm::llama_decode_attn(static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(kcache),
-                                   static_cast<bf16_t*>(vcache), static_cast<bf16_t*>(o), H, D, pos, theta, scale,
-                                   ivlm_stream(stream), cos_tab, sin_tab, nullptr);
+    return ivlm::llama_decode_attn(qkv, io_dtype == IVLM_F32, static_cast<bf16_t*>(kcache), static_cast<bf16_t*>(vcache), tmax, o,
+                                   H, D, pos, theta, scale, ivlm_stream(stream), cos_tab, sin_tab, pos_dev);
 }
 
-extern "C" int ivlm_llama_decode_attn_devpos(const void* qkv, void* kcache, void* vcache, void* o, int H, int D,
-                                             const int32_t* pos_dev, float theta, float scale, const float* cos_tab,
-                                             const float* sin_tab, ivlm_stream_t stream) {
+extern "C" int ivlm_llama_decode_attn_batch(const void* qkv, int io_dtype, int64_t ldq, void* kcache, void* vcache,
+                                            int64_t cache_stride, int tmax, void* o, int64_t ldo, int B, int H, int D,
+                                            const int32_t* pos_dev, float theta, float scale, const float* cos_tab,
+                                            const float* sin_tab, ivlm_stream_t stream) {
     ivlm_enter();
-    if (!pos_dev) return IVLM_ERR_INVALID_ARG;
-    return ivlm::llama_decode_attn(static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(kcache),
-                                   static_cast<bf16_t*>(vcache), static_cast<bf16_t*>(o), H, D, 0, theta, scale,
-                                   ivlm_stream(stream), cos_tab, sin_tab, pos_dev);
-}
-
-extern "C" int ivlm_llama_decode_attn_batch(const void* qkv, int64_t ldq, void* kcache, void* vcache, int64_t cache_stride,
-                                            void* o, int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta,
-                                            float scale, const float* cos_tab, const float* sin_tab, ivlm_stream_t stream) {
-    ivlm_enter();
-    return ivlm::llama_decode_attn_batch(static_cast<const bf16_t*>(qkv), ldq, static_cast<bf16_t*>(kcache),
-                                         static_cast<bf16_t*>(vcache), cache_stride, static_cast<bf16_t*>(o), ldo, B, H, D,
-                                         pos_dev, theta, scale, cos_tab, sin_tab, ivlm_stream(stream));
+    return ivlm::llama_decode_attn_batch(qkv, io_dtype == IVLM_F32, ldq, static_cast<bf16_t*>(kcache),
+                                         static_cast<bf16_t*>(vcache), cache_stride, tmax, o, ldo, B, H, D, pos_dev, theta, scale,
+                                         cos_tab, sin_tab, ivlm_stream(stream));
 }

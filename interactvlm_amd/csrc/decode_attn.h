@@ -12,24 +12,23 @@ constexpr int kDecThreads = 1024, kDecGroups = kDecThreads / 16;  // 64 key rows
 
 // body shared by the stand-alone kernel below and the fused attention + o_proj kernel (decode_fused.hip).
 // COHERENT_OUT: the output row is written with agent-scope (sc1) stores, for consumers inside the same launch.
-// COHERENT_IN: qkv was produced by other blocks of the same launch: read it with agent-scope loads, after wait_fn()
-// (called once per thread, after the K/V rows are in flight; returns false => give up) has seen the producers arrive.
-struct NoWait {
-    __device__ __forceinline__ bool operator()() const { return true; }
-};
-template <bool COHERENT_OUT, bool COHERENT_IN = false, class WaitFn = NoWait, int THREADS = 1024>
-__device__ __forceinline__ void llama_decode_attn_body(const int h, const bf16_t* __restrict__ qkv /*[3,H,D]*/,
+// F32IO: qkv and the output row are fp32 (the decode path keeps fp32 activations between its weight-streaming kernels: q and
+// the softmax weights are then NOT rounded to bf16 - only the K/V rows appended to the bf16 cache are); otherwise bf16 in/out
+// with the roundings of the MFMA prefill path (q, k after RoPE and P rounded to bf16).
+template <bool COHERENT_OUT, bool F32IO = false, int THREADS = 1024>
+__device__ __forceinline__ void llama_decode_attn_body(const int h, const void* __restrict__ qkv_v /*[3,H,D]*/,
                                                                 bf16_t* __restrict__ kcache /*[Tmax,H,D]*/,
-                                                                bf16_t* __restrict__ vcache, bf16_t* __restrict__ o,
+                                                                bf16_t* __restrict__ vcache, void* __restrict__ o_v,
                                                                 int H, int D, int pos_arg, float theta, float scale,
                                                                 const float* __restrict__ ct,
                                                                 const float* __restrict__ stab,
-                                                                const int32_t* __restrict__ pos_dev,
-                                                                WaitFn wait_fn = WaitFn()) {
+                                                                const int32_t* __restrict__ pos_dev, int tmax = 0) {
     constexpr int kDecThreads = THREADS, kDecGroups = THREADS / 16;  // (shadow the namespace defaults)
     // position from device memory when given: lets one captured HIP graph serve every decode step
     const int pos = pos_dev ? __builtin_amdgcn_readfirstlane(*pos_dev) : pos_arg;
     (void)theta;
+    // a sequence that has filled its cache slab (batched generation keeps stepping finished sequences) must not append
+    if ((tmax > 0 && pos >= tmax) || pos >= kMaxT) return;
     __shared__ float q_s[kMaxD];
     __shared__ float knew_s[kMaxD];
     __shared__ float vnew_s[kMaxD];
@@ -57,15 +56,12 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const bf16_t
         kr[i] = *reinterpret_cast<const u32x4_t*>(kb + j * rstride);
         vr[i] = *reinterpret_cast<const u32x4_t*>(vb + j * rstride);
     }
-    if (!wait_fn()) return;
-    auto ld = [](const bf16_t* p) -> bf16_t {
-        if (COHERENT_IN) return __hip_atomic_load(const_cast<bf16_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return *p;
-    };
+    const bf16_t* qkv = static_cast<const bf16_t*>(qkv_v);
+    const float* qkvf = static_cast<const float*>(qkv_v);
+    auto ld = [&](int64_t e) -> float { return F32IO ? qkvf[e] : bf16_to_f32(qkv[e]); };
     // ---- RoPE on q and the new k; append k, v to the cache -------------------------------------
     if (t < half) {
-        const bf16_t* q = qkv + h * D;
-        const bf16_t* k = qkv + (int64_t)H * D + h * D;
+        const int64_t q = (int64_t)h * D, k = (int64_t)H * D + h * D;
         float c, s;
         if (ct) {
             c = ct[pos * half + t];
@@ -75,23 +71,24 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const bf16_t
             c = cosf(ang);
             s = sinf(ang);
         }
-        const float q0 = bf16_to_f32(ld(q + t)), q1 = bf16_to_f32(ld(q + t + half));
-        const float k0 = bf16_to_f32(ld(k + t)), k1 = bf16_to_f32(ld(k + t + half));
-        // round q, k to bf16 exactly like the prefill path (rope_kv_kernel) so both paths see the same values
-        const bf16_t qa = f32_to_bf16(q0 * c - q1 * s), qb = f32_to_bf16(q1 * c + q0 * s);
-        const bf16_t ka = f32_to_bf16(k0 * c - k1 * s), kb = f32_to_bf16(k1 * c + k0 * s);
-        q_s[t] = bf16_to_f32(qa);
-        q_s[t + half] = bf16_to_f32(qb);
-        knew_s[t] = bf16_to_f32(ka);
-        knew_s[t + half] = bf16_to_f32(kb);
+        const float q0 = ld(q + t), q1 = ld(q + t + half);
+        const float k0 = ld(k + t), k1 = ld(k + t + half);
+        const float qaf = q0 * c - q1 * s, qbf = q1 * c + q0 * s, kaf = k0 * c - k1 * s, kbf = k1 * c + k0 * s;
+        // bf16 I/O: round q, k to bf16 exactly like the prefill path (rope_kv_kernel) so both paths see the same values
+        const bf16_t qa = f32_to_bf16(qaf), qb = f32_to_bf16(qbf);
+        const bf16_t ka = f32_to_bf16(kaf), kb = f32_to_bf16(kbf);
+        q_s[t] = F32IO ? qaf : bf16_to_f32(qa);
+        q_s[t + half] = F32IO ? qbf : bf16_to_f32(qb);
+        knew_s[t] = F32IO ? kaf : bf16_to_f32(ka);
+        knew_s[t + half] = F32IO ? kbf : bf16_to_f32(kb);
         bf16_t* kc = kcache + ((int64_t)pos * H + h) * D;
         kc[t] = ka;
         kc[t + half] = kb;
     } else if (t >= 128 && t < 128 + D) {
         const int d = t - 128;
-        const bf16_t v = ld(qkv + 2 * (int64_t)H * D + h * D + d);
-        vnew_s[d] = bf16_to_f32(v);
-        vcache[((int64_t)pos * H + h) * D + d] = v;
+        const float v = ld(2 * (int64_t)H * D + h * D + d);
+        vnew_s[d] = v;
+        vcache[((int64_t)pos * H + h) * D + d] = f32_to_bf16(v);
     }
     __syncthreads();
     // ---- scores ------------------------------------------------------------------------------------------------
@@ -162,7 +159,7 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const bf16_t
     for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
     auto pv = [&](const u32x4_t& vv, int j) {
         if (j < nkeys && sub < nch) {
-            const float p = bf16_to_f32(f32_to_bf16(sc[j] * inv_sum));
+            const float p = F32IO ? sc[j] * inv_sum : bf16_to_f32(f32_to_bf16(sc[j] * inv_sum));
             if (j < pos) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -196,8 +193,15 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const bf16_t
         float r = 0.0f;
 #pragma unroll
         for (int g2 = 0; g2 < kDecGroups; ++g2) r += part[g2][t];
-        if (COHERENT_OUT) __hip_atomic_store(o + h * D + t, f32_to_bf16(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else o[h * D + t] = f32_to_bf16(r);
+        if (F32IO) {
+            float* o = static_cast<float*>(o_v);
+            if (COHERENT_OUT) __hip_atomic_store(o + h * D + t, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else o[h * D + t] = r;
+        } else {
+            bf16_t* o = static_cast<bf16_t*>(o_v);
+            if (COHERENT_OUT) __hip_atomic_store(o + h * D + t, f32_to_bf16(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else o[h * D + t] = f32_to_bf16(r);
+        }
     }
 }
 

@@ -25,14 +25,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 struct AttnOprojArgs {
-    const bf16_t* qkv;   // [3, H, D] of the new token
+    const float* qkv;    // [3, H, D] of the new token (fp32: output of the q|k|v GEMV)
     bf16_t* kcache;      // [Tmax, H, D] this layer
     bf16_t* vcache;
-    bf16_t* attn;        // [H*D] scratch: attention output (exchanged inside the launch)
+    float* attn;         // [H*D] scratch: attention output (exchanged inside the launch), fp32
     const bf16_t* wo;    // [hidden, hidden]
-    const bf16_t* x;     // [hidden] residual
-    bf16_t* x_out;       // [hidden]
-    int H, D;
+    const float* x;      // [hidden] residual stream (fp32)
+    float* x_out;        // [hidden]
+    int H, D, tmax;
     float theta, scale;
     const float* cos_tab;
     const float* sin_tab;
@@ -42,13 +42,17 @@ struct AttnOprojArgs {
     int32_t* status;           // [0] != 0: a bounded wait expired
 };
 
-__device__ __forceinline__ float dot8(const u32x4_t& w, const u32x4_t& x) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t wj = w[j], xj = x[j];
-        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, wj), __builtin_bit_cast(bf16x2_t, xj), acc, false);
-    }
+typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+// 8 bf16 weights x 8 fp32 activations: exact products, fp32 accumulation
+__device__ __forceinline__ float dot8f(const u32x4_t& w, const f32x4v_t& xa, const f32x4v_t& xb, float acc) {
+    acc = fmaf(__uint_as_float(w[0] << 16), xa[0], acc);
+    acc = fmaf(__uint_as_float(w[0] & 0xffff0000u), xa[1], acc);
+    acc = fmaf(__uint_as_float(w[1] << 16), xa[2], acc);
+    acc = fmaf(__uint_as_float(w[1] & 0xffff0000u), xa[3], acc);
+    acc = fmaf(__uint_as_float(w[2] << 16), xb[0], acc);
+    acc = fmaf(__uint_as_float(w[2] & 0xffff0000u), xb[1], acc);
+    acc = fmaf(__uint_as_float(w[3] << 16), xb[2], acc);
+    acc = fmaf(__uint_as_float(w[3] & 0xffff0000u), xb[3], acc);
     return acc;
 }
 
@@ -56,16 +60,16 @@ template <int NB>  // NB = 16-byte chunks per lane per row = hidden / 512 (8 for
 __global__ __launch_bounds__(kDecThreads) void attn_oproj_kernel(AttnOprojArgs a) {
     const int hidden = a.H * a.D;
     if ((int)blockIdx.x < a.H) {
-        llama_decode_attn_body<true>(blockIdx.x, a.qkv, a.kcache, a.vcache, a.attn, a.H, a.D, 0, a.theta, a.scale, a.cos_tab,
-                                     a.sin_tab, a.pos_dev);
+        llama_decode_attn_body<true, true>(blockIdx.x, a.qkv, a.kcache, a.vcache, a.attn, a.H, a.D, 0, a.theta, a.scale,
+                                           a.cos_tab, a.sin_tab, a.pos_dev, a.tmax);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's agent-scope stores are performed
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(a.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    __shared__ __attribute__((aligned(16))) unsigned char xs_raw[kMaxD * 128 * 2];  // hidden <= 16384 bf16 (32 KB)
+    __shared__ __attribute__((aligned(16))) unsigned char xs_raw[8192 * 4];  // hidden <= 8192 fp32 (32 KB), two planes
     __shared__ int s_ok;
-    u32x4_t* xs = reinterpret_cast<u32x4_t*>(xs_raw);
+    const f32x4v_t* xs = reinterpret_cast<const f32x4v_t*>(xs_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = ((int)blockIdx.x - a.H) * kRowsPerBlock + wave * kRowsPerWave;
     const int nchunk = hidden >> 3;
@@ -99,11 +103,11 @@ __global__ __launch_bounds__(kDecThreads) void attn_oproj_kernel(AttnOprojArgs a
     __syncthreads();
     if (!s_ok) return;
     // ---- stage the attention vector (agent-scope loads: written by other CUs inside this launch) ---------------------
-    {
-        uint32_t* xs32 = reinterpret_cast<uint32_t*>(xs_raw);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.attn);
-        for (int i = threadIdx.x; i < (hidden >> 1); i += kDecThreads)
-            xs32[i] = __hip_atomic_load(const_cast<uint32_t*>(src) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {   // element i = 8c + j -> plane (j >> 2), slot 4c + (j & 3): consecutive lanes then read consecutive 16-byte slots
+        float* xs32 = reinterpret_cast<float*>(xs_raw);
+        for (int i = threadIdx.x; i < hidden; i += kDecThreads)
+            xs32[((i >> 2) & 1) * (hidden >> 1) + ((i >> 3) << 2) + (i & 3)] =
+                __hip_atomic_load(a.attn + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
 #pragma unroll
@@ -112,28 +116,28 @@ __global__ __launch_bounds__(kDecThreads) void attn_oproj_kernel(AttnOprojArgs a
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             const int cc = lane + 64 * c;
-            if (cc < nchunk) acc += dot8(w[r][c], xs[cc]);
+            if (cc < nchunk) acc = dot8f(w[r][c], xs[cc], xs[nchunk + cc], acc);
         }
         acc = wave_sum(acc);
         const int n = row0 + r;
-        if (lane == 0 && n < hidden) a.x_out[n] = f32_to_bf16(acc + bf16_to_f32(a.x[n]));
+        if (lane == 0 && n < hidden) a.x_out[n] = acc + a.x[n];
     }
 }
 
 }  // namespace
 
-int llama_attn_oproj(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* attn_scratch, const bf16_t* wo,
-                     const bf16_t* x, bf16_t* x_out, int H, int D, float theta, float scale, const float* cos_tab,
+int llama_attn_oproj(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* attn_scratch, const bf16_t* wo,
+                     const float* x, float* x_out, int H, int D, float theta, float scale, const float* cos_tab,
                      const float* sin_tab, const int32_t* pos_dev, const int32_t* step_dev, int32_t* counter, int32_t* status,
                      hipStream_t st) {
     if (!qkv || !kcache || !vcache || !attn_scratch || !wo || !x || !x_out || !pos_dev || !step_dev || !counter || !status)
         return IVLM_ERR_INVALID_ARG;
     if (H <= 0 || D <= 0 || D > kMaxD || (D & 15)) return IVLM_ERR_INVALID_ARG;
     const int hidden = H * D;
-    if (hidden % 512 != 0 || hidden > 16384) return IVLM_ERR_UNSUPPORTED;
+    if (hidden % 512 != 0 || hidden > 8192 || tmax <= 0) return IVLM_ERR_UNSUPPORTED;
     AttnOprojArgs a;
     a.qkv = qkv; a.kcache = kcache; a.vcache = vcache; a.attn = attn_scratch; a.wo = wo; a.x = x; a.x_out = x_out;
-    a.H = H; a.D = D; a.theta = theta; a.scale = scale; a.cos_tab = cos_tab; a.sin_tab = sin_tab;
+    a.H = H; a.D = D; a.tmax = tmax; a.theta = theta; a.scale = scale; a.cos_tab = cos_tab; a.sin_tab = sin_tab;
     a.pos_dev = pos_dev; a.step_dev = step_dev; a.counter = counter; a.status = status;
     const int grid = H + (hidden + kRowsPerBlock - 1) / kRowsPerBlock;
     {  // consumers wait for producers inside the launch: the whole grid must be resident (one block per CU)
@@ -157,13 +161,12 @@ int llama_attn_oproj(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* 
 
 }  // namespace ivlm
 
-extern "C" int ivlm_llama_attn_oproj(const void* qkv, void* kcache, void* vcache, void* attn_scratch, const void* wo,
-                                     const void* x, void* x_out, int H, int D, float theta, float scale,
+extern "C" int ivlm_llama_attn_oproj(const float* qkv, void* kcache, void* vcache, int tmax, float* attn_scratch, const void* wo,
+                                     const float* x, float* x_out, int H, int D, float theta, float scale,
                                      const float* cos_tab, const float* sin_tab, const int32_t* pos_dev,
                                      const int32_t* step_dev, int32_t* counter, int32_t* status, ivlm_stream_t stream) {
     ivlm_enter();
-    return ivlm::llama_attn_oproj(static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(kcache), static_cast<bf16_t*>(vcache),
-                                  static_cast<bf16_t*>(attn_scratch), static_cast<const bf16_t*>(wo),
-                                  static_cast<const bf16_t*>(x), static_cast<bf16_t*>(x_out), H, D, theta, scale, cos_tab,
-                                  sin_tab, pos_dev, step_dev, counter, status, ivlm_stream(stream));
+    return ivlm::llama_attn_oproj(qkv, static_cast<bf16_t*>(kcache), static_cast<bf16_t*>(vcache), tmax, attn_scratch,
+                                  static_cast<const bf16_t*>(wo), x, x_out, H, D, theta, scale, cos_tab, sin_tab, pos_dev, step_dev,
+                                  counter, status, ivlm_stream(stream));
 }

@@ -65,67 +65,87 @@ __global__ __launch_bounds__(kT) void im2col3x3_nhwc_kernel(const bf16_t* __rest
     }
 }
 
-__device__ __forceinline__ uint4 mul8(const uint4& a, const uint4& b) {
-    uint4 r;
-    const uint32_t* pa = &a.x;
-    const uint32_t* pb = &b.x;
-    uint32_t* pr = &r.x;
+// ---- 8-element row fragments in either storage type ---------------------------------------------------------------
+// kind: 0 = bf16, 1 = fp32, 2 (stores only) = "split": the row is written as [hi(cols) | lo(cols)] bf16 with
+// x = hi + lo to 2^-17 - the A operand of a GEMM against [W | W] (K' = 2K), i.e. an fp32-activation GEMM on the bf16 MFMA
+// path (used where the FLOPs are negligible and the precision is not: the SAM mask decoder).
+__device__ __forceinline__ void load8(const void* base, int kind, int64_t elem, float* f) {
+    if (kind == 1) {
+        const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem);
+        const float4 a = p[0], b = p[1];
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else {
+        const uint4 u = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(base) + elem);
+        f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+        f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+        f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+        f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void store8(void* base, int kind, int64_t elem, int cols, const float* f) {
+    if (kind == 1) {
+        float4* p = reinterpret_cast<float4*>(static_cast<float*>(base) + elem);
+        p[0] = make_float4(f[0], f[1], f[2], f[3]);
+        p[1] = make_float4(f[4], f[5], f[6], f[7]);
+        return;
+    }
+    bf16_t* o = static_cast<bf16_t*>(base) + elem;
+    *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                                              pack_bf16x2(f[6], f[7]));
+    if (kind == 2) {
+        float l[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        pr[j] = pack_bf16x2(__uint_as_float(pa[j] << 16) * __uint_as_float(pb[j] << 16),
-                            __uint_as_float(pa[j] & 0xffff0000u) * __uint_as_float(pb[j] & 0xffff0000u));
-    return r;
+        for (int j = 0; j < 8; ++j) l[j] = f[j] - bf16_to_f32(f32_to_bf16(f[j]));
+        *reinterpret_cast<uint4*>(o + cols) = make_uint4(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]),
+                                                         pack_bf16x2(l[4], l[5]), pack_bf16x2(l[6], l[7]));
+    }
 }
 
-__device__ __forceinline__ uint4 add8(const uint4& a, const uint4& b) {
-    uint4 r;
-    const uint32_t* pa = &a.x;
-    const uint32_t* pb = &b.x;
-    uint32_t* pr = &r.x;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        pr[j] = pack_bf16x2(__uint_as_float(pa[j] << 16) + __uint_as_float(pb[j] << 16),
-                            __uint_as_float(pa[j] & 0xffff0000u) + __uint_as_float(pb[j] & 0xffff0000u));
-    return r;
-}
-
-// dst[r] = (idx[r] >= 0 ? src[idx[r]] : 0) (+ add[r]);  cols % 8 == 0; row strides in elements
-__global__ __launch_bounds__(kT) void gather_rows_kernel(bf16_t* __restrict__ dst, int64_t ldd,
-                                                         const bf16_t* __restrict__ src, int64_t lds_,
-                                                         const int32_t* __restrict__ idx,
-                                                         const bf16_t* __restrict__ add, int64_t lda, int64_t rows,
-                                                         int cols) {
+// dst[r] = (idx ? (idx[r] >= 0 ? src[idx[r]] : 0) : src[r]) (+ add[r]);  cols % 8 == 0; row strides in elements
+__global__ __launch_bounds__(kT) void gather_rows_kernel(void* __restrict__ dst, int dst_kind, int64_t ldd,
+                                                         const void* __restrict__ src, int src_kind, int64_t lds_,
+                                                         const int32_t* __restrict__ idx, const void* __restrict__ add,
+                                                         int add_kind, int64_t lda, int64_t rows, int cols) {
     const int c8n = cols >> 3;
     const int64_t total = rows * c8n;
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
         const int c8 = (int)(i % c8n);
         const int64_t r = i / c8n;
-        const int s = idx[r];
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (s >= 0) v = *reinterpret_cast<const uint4*>(src + (int64_t)s * lds_ + c8 * 8);
-        if (add) v = add8(v, *reinterpret_cast<const uint4*>(add + r * lda + c8 * 8));
-        *reinterpret_cast<uint4*>(dst + r * ldd + c8 * 8) = v;
+        const int64_t s = idx ? (int64_t)idx[r] : r;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (s >= 0) load8(src, src_kind, s * lds_ + c8 * 8, v);
+        if (add) {
+            float a[8];
+            load8(add, add_kind, r * lda + c8 * 8, a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += a[j];
+        }
+        store8(dst, dst_kind, r * ldd + c8 * 8, cols, v);
     }
 }
 
 // out[r] = a[r] (+|*) b[r % b_rows]
-__global__ __launch_bounds__(kT) void add_rows_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ a,
-                                                      const bf16_t* __restrict__ b, int64_t rows, int cols,
-                                                      int64_t b_rows, int op) {
+__global__ __launch_bounds__(kT) void add_rows_kernel(void* __restrict__ out, int out_kind, const void* __restrict__ a,
+                                                      int a_kind, const void* __restrict__ b, int b_kind, int64_t rows,
+                                                      int cols, int64_t b_rows, int op) {
     const int c8n = cols >> 3;
     const int64_t total = rows * c8n;
+    const int64_t ldo = out_kind == 2 ? 2 * (int64_t)cols : cols;
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
         const int c8 = (int)(i % c8n);
         const int64_t r = i / c8n;
-        const uint4 va = *reinterpret_cast<const uint4*>(a + r * cols + c8 * 8);
-        const uint4 vb = *reinterpret_cast<const uint4*>(b + (r % b_rows) * cols + c8 * 8);
-        *reinterpret_cast<uint4*>(out + r * cols + c8 * 8) = op ? mul8(va, vb) : add8(va, vb);
+        float va[8], vb[8];
+        load8(a, a_kind, r * cols + c8 * 8, va);
+        load8(b, b_kind, (r % b_rows) * cols + c8 * 8, vb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) va[j] = op ? va[j] * vb[j] : va[j] + vb[j];
+        store8(out, out_kind, r * ldo + c8 * 8, cols, va);
     }
 }
 
 // pe[(y,x), c]: c < F -> sin, c >= F -> cos of 2*pi*((2*(x+.5)/w-1)*g[0,c'] + (2*(y+.5)/h-1)*g[1,c'])
 __global__ __launch_bounds__(kT) void dense_pe_kernel(const float* __restrict__ gauss /*[2,F]*/,
-                                                      bf16_t* __restrict__ pe /*[h*w, 2F]*/, int h, int w, int F) {
+                                                      void* __restrict__ pe /*[h*w, 2F]*/, int pe_f32, int h, int w, int F) {
     const int64_t total = (int64_t)h * w * 2 * F;
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
         const int c = (int)(i % (2 * F));
@@ -137,7 +157,9 @@ __global__ __launch_bounds__(kT) void dense_pe_kernel(const float* __restrict__ 
         const float cy = 2.0f * (((float)yy + 0.5f) / (float)h) - 1.0f;
         float t = cx * gauss[f] + cy * gauss[F + f];
         t = 6.283185307179586f * t;
-        pe[i] = f32_to_bf16(c < F ? sinf(t) : cosf(t));
+        const float val = c < F ? sinf(t) : cosf(t);
+        if (pe_f32) static_cast<float*>(pe)[i] = val;
+        else static_cast<bf16_t*>(pe)[i] = f32_to_bf16(val);
     }
 }
 
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(kT) void rope_kv_kernel(bf16_t* __restrict__ qkv, i
 
 // up [B, gh, gw, 2,2, 2,2, C] (two k2s2 transposed convs, channels last)  x  hyper [B, C]
 //   -> low [B, 4gh, 4gw] fp32 at (4y + 2dy + dy2, 4x + 2dx + dx2)
-__global__ __launch_bounds__(kT) void mask_dot_kernel(const bf16_t* __restrict__ up, const bf16_t* __restrict__ hyper,
+__global__ __launch_bounds__(kT) void mask_dot_kernel(const void* __restrict__ up, const void* __restrict__ hyper, int kind,
                                                       float* __restrict__ low, int B, int gh, int gw, int C) {
     const int64_t total = (int64_t)B * gh * gw * 16;
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
@@ -211,19 +233,13 @@ __global__ __launch_bounds__(kT) void mask_dot_kernel(const bf16_t* __restrict__
         const int64_t cell = i >> 4;
         const int xx = (int)(cell % gw), yy = (int)((cell / gw) % gh), b = (int)(cell / ((int64_t)gw * gh));
         const int dy = sub >> 3, dx = (sub >> 2) & 1, dy2 = (sub >> 1) & 1, dx2 = sub & 1;
-        const bf16_t* u = up + i * C;
-        const bf16_t* hv = hyper + (int64_t)b * C;
         float acc = 0.0f;
         for (int c = 0; c < C; c += 8) {
-            const uint4 a4 = *reinterpret_cast<const uint4*>(u + c);
-            const uint4 h4 = *reinterpret_cast<const uint4*>(hv + c);
-            const uint32_t* pa = &a4.x;
-            const uint32_t* ph = &h4.x;
+            float a[8], h[8];
+            load8(up, kind, i * C + c, a);
+            load8(hyper, kind, (int64_t)b * C + c, h);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc += __uint_as_float(pa[j] << 16) * __uint_as_float(ph[j] << 16);
-                acc += __uint_as_float(pa[j] & 0xffff0000u) * __uint_as_float(ph[j] & 0xffff0000u);
-            }
+            for (int j = 0; j < 8; ++j) acc += a[j] * h[j];
         }
         const int Y = 4 * yy + 2 * dy + dy2, X = 4 * xx + 2 * dx + dx2;
         low[((int64_t)b * 4 * gh + Y) * (4 * gw) + X] = acc;
@@ -285,22 +301,25 @@ int im2col3x3_nhwc(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hip
     im2col3x3_nhwc_kernel<<<grid_for((int64_t)B * H * W * 9 * (C >> 3)), kT, 0, st>>>(x, out, B, H, W, C);
     return ivlm_launch_status();
 }
-int gather_rows(bf16_t* dst, int64_t ldd, const bf16_t* src, int64_t lds_, const int32_t* idx, const bf16_t* add,
-                int64_t lda, int64_t rows, int cols, hipStream_t st) {
-    if (!dst || !src || !idx || rows <= 0 || (cols & 7) || (ldd & 7) || (lds_ & 7) || (lda & 7))
-        return IVLM_ERR_INVALID_ARG;
-    gather_rows_kernel<<<grid_for(rows * (cols >> 3)), kT, 0, st>>>(dst, ldd, src, lds_, idx, add, lda, rows, cols);
+int gather_rows(void* dst, int dst_kind, int64_t ldd, const void* src, int src_kind, int64_t lds_, const int32_t* idx,
+                const void* add, int add_kind, int64_t lda, int64_t rows, int cols, hipStream_t st) {
+    if (!dst || !src || rows <= 0 || (cols & 7) || (ldd & 7) || (lds_ & 7) || (lda & 7)) return IVLM_ERR_INVALID_ARG;
+    if (dst_kind < 0 || dst_kind > 2 || (src_kind & ~1) || (add_kind & ~1)) return IVLM_ERR_INVALID_ARG;
+    if (dst_kind == 2 && ldd < 2 * (int64_t)cols) return IVLM_ERR_INVALID_ARG;
+    gather_rows_kernel<<<grid_for(rows * (cols >> 3)), kT, 0, st>>>(dst, dst_kind, ldd, src, src_kind, lds_, idx, add,
+                                                                    add_kind, lda, rows, cols);
     return ivlm_launch_status();
 }
-int add_rows(bf16_t* out, const bf16_t* a, const bf16_t* b, int64_t rows, int cols, int64_t b_rows, hipStream_t st,
-             int op) {
+int add_rows(void* out, int out_kind, const void* a, int a_kind, const void* b, int b_kind, int64_t rows, int cols,
+             int64_t b_rows, hipStream_t st, int op) {
     if (!out || !a || !b || rows <= 0 || b_rows <= 0 || (cols & 7)) return IVLM_ERR_INVALID_ARG;
-    add_rows_kernel<<<grid_for(rows * (cols >> 3)), kT, 0, st>>>(out, a, b, rows, cols, b_rows, op);
+    if (out_kind < 0 || out_kind > 2 || (a_kind & ~1) || (b_kind & ~1)) return IVLM_ERR_INVALID_ARG;
+    add_rows_kernel<<<grid_for(rows * (cols >> 3)), kT, 0, st>>>(out, out_kind, a, a_kind, b, b_kind, rows, cols, b_rows, op);
     return ivlm_launch_status();
 }
-int dense_pe(const float* gauss, bf16_t* pe, int h, int w, int F, hipStream_t st) {
+int dense_pe(const float* gauss, void* pe, int pe_f32, int h, int w, int F, hipStream_t st) {
     if (!gauss || !pe) return IVLM_ERR_INVALID_ARG;
-    dense_pe_kernel<<<grid_for((int64_t)h * w * 2 * F), kT, 0, st>>>(gauss, pe, h, w, F);
+    dense_pe_kernel<<<grid_for((int64_t)h * w * 2 * F), kT, 0, st>>>(gauss, pe, pe_f32, h, w, F);
     return ivlm_launch_status();
 }
 int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, bf16_t* kcache, bf16_t* vcache,
@@ -315,9 +334,9 @@ int rope_table(float* cos_tab, float* sin_tab, int T, int D, float theta, hipStr
     rope_table_kernel<<<(T * (D >> 1) + kT - 1) / kT, kT, 0, st>>>(cos_tab, sin_tab, T, D, theta);
     return ivlm_launch_status();
 }
-int mask_dot(const bf16_t* up, const bf16_t* hyper, float* low, int B, int gh, int gw, int C, hipStream_t st) {
-    if (!up || !hyper || !low || (C & 7)) return IVLM_ERR_INVALID_ARG;
-    mask_dot_kernel<<<grid_for((int64_t)B * gh * gw * 16), kT, 0, st>>>(up, hyper, low, B, gh, gw, C);
+int mask_dot(const void* up, const void* hyper, int kind, float* low, int B, int gh, int gw, int C, hipStream_t st) {
+    if (!up || !hyper || !low || (C & 7) || (kind & ~1)) return IVLM_ERR_INVALID_ARG;
+    mask_dot_kernel<<<grid_for((int64_t)B * gh * gw * 16), kT, 0, st>>>(up, hyper, kind, low, B, gh, gw, C);
     return ivlm_launch_status();
 }
 
@@ -335,19 +354,22 @@ int ivlm_im2col3x3_nhwc(const void* x, void* out, int B, int H, int W, int C, iv
     ivlm_enter();
     return ivlm::im2col3x3_nhwc(CBF(x), BF(out), B, H, W, C, ivlm_stream(s));
 }
-int ivlm_gather_rows(void* dst, int64_t ldd, const void* src, int64_t lds_, const int32_t* idx, const void* add,
-                     int64_t lda, int64_t rows, int cols, ivlm_stream_t s) {
+int ivlm_gather_rows(void* dst, int dst_kind, int64_t ldd, const void* src, int src_dtype, int64_t lds_, const int32_t* idx,
+                     const void* add, int add_dtype, int64_t lda, int64_t rows, int cols, ivlm_stream_t s) {
     ivlm_enter();
-    return ivlm::gather_rows(BF(dst), ldd, CBF(src), lds_, idx, CBF(add), lda, rows, cols, ivlm_stream(s));
+    return ivlm::gather_rows(dst, dst_kind == IVLM_F32 ? 1 : (dst_kind == IVLM_BF16 ? 0 : (dst_kind == IVLM_BF16_SPLIT ? 2 : -1)),
+                             ldd, src, src_dtype == IVLM_F32, lds_, idx, add, add_dtype == IVLM_F32, lda, rows, cols,
+                             ivlm_stream(s));
 }
-int ivlm_add_rows(void* out, const void* a, const void* b, int64_t rows, int cols, int64_t b_rows, int op,
-                  ivlm_stream_t s) {
+int ivlm_add_rows(void* out, int out_kind, const void* a, int a_dtype, const void* b, int b_dtype, int64_t rows, int cols,
+                  int64_t b_rows, int op, ivlm_stream_t s) {
     ivlm_enter();
-    return ivlm::add_rows(BF(out), CBF(a), CBF(b), rows, cols, b_rows, ivlm_stream(s), op);
+    return ivlm::add_rows(out, out_kind == IVLM_F32 ? 1 : (out_kind == IVLM_BF16 ? 0 : (out_kind == IVLM_BF16_SPLIT ? 2 : -1)),
+                          a, a_dtype == IVLM_F32, b, b_dtype == IVLM_F32, rows, cols, b_rows, ivlm_stream(s), op);
 }
-int ivlm_dense_pe(const void* gauss, void* pe, int h, int w, int F, ivlm_stream_t s) {
+int ivlm_dense_pe(const void* gauss, void* pe, int pe_dtype, int h, int w, int F, ivlm_stream_t s) {
     ivlm_enter();
-    return ivlm::dense_pe(static_cast<const float*>(gauss), BF(pe), h, w, F, ivlm_stream(s));
+    return ivlm::dense_pe(static_cast<const float*>(gauss), pe, pe_dtype == IVLM_F32, h, w, F, ivlm_stream(s));
 }
 int ivlm_rope_kv(void* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void* kcache, void* vcache,
                  const float* cos_tab, const float* sin_tab, ivlm_stream_t s) {
@@ -358,9 +380,9 @@ int ivlm_rope_table(float* cos_tab, float* sin_tab, int T, int D, float theta, i
     ivlm_enter();
     return ivlm::rope_table(cos_tab, sin_tab, T, D, theta, ivlm_stream(s));
 }
-int ivlm_mask_dot(const void* up, const void* hyper, float* low, int B, int gh, int gw, int C, ivlm_stream_t s) {
+int ivlm_mask_dot(const void* up, const void* hyper, int dtype, float* low, int B, int gh, int gw, int C, ivlm_stream_t s) {
     ivlm_enter();
-    return ivlm::mask_dot(CBF(up), CBF(hyper), low, B, gh, gw, C, ivlm_stream(s));
+    return ivlm::mask_dot(up, hyper, dtype == IVLM_F32, low, B, gh, gw, C, ivlm_stream(s));
 }
 int ivlm_normalize_pad_u8(const uint8_t* src, int H, int W, int y0, int x0, int ch, int cw, const float* mean3_host,
                           const float* std3_host, void* out, int out_bf16, int OH, int OW, ivlm_stream_t s) {

@@ -206,6 +206,7 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
     if ((g.lda & 7) || (g.ldw & 7)) return IVLM_ERR_UNSUPPORTED;  // 16-byte DMA granules
     if (g.act == ACT_SWIGLU && ((g.N & 3) || g.residual)) return IVLM_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) return IVLM_ERR_INVALID_ARG;
+    if (g.a_f32) return IVLM_ERR_UNSUPPORTED;
     switch (g.act) {
         case ACT_NONE: return launch<ACT_NONE>(g, st);
         case ACT_GELU: return launch<ACT_GELU>(g, st);
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             v[j] = gemm_act(v[j], g.act);
             if (g.residual) {
                 const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
-                v[j] += bf16_to_f32(g.residual[rrow * g.ldr + n + j]);
+                v[j] += gemm_residual_at(g, g.residual, rrow * g.ldr + n + j);
             }
         }
         const int64_t o = (int64_t)m * g.ldc + n;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }  // namespace
 
 int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st) {
-    if (splits < 2 || g.batch != 1 || g.act == ACT_SWIGLU || g.rms_w || !workspace) return IVLM_ERR_INVALID_ARG;
+    if (splits < 2 || g.batch != 1 || g.act == ACT_SWIGLU || g.rms_w || g.out_rows || !workspace) return IVLM_ERR_INVALID_ARG;
     if (g.K % (splits * 8) != 0 || (g.N & 3) || (g.ldc & 3)) return IVLM_ERR_UNSUPPORTED;
     if (ws_bytes < (size_t)splits * g.M * g.N * sizeof(float)) return IVLM_ERR_WORKSPACE;
     GemmArgs p = g;
@@ -293,9 +294,11 @@ int linear_bf16(const GemmArgs& g, hipStream_t st) {
         // (measured on the LLaMA-7B shapes, tools/bench_skinny.py: the wave-per-row GEMV wins for M <= 4 while its
         //  activation rows fit LDS - 5.0-5.7 TB/s at M = 1 - and falls to 0.9-2.5 TB/s at M = 8; this kernel holds
         //  3.4-4.4 TB/s for every M <= 8 and 2.9-3.4 TB/s at M = 16, where the 128x64 tile GEMM reaches 0.7-1.8 TB/s)
-        if (skinny) return gemv_mfma_bf16(g, st);
+        // fp32 activations: exact in the GEMV (fp32 x in LDS) for one row, hi + lo bf16 operand split on the MFMA for more
+        if (!g.out_rows && (skinny || (g.a_f32 && g.M >= 2))) return gemv_mfma_bf16(g, st);
     }
-    if (g.M <= 8 && g.batch == 1) return gemv_bf16(g, st);
+    if (g.M <= 8 && g.batch == 1 && !g.out_rows) return gemv_bf16(g, st);
+    if (g.a_f32) return IVLM_ERR_UNSUPPORTED;  // the tile kernels DMA bf16 operands (use ivlm_gather_rows split + K' = 2K)
     if (g.rms_w) return IVLM_ERR_UNSUPPORTED;  // the RMSNorm fusion exists on the decode (GEMV) path only
     return gemm_bf16(g, st);
 }
@@ -303,11 +306,6 @@ int linear_bf16(const GemmArgs& g, hipStream_t st) {
 }  // namespace ivlm
 
 static int g_tile_override = 0;
-
-extern "C" int ivlm_gemv_slab_enable(int on) {  // benchmark/test hook: 0 = wave-per-row GEMV kernel for M == 1 as well
-    ivlm::gemv_set_slab(on);
-    return 0;
-}
 
 extern "C" int ivlm_gemv_mfma_min_m(int min_m) {  // benchmark/test hook: 0 = automatic choice
     ivlm::gemv_mfma_set_min_m(min_m);
@@ -323,9 +321,13 @@ extern "C" int ivlm_gemm_tile_override(int tile) {
 extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                               const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N, int K,
                               int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
-                              int64_t strideR, const void* rms_w, float rms_eps, ivlm_stream_t stream) {
+                              int64_t strideR, const void* rms_w, float rms_eps, int flags, const int32_t* out_rows,
+                              ivlm_stream_t stream) {
     ivlm_enter();
     ivlm::GemmArgs g;
+    g.out_rows = out_rows;
+    g.a_f32 = (flags & IVLM_GEMM_A_F32) ? 1 : 0;
+    g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
     g.rms_w = static_cast<const bf16_t*>(rms_w);
     g.rms_eps = rms_eps;
     g.tile = g_tile_override;
@@ -351,9 +353,11 @@ extern "C" size_t ivlm_gemm_splitk_workspace_bytes(int M, int N, int splits) {
 extern "C" int ivlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                                      const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N,
                                      int K, int act, int out_f32, int splits, void* workspace, size_t workspace_bytes,
-                                     ivlm_stream_t stream) {
+                                     int flags, ivlm_stream_t stream) {
     ivlm_enter();
+    if (flags & IVLM_GEMM_A_F32) return IVLM_ERR_UNSUPPORTED;
     ivlm::GemmArgs g;
+    g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
     g.tile = g_tile_override;
     g.A = static_cast<const bf16_t*>(A);
     g.W = static_cast<const bf16_t*>(W);
@@ -366,23 +370,4 @@ extern "C" int ivlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     g.act = act;
     g.out_f32 = out_f32;
     return ivlm::gemm_bf16_splitk(g, splits, static_cast<float*>(workspace), workspace_bytes, ivlm_stream(stream));
-}
-
-extern "C" int ivlm_gemm_bf16_tailsplit(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
-                                        const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N,
-                                        int K, int act, int out_f32, int splits, void* workspace, size_t workspace_bytes,
-                                        ivlm_stream_t stream) {
-    ivlm_enter();
-    ivlm::GemmArgs g;
-    g.A = static_cast<const bf16_t*>(A);
-    g.W = static_cast<const bf16_t*>(W);
-    g.C = C;
-    g.bias = static_cast<const bf16_t*>(bias);
-    g.residual = static_cast<const bf16_t*>(residual);
-    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
-    g.res_mod = res_mod;
-    g.M = M; g.N = N; g.K = K;
-    g.act = act;
-    g.out_f32 = out_f32;
-    return ivlm::gemm_bf16_tailsplit(g, splits, static_cast<float*>(workspace), workspace_bytes, ivlm_stream(stream));
 }

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 template <int ACT>
 int launch256(const GemmArgs& g, hipStream_t st) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    dim3 grid(g.tile_count > 0 ? g.tile_count : tiles, 1, g.batch);
+    dim3 grid(tiles, 1, g.batch);
 #define IVLM_GO(F32)                                                                                             \
     do {                                                                                                         \
         auto kfn = gemm256_kernel<ACT, F32>;                                                                     \
@@ -202,81 +202,6 @@ int gemm_bf16_256p(const GemmArgs& g, hipStream_t st) {
         case ACT_SIGMOID: return launch256<ACT_SIGMOID>(g, st);
         default: return IVLM_ERR_INVALID_ARG;
     }
-}
-
-namespace {
-// tail tiles: sum the K-slice partials in slice order, then bias / activation / residual and the store
-template <bool OUT_F32>
-__global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ part, int splits, GemmArgs g) {
-    // blockIdx.y = 16-row band of the tile: 16 blocks per tile, so that even a 16-tile tail keeps every CU busy (one block
-    // per tile would leave the sum bound by a single CU's ~30 GB/s)
-    int m0, n0;
-    gemm_tile_origin(g, 256, 256, m0, n0);
-    m0 += blockIdx.y * 16;
-    const int64_t slice = (int64_t)g.M * g.N;
-    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
-        const int m = m0 + (i >> 6), n = n0 + (i & 63) * 4;
-        if (m >= g.M || n >= g.N) continue;
-        const float* p = part + (int64_t)m * g.N + n;
-        float4 acc = *reinterpret_cast<const float4*>(p);
-        for (int sidx = 1; sidx < splits; ++sidx) {
-            const float4 t = *reinterpret_cast<const float4*>(p + sidx * slice);
-            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-        }
-        float v[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (g.bias) v[j] += bf16_to_f32(g.bias[n + j]);
-            v[j] = gemm_act(v[j], g.act);
-            if (g.residual) {
-                const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
-                v[j] += bf16_to_f32(g.residual[rrow * g.ldr + n + j]);
-            }
-        }
-        const int64_t o = (int64_t)m * g.ldc + n;
-        if (OUT_F32) *reinterpret_cast<float4*>(static_cast<float*>(g.C) + o) = make_float4(v[0], v[1], v[2], v[3]);
-        else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-    }
-}
-}  // namespace
-
-int gemm_bf16_tailsplit(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st) {
-    if (splits < 2 || g.batch != 1 || g.act == ACT_SWIGLU || g.rms_w || !workspace) return IVLM_ERR_INVALID_ARG;
-    if (!g.A || !g.W || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0) return IVLM_ERR_INVALID_ARG;
-    if (g.K % (splits * 64) != 0 || (g.N & 3) || (g.ldc & 3) || (g.lda & 7) || (g.ldw & 7)) return IVLM_ERR_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) return IVLM_ERR_INVALID_ARG;
-    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    const int tail = tiles % 256;  // (256 = one round on the 256 CUs; the raster's XCD map needs the offset to be a multiple of 8)
-    if (tiles <= 256 || tail == 0 || tail * splits > 256) return IVLM_ERR_UNSUPPORTED;
-    if (ws_bytes < (size_t)splits * g.M * g.N * sizeof(float)) return IVLM_ERR_WORKSPACE;
-    GemmArgs main_part = g;
-    main_part.tile_offset = 0;
-    main_part.tile_count = tiles - tail;
-    int rc = gemm_bf16_256p(main_part, st);
-    if (rc != IVLM_OK) return rc;
-    GemmArgs p = g;
-    p.tile_offset = tiles - tail;
-    p.tile_count = tail;
-    p.K = g.K / splits;
-    p.batch = splits;
-    p.strideA = p.K;
-    p.strideW = p.K;
-    p.strideC = (int64_t)g.M * g.N;
-    p.strideR = 0;
-    p.C = workspace;
-    p.ldc = g.N;
-    p.out_f32 = 1;
-    p.bias = nullptr;
-    p.residual = nullptr;
-    p.act = ACT_NONE;
-    rc = gemm_bf16_256p(p, st);
-    if (rc != IVLM_OK) return rc;
-    GemmArgs r = g;
-    r.tile_offset = tiles - tail;
-    r.tile_count = tail;
-    if (g.out_f32) tail_reduce_kernel<true><<<dim3(tail, 16), 256, 0, st>>>(workspace, splits, r);
-    else tail_reduce_kernel<false><<<dim3(tail, 16), 256, 0, st>>>(workspace, splits, r);
-    return ivlm_launch_status();
 }
 
 }  // namespace ivlm

@@ -46,7 +46,7 @@ __device__ __forceinline__ void gemm_tile_origin(const GemmArgs& g, int BM, int 
     const int tiles_m = (g.M + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
     constexpr int kXcd = 8, kGroupM = 8;
-    const int bid = blockIdx.x + g.tile_offset;  // (tile_offset is a multiple of 8: the XCD of a block stays bid % 8)
+    const int bid = blockIdx.x;
     const int xcd = bid % kXcd, loc = bid / kXcd;
     const int q = nwg / kXcd, r = nwg % kXcd;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -58,13 +58,22 @@ __device__ __forceinline__ void gemm_tile_origin(const GemmArgs& g, int BM, int 
     n0 = (in_group / gsz) * BN;
 }
 
+// one residual element (bf16 or fp32 stream)
+__device__ __forceinline__ float gemm_residual_at(const GemmArgs& g, const bf16_t* R, int64_t idx) {
+    return g.res_f32 ? reinterpret_cast<const float*>(R)[idx] : bf16_to_f32(R[idx]);
+}
+
 // Epilogue for one accumulator fragment: the lane owns C[m][n .. n+3] (operands were swapped so that the four
 // registers are consecutive N).  bias -> activation (or SwiGLU) -> residual -> store.
 template <int ACT, bool OUT_F32>
 __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m, int n, const f32x4_t& acc) {
     if (m >= g.M || n >= g.N) return;
+    if (g.out_rows) {  // scatter epilogue: destination (and residual) row from the map; negative = dropped
+        m = g.out_rows[m];
+        if (m < 0) return;
+    }
     const bf16_t* __restrict__ bias = g.bias;
-    const bf16_t* __restrict__ R = g.residual ? g.residual + (int64_t)bz * g.strideR : nullptr;
+    const bf16_t* __restrict__ R = g.residual ? g.residual + (int64_t)bz * g.strideR * (g.res_f32 ? 2 : 1) : nullptr;
     const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
     float v[4] = {acc[0], acc[1], acc[2], acc[3]};
     if ((g.N & 3) == 0) {
@@ -92,11 +101,16 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = gemm_act(v[j], ACT);
         if (R) {
-            const uint2 r2 = *reinterpret_cast<const uint2*>(R + rrow * g.ldr + n);
-            v[0] += bf16_to_f32((bf16_t)(r2.x & 0xffff));
-            v[1] += bf16_to_f32((bf16_t)(r2.x >> 16));
-            v[2] += bf16_to_f32((bf16_t)(r2.y & 0xffff));
-            v[3] += bf16_to_f32((bf16_t)(r2.y >> 16));
+            if (g.res_f32) {  // fp32 residual stream
+                const float4 r4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(R) + rrow * g.ldr + n);
+                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            } else {
+                const uint2 r2 = *reinterpret_cast<const uint2*>(R + rrow * g.ldr + n);
+                v[0] += bf16_to_f32((bf16_t)(r2.x & 0xffff));
+                v[1] += bf16_to_f32((bf16_t)(r2.x >> 16));
+                v[2] += bf16_to_f32((bf16_t)(r2.y & 0xffff));
+                v[3] += bf16_to_f32((bf16_t)(r2.y >> 16));
+            }
         }
         const int64_t o = (int64_t)m * g.ldc + n;
         if (OUT_F32) {
@@ -112,7 +126,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
             if (n + j >= g.N) break;
             float x = v[j] + (bias ? bf16_to_f32(bias[n + j]) : 0.0f);
             x = gemm_act(x, ACT);
-            if (R) x += bf16_to_f32(R[rrow * g.ldr + n + j]);
+            if (R) x += gemm_residual_at(g, R, rrow * g.ldr + n + j);
             const int64_t o = (int64_t)m * g.ldc + n + j;
             if (OUT_F32)
                 (static_cast<float*>(g.C) + (int64_t)bz * g.strideC)[o] = x;

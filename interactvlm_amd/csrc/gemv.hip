@@ -40,31 +40,39 @@ __device__ __forceinline__ float act_apply(float x, int act) {
 }
 
 // ROWS weight rows per wave (2: enables the SwiGLU epilogue and doubles the loads in flight; 1: small N, more
-// waves).  XLDS: the activation rows (optionally RMS-normalised: x * gamma, bf16) are staged ONCE per block in LDS
+// waves).  XLDS: the activation rows (optionally RMS-normalised: x * gamma) are staged ONCE per block in LDS
 // together with their row scale, instead of every wave re-deriving them from global memory for every weight row.
-// Intra-launch producer / consumer hooks (gemv_pair_kernel below): a consumer block issues its first weight loads, then
-// waits until *wait_ctr >= wait_target before it reads its input vector (with agent-scope loads); a producer block
-// writes its outputs with agent-scope stores and bumps *arrive_ctr once when done.
-struct GemvSync {
-    const int32_t* wait_ctr = nullptr;
-    int wait_target = 0;
-    int32_t* arrive_ctr = nullptr;
-    int32_t* status = nullptr;
-};
-constexpr long long kGemvWaitTicks = 100000000LL;  // 1 s of the 100 MHz wall clock
+// AF32: the activations are fp32 (fp32 residual stream / fp32 hidden states): they stay fp32 in LDS and every product
+// bf16 weight x fp32 activation is exact - the decode path carries no operand rounding at all (it is HBM-bound: the
+// extra LDS bytes and the 8 FMAs per 16-byte weight chunk instead of 8 packed multiplies are free).
+typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
 
-template <int M, int ROWS, bool RMS, bool XLDS, bool COH_X = false, bool COH_OUT = false>
-__device__ __forceinline__ void gemv_body(const GemmArgs& g, const int vblock, const int vgrid, const GemvSync sy) {
+__device__ __forceinline__ float dot8f(const u32x4_t& w, const f32x4v_t& xa, const f32x4v_t& xb) {
+    float acc = __uint_as_float(w[0] << 16) * xa[0];
+    acc = fmaf(__uint_as_float(w[0] & 0xffff0000u), xa[1], acc);
+    acc = fmaf(__uint_as_float(w[1] << 16), xa[2], acc);
+    acc = fmaf(__uint_as_float(w[1] & 0xffff0000u), xa[3], acc);
+    acc = fmaf(__uint_as_float(w[2] << 16), xb[0], acc);
+    acc = fmaf(__uint_as_float(w[2] & 0xffff0000u), xb[1], acc);
+    acc = fmaf(__uint_as_float(w[3] << 16), xb[2], acc);
+    acc = fmaf(__uint_as_float(w[3] & 0xffff0000u), xb[3], acc);
+    return acc;
+}
+
+template <int M, int ROWS, bool RMS, bool XLDS, bool AF32>
+__global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float s_red[4][M];
     __shared__ float s_rstd[M];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nchunk = g.K >> 3;  // 16-byte chunks per row
-    u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);  // [M][nchunk] when XLDS
+    const int nchunk = g.K >> 3;  // 8-element chunks per row (16 bytes of weights)
+    u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);      // bf16 image [M][nchunk] (XLDS && !AF32)
+    f32x4v_t* xf = reinterpret_cast<f32x4v_t*>(smem);    // fp32 image [M][2 planes][nchunk] float4 (XLDS && AF32)
+    const float* Af = reinterpret_cast<const float*>(g.A);
 
     constexpr int U = ROWS == 2 ? 4 : 8;  // 8 x 16-byte weight loads in flight per lane per step
-    const int wave_global = vblock * 4 + wave;
-    const int nwaves = vgrid * 4;
+    const int wave_global = blockIdx.x * 4 + wave;
+    const int nwaves = gridDim.x * 4;
     const int ngroups = (g.N + ROWS - 1) / ROWS;
     const int nbatch = (nchunk + 64 * U - 1) / (64 * U);
     const int my_groups = wave_global < ngroups ? (ngroups - wave_global + nwaves - 1) / nwaves : 0;
@@ -90,45 +98,35 @@ __device__ __forceinline__ void gemv_body(const GemmArgs& g, const int vblock, c
         float ssq[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) ssq[m] = 0.0f;
-        if (COH_X) {
-            // x was produced by other blocks of this launch: agent-scope loads.  ALL of this thread's loads are issued
-            // before the first is used (a load-use-per-iteration loop costs one memory round trip per iteration: 5-6
-            // round trips for the 22 KB vector of down_proj).  XLDS, M == 1, no RMS fusion on this path.
-            constexpr int kMaxDw = 48;  // <= 48 KB of x / (256 threads x 4 B); lane-consecutive dwords: fully coalesced
-            uint32_t v[kMaxDw];
-            const uint32_t* xp = reinterpret_cast<const uint32_t*>(g.A);
-            uint32_t* xs32 = reinterpret_cast<uint32_t*>(xs);
-            const int ndw = g.K >> 1;
-            const int nper = (ndw + 255) >> 8;  // dwords per thread (22 for K = 11008)
-#pragma unroll
-            for (int i = 0; i < kMaxDw; ++i)
-                if (i < nper) {
-                    const int d = min((int)threadIdx.x + 256 * i, ndw - 1);
-                    v[i] = __hip_atomic_load(const_cast<uint32_t*>(xp) + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-            for (int i = 0; i < kMaxDw; ++i)
-                if (i < nper) {
-                    const int d = threadIdx.x + 256 * i;
-                    if (d < ndw) xs32[d] = v[i];
-                }
-            __syncthreads();
-            return;
-        }
         for (int c = threadIdx.x; c < nchunk; c += 256) {
             u32x4_t gv;
             if (RMS) gv = *(reinterpret_cast<const u32x4_t*>(g.rms_w) + c);
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                u32x4_t xv = *(reinterpret_cast<const u32x4_t*>(g.A + (int64_t)m * g.lda) + c);
-                if (RMS) {
-                    ssq[m] += dot8(xv, xv);
+                if (AF32) {
+                    const f32x4v_t* xp = reinterpret_cast<const f32x4v_t*>(Af + (int64_t)m * g.lda) + 2 * c;
+                    f32x4v_t xa = xp[0], xb = xp[1];
+                    if (RMS) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        xv[j] = pack_bf16x2(__uint_as_float(xv[j] << 16) * __uint_as_float(gv[j] << 16),
-                                            __uint_as_float(xv[j] & 0xffff0000u) * __uint_as_float(gv[j] & 0xffff0000u));
+                        for (int j = 0; j < 4; ++j) ssq[m] += xa[j] * xa[j] + xb[j] * xb[j];
+                        xa[0] *= __uint_as_float(gv[0] << 16); xa[1] *= __uint_as_float(gv[0] & 0xffff0000u);
+                        xa[2] *= __uint_as_float(gv[1] << 16); xa[3] *= __uint_as_float(gv[1] & 0xffff0000u);
+                        xb[0] *= __uint_as_float(gv[2] << 16); xb[1] *= __uint_as_float(gv[2] & 0xffff0000u);
+                        xb[2] *= __uint_as_float(gv[3] << 16); xb[3] *= __uint_as_float(gv[3] & 0xffff0000u);
+                    }
+                    xf[(2 * m) * nchunk + c] = xa;  // two planes: consecutive lanes read consecutive 16 bytes
+                    xf[(2 * m + 1) * nchunk + c] = xb;
+                } else {
+                    u32x4_t xv = *(reinterpret_cast<const u32x4_t*>(g.A + (int64_t)m * g.lda) + c);
+                    if (RMS) {
+                        ssq[m] += dot8(xv, xv);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            xv[j] = pack_bf16x2(__uint_as_float(xv[j] << 16) * __uint_as_float(gv[j] << 16),
+                                                __uint_as_float(xv[j] & 0xffff0000u) * __uint_as_float(gv[j] & 0xffff0000u));
+                    }
+                    xs[m * nchunk + c] = xv;
                 }
-                if (XLDS) xs[m * nchunk + c] = xv;
             }
         }
         if (RMS) {
@@ -145,7 +143,7 @@ __device__ __forceinline__ void gemv_body(const GemmArgs& g, const int vblock, c
                                               s_red[3][threadIdx.x]) / (float)g.K + g.rms_eps);
             __syncthreads();
         }
-        };
+    };
 
     float a0[M], a1[M];
 #pragma unroll
@@ -160,22 +158,24 @@ __device__ __forceinline__ void gemv_body(const GemmArgs& g, const int vblock, c
             if (cc < nchunk) {
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    u32x4_t xv;
-                    if (XLDS) {
-                        xv = xs[m * nchunk + cc];
-                    } else {
-                        xv = *(reinterpret_cast<const u32x4_t*>(g.A + (int64_t)m * g.lda) + cc);
-                        if (RMS) {
-                            const u32x4_t gv = *(reinterpret_cast<const u32x4_t*>(g.rms_w) + cc);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                xv[j] = pack_bf16x2(
-                                    __uint_as_float(xv[j] << 16) * __uint_as_float(gv[j] << 16),
-                                    __uint_as_float(xv[j] & 0xffff0000u) * __uint_as_float(gv[j] & 0xffff0000u));
+                    if (AF32) {
+                        f32x4v_t xa, xb;
+                        if (XLDS) {
+                            xa = xf[(2 * m) * nchunk + cc];
+                            xb = xf[(2 * m + 1) * nchunk + cc];
+                        } else {
+                            const f32x4v_t* xp = reinterpret_cast<const f32x4v_t*>(Af + (int64_t)m * g.lda) + 2 * cc;
+                            xa = xp[0];
+                            xb = xp[1];
                         }
+                        a0[m] += dot8f(wa[u], xa, xb);
+                        if (ROWS == 2) a1[m] += dot8f(wb[u], xa, xb);
+                    } else {
+                        const u32x4_t xv = XLDS ? xs[m * nchunk + cc]
+                                                : *(reinterpret_cast<const u32x4_t*>(g.A + (int64_t)m * g.lda) + cc);
+                        a0[m] += dot8(wa[u], xv);
+                        if (ROWS == 2) a1[m] += dot8(wb[u], xv);
                     }
-                    a0[m] += dot8(wa[u], xv);
-                    if (ROWS == 2) a1[m] += dot8(wb[u], xv);
                 }
             }
         }
@@ -200,7 +200,6 @@ __device__ __forceinline__ void gemv_body(const GemmArgs& g, const int vblock, c
                     const float o = (v0 / (1.0f + __expf(-v0))) * v1;
                     const int64_t idx = (int64_t)m * g.ldc + pr;
                     if (g.out_f32) static_cast<float*>(g.C)[idx] = o;
-                    else if (COH_OUT) __hip_atomic_store(static_cast<bf16_t*>(g.C) + idx, f32_to_bf16(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else static_cast<bf16_t*>(g.C)[idx] = f32_to_bf16(o);
                     continue;
                 }
@@ -208,8 +207,14 @@ __device__ __forceinline__ void gemv_body(const GemmArgs& g, const int vblock, c
                 v1 = act_apply(v1, g.act);
                 if (g.residual) {
                     const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
-                    v0 += bf16_to_f32(g.residual[rrow * g.ldr + n0]);
-                    v1 += bf16_to_f32(g.residual[rrow * g.ldr + n1]);
+                    if (g.res_f32) {
+                        const float* R = reinterpret_cast<const float*>(g.residual);
+                        v0 += R[rrow * g.ldr + n0];
+                        v1 += R[rrow * g.ldr + n1];
+                    } else {
+                        v0 += bf16_to_f32(g.residual[rrow * g.ldr + n0]);
+                        v1 += bf16_to_f32(g.residual[rrow * g.ldr + n1]);
+                    }
                 }
                 if (g.out_f32) {
                     float* C = static_cast<float*>(g.C) + (int64_t)m * g.ldc;
@@ -230,25 +235,7 @@ __device__ __forceinline__ void gemv_body(const GemmArgs& g, const int vblock, c
     //      step s is consumed, including across row groups and across the block prologue ---------------------
     u32x4_t wa0[U], wb0[U], wa1[U], wb1[U];
     if (nsteps > 0) issue(wa0, wb0, 0);
-    if (sy.wait_ctr) {  // consumer: the first weight loads are in flight; now wait for the producers of the input vector
-        __shared__ int s_ok;
-        if (threadIdx.x == 0) {
-            int ok = 1;
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(const_cast<int32_t*>(sy.wait_ctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.wait_target) {
-                __builtin_amdgcn_s_sleep(100);  // ~2.7 us: up to ~1000 blocks poll this one line; the wait itself is 20+ us
-                if (wall_clock64() - t0 > kGemvWaitTicks) {
-                    __hip_atomic_store(sy.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-            }
-            s_ok = ok;
-        }
-        __syncthreads();
-        if (!s_ok) return;
-    }
-    if (XLDS || RMS) prologue();
+    if (XLDS) prologue();
     for (int s2 = 0; s2 < nsteps; s2 += 2) {
         if (s2 + 1 < nsteps) issue(wa1, wb1, s2 + 1);
         consume(wa0, wb0, s2);
@@ -256,42 +243,6 @@ __device__ __forceinline__ void gemv_body(const GemmArgs& g, const int vblock, c
             if (s2 + 2 < nsteps) issue(wa0, wb0, s2 + 2);
             consume(wa1, wb1, s2 + 1);
         }
-    }
-    if (sy.arrive_ctr) {  // producer: outputs performed, one arrival per block
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(sy.arrive_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-template <int M, int ROWS, bool RMS, bool XLDS>
-__global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
-    gemv_body<M, ROWS, RMS, XLDS>(g, blockIdx.x, gridDim.x, GemvSync());
-}
-
-// (opt-in; measured SLOWER than two launches on MI355X: 80-90 us vs 51 us - each half alone runs at its stand-alone speed
-// inside this kernel, 37 + 21 us, but the two streaming patterns sharing one grid cost another 22 us)
-// gate|up (RMSNorm + SwiGLU fused) and down (+ residual) of one decoder layer in ONE launch: blocks [0, na) are the gate|up
-// GEMV; blocks [na, na + nb) are the down GEMV - they stream their first weight rows immediately and wait on `counter`
-// for the na producers before staging h.  Counter monotonic over the tokens of a generation (target = na * (step + 1)).
-struct GemvPairArgs {
-    GemmArgs ga, gb;
-    int na, nb;
-    const int32_t* step_dev;
-    int32_t* counter;
-    int32_t* status;
-};
-__global__ __launch_bounds__(256) void gemv_pair_kernel(GemvPairArgs p) {
-    if ((int)blockIdx.x < p.na) {
-        GemvSync sy;
-        sy.arrive_ctr = p.counter;
-        gemv_body<1, 2, true, true, false, true>(p.ga, blockIdx.x, p.na, sy);
-    } else {
-        GemvSync sy;
-        sy.wait_ctr = p.counter;
-        sy.wait_target = p.na * (*p.step_dev + 1);
-        sy.status = p.status;
-        gemv_body<1, 1, false, true, true, false>(p.gb, (int)blockIdx.x - p.na, p.nb, sy);
     }
 }
 
@@ -351,63 +302,38 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 
 template <int M>
 static int launch_gemv(const GemmArgs& g, hipStream_t st) {
-    const size_t xbytes = (size_t)M * g.K * 2;
+    const size_t xbytes = (size_t)M * g.K * (g.a_f32 ? 4 : 2);
     // (x staged in LDS also when the GEMV shares the CUs with the encoder's 128-KB-LDS GEMM blocks: never staging it costs
     //  12 ms end to end, staging only K = 4096 vectors 1 ms - LDS room is not what slows the decode next to the encoder)
     const bool xlds = xbytes <= 48 * 1024;
+    if (g.rms_w && !xlds) return IVLM_ERR_UNSUPPORTED;  // (such shapes take the skinny MFMA kernel)
     const bool rows2 = g.act == ACT_SWIGLU || g.N > 8192;  // small N: one row per wave = twice the waves
     const int ngroups = rows2 ? (g.N + 1) / 2 : g.N;
     int blocks = (ngroups + 3) / 4;
     const int cap = 256 * 4;  // 4 resident blocks per CU; waves stride over the remaining rows
     if (blocks > cap) blocks = cap;
     const size_t lds = xlds ? xbytes : 0;
-#define IVLM_GEMV_GO(ROWS, RMS, XL) gemv_kernel<M, ROWS, RMS, XL><<<blocks, 256, lds, st>>>(g)
-    if (rows2) {
-        if (g.rms_w) { if (xlds) IVLM_GEMV_GO(2, true, true); else IVLM_GEMV_GO(2, true, false); }
-        else { if (xlds) IVLM_GEMV_GO(2, false, true); else IVLM_GEMV_GO(2, false, false); }
-    } else {
-        if (g.rms_w) { if (xlds) IVLM_GEMV_GO(1, true, true); else IVLM_GEMV_GO(1, true, false); }
-        else { if (xlds) IVLM_GEMV_GO(1, false, true); else IVLM_GEMV_GO(1, false, false); }
+#define IVLM_GEMV_GO(ROWS, RMS, XL, AF) gemv_kernel<M, ROWS, RMS, XL, AF><<<blocks, 256, lds, st>>>(g)
+#define IVLM_GEMV_ROWS(ROWS)                                                                   \
+    if (g.a_f32) {                                                                             \
+        if (g.rms_w) IVLM_GEMV_GO(ROWS, true, true, true);                                     \
+        else if (xlds) IVLM_GEMV_GO(ROWS, false, true, true);                                  \
+        else IVLM_GEMV_GO(ROWS, false, false, true);                                           \
+    } else {                                                                                   \
+        if (g.rms_w) IVLM_GEMV_GO(ROWS, true, true, false);                                    \
+        else if (xlds) IVLM_GEMV_GO(ROWS, false, true, false);                                 \
+        else IVLM_GEMV_GO(ROWS, false, false, false);                                          \
     }
+    if (rows2) { IVLM_GEMV_ROWS(2) } else { IVLM_GEMV_ROWS(1) }
+#undef IVLM_GEMV_ROWS
 #undef IVLM_GEMV_GO
     return ivlm_launch_status();
 }
 
-// opt-in: measured slower than the wave-per-row kernel as a stand-alone launch (qkv 20.9 vs 18.7 us, o 18.6 vs 14.6 us):
-// one 512-thread block per CU cannot overlap its own prologue / epilogue with streaming the way 4 small blocks per CU do
-// h = SwiGLU(W_gu . RMSNorm(x2)), x_out = x2 + W_down . h in one launch (decode, M == 1)
-int gemv_gu_down(const bf16_t* x2, const bf16_t* ln_w, float eps, const bf16_t* wgu, const bf16_t* wdown, bf16_t* h_scratch,
-                 bf16_t* x_out, int hidden, int inter, const int32_t* step_dev, int32_t* counter, int32_t* status,
-                 hipStream_t st) {
-    if (!x2 || !ln_w || !wgu || !wdown || !h_scratch || !x_out || !step_dev || !counter || !status) return IVLM_ERR_INVALID_ARG;
-    if ((hidden & 7) || (inter & 7) || (size_t)inter * 2 > 48 * 1024 || (size_t)hidden * 2 > 48 * 1024) return IVLM_ERR_UNSUPPORTED;
-    GemvPairArgs p;
-    p.ga = GemmArgs();
-    p.ga.A = x2; p.ga.lda = hidden; p.ga.W = wgu; p.ga.ldw = hidden; p.ga.C = h_scratch; p.ga.ldc = inter;
-    p.ga.M = 1; p.ga.N = 2 * inter; p.ga.K = hidden; p.ga.act = ACT_SWIGLU; p.ga.rms_w = ln_w; p.ga.rms_eps = eps;
-    p.gb = GemmArgs();
-    p.gb.A = h_scratch; p.gb.lda = inter; p.gb.W = wdown; p.gb.ldw = inter; p.gb.C = x_out; p.gb.ldc = hidden;
-    p.gb.M = 1; p.gb.N = hidden; p.gb.K = inter; p.gb.act = ACT_NONE; p.gb.residual = x2; p.gb.ldr = hidden;
-    auto blocks_of = [](int ngroups) { int b = (ngroups + 3) / 4; return b > 1024 ? 1024 : b; };
-    p.na = blocks_of(inter);   // 2 rows (one gate/up pair) per wave
-    p.nb = blocks_of(hidden);  // 1 row per wave
-    p.step_dev = step_dev; p.counter = counter; p.status = status;
-    const size_t lds = (size_t)std::max(hidden, inter) * 2;
-    gemv_pair_kernel<<<p.na + p.nb, 256, lds, st>>>(p);
-    return ivlm_launch_status();
-}
-
-static int g_gemv_slab = 0;
-void gemv_set_slab(int on) { g_gemv_slab = on; }
-
 int gemv_bf16(const GemmArgs& g, hipStream_t st) {
     if (!g.A || !g.W || !g.C || g.M <= 0 || g.M > kMaxM || g.N <= 0 || g.K <= 0) return IVLM_ERR_INVALID_ARG;
-    if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || g.batch != 1) return IVLM_ERR_UNSUPPORTED;
+    if ((g.K & 7) || (g.lda & (g.a_f32 ? 3 : 7)) || (g.ldw & 7) || g.batch != 1) return IVLM_ERR_UNSUPPORTED;
     if (g.act == ACT_SWIGLU && ((g.N & 1) || g.residual)) return IVLM_ERR_UNSUPPORTED;
-    if (g.M == 1 && g_gemv_slab && g.N >= 1024) {  // decode: flat slab streaming (gemv_slab.hip) when the shape qualifies
-        const int rc = gemv_slab_bf16(g, st);
-        if (rc != IVLM_ERR_UNSUPPORTED) return rc;
-    }
     switch (g.M) {
         case 1: return launch_gemv<1>(g, st);
         case 2: return launch_gemv<2>(g, st);
@@ -431,14 +357,4 @@ int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st)
 extern "C" int ivlm_argmax_f32(const float* x, int rows, int cols, int32_t* out, ivlm_stream_t stream) {
     ivlm_enter();
     return ivlm::argmax_f32(x, rows, cols, out, ivlm_stream(stream));
-}
-
-extern "C" int ivlm_llama_gateup_down(const void* x2, const void* ln_w, float eps, const void* wgu, const void* wdown,
-                                      void* h_scratch, void* x_out, int hidden, int inter, const int32_t* step_dev,
-                                      int32_t* counter, int32_t* status, ivlm_stream_t stream) {
-    ivlm_enter();
-    return ivlm::gemv_gu_down(static_cast<const bf16_t*>(x2), static_cast<const bf16_t*>(ln_w), eps,
-                              static_cast<const bf16_t*>(wgu), static_cast<const bf16_t*>(wdown),
-                              static_cast<bf16_t*>(h_scratch), static_cast<bf16_t*>(x_out), hidden, inter, step_dev, counter,
-                              status, ivlm_stream(stream));
 }

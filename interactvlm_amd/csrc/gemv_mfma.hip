@@ -15,6 +15,9 @@
 //     accumulator) is fused exactly as in gemv.hip;
 //   * the 8 partial 16x16 tiles are summed through LDS in a fixed order (deterministic), then bias / activation /
 //     SwiGLU over interleaved gate-up rows / residual and the store.
+//   * AF32: fp32 activation rows (fp32 residual stream): each 8-element x fragment is split into a bf16 "hi" and a bf16 "lo"
+//     part (x = hi + lo to 2^-17) and meets the weight fragment in TWO MFMAs - the kernel is HBM-bound, the second MFMA is
+//     free, and the batched decode step then agrees with the batch-1 GEMV (exact fp32 products) to ~1e-5 relative.
 #include "gemm_common.h"
 
 namespace ivlm {
@@ -34,7 +37,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     }
 }
 
-template <bool RMS>
+template <bool RMS, bool AF32>
 __global__ __launch_bounds__(kThreads, 2) void skinny_mfma_kernel(GemmArgs g) {
     __shared__ float s_part[kWaves][16][17];  // [wave][m][n]
     __shared__ float s_ssq[kWaves][16];
@@ -48,24 +51,57 @@ __global__ __launch_bounds__(kThreads, 2) void skinny_mfma_kernel(GemmArgs g) {
     const int s0 = wave * per, s1 = min(s0 + per, nsteps);
     const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(g.W + (int64_t)min(n0 + r, g.N - 1) * g.ldw);
     const bool xrow = r < g.M;
-    const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(g.A + (int64_t)(xrow ? r : 0) * g.lda);
+    const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(g.A + (int64_t)(xrow ? r : 0) * g.lda * (AF32 ? 2 : 1));
     const u32x4_t* gp = reinterpret_cast<const u32x4_t*>(g.rms_w);
     const u32x4_t zero = {0u, 0u, 0u, 0u};
     f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
     float ssq = 0.0f;
     for (int s = s0; s < s1; s += kU) {
-        u32x4_t w[kU], x[kU], gm[kU];
+        u32x4_t w[kU], x[kU], x2[kU], gm[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int c = (s + u) * 4 + kg;
             const bool ok = (s + u) < s1 && c < nchunk;
             const int cc = ok ? c : 0;  // clamped (unconditional) weight loads keep the buffers in registers
             w[u] = __builtin_nontemporal_load(wp + cc);
-            x[u] = (ok && xrow) ? xp[cc] : zero;
+            if (AF32) {  // 8 fp32 activations = two 16-byte loads
+                x[u] = (ok && xrow) ? xp[2 * cc] : zero;
+                x2[u] = (ok && xrow) ? xp[2 * cc + 1] : zero;
+            } else {
+                x[u] = (ok && xrow) ? xp[cc] : zero;
+            }
             if (RMS) gm[u] = gp[cc];
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
+            if (AF32) {
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[j] = __uint_as_float(x[u][j]);
+                    f[4 + j] = __uint_as_float(x2[u][j]);
+                }
+                if (RMS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ssq += f[2 * j] * f[2 * j] + f[2 * j + 1] * f[2 * j + 1];
+                        f[2 * j] *= __uint_as_float(gm[u][j] << 16);
+                        f[2 * j + 1] *= __uint_as_float(gm[u][j] & 0xffff0000u);
+                    }
+                }
+                u32x4_t hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16_t h0 = f32_to_bf16(f[2 * j]), h1 = f32_to_bf16(f[2 * j + 1]);
+                    hi[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                    lo[j] = pack_bf16x2(f[2 * j] - bf16_to_f32(h0), f[2 * j + 1] - bf16_to_f32(h1));
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[u]), __builtin_bit_cast(bf16x8_t, hi),
+                                                              acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[u]), __builtin_bit_cast(bf16x8_t, lo),
+                                                              acc, 0, 0, 0);
+                continue;
+            }
             u32x4_t xv = x[u];
             if (RMS) {
 #pragma unroll
@@ -115,7 +151,7 @@ __global__ __launch_bounds__(kThreads, 2) void skinny_mfma_kernel(GemmArgs g) {
         v = act_apply(v, g.act);
         if (g.residual) {
             const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
-            v += bf16_to_f32(g.residual[rrow * g.ldr + col]);
+            v += gemm_residual_at(g, g.residual, rrow * g.ldr + col);
         }
     }
     if (g.out_f32) static_cast<float*>(g.C)[(int64_t)m * g.ldc + col] = v;
@@ -126,11 +162,16 @@ __global__ __launch_bounds__(kThreads, 2) void skinny_mfma_kernel(GemmArgs g) {
 
 int gemv_mfma_bf16(const GemmArgs& g, hipStream_t st) {
     if (!g.A || !g.W || !g.C || g.M <= 0 || g.M > 16 || g.N <= 0 || g.K <= 0) return IVLM_ERR_INVALID_ARG;
-    if ((g.K & 7) || (g.lda & 7) || (g.ldw & 7) || g.batch != 1) return IVLM_ERR_UNSUPPORTED;
+    if ((g.K & 7) || (g.lda & (g.a_f32 ? 3 : 7)) || (g.ldw & 7) || g.batch != 1) return IVLM_ERR_UNSUPPORTED;
     if (g.act == ACT_SWIGLU && ((g.N & 1) || g.residual)) return IVLM_ERR_UNSUPPORTED;
     const int blocks = (g.N + 15) / 16;
-    if (g.rms_w) skinny_mfma_kernel<true><<<blocks, kThreads, 0, st>>>(g);
-    else skinny_mfma_kernel<false><<<blocks, kThreads, 0, st>>>(g);
+    if (g.a_f32) {
+        if (g.rms_w) skinny_mfma_kernel<true, true><<<blocks, kThreads, 0, st>>>(g);
+        else skinny_mfma_kernel<false, true><<<blocks, kThreads, 0, st>>>(g);
+    } else {
+        if (g.rms_w) skinny_mfma_kernel<true, false><<<blocks, kThreads, 0, st>>>(g);
+        else skinny_mfma_kernel<false, false><<<blocks, kThreads, 0, st>>>(g);
+    }
     return ivlm_launch_status();
 }
 

@@ -8,23 +8,25 @@ namespace ivlm {
 enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICK_GELU = 2, ACT_RELU = 3, ACT_SILU = 4, ACT_SWIGLU = 5, ACT_SIGMOID = 6 };
 
 struct GemmArgs {
-    const bf16_t* A = nullptr;  // activations [M,K], row stride lda (elements)
+    const bf16_t* A = nullptr;  // activations [M,K], row stride lda (elements); float when a_f32 (skinny paths only)
     const bf16_t* W = nullptr;  // weights     [N,K], row stride ldw  (nn.Linear layout)
     void* C = nullptr;          // output      [M,N] (or [M,N/2] for ACT_SWIGLU), row stride ldc
     const bf16_t* bias = nullptr;      // [N] or null
-    const bf16_t* residual = nullptr;  // [*,N] added after the activation, row stride ldr, or null
+    const bf16_t* residual = nullptr;  // [*,N] added after the activation, row stride ldr, or null; float when res_f32
     int64_t lda = 0, ldw = 0, ldc = 0, ldr = 0;
     int res_mod = 0;   // >0: residual row = m % res_mod (broadcast tables such as pos_embed)
     int M = 0, N = 0, K = 0;
     int act = ACT_NONE;
     int out_f32 = 0;   // 1: C is float
+    // scatter epilogue (tile GEMM only): row m of the product is written to row out_rows[m] of C (and takes its residual from
+    // that row); rows with out_rows[m] < 0 are dropped.  SAM's window_unpartition + shortcut without a separate pass.
+    const int32_t* out_rows = nullptr;
+    int a_f32 = 0;     // 1: A is float (M <= 16 weight-streaming paths: the products are exact, no operand rounding)
+    int res_f32 = 0;   // 1: residual is float (fp32 residual stream)
     // batched (strided) variant: blockIdx.z = batch
     int batch = 1;
     int64_t strideA = 0, strideW = 0, strideC = 0, strideR = 0;
     int tile = 0;  // 0: choose, 128 / 256: force the block tile (benchmarks, tests)
-    // a launch may cover only the tiles [tile_offset, tile_offset + tile_count) of the raster (tile_count 0 = all): the tail
-    // round of a GEMM whose tile count is not a multiple of the CU count runs separately, K split over the idle CUs
-    int tile_offset = 0, tile_count = 0;
     // GEMV path only: fuse the preceding RMSNorm, out = W . (x * rsqrt(mean(x^2)+eps) * rms_w)
     const bf16_t* rms_w = nullptr;
     float rms_eps = 0.0f;
@@ -34,27 +36,18 @@ struct GemmArgs {
 int gemm_bf16(const GemmArgs& g, hipStream_t st);
 // 256x256 tile with the 8-phase ping-pong K loop (gemm256.hip); same contract as gemm_bf16
 int gemm_bf16_256p(const GemmArgs& g, hipStream_t st);
-// the same kernel with the last (tiles % 256) tiles - the under-filled final round - computed as `splits` K slices over the
-// otherwise idle CUs (fp32 partials in `workspace` [splits, M, N]) and reduced with the epilogue by a small second kernel
-int gemm_bf16_tailsplit(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st);
-// decode MLP in one launch: h = SwiGLU(W_gu . RMSNorm(x2)), x_out = x2 + W_down . h (down blocks wait on a device counter)
-int gemv_gu_down(const bf16_t* x2, const bf16_t* ln_w, float eps, const bf16_t* wgu, const bf16_t* wdown, bf16_t* h_scratch,
-                 bf16_t* x_out, int hidden, int inter, const int32_t* step_dev, int32_t* counter, int32_t* status,
-                 hipStream_t st);
-// M == 1 decode GEMV as flat slab streaming (gemv_slab.hip); IVLM_ERR_UNSUPPORTED = shape does not qualify
-int gemv_slab_bf16(const GemmArgs& g, hipStream_t st);
-void gemv_set_slab(int on);
 // split-K variant for small M (fp32 partials in `workspace`, >= splits*M*N*4 bytes); act != SWIGLU
 int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st);
 // nn.Linear dispatch: GEMV (M <= 8) or the MFMA tile kernel
 int linear_bf16(const GemmArgs& g, hipStream_t st);
 
 // ---- normalisation ---------------------------------------------------------------------------
-// y = (x-mean)/sqrt(var+eps)*w+b over the last dim (rows x cols); bf16 in/out, fp32 statistics.
-int layernorm_bf16(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int64_t rows, int cols, float eps,
-                   hipStream_t st, int gelu = 0);
-// y = x * rsqrt(mean(x^2)+eps) * w  (LLaMA RMSNorm; fp32 statistics, HF casts back before the weight multiply)
-int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int cols, float eps, hipStream_t st);
+// y = (x-mean)/sqrt(var+eps)*w+b over the last dim (rows x cols); x / y bf16 or fp32, fp32 statistics.
+// out_rows != null: row r is written to row out_rows[r] of y (SAM's window_partition folded into norm1)
+int layernorm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols, float eps,
+              hipStream_t st, int gelu = 0, const int32_t* out_rows = nullptr);
+// y = x * rsqrt(mean(x^2)+eps) * w  (LLaMA RMSNorm; fp32 statistics; a bf16 input is cast back before the weight multiply as HF does)
+int rmsnorm(const void* x, int x_f32, const bf16_t* w, void* y, int y_f32, int64_t rows, int cols, float eps, hipStream_t st);
 
 // ---- attention ---------------------------------------------------------------------------------
 struct AttnArgs {
@@ -77,6 +70,9 @@ struct AttnArgs {
 
 // softmax(scale * Q.K^T (+ rel-pos bias) (+ causal mask)) . V ; bf16 in/out, fp32 softmax. D in {16,32,64,80,128}.
 int attention_bf16(const AttnArgs& a, hipStream_t st);
+// fp32 operands end to end (SAM mask decoder): D in {16, 32}; strides[12] as the C ABI documents
+int attention_f32(const float* q, const float* k, const float* v, float* o, const int64_t* st12, int B, int H, int Sq, int Sk,
+                  int D, float scale, int kv_div, hipStream_t st);
 // decomposed relative-position bias terms of SAM's ViT (image_encoder.py:354-392) as fp32 tables
 int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const bf16_t* tab_h, const bf16_t* tab_w,
                 int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, hipStream_t st);
@@ -84,17 +80,18 @@ int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
 // ---- data movement / elementwise (elementwise.hip) -----------------------------------------------
 int im2col_nchw(const bf16_t* x, bf16_t* out, int B, int C, int H, int W, int ks, int stride, int Kpad, hipStream_t st);
 int im2col3x3_nhwc(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st);
-int gather_rows(bf16_t* dst, int64_t ldd, const bf16_t* src, int64_t lds_, const int32_t* idx, const bf16_t* add,
-                int64_t lda, int64_t rows, int cols, hipStream_t st);
-int add_rows(bf16_t* out, const bf16_t* a, const bf16_t* b, int64_t rows, int cols, int64_t b_rows, hipStream_t st,
-             int op = 0);  // op 0: a + b, 1: a * b
-int dense_pe(const float* gauss, bf16_t* pe, int h, int w, int F, hipStream_t st);
+// kinds: 0 bf16, 1 fp32, 2 (outputs only) split [hi | lo] bf16 rows of width 2*cols
+int gather_rows(void* dst, int dst_kind, int64_t ldd, const void* src, int src_kind, int64_t lds_, const int32_t* idx,
+                const void* add, int add_kind, int64_t lda, int64_t rows, int cols, hipStream_t st);
+int add_rows(void* out, int out_kind, const void* a, int a_kind, const void* b, int b_kind, int64_t rows, int cols,
+             int64_t b_rows, hipStream_t st, int op = 0);  // op 0: a + b, 1: a * b
+int dense_pe(const float* gauss, void* pe, int pe_f32, int h, int w, int F, hipStream_t st);
 int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, bf16_t* kcache, bf16_t* vcache,
             hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr);
 int rope_table(float* cos_tab, float* sin_tab, int T, int D, float theta, hipStream_t st);
 int normalize_pad_u8(const uint8_t* src, int H, int W, int y0, int x0, int ch, int cw, const float* mean3,
                      const float* std3, void* out, int out_bf16, int OH, int OW, hipStream_t st);
-int mask_dot(const bf16_t* up, const bf16_t* hyper, float* low, int B, int gh, int gw, int C, hipStream_t st);
+int mask_dot(const void* up, const void* hyper, int kind, float* low, int B, int gh, int gw, int C, hipStream_t st);
 
 // ---- metrics / SMPL-X transfer (metrics.hip) ------------------------------------------------------------
 int contact_prf(const float* gt, const float* pred, int B, int n, float thr, float* out, hipStream_t st);
@@ -115,11 +112,12 @@ int phong_shade(const int32_t* p2v, const float* bary, const float* verts, const
                 const float* bg3_host, uint8_t* out, hipStream_t st);
 
 // ---- single-token decode (decode.hip) ---------------------------------------------------------------
-int llama_decode_attn(const bf16_t* qkv, bf16_t* kcache, bf16_t* vcache, bf16_t* o, int H, int D, int pos, float theta,
-                      float scale, hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr, const int32_t* pos_dev = nullptr);
-
-int llama_decode_attn_batch(const bf16_t* qkv, int64_t ldq, bf16_t* kcache, bf16_t* vcache, int64_t cache_stride, bf16_t* o,
-                            int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta, float scale,
+// qkv / o bf16 or fp32 (io_f32); tmax = rows of the cache slab (a position >= tmax is skipped, never appended)
+int llama_decode_attn(const void* qkv, int io_f32, bf16_t* kcache, bf16_t* vcache, int tmax, void* o, int H, int D, int pos,
+                      float theta, float scale, hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr,
+                      const int32_t* pos_dev = nullptr);
+int llama_decode_attn_batch(const void* qkv, int io_f32, int64_t ldq, bf16_t* kcache, bf16_t* vcache, int64_t cache_stride,
+                            int tmax, void* o, int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta, float scale,
                             const float* cos_tab, const float* sin_tab, hipStream_t st);
 
 // ---- skinny GEMM (gemv.hip): M <= 8 rows of activations against streamed weights -------------------

@@ -1,4 +1,6 @@
-// Row normalisations for gfx950 (bf16 in/out, fp32 statistics), one wave per row, 16-byte loads.
+// Row normalisations for gfx950 (bf16 or fp32 in/out, fp32 statistics), one wave per row, 16-byte loads.
+// The residual streams of the three transformers are fp32 (GEMM residual epilogues write fp32): the norms read fp32 rows and
+// write the bf16 MFMA operand (or fp32 again where the normalised row is itself a stream: CLIP pre_layrnorm, SAM decoder).
 //   LayerNorm  : SAM ViT (eps 1e-6, image_encoder.py:158,172), SAM decoder (eps 1e-5, transformer.py:134-144),
 //                LayerNorm2d over channels when activations are kept NHWC (common.py:32-42), CLIP (HF, 1e-5)
 //   RMSNorm    : HF LlamaRMSNorm (x * rsqrt(mean(x^2)+eps) cast to bf16, THEN times weight)
@@ -21,22 +23,29 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
                       pack_bf16x2(f[6], f[7]));
 }
 
-template <bool RMS, int MAXC, bool GELU>
-__global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                   const bf16_t* __restrict__ b, bf16_t* __restrict__ y, int64_t rows,
-                                                   int cols, float eps) {
+template <bool RMS, int MAXC, bool GELU, bool XF32, bool YF32>
+__global__ __launch_bounds__(256) void norm_kernel(const void* __restrict__ xv, const bf16_t* __restrict__ w,
+                                                   const bf16_t* __restrict__ b, void* __restrict__ yv, int64_t rows,
+                                                   int cols, float eps, const int32_t* __restrict__ out_rows) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nchunk = cols >> 3;  // cols % 8 == 0
-    const uint4* xr = reinterpret_cast<const uint4*>(x + row * cols);
+    const uint4* xr = reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(xv) + row * cols);
+    const float4* xr4 = reinterpret_cast<const float4*>(static_cast<const float*>(xv) + row * cols);
     float v[MAXC][8];
     float s = 0.0f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int idx = c * 64 + lane;
         if (idx < nchunk) {
-            unpack8(xr[idx], v[c]);
+            if (XF32) {
+                const float4 a = xr4[2 * idx], bq = xr4[2 * idx + 1];
+                v[c][0] = a.x; v[c][1] = a.y; v[c][2] = a.z; v[c][3] = a.w;
+                v[c][4] = bq.x; v[c][5] = bq.y; v[c][6] = bq.z; v[c][7] = bq.w;
+            } else {
+                unpack8(xr[idx], v[c]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += RMS ? v[c][j] * v[c][j] : v[c][j];
         }
@@ -61,7 +70,9 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
         q = wave_sum(q);
         rstd = rsqrtf(q / (float)cols + eps);
     }
-    uint4* yr = reinterpret_cast<uint4*>(y + row * cols);
+    const int64_t orow = out_rows ? (int64_t)out_rows[row] : row;
+    uint4* yr = reinterpret_cast<uint4*>(static_cast<bf16_t*>(yv) + orow * cols);
+    float4* yr4 = reinterpret_cast<float4*>(static_cast<float*>(yv) + orow * cols);
     const uint4* wr = reinterpret_cast<const uint4*>(w);
     const uint4* br = reinterpret_cast<const uint4*>(b);
 #pragma unroll
@@ -72,7 +83,8 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
             unpack8(wr[idx], wv);
             if (RMS) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = bf16_to_f32(f32_to_bf16(v[c][j] * rstd)) * wv[j];
+                for (int j = 0; j < 8; ++j)  // HF casts the normalised row to the input dtype before the weight multiply
+                    o[j] = (XF32 ? v[c][j] * rstd : bf16_to_f32(f32_to_bf16(v[c][j] * rstd))) * wv[j];
             } else {
                 float bv[8];
                 unpack8(br[idx], bv);
@@ -82,36 +94,48 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
                     if (GELU) o[j] = 0.5f * o[j] * (1.0f + erff(o[j] * 0.70710678118654752f));
                 }
             }
-            yr[idx] = pack8(o);
+            if (YF32) {
+                yr4[2 * idx] = make_float4(o[0], o[1], o[2], o[3]);
+                yr4[2 * idx + 1] = make_float4(o[4], o[5], o[6], o[7]);
+            } else {
+                yr[idx] = pack8(o);
+            }
         }
     }
 }
 
 }  // namespace
 
-int layernorm_bf16(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int64_t rows, int cols, float eps,
-                   hipStream_t st, int gelu) {
+template <bool RMS, int MAXC, bool GELU>
+static void launch_norm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols,
+                        float eps, hipStream_t st, const int32_t* out_rows = nullptr) {
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (x_f32 && y_f32) norm_kernel<RMS, MAXC, GELU, true, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows);
+    else if (x_f32) norm_kernel<RMS, MAXC, GELU, true, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows);
+    else if (y_f32) norm_kernel<RMS, MAXC, GELU, false, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows);
+    else norm_kernel<RMS, MAXC, GELU, false, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows);
+}
+
+int layernorm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols, float eps,
+              hipStream_t st, int gelu, const int32_t* out_rows) {
     if (!x || !w || !b || !y || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
     if ((cols & 7) || cols > kMaxChunks * 512) return IVLM_ERR_UNSUPPORTED;
-    const unsigned grid = (unsigned)((rows + 3) / 4);
     if (gelu) {
         if (cols > 4 * 512) return IVLM_ERR_UNSUPPORTED;
-        norm_kernel<false, 4, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps);
+        launch_norm<false, 4, true>(x, x_f32, w, b, y, y_f32, rows, cols, eps, st, out_rows);
     } else if (cols <= 4 * 512) {
-        norm_kernel<false, 4, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps);
+        launch_norm<false, 4, false>(x, x_f32, w, b, y, y_f32, rows, cols, eps, st, out_rows);
     } else {
-        norm_kernel<false, kMaxChunks, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps);
+        launch_norm<false, kMaxChunks, false>(x, x_f32, w, b, y, y_f32, rows, cols, eps, st, out_rows);
     }
     return ivlm_launch_status();
 }
 
-int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int cols, float eps, hipStream_t st) {
+int rmsnorm(const void* x, int x_f32, const bf16_t* w, void* y, int y_f32, int64_t rows, int cols, float eps, hipStream_t st) {
     if (!x || !w || !y || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
     if ((cols & 7) || cols > kMaxChunks * 512) return IVLM_ERR_UNSUPPORTED;
-    if (cols <= 4 * 512)
-        norm_kernel<true, 4, false><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(x, w, nullptr, y, rows, cols, eps);
-    else
-        norm_kernel<true, kMaxChunks, false><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(x, w, nullptr, y, rows, cols, eps);
+    if (cols <= 4 * 512) launch_norm<true, 4, false>(x, x_f32, w, nullptr, y, y_f32, rows, cols, eps, st);
+    else launch_norm<true, kMaxChunks, false>(x, x_f32, w, nullptr, y, y_f32, rows, cols, eps, st);
     return ivlm_launch_status();
 }
 
@@ -119,19 +143,18 @@ int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int 
 
 extern "C" {
 
-int ivlm_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int64_t rows, int cols, float eps,
-                        int gelu, ivlm_stream_t stream) {
+int ivlm_layernorm(const void* x, int x_dtype, const void* w, const void* b, void* y, int y_dtype, int64_t rows, int cols,
+                   float eps, int gelu, const int32_t* out_rows, ivlm_stream_t stream) {
     ivlm_enter();
-    return ivlm::layernorm_bf16(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w),
-                                static_cast<const bf16_t*>(b), static_cast<bf16_t*>(y), rows, cols, eps,
-                                ivlm_stream(stream), gelu);
+    return ivlm::layernorm(x, x_dtype == IVLM_F32, static_cast<const bf16_t*>(w), static_cast<const bf16_t*>(b), y,
+                           y_dtype == IVLM_F32, rows, cols, eps, ivlm_stream(stream), gelu, out_rows);
 }
 
-int ivlm_rmsnorm_bf16(const void* x, const void* w, void* y, int64_t rows, int cols, float eps,
-                      ivlm_stream_t stream) {
+int ivlm_rmsnorm(const void* x, int x_dtype, const void* w, void* y, int y_dtype, int64_t rows, int cols, float eps,
+                 ivlm_stream_t stream) {
     ivlm_enter();
-    return ivlm::rmsnorm_bf16(static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), static_cast<bf16_t*>(y),
-                              rows, cols, eps, ivlm_stream(stream));
+    return ivlm::rmsnorm(x, x_dtype == IVLM_F32, static_cast<const bf16_t*>(w), y, y_dtype == IVLM_F32, rows, cols, eps,
+                         ivlm_stream(stream));
 }
 
 }  // extern "C"

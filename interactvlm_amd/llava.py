@@ -18,6 +18,7 @@ from .sam import _LN, _Lin, _dev
 from .weights import CLIP_PREFIX, ClipCfg, LlamaCfg
 
 BF16 = torch.bfloat16
+F32 = torch.float32
 
 
 class ClipTower:
@@ -26,6 +27,7 @@ class ClipTower:
     def __init__(self, w, cfg: ClipCfg, device, prefix=CLIP_PREFIX):
         self.cfg, self.device = cfg, device
         self._graphs = {}
+        self._patch_rows = {}
         e = prefix + ".embeddings"
         K = 3 * cfg.patch * cfg.patch
         self.kpad = ((K + 63) // 64) * 64
@@ -33,7 +35,7 @@ class ClipTower:
         self.patch_w = _dev(torch.nn.functional.pad(pw, (0, self.kpad - K)), device)
         pos = w[e + ".position_embedding.weight"]
         self.pos = _dev(pos, device)
-        self.cls_row = _dev((w[e + ".class_embedding"].float() + pos[0].float()).reshape(1, -1), device)
+        self.cls_row = (w[e + ".class_embedding"].float() + pos[0].float()).reshape(1, -1).to(device).contiguous()  # fp32
         self.pre_ln = _LN(w, prefix + ".pre_layrnorm", device, cfg.eps)
         n_run = cfg.layers + 1 + cfg.select_layer if cfg.select_layer < 0 else cfg.select_layer
         self.layers = []
@@ -71,23 +73,28 @@ class ClipTower:
         return static_out.clone()
 
     def _forward(self, images):
+        """-> penultimate-layer patch features, bf16 [B, T-1, hidden] (the mm_projector's MFMA operand).  The residual
+        stream is fp32 between the GEMMs (residual epilogues write fp32, the LayerNorms read it)."""
         c = self.cfg
         B = images.shape[0]
         T, Hh, hd = c.tokens, c.heads, c.hidden // c.heads
         cols = ops.im2col_nchw(images.to(BF16).contiguous(), c.patch, c.patch, self.kpad)  # [B*(T-1), kpad]
-        x = torch.empty(B, T, c.hidden, dtype=BF16, device=images.device)
+        x = torch.empty(B, T, c.hidden, dtype=F32, device=images.device)
         for b in range(B):  # patch GEMM writes rows 1..T-1 and adds their position embeddings in the epilogue
             ops.linear(cols[b * (T - 1): (b + 1) * (T - 1)], self.patch_w, residual=self.pos[1:], out=x[b, 1:])
-            x[b, 0:1].copy_(self.cls_row)  # class_embedding + position_embedding[0] (precomputed constant)
-        x = self.pre_ln(x.view(B * T, c.hidden))
+            ops.gather_rows(self.cls_row, out=x[b, 0:1])  # class_embedding + position_embedding[0] (precomputed constant)
+        x = self.pre_ln(x.view(B * T, c.hidden), out_f32=True)
         for L in self.layers:
             y = L["ln1"](x)
             qkv = ops.linear(y, L["qkv_w"], L["qkv_b"]).view(B, T, 3, Hh, hd)
             q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
             a = ops.attention(q, k, v, hd ** -0.5, prescale_q=True)
-            x = L["out"](a.permute(0, 2, 1, 3).reshape(B * T, c.hidden), residual=x)
-            x = L["fc2"](L["fc1"](L["ln2"](x), act="quick_gelu"), residual=x)
-        return x.view(B, T, c.hidden)[:, 1:]
+            x = L["out"](a.permute(0, 2, 1, 3).reshape(B * T, c.hidden), residual=x, out_f32=True)
+            x = L["fc2"](L["fc1"](L["ln2"](x), act="quick_gelu"), residual=x, out_f32=True)
+        if B not in self._patch_rows:  # drop the CLS row of every image
+            r = torch.arange(B * T, dtype=torch.int32).view(B, T)[:, 1:].reshape(-1)
+            self._patch_rows[B] = r.to(images.device)
+        return ops.gather_rows(x, self._patch_rows[B], out_kind="bf16").view(B, T - 1, c.hidden)
 
 
 class Llama:
@@ -114,32 +121,22 @@ class Llama:
         self.rope = ops.rope_table(max_len, hd, cfg.theta, device)  # fp32 cos/sin, computed once
         self._dgraph = None
         self._fused = None
-        self._dataflow = None
         self.fuse_attn_oproj = True
-        self.fuse_gateup_down = False  # one launch for gate|up + down: measured slower (88 vs 51 us), see csrc/gemv.hip
-        # all layers in one dataflow launch (csrc/decode_layers.hip): correct, but 3.25-3.5 ms/token vs 2.72 for the per-layer
-        # launches: every role is an all-to-all dependency, and one resident block per CU cannot both stream its role with all
-        # CUs and keep the next role's rows prefetched - opt-in experiment
-        self.dataflow_layers = False
-        # device-side table of the per-layer weight addresses for the persistent generation kernel
-        self.layer_ptrs = torch.tensor(
-            [[L[k].data_ptr() for k in ("ln1", "qkv", "o", "ln2", "gu", "down")] for L in self.layers],
-            dtype=torch.int64, device=device)
-        self.can_fuse_generate = (cfg.hidden >= 512 and cfg.inter >= 512 and cfg.hidden % 8 == 0 and cfg.inter % 8 == 0
-                                  and hd <= 128 and hd % 16 == 0)
 
     def embed_ids(self, ids_i32, out=None):
-        """embed_tokens gather: ids int32 [n] -> [n, hidden]."""
-        return ops.gather_rows(self.embed, ids_i32, out=out)
+        """embed_tokens gather: ids int32 [n] -> fp32 [n, hidden] (the start of the fp32 residual stream)."""
+        return ops.gather_rows(self.embed, ids_i32, out=out, out_kind="f32")
 
     def forward(self, x, pos0, cache=None):
-        """x [T, hidden] input embeddings at positions pos0..pos0+T-1 -> final-norm hidden [T, hidden];
+        """x fp32 [T, hidden] input embeddings at positions pos0..pos0+T-1 -> final-norm hidden fp32 [T, hidden];
         appends to the KV cache (prefill: T = prompt, decode: T = 1).  cache = (k, v) [layers, Tmax, H, hd] views of
-        another sequence's slab (batched generation); default: this instance's single-sequence cache."""
+        another sequence's slab (batched generation); default: this instance's single-sequence cache.
+        Precision: the residual stream is fp32 (GEMM residual epilogues write fp32, RMSNorm reads it); the MFMA operands
+        (normed rows, attention output, SwiGLU product) are bf16."""
         c = self.cfg
         T = x.shape[0]
         H, hd = c.heads, c.hidden // c.heads
-        assert pos0 + T <= self.max_len
+        assert pos0 + T <= self.max_len and x.dtype == F32
         if T == 1 and cache is None:
             return self._decode_step(x, pos0)
         kc, vc = cache if cache is not None else (self.kcache, self.vcache)
@@ -151,14 +148,14 @@ class Llama:
             k = kc[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
             v = vc[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
             a = ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=pos0)
-            x = ops.linear(a.permute(0, 2, 1, 3).reshape(T, c.hidden), L["o"], residual=x)
+            x = ops.linear(a.permute(0, 2, 1, 3).reshape(T, c.hidden), L["o"], residual=x, out_f32=True)
             h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps), L["gu"], act="swiglu")
-            x = ops.linear(h, L["down"], residual=x)
-        return ops.rmsnorm(x, self.norm, c.eps)
+            x = ops.linear(h, L["down"], residual=x, out_f32=True)
+        return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
 
     def forward_packed(self, xs, kc, vc):
-        """Prefill of B sequences in ONE pass over the weights: xs = [x_b [T_b, hidden]] (lengths may differ), kc / vc
-        [layers, B, Tmax, H, hd] cache slabs -> [final-norm hidden [T_b, hidden]].  The four projections of a layer run
+        """Prefill of B sequences in ONE pass over the weights: xs = [x_b fp32 [T_b, hidden]] (lengths may differ), kc / vc
+        [layers, B, Tmax, H, hd] cache slabs -> [final-norm hidden fp32 [T_b, hidden]].  The four projections of a layer run
         on the packed rows (M = sum T_b: one efficient GEMM instead of B skinny ones, weights streamed once); RoPE + cache
         append and the causal attention stay per sequence.  Row-wise identical arithmetic to ``forward``."""
         c = self.cfg
@@ -180,10 +177,10 @@ class Llama:
                 v = vc[li, b, :T].permute(1, 0, 2).unsqueeze(0)
                 ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=0,
                               out=a[offs[b]: offs[b + 1]].view(1, T, H, hd).permute(0, 2, 1, 3))
-            x = ops.linear(a, L["o"], residual=x)
+            x = ops.linear(a, L["o"], residual=x, out_f32=True)
             h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps), L["gu"], act="swiglu")
-            x = ops.linear(h, L["down"], residual=x)
-        x = ops.rmsnorm(x, self.norm, c.eps)
+            x = ops.linear(h, L["down"], residual=x, out_f32=True)
+        x = ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
         return [x[offs[b]: offs[b + 1]] for b in range(len(lens))]
 
     # ---- one decode step as a replayable HIP graph ------------------------------------------------------------------
@@ -200,16 +197,10 @@ class Llama:
             if self.fuse_attn_oproj and c.hidden in (512, 1024, 4096, 5120) and c.heads + c.hidden // 32 <= n_cu:
                 # fused attention + o_proj launches: per-layer arrival counters, tokens-decoded counter, status word
                 st["fused"] = dict(step=torch.zeros(1, dtype=torch.int32, device=dev),
-                                   counters=torch.zeros(2 * c.layers, 32, dtype=torch.int32, device=dev),  # 128-B apart
+                                   counters=torch.zeros(c.layers, 32, dtype=torch.int32, device=dev),  # 128-B apart
                                    status=torch.zeros(1, dtype=torch.int32, device=dev),
-                                   scratch=torch.zeros(c.layers, c.hidden, dtype=BF16, device=dev),
-                                   hscratch=torch.zeros(c.inter, dtype=BF16, device=dev))
+                                   scratch=torch.zeros(c.layers, c.hidden, dtype=F32, device=dev))
             self._fused = st.get("fused")
-            if self.dataflow_layers and (c.hidden, c.inter) in ((4096, 11008), (5120, 13824), (1024, 1376), (512, 1024)):
-                nbytes = _lib.load().ivlm_llama_decode_layers_workspace_bytes(c.layers, c.hidden, c.inter)
-                st["dataflow"] = dict(ws=torch.zeros(nbytes, dtype=torch.uint8, device=dev),
-                                      step=torch.zeros(1, dtype=torch.int32, device=dev), zero_bytes=c.layers * 5 * 32 * 4 + 256)
-            self._dataflow = st.get("dataflow")
 
             def body():
                 e = self.embed_ids(st["tok"])
@@ -220,8 +211,6 @@ class Llama:
                 st["pos64"].add_(1)
                 if self._fused is not None:
                     self._fused["step"].add_(1)
-                if self._dataflow is not None:
-                    self._dataflow["step"].add_(1)
 
             saved = (self.kcache[:, :1].clone(), self.vcache[:, :1].clone())  # the warm-up / capture runs write row 0
             side = torch.cuda.Stream(device=dev)
@@ -234,8 +223,6 @@ class Llama:
             if self._fused is not None:
                 self._fused["step"].zero_()
                 self._fused["counters"].zero_()
-            if self._dataflow is not None:
-                self.reset_dataflow()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 body()
@@ -259,22 +246,20 @@ class Llama:
         return bc[0][:, :B], bc[1][:, :B]
 
     def decode_step_batch(self, x, pos_dev, kc, vc):
-        """x bf16 [B, hidden] (one new token per sequence), pos_dev int32 [B], kc/vc [layers, B, Tmax, H, hd] ->
-        final-norm hidden [B, hidden]; same arithmetic per row as ``_decode_step``."""
+        """x fp32 [B, hidden] (one new token per sequence), pos_dev int32 [B], kc/vc [layers, B, Tmax, H, hd] ->
+        final-norm hidden fp32 [B, hidden]; same arithmetic per row as ``_decode_step`` (fp32 activations: the skinny MFMA
+        kernel splits them into hi + lo bf16 operands, the batch-1 GEMV multiplies them exactly - equal to ~1e-5)."""
         c = self.cfg
         H, hd = c.heads, c.hidden // c.heads
-        # the skinny-GEMM kernels fuse the RMSNorm prologue: wave-per-row GEMV for M <= 8, split-K MFMA up to 16 rows
-        fuse = x.shape[0] <= 8 or (x.shape[0] <= 16 and c.hidden >= 1024)
+        if x.shape[0] > 16:
+            raise ops.IvlmError("decode_step_batch: at most 16 sequences per step (weight-streaming kernels)")
         for li, L in enumerate(self.layers):
-            qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps)) if fuse else ops.linear(ops.rmsnorm(x, L["ln1"], c.eps), L["qkv"])
+            qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps), out_f32=True)
             a = ops.llama_decode_attn_batch(qkv, kc[li], vc[li], H, hd, pos_dev, c.theta, hd ** -0.5, table=self.rope)
-            x = ops.linear(a, L["o"], residual=x)
-            if fuse:
-                h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))
-            else:
-                h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps), L["gu"], act="swiglu")
-            x = ops.linear(h, L["down"], residual=x)
-        return ops.rmsnorm(x, self.norm, c.eps)
+            x = ops.linear(a, L["o"], residual=x, out_f32=True)
+            h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps), out_f32=True)
+            x = ops.linear(h, L["down"], residual=x, out_f32=True)
+        return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
 
     def decode_graph_batch(self, B):
         """One batched decode step (embed -> layers -> norm -> lm_head -> argmax, positions += 1) as a HIP graph."""
@@ -307,56 +292,29 @@ class Llama:
             self._bgraphs[B] = st
         return st
 
-    def reset_dataflow(self):
-        """start of a generation: arrival counters, status word and the tokens-decoded counter back to zero"""
-        df = self._dataflow
-        df["ws"][: df["zero_bytes"]].zero_()
-        df["step"].zero_()
-
-    def dataflow_status(self):
-        df = self._dataflow
-        return int(df["ws"][df["zero_bytes"] - 256: df["zero_bytes"] - 252].view(torch.int32)[0])
-
     def _decode_step(self, x, pos):
-        """One new token: 5 launches per layer (RMSNorm fused into the q|k|v and gate|up GEMVs, RoPE + cache append
-        fused into the attention kernel, residual adds and SwiGLU in the GEMV epilogues)."""
+        """One new token, x fp32 [1, hidden]: 4 launches per layer (RMSNorm fused into the q|k|v and gate|up GEMVs, RoPE +
+        cache append + attention + o_proj + residual in one launch, SwiGLU and the other residual add in GEMV epilogues).
+        Every activation between the weight-streaming kernels is fp32 and the bf16-weight x fp32-activation products are
+        exact: no operand rounding on the decode path (it is HBM-bound; the fp32 traffic is a few hundred KB per token)."""
         c = self.cfg
         H, hd = c.heads, c.hidden // c.heads
-        if self._dataflow is not None and isinstance(pos, torch.Tensor):  # all layers in one dataflow launch
-            df = self._dataflow
-            x = ops.llama_decode_layers(self.layer_ptrs, c.layers, H, hd, c.hidden, c.inter, c.eps, c.theta, self.rope,
-                                        self.kcache, self.vcache, x, pos, df["step"], df["ws"])
-            return ops.rmsnorm(x, self.norm, c.eps)
         fz = self._fused if isinstance(pos, torch.Tensor) else None
         for li, L in enumerate(self.layers):
-            qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps))
+            qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps), out_f32=True)
             if fz is not None:  # attention + o_proj + residual in one launch (W_o streams while the attention runs)
                 x = ops.llama_attn_oproj(qkv, self.kcache[li], self.vcache[li], L["o"], x, H, hd, pos, fz["step"],
                                          fz["counters"][li], fz["status"], c.theta, hd ** -0.5, self.rope, fz["scratch"][li])
-                if self.fuse_gateup_down:  # gate|up + down + residual in one launch (down streams while gate|up runs)
-                    x = ops.llama_gateup_down(x, L["ln2"], c.eps, L["gu"], L["down"], fz["step"],
-                                              fz["counters"][c.layers + li], fz["status"], fz["hscratch"])
-                else:
-                    h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))
-                    x = ops.linear(h, L["down"], residual=x)
-                continue
-            a = ops.llama_decode_attn(qkv, self.kcache[li], self.vcache[li], H, hd, pos, c.theta, hd ** -0.5, table=self.rope)
-            x = ops.linear(a, L["o"], residual=x)
-            h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps))
-            x = ops.linear(h, L["down"], residual=x)
-        return ops.rmsnorm(x, self.norm, c.eps)
-
-    def generate_fused(self, hidden_all, pos0, n_max, eos, forced=None):
-        """All decode steps in one persistent launch (ops.llama_generate).  hidden_all [>= pos0+n_max-1, hidden]: row
-        pos0-1 must hold the final-normed hidden state of the last prompt position; rows pos0.. are filled in.
-        -> (new_ids, argmax_ids, status) int32 device tensors."""
-        c = self.cfg
-        H, hd = c.heads, c.hidden // c.heads
-        assert pos0 + n_max - 1 <= self.max_len
-        return ops.llama_generate(self.layer_ptrs, c.layers, H, hd, c.hidden, c.inter, self.lm_head.shape[0], c.eps,
-                                  hd ** -0.5, self.rope, self.kcache, self.vcache, self.max_len, self.embed, self.norm,
-                                  self.lm_head, hidden_all, pos0, n_max, eos, forced)
+            else:
+                a = ops.llama_decode_attn(qkv, self.kcache[li], self.vcache[li], H, hd, pos, c.theta, hd ** -0.5,
+                                          table=self.rope)
+                x = ops.linear(a, L["o"], residual=x, out_f32=True)
+            h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps), out_f32=True)
+            x = ops.linear(h, L["down"], residual=x, out_f32=True)
+        return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
 
     def logits(self, hidden_rows):
-        """lm_head on [n, hidden] -> f32 [n, vocab]."""
+        """lm_head on fp32 [n, hidden] -> f32 [n, vocab] (n <= 16: exact fp32 activations on the weight-streaming kernels)."""
+        if hidden_rows.shape[0] > 16:
+            hidden_rows = ops.gather_rows(hidden_rows, out_kind="bf16")
         return ops.linear(hidden_rows, self.lm_head, out_f32=True)

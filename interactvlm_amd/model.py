@@ -27,15 +27,13 @@ from .sam import SamImageEncoder, SamMaskDecoder, _Lin, _dev, postprocess_masks
 from .weights import IvlmCfg
 
 BF16 = torch.bfloat16
-
-
-def forced_dev_early(forced, device):
-    return None if forced is None else torch.tensor([int(t) for t in forced], dtype=torch.int32, device=device)
+F32 = torch.float32
 
 
 class _CamPoseEncoder:
     """CamPoseEncoder / ViewIndexCamPoseEncoder / VIv1CamPoseEncoder (components.py:491-572).
-    The 5-wide first layer is zero-padded to K=8 (16-byte rows) for the streaming GEMV."""
+    The 5-wide first layer is zero-padded to K=8 (16-byte rows) for the streaming GEMV.  fp32 activations (V rows: the
+    weight-streaming kernel multiplies bf16 weights with fp32 activations exactly)."""
 
     def __init__(self, w, kind, V, device, prefix="cam_pose_encoder"):
         self.kind, self.V = kind, V
@@ -54,17 +52,18 @@ class _CamPoseEncoder:
             self.views = [lin(f"{prefix}.view_transforms.{v}") for v in range(V)]
 
     def __call__(self, cam_params):
-        """cam_params [V,5] -> view encodings bf16 [V,256] (row v = encoder(cam_params[v], view_idx=v))."""
-        c = torch.nn.functional.pad(cam_params.to(BF16), (0, 3)).contiguous()
+        """cam_params [V,5] -> view encodings fp32 [V,256] (row v = encoder(cam_params[v], view_idx=v))."""
+        c = torch.nn.functional.pad(cam_params.to(F32), (0, 3)).contiguous()
         if self.kind == "simple":
-            return ops.linear(c, self.l1[0], self.l1[1], act="relu")
-        if self.kind == "view_index":  # Linear-ReLU-Linear-Sigmoid, then per-view Linear
-            h = ops.linear(c, self.s0[0], self.s0[1], act="relu")
-            base = ops.linear(h, self.s2[0], self.s2[1], act="sigmoid")
-            return torch.cat([ops.linear(base[v: v + 1], *self.views[v]) for v in range(self.V)], 0)
-        h = ops.linear(c, self.s0[0], self.s0[1], act="relu")
-        base = ops.linear(h, self.s2[0], self.s2[1], act="relu")
-        return torch.cat([ops.linear(base[v: v + 1], *self.views[v], act="sigmoid") for v in range(self.V)], 0)
+            return ops.linear(c, self.l1[0], self.l1[1], act="relu", out_f32=True)
+        h = ops.linear(c, self.s0[0], self.s0[1], act="relu", out_f32=True)
+        # view_index: Linear-ReLU-Linear-Sigmoid, then per-view Linear; vi_v1: Linear-ReLU-Linear-ReLU, per-view Linear-Sigmoid
+        vi = self.kind == "view_index"
+        base = ops.linear(h, self.s2[0], self.s2[1], act="sigmoid" if vi else "relu", out_f32=True)
+        enc = torch.empty(self.V, self.views[0][0].shape[0], dtype=F32, device=base.device)
+        for v in range(self.V):
+            ops.linear(base[v: v + 1], *self.views[v], act="none" if vi else "sigmoid", out=enc[v: v + 1])
+        return enc
 
 
 class InteractVLMForCausalLM:
@@ -88,10 +87,6 @@ class InteractVLMForCausalLM:
         self.graph_decode = not os.environ.get("IVLM_NO_GRAPHS")
         self.sam_after_prefill = False  # measured: 107.6 vs 106.6 ms - overlapping the decode instead of the prefill is not better
         self.packed_prefill = True  # generate_batch: prefill all prompts of a batch as one packed pass (rows independent)
-        # persistent one-launch greedy decode (csrc/generate.hip): correct and bit-reproducible, but measured SLOWER than the
-        # per-op path on MI355X (3.43 vs 2.93 ms/token for 7B: every phase boundary costs ~9 us of device-wide sync
-        # skew + store/load latency, more than a kernel boundary) - kept as an opt-in experiment
-        self.fused_generate = False
         self.fused_lowres_lift = False  # measured slower than lifting the (cache-resident) full-res masks
         self._side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._hi_stream = torch.cuda.Stream(device=dev, priority=-1) if dev.type == "cuda" else None
@@ -166,16 +161,17 @@ class InteractVLMForCausalLM:
         return embedding
 
     def _split(self, x, human):
-        """AttentionSplitter (components.py:155-193) on [n,V,256]: one softmax over V keys of width 128."""
+        """AttentionSplitter (components.py:155-193) on fp32 [n,V,256]: one softmax over V keys of width 128."""
         a = self.attention_splitter
         n, V, C = x.shape
-        xp = a["input_proj"](x.reshape(n * V, C).contiguous())
-        k, v = a["key"](xp), a["value"](xp)
-        q = a["query_human" if human else "query_object"](xp)
+        lin = lambda L, t: ops.linear(t, L.w, L.b, out_f32=True)  # n*V <= 16 fp32 rows: exact products
+        xp = lin(a["input_proj"], x.reshape(n * V, C).contiguous())
+        k, v = lin(a["key"], xp), lin(a["value"], xp)
+        q = lin(a["query_human" if human else "query_object"], xp)
         hd = q.shape[-1]
         one_head = lambda t: t.view(n, 1, V, hd)  # a single head of width 128
-        o = ops.attention(one_head(q), one_head(k), one_head(v), hd ** -0.5)
-        return a["output_proj"](o.reshape(n * V, hd)).view(n, V, C)
+        o = ops.attention_f32(one_head(q), one_head(k), one_head(v), hd ** -0.5)
+        return lin(a["output_proj"], o.reshape(n * V, hd)).view(n, V, C)
 
     # ------------------------------------------------------------------------------------------
     def _input_embeds(self, ids_row, image_features):
@@ -185,10 +181,10 @@ class InteractVLMForCausalLM:
         pos = int((ids == IMAGE_TOKEN_INDEX).nonzero()[0])
         n_img = image_features.shape[0]
         L = ids.numel()
-        x = torch.empty(L - 1 + n_img, self.config.llama.hidden, dtype=BF16, device=self.device)
+        x = torch.empty(L - 1 + n_img, self.config.llama.hidden, dtype=F32, device=self.device)  # fp32 residual stream
         idx = ids.clamp(min=0).to(torch.int32)
         self.llm.embed_ids(idx[:pos].contiguous(), out=x[:pos])
-        x[pos: pos + n_img].copy_(image_features)
+        ops.gather_rows(image_features, out=x[pos: pos + n_img])
         if L - pos - 1 > 0:
             self.llm.embed_ids(idx[pos + 1:].contiguous(), out=x[pos + n_img:])
         return x
@@ -197,7 +193,7 @@ class InteractVLMForCausalLM:
         """llava_arch.py:93-96."""
         f = self.vision_tower(images_clip.to(self.device))
         B, T, C = f.shape
-        return self.mm_projector(f.reshape(B * T, C)).view(B, T, -1)
+        return self.mm_projector(f.reshape(B * T, C), out_f32=True).view(B, T, -1)  # fp32: rows of the LLM's input stream
 
     def _seg_token_ids(self):
         ids = [self.seg_token_idx]
@@ -222,7 +218,10 @@ class InteractVLMForCausalLM:
         if rows.numel() == 0:
             return torch.zeros((0,) + tuple(original_size), dtype=torch.float32, device=self.device), None
         sel = hidden[rows.to(hidden.device)].contiguous()
-        emb = self.text_hidden_fcs[1](self.text_hidden_fcs[0](sel, act="relu"))  # [n_seg, 256]
+        if sel.shape[0] > 16:
+            raise ops.IvlmError("more than 16 [SEG] rows in one sample")
+        # [n_seg, 256] fp32: a few fp32 rows through the weight-streaming kernels (exact bf16-weight x fp32 products)
+        emb = self.text_hidden_fcs[1](self.text_hidden_fcs[0](sel, act="relu", out_f32=True), out_f32=True)
         if self.debug_taps is not None:
             self.debug_taps.update(hidden=hidden, seg_emb=emb, sam_emb=image_embeddings)
         k = int(rows[0]) - self.img_emb_len + 1
@@ -296,23 +295,11 @@ class InteractVLMForCausalLM:
             raise ops.IvlmError(f"prompt of {T0} positions does not fit the KV cache (max_len={self.llm.max_len})")
         if forced_new_tokens is not None:
             forced_new_tokens = list(forced_new_tokens)[:n_max]
-        hidden_all = torch.empty(T0 + n_max, self.config.llama.hidden, dtype=BF16, device=self.device)
+        hidden_all = torch.empty(T0 + n_max, self.config.llama.hidden, dtype=F32, device=self.device)
         h = self.llm.forward(x, 0)
         hidden_all[:T0].copy_(h)
         if after_prefill is not None:
             after_prefill()  # evaluate(): the SAM encoder is enqueued here, between the prefill and the decode loop
-        if self.fused_generate and self.llm.can_fuse_generate:
-            if forced_new_tokens is not None:
-                assert all(0 <= int(t) < self.llm.embed.shape[0] for t in forced_new_tokens)
-            new_t, arg_t, status = self.llm.generate_fused(hidden_all, T0, n_max, eos_token_id, forced_dev_early(
-                forced_new_tokens, self.device))
-            st = status.cpu()  # the one host sync of the generation
-            if int(st[1]) != 0:
-                raise ops.IvlmError("llama_generate: device-wide barrier timed out (GPU oversubscribed?)")
-            n = int(st[0])
-            self.last_argmax = [arg_t[i: i + 1] for i in range(n)]
-            out_ids = torch.cat([ids.cpu(), new_t[:n].cpu().to(ids.dtype)])[None]
-            return out_ids, hidden_all[: T0 + n - 1]
         new_ids = []
         last = h[T0 - 1: T0]
         pos = T0
@@ -332,8 +319,6 @@ class InteractVLMForCausalLM:
                 fz["step"].zero_()
                 fz["counters"].zero_()
                 fz["status"].zero_()
-            if dg.get("dataflow") is not None:
-                self.llm.reset_dataflow()
             nxt = ops.argmax(self.llm.logits(last))
             for step in range(n_max):
                 self.last_argmax.append(nxt)
@@ -352,9 +337,11 @@ class InteractVLMForCausalLM:
                 nxt = dg["nxt"].clone()
                 pos += 1
             if fz is not None and int(fz["status"].item()) != 0:
-                raise ops.IvlmError("fused decode launch: a bounded device-side wait expired (results invalid)")
-            if dg.get("dataflow") is not None and self.llm.dataflow_status() != 0:
-                raise ops.IvlmError("dataflow decode launch: a bounded device-side wait expired (results invalid)")
+                # a bounded device-side wait of the fused attention + o_proj launch expired (its blocks were not co-resident,
+                # e.g. a third stream holding the CUs): drop to the two-launch path for good and redo this generation
+                self.llm.fuse_attn_oproj = False
+                self.llm._dgraph = None
+                return self.generate(images_clip, input_ids, max_new_tokens, eos_token_id, forced_new_tokens, None)
             out_ids = torch.cat([ids.cpu(), torch.tensor(new_ids, dtype=ids.dtype)])[None]
             return out_ids, hidden_all[:pos]
         for step in range(n_max):
@@ -402,8 +389,8 @@ class InteractVLMForCausalLM:
         if min(n_seq) <= 0:
             raise ops.IvlmError(f"a prompt of {max(T0)} positions does not fit the KV cache (max_len={self.llm.max_len})")
         n_max = max(n_seq)
-        hidden_all = torch.empty(B, max(T0) + n_max, self.config.llama.hidden, dtype=BF16, device=dev)
-        last = torch.empty(B, self.config.llama.hidden, dtype=BF16, device=dev)
+        hidden_all = torch.empty(B, max(T0) + n_max, self.config.llama.hidden, dtype=F32, device=dev)
+        last = torch.empty(B, self.config.llama.hidden, dtype=F32, device=dev)
         if self.packed_prefill and B > 1:  # the B prompts in one pass over the weights
             hs = self.llm.forward_packed(xs, kc, vc)
         else:
@@ -438,7 +425,8 @@ class InteractVLMForCausalLM:
                         done[b] = True
             if all(done):
                 break
-            # (finished sequences keep stepping - their rows are ignored; n_max keeps every position inside the cache)
+            # (finished sequences keep stepping - their rows are ignored; a sequence whose position has reached the end of its
+            #  cache slab is skipped by the attention kernel: nothing is appended past Tmax)
             if use_graph:
                 dg["tok"].copy_(tok_t)
                 idx = dg["pos"].to(torch.int64)  # positions BEFORE the step's += 1

@@ -270,70 +270,53 @@ def _splitk_choice(M, N, K, act, rms):
     return best
 
 
-# opt-in: +12 % on SAM mlp2 in the warm micro-benchmark (244 -> 216 us), but 2 ms SLOWER end to end - three launches and
-# 67 MB of fp32 partials per GEMM next to a second stream that wants the same caches
-TAILSPLIT = False
+GEMM_A_F32, GEMM_RES_F32 = 1, 2
+F32 = torch.float32
 
 
-def _tail_choice(M, N, K, act, rms):
-    """K slices for the under-filled last round of a big GEMM on 256 x 256 tiles (0 = not applicable): the tile count is
-    above one round of the 256 CUs, the remainder at most half a round, and K long enough to be worth slicing."""
-    if not TAILSPLIT or act == "swiglu" or rms is not None or M < 4096 or N % 4 or K < 2048 or K % 64:
-        return 0
-    tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    tail = tiles % 256
-    if tiles <= 256 or tail == 0 or tail > 128:
-        return 0
-    k64 = K // 64
-    for sp in range(min(256 // tail, 8), 1, -1):
-        if k64 % sp == 0:
-            return sp
-    return 0
-
-
-def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False, rms=None):
-    """act(x @ weight.T + bias) + residual.  x [..., K] bf16 (last dim contiguous, uniform row stride),
-    weight [N, K] bf16."""
+def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False, rms=None, out_rows=None):
+    """act(x @ weight.T + bias) + residual.  out_rows (int32 [M], tile GEMM path): scatter epilogue, see ivlm_hip.h.  x [..., K] bf16 - or fp32 for M <= 16 rows (weight-streaming kernels: exact
+    products) - last dim contiguous, uniform row stride; weight [N, K] bf16; residual bf16 or fp32 (fp32 residual stream)."""
     lib = _lib.load()
     K = x.shape[-1]
     N = weight.shape[0]
-    assert weight.shape[1] == K and x.dtype == BF16 and weight.dtype == BF16
+    assert weight.shape[1] == K and x.dtype in (BF16, F32) and weight.dtype == BF16
     x2 = x.reshape(-1, K)
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     M = x2.shape[0]
+    flags = 0
+    if x.dtype == F32:
+        if M > 16:
+            raise IvlmError("linear: fp32 activations only on the M <= 16 weight-streaming paths (use split_rows + [W|W])")
+        flags |= GEMM_A_F32
     n_out = N // 2 if act == "swiglu" else N
     if out is None:
-        out = torch.empty(x.shape[:-1] + (n_out,), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+        out = torch.empty(x.shape[:-1] + (n_out,), dtype=F32 if out_f32 else BF16, device=x.device)
     o2 = out.reshape(-1, n_out)
     assert o2.stride(-1) == 1 and weight.stride(-1) == 1
     r2, ldr = None, 0
     if residual is not None:
         r2 = residual.reshape(-1, N)
-        assert r2.dtype == BF16 and r2.stride(-1) == 1
+        assert r2.dtype in (BF16, F32) and r2.stride(-1) == 1
         ldr = r2.stride(0)
+        if r2.dtype == F32:
+            flags |= GEMM_RES_F32
     if bias is not None:
         assert bias.dtype == BF16 and bias.is_contiguous()
     call = lambda: check(lib.ivlm_gemm_bf16(
         x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
-        _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == torch.float32 else 0, 1, 0, 0, 0, 0,
-        _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, _stream()), "gemm_bf16")
-    splits = _splitk_choice(M, N, K, act, rms)
+        _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, 1, 0, 0, 0, 0,
+        _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, flags, _p(out_rows), _stream()), "gemm_bf16")
+    splits = _splitk_choice(M, N, K, act, rms) if (x.dtype == BF16 and out_rows is None) else 1
     if splits > 1 and o2.stride(0) % 4 == 0:
-        ws = torch.empty(splits * M * N, dtype=torch.float32, device=x.device)  # caching allocator: stream-safe
+        ws = torch.empty(splits * M * N, dtype=F32, device=x.device)  # caching allocator: stream-safe
         call = lambda: check(lib.ivlm_gemm_bf16_splitk(
             x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
-            _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out_f32 else 0, splits, ws.data_ptr(),
-            ws.numel() * 4, _stream()), "gemm_bf16_splitk")
-    tsp = _tail_choice(M, N, K, act, rms) if splits <= 1 else 0
-    if tsp > 1 and o2.stride(0) % 4 == 0:
-        ws = torch.empty(tsp * M * N, dtype=torch.float32, device=x.device)  # only the tail tiles' region is touched
-        call = lambda: check(lib.ivlm_gemm_bf16_tailsplit(
-            x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
-            _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out_f32 else 0, tsp, ws.data_ptr(),
-            ws.numel() * 4, _stream()), "gemm_bf16_tailsplit")
+            _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, splits, ws.data_ptr(),
+            ws.numel() * 4, flags, _stream()), "gemm_bf16_splitk")
     if TIMER.enabled:  # work = algorithmic FLOPs (MFMA path) or weight bytes (GEMV path)
-        if M > 8:
+        if M > 16:
             TIMER.time("gemm_bf16_mfma", 2.0 * M * N * K, call, tag=(M, N, K, act))
         else:
             TIMER.time("gemv_bf16", 2.0 * N * K, call, tag=(M, N, K, act))
@@ -342,23 +325,28 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     return out
 
 
-def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None):
+def _dtc(t):
+    return IVLM_F32 if t.dtype == F32 else IVLM_BF16
+
+
+def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None, out_f32=False, out_rows=None):
+    """x bf16 or fp32 [..., cols] -> bf16 (the next GEMM's operand) or fp32 (out_f32: the row is itself a stream)."""
     lib = _lib.load()
-    x = _req(x, BF16, "x")
-    y = torch.empty_like(x) if out is None else out
+    x = _req(x, None, "x")
+    y = torch.empty(x.shape, dtype=F32 if out_f32 else BF16, device=x.device) if out is None else out
     cols = x.shape[-1]
-    check(lib.ivlm_layernorm_bf16(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), x.numel() // cols,
-                                  cols, float(eps), 1 if gelu else 0, _stream()), "layernorm")
+    check(lib.ivlm_layernorm(x.data_ptr(), _dtc(x), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), _dtc(y),
+                             x.numel() // cols, cols, float(eps), 1 if gelu else 0, _p(out_rows), _stream()), "layernorm")
     return y
 
 
-def rmsnorm(x, weight, eps=1e-5):
+def rmsnorm(x, weight, eps=1e-5, out_f32=False):
     lib = _lib.load()
-    x = _req(x, BF16, "x")
-    y = torch.empty_like(x)
+    x = _req(x, None, "x")
+    y = torch.empty(x.shape, dtype=F32 if out_f32 else BF16, device=x.device)
     cols = x.shape[-1]
-    check(lib.ivlm_rmsnorm_bf16(x.data_ptr(), weight.data_ptr(), y.data_ptr(), x.numel() // cols, cols, float(eps),
-                                _stream()), "rmsnorm")
+    check(lib.ivlm_rmsnorm(x.data_ptr(), _dtc(x), weight.data_ptr(), y.data_ptr(), _dtc(y), x.numel() // cols, cols,
+                           float(eps), _stream()), "rmsnorm")
     return y
 
 
@@ -391,6 +379,25 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, presca
     return out
 
 
+def attention_f32(q, k, v, scale, out=None):
+    """fp32 q [B,H,Sq,D], k/v [Bk,H,Sk,D] (D in 16, 32; arbitrary strides % 4) -> o [B,H,Sq,D] fp32 as a view of a
+    [B,Sq,H,D] buffer; scores = (q.k) * scale, no operand rounding (SAM mask decoder)."""
+    import ctypes
+
+    lib = _lib.load()
+    B, H, Sq, D = q.shape
+    Bk, Sk = k.shape[0], k.shape[2]
+    assert q.dtype == F32 and k.dtype == F32 and v.dtype == F32 and B % Bk == 0
+    assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    if out is None:
+        out = torch.empty(B, Sq, H, D, dtype=F32, device=q.device).permute(0, 2, 1, 3)
+    st = (ctypes.c_int64 * 12)(q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                               v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2))
+    check(lib.ivlm_attention_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), ctypes.cast(st, ctypes.c_void_p),
+                                 B, H, Sq, Sk, D, float(scale), B // Bk, _stream()), "attention_f32")
+    return out
+
+
 def relpos_tables_cat(tab_h, tab_w):
     """[rel_pos_h ; rel_pos_w] padded with zero rows to a multiple of 8: the weight matrix of the GEMM formulation."""
     n = tab_h.shape[0] + tab_w.shape[0]
@@ -418,7 +425,7 @@ def relpos_bias(q, tab_h, tab_w, SH, SW, cat=None):
         npad, M = cat.shape[0], B * S
         G = torch.empty(H, M, npad, dtype=BF16, device=q.device)
         call = lambda: check(lib.ivlm_gemm_bf16(q.data_ptr(), q.stride(2), cat.data_ptr(), D, G.data_ptr(), npad, 0, 0, 0, 0,
-                                                M, npad, D, 0, 0, H, q.stride(1), 0, M * npad, 0, 0, 0.0, _stream()),
+                                                M, npad, D, 0, 0, H, q.stride(1), 0, M * npad, 0, 0, 0.0, 0, 0, _stream()),
                              "relpos gemm")
         if TIMER.enabled:
             TIMER.time("gemm_bf16_mfma", 2.0 * H * M * npad * D, call, tag=("relpos", M, npad, D))
@@ -465,41 +472,68 @@ def im2col3x3_nhwc(x):
     return out
 
 
-def gather_rows(src, idx, add=None, out=None):
-    """out[r] = src[idx[r]] (zeros where idx < 0) (+ add[r]); src [R,C] / add [n,C] rows may be strided."""
+_KIND = {"bf16": IVLM_BF16, "f32": IVLM_F32, "split": 2}
+
+
+def gather_rows(src, idx=None, add=None, out=None, out_kind=None):
+    """out[r] = src[idx[r]] (zeros where idx < 0; idx None: out[r] = src[r]) (+ add[r]); src [R,C] / add [n,C] rows may be
+    strided, bf16 or fp32.  out_kind 'bf16' | 'f32' | 'split' ([hi | lo] bf16 rows of width 2C, see split_rows); default: the
+    dtype of ``out`` if given, else of ``add`` if given, else of ``src``."""
     lib = _lib.load()
-    assert src.dtype == BF16 and src.stride(-1) == 1 and idx.dtype == torch.int32 and idx.is_contiguous()
-    rows, cols = idx.numel(), src.shape[-1]
+    assert src.dtype in (BF16, F32) and src.stride(-1) == 1
+    cols = src.shape[-1]
+    if idx is not None:
+        assert idx.dtype == torch.int32 and idx.is_contiguous()
+        rows = idx.numel()
+    else:
+        src = src.reshape(-1, cols)
+        rows = src.shape[0]
+    if out_kind is None:
+        ref = out if out is not None else (add if add is not None else src)
+        out_kind = "f32" if ref.dtype == F32 else "bf16"
     if out is None:
-        out = torch.empty(rows, cols, dtype=BF16, device=src.device)
-    assert out.stride(-1) == 1
+        out = (torch.empty(rows, 2 * cols, dtype=BF16, device=src.device) if out_kind == "split"
+               else torch.empty(rows, cols, dtype=F32 if out_kind == "f32" else BF16, device=src.device))
+    assert out.stride(-1) == 1 and out.dtype == (F32 if out_kind == "f32" else BF16)
     lda = 0
     if add is not None:
-        assert add.dtype == BF16 and add.stride(-1) == 1
+        assert add.dtype in (BF16, F32) and add.stride(-1) == 1
         lda = add.stride(0)
-    check(lib.ivlm_gather_rows(out.data_ptr(), out.stride(0), src.data_ptr(), src.stride(0), idx.data_ptr(), _p(add),
-                               lda, rows, cols, _stream()), "gather_rows")
+    check(lib.ivlm_gather_rows(out.data_ptr(), _KIND[out_kind], out.stride(0), src.data_ptr(), _dtc(src), src.stride(0),
+                               _p(idx), _p(add), _dtc(add) if add is not None else 0, lda, rows, cols, _stream()),
+          "gather_rows")
     return out
 
 
-def add_rows(a, b, out=None, op="add"):
-    """a [R,C] (+|*) b [r,C] broadcast with row modulo (R % r == 0 not required)."""
+def split_rows(x):
+    """fp32 [..., C] -> bf16 [..., 2C] = [hi | lo] with x = hi + lo to 2^-17: the A operand of an fp32-activation GEMM on the
+    bf16 matrix cores, to be multiplied with ``torch.cat([W, W], 1)`` (K' = 2K)."""
+    C = x.shape[-1]
+    return gather_rows(x.reshape(-1, C), out_kind="split").view(x.shape[:-1] + (2 * C,))
+
+
+def add_rows(a, b, out=None, op="add", out_kind=None):
+    """a [R,C] (+|*) b [r,C] broadcast with row modulo (R % r == 0 not required); a / b bf16 or fp32 -> bf16, fp32 or split."""
     lib = _lib.load()
-    a = _req(a, BF16, "a")
-    b = _req(b, BF16, "b")
+    a = _req(a, None, "a")
+    b = _req(b, None, "b")
     cols = a.shape[-1]
-    out = torch.empty_like(a) if out is None else out
-    check(lib.ivlm_add_rows(out.data_ptr(), a.data_ptr(), b.data_ptr(), a.numel() // cols, cols, b.numel() // cols,
-                            1 if op == "mul" else 0, _stream()), "add_rows")
+    if out_kind is None:
+        out_kind = "f32" if (out if out is not None else a).dtype == F32 else "bf16"
+    if out is None:
+        out = (torch.empty(a.shape[:-1] + (2 * cols,), dtype=BF16, device=a.device) if out_kind == "split"
+               else torch.empty(a.shape, dtype=F32 if out_kind == "f32" else BF16, device=a.device))
+    check(lib.ivlm_add_rows(out.data_ptr(), _KIND[out_kind], a.data_ptr(), _dtc(a), b.data_ptr(), _dtc(b),
+                            a.numel() // cols, cols, b.numel() // cols, 1 if op == "mul" else 0, _stream()), "add_rows")
     return out
 
 
-def dense_pe(gauss, h, w):
+def dense_pe(gauss, h, w, dtype=torch.float32):
     lib = _lib.load()
     gauss = _req(gauss, torch.float32, "gauss")
-    F = gauss.shape[1]
-    pe = torch.empty(h * w, 2 * F, dtype=BF16, device=gauss.device)
-    check(lib.ivlm_dense_pe(gauss.data_ptr(), pe.data_ptr(), h, w, F, _stream()), "dense_pe")
+    nf = gauss.shape[1]
+    pe = torch.empty(h * w, 2 * nf, dtype=dtype, device=gauss.device)
+    check(lib.ivlm_dense_pe(gauss.data_ptr(), pe.data_ptr(), _dtc(pe), h, w, nf, _stream()), "dense_pe")
     return pe
 
 
@@ -523,109 +557,58 @@ def rope_table(T, D, theta, device):
 
 def mask_dot(up, hyper, B, gh, gw):
     lib = _lib.load()
-    up = _req(up, BF16, "up")
-    hyper = _req(hyper, BF16, "hyper")
+    up = _req(up, None, "up")
+    hyper = _req(hyper, up.dtype, "hyper")
     C = hyper.shape[-1]
-    low = torch.empty(B, 4 * gh, 4 * gw, dtype=torch.float32, device=up.device)
-    check(lib.ivlm_mask_dot(up.data_ptr(), hyper.data_ptr(), low.data_ptr(), B, gh, gw, C, _stream()), "mask_dot")
+    low = torch.empty(B, 4 * gh, 4 * gw, dtype=F32, device=up.device)
+    check(lib.ivlm_mask_dot(up.data_ptr(), hyper.data_ptr(), _dtc(up), low.data_ptr(), B, gh, gw, C, _stream()), "mask_dot")
     return low
 
 
 def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, table=None):
-    """qkv bf16 [1, 3*H*D] of the newest token -> o bf16 [1, H*D]; RoPE + cache append fused.
-    pos: python int, or an int32 device tensor [1] (read by the kernel: HIP-graph friendly)."""
+    """qkv bf16 | fp32 [1, 3*H*D] of the newest token -> o (same dtype) [1, H*D]; RoPE + cache append fused.
+    pos: python int, or an int32 device tensor [1] (read by the kernel: HIP-graph friendly).  kcache [Tmax, H, D]."""
     lib = _lib.load()
-    assert qkv.dtype == BF16 and qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
+    assert qkv.dtype in (BF16, F32) and qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
     if out is None:
-        out = torch.empty(1, H * D, dtype=BF16, device=qkv.device)
-    if isinstance(pos, torch.Tensor):
+        out = torch.empty(1, H * D, dtype=qkv.dtype, device=qkv.device)
+    dev_pos = isinstance(pos, torch.Tensor)
+    if dev_pos:
         assert pos.dtype == torch.int32 and pos.is_cuda
-        check(lib.ivlm_llama_decode_attn_devpos(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), H, D,
-                                                pos.data_ptr(), float(theta), float(scale),
-                                                _p(table[0]) if table else 0, _p(table[1]) if table else 0, _stream()),
-              "llama_decode_attn_devpos")
-        return out
-    check(lib.ivlm_llama_decode_attn(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), H, D,
-                                     int(pos), float(theta), float(scale), _p(table[0]) if table else 0,
+    check(lib.ivlm_llama_decode_attn(qkv.data_ptr(), _dtc(qkv), kcache.data_ptr(), vcache.data_ptr(), kcache.shape[0],
+                                     out.data_ptr(), H, D, 0 if dev_pos else int(pos), pos.data_ptr() if dev_pos else 0,
+                                     float(theta), float(scale), _p(table[0]) if table else 0,
                                      _p(table[1]) if table else 0, _stream()), "llama_decode_attn")
     return out
 
 
 def llama_decode_attn_batch(qkv, kcache, vcache, H, D, pos_dev, theta, scale, table=None, out=None):
-    """One decode step of B sequences: qkv bf16 [B, 3*H*D], kcache/vcache bf16 [B, Tmax, H, D] (one slab per sequence),
-    pos_dev int32 [B] on the device -> o bf16 [B, H*D]."""
+    """One decode step of B sequences: qkv bf16 | fp32 [B, 3*H*D], kcache/vcache bf16 [B, Tmax, H, D] (one slab per
+    sequence), pos_dev int32 [B] on the device -> o [B, H*D].  A sequence whose position has reached Tmax is skipped."""
     lib = _lib.load()
     B = qkv.shape[0]
-    assert qkv.dtype == BF16 and qkv.stride(1) == 1 and kcache.dim() == 4 and kcache.shape[0] == B
+    assert qkv.dtype in (BF16, F32) and qkv.stride(1) == 1 and kcache.dim() == 4 and kcache.shape[0] == B
     assert kcache[0].is_contiguous() and vcache[0].is_contiguous() and kcache.stride(0) == vcache.stride(0)
     assert pos_dev.dtype == torch.int32 and pos_dev.is_cuda and pos_dev.numel() == B and pos_dev.is_contiguous()
     if out is None:
-        out = torch.empty(B, H * D, dtype=BF16, device=qkv.device)
-    check(lib.ivlm_llama_decode_attn_batch(qkv.data_ptr(), qkv.stride(0), kcache.data_ptr(), vcache.data_ptr(),
-                                           kcache.stride(0), out.data_ptr(), out.stride(0), B, H, D, pos_dev.data_ptr(),
-                                           float(theta), float(scale), _p(table[0]) if table else 0,
+        out = torch.zeros(B, H * D, dtype=qkv.dtype, device=qkv.device)
+    check(lib.ivlm_llama_decode_attn_batch(qkv.data_ptr(), _dtc(qkv), qkv.stride(0), kcache.data_ptr(), vcache.data_ptr(),
+                                           kcache.stride(0), kcache.shape[1], out.data_ptr(), out.stride(0), B, H, D,
+                                           pos_dev.data_ptr(), float(theta), float(scale), _p(table[0]) if table else 0,
                                            _p(table[1]) if table else 0, _stream()), "llama_decode_attn_batch")
     return out
 
 
 def llama_attn_oproj(qkv, kcache, vcache, wo, x, H, D, pos_dev, step_dev, counter, status, theta, scale, table, scratch):
-    """One launch: single-token attention of every head + o_proj GEMV + residual -> x_out bf16 [1, H*D]."""
+    """One launch: single-token attention of every head + o_proj GEMV + residual -> x_out fp32 [1, H*D] (qkv, x fp32)."""
     lib = _lib.load()
-    out = torch.empty(1, H * D, dtype=BF16, device=qkv.device)
-    check(lib.ivlm_llama_attn_oproj(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), scratch.data_ptr(), wo.data_ptr(),
-                                    x.data_ptr(), out.data_ptr(), H, D, float(theta), float(scale), table[0].data_ptr(),
-                                    table[1].data_ptr(), pos_dev.data_ptr(), step_dev.data_ptr(), counter.data_ptr(),
-                                    status.data_ptr(), _stream()), "llama_attn_oproj")
+    assert qkv.dtype == F32 and x.dtype == F32 and scratch.dtype == F32
+    out = torch.empty(1, H * D, dtype=F32, device=qkv.device)
+    check(lib.ivlm_llama_attn_oproj(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), kcache.shape[0], scratch.data_ptr(),
+                                    wo.data_ptr(), x.data_ptr(), out.data_ptr(), H, D, float(theta), float(scale),
+                                    table[0].data_ptr(), table[1].data_ptr(), pos_dev.data_ptr(), step_dev.data_ptr(),
+                                    counter.data_ptr(), status.data_ptr(), _stream()), "llama_attn_oproj")
     return out
-
-
-def llama_gateup_down(x2, ln_w, eps, wgu, wdown, step_dev, counter, status, scratch):
-    """One launch: x_out = x2 + W_down . SwiGLU(W_gu . RMSNorm(x2)) for one decode token, bf16 [1, hidden]."""
-    lib = _lib.load()
-    hidden, inter = wdown.shape[0], wdown.shape[1]
-    out = torch.empty(1, hidden, dtype=BF16, device=x2.device)
-    check(lib.ivlm_llama_gateup_down(x2.data_ptr(), ln_w.data_ptr(), float(eps), wgu.data_ptr(), wdown.data_ptr(),
-                                     scratch.data_ptr(), out.data_ptr(), hidden, inter, step_dev.data_ptr(), counter.data_ptr(),
-                                     status.data_ptr(), _stream()), "llama_gateup_down")
-    return out
-
-
-def llama_decode_layers(layer_ptrs, L, H, D, hidden, inter, eps, theta, rope, kcache, vcache, x0, pos_dev, step_dev, ws):
-    """All decoder layers of one token in one dataflow launch -> residual stream after the last layer, bf16 [1, hidden]."""
-    lib = _lib.load()
-    out = torch.empty(1, hidden, dtype=BF16, device=x0.device)
-    check(lib.ivlm_llama_decode_layers(layer_ptrs.data_ptr(), L, H, D, hidden, inter, float(eps), float(theta), float(D) ** -0.5,
-                                       rope[0].data_ptr(), rope[1].data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
-                                       kcache.stride(0), x0.data_ptr(), out.data_ptr(), pos_dev.data_ptr(), step_dev.data_ptr(),
-                                       ws.data_ptr(), ws.numel(), _stream()), "llama_decode_layers")
-    return out
-
-
-def llama_generate(layer_ptrs, L, H, D, hidden, inter, vocab, eps, scale, rope, kcache, vcache, max_len, embed, final_norm,
-                   lm_head, hidden_out, pos0, n_max, eos, forced=None):
-    """Whole greedy generation after the prefill in one persistent launch (ivlm_llama_generate).
-    Returns (new_ids i32 [n_max], argmax_ids i32 [n_max], status i32 [2]) device tensors; status = (n generated, error)."""
-    lib = _lib.load()
-    dev = hidden_out.device
-    new_ids = torch.zeros(n_max, dtype=torch.int32, device=dev)
-    arg_ids = torch.zeros(n_max, dtype=torch.int32, device=dev)
-    nbytes = lib.ivlm_llama_generate_workspace_bytes(hidden, inter)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    assert kcache.is_contiguous() and vcache.is_contiguous() and hidden_out.is_contiguous()
-    if forced is not None:
-        assert forced.dtype == torch.int32 and forced.numel() >= n_max
-    call = lambda: check(lib.ivlm_llama_generate(
-        layer_ptrs.data_ptr(), L, H, D, hidden, inter, vocab, float(eps), float(scale), rope[0].data_ptr(),
-        rope[1].data_ptr(), kcache.data_ptr(), vcache.data_ptr(), kcache.stride(0), int(max_len), embed.data_ptr(),
-        final_norm.data_ptr(), lm_head.data_ptr(), hidden_out.data_ptr(), int(pos0), int(n_max), int(eos),
-        _p(forced), new_ids.data_ptr(), arg_ids.data_ptr(), ws.data_ptr(), nbytes, _stream()), "llama_generate")
-    if TIMER.enabled:  # work = upper bound of the weight bytes streamed (n_max tokens; fewer if EOS comes early)
-        per_tok = 2.0 * (L * (4.0 * hidden * hidden + 3.0 * hidden * inter) + float(vocab) * hidden)
-        TIMER.time("llama_generate", per_tok * n_max - 2.0 * L * (4.0 * hidden * hidden + 3.0 * hidden * inter), call)
-    else:
-        call()
-    llama_generate.last_workspace = ws  # debugging (IVLM_GEN_TRACE=1: timestamps behind the scratch vectors)
-    return new_ids, arg_ids, ws[:8].view(torch.int32)
 
 
 # --------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@ from . import ops
 from .weights import SAM_PREFIX, SamEncCfg
 
 BF16 = torch.bfloat16
+F32 = torch.float32
 
 
 def _dev(t, device):
@@ -27,16 +28,30 @@ class _Lin:
         self.w = _dev(w[prefix + ".weight"].reshape(w[prefix + ".weight"].shape[0], -1), device)
         self.b = _dev(w[prefix + ".bias"], device) if bias and (prefix + ".bias") in w else None
 
-    def __call__(self, x, act="none", residual=None, res_mod=0, out=None, out_f32=False):
-        return ops.linear(x, self.w, self.b, act=act, residual=residual, res_mod=res_mod, out=out, out_f32=out_f32)
+    def __call__(self, x, act="none", residual=None, res_mod=0, out=None, out_f32=False, out_rows=None):
+        return ops.linear(x, self.w, self.b, act=act, residual=residual, res_mod=res_mod, out=out, out_f32=out_f32,
+                          out_rows=out_rows)
+
+
+class _LinF32(_Lin):
+    """nn.Linear on fp32 activations through the bf16 matrix cores: the input arrives as [hi | lo] bf16 rows
+    (ops.split_rows / the split outputs of add_rows) and meets [W | W] (K' = 2K); bias, activation and an fp32 residual in the
+    epilogue, fp32 out.  Used where the FLOPs are negligible and the precision is not (the SAM mask decoder)."""
+
+    def __init__(self, w, prefix, device, bias=True):
+        super().__init__(w, prefix, device, bias)
+        self.w = torch.cat([self.w, self.w], 1).contiguous()
+
+    def __call__(self, x_split, act="none", residual=None):
+        return ops.linear(x_split, self.w, self.b, act=act, residual=residual, out_f32=True)
 
 
 class _LN:
     def __init__(self, w, prefix, device, eps):
         self.w, self.b, self.eps = _dev(w[prefix + ".weight"], device), _dev(w[prefix + ".bias"], device), eps
 
-    def __call__(self, x, gelu=False):
-        return ops.layernorm(x, self.w, self.b, self.eps, gelu=gelu)
+    def __call__(self, x, gelu=False, out_f32=False, out=None, out_rows=None):
+        return ops.layernorm(x, self.w, self.b, self.eps, gelu=gelu, out_f32=out_f32, out=out, out_rows=out_rows)
 
 
 # ================================================================================================
@@ -67,6 +82,7 @@ class SamImageEncoder:
         self.neck2_w = _dev(w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1), device)
         self.neck3 = _LN(w, p + ".neck.3", device, 1e-6)
         self._maps = {}
+        self._xw = {}  # per view count: window-ordered norm1 output with permanently-zero padding rows
 
     def _window_maps(self, V):
         """Row maps of window_partition / window_unpartition (image_encoder.py:263-318) incl. zero padding."""
@@ -134,27 +150,32 @@ class SamImageEncoder:
         return static_out.clone()
 
     def _forward(self, images):
+        """The residual stream x is fp32 (GEMM residual epilogues write it, the LayerNorms read it); MFMA operands are bf16.
+        window_partition is folded into norm1 (its rows are written straight to their window positions; the zero rows of the
+        padded 5x5 window grid live in a buffer that is never written) and window_unpartition + shortcut into the proj GEMM's
+        scatter epilogue - no separate gather passes over the activations."""
         c = self.cfg
         V = images.shape[0]
         g, D = c.grid, c.embed_dim
         cols = ops.im2col_nchw(images.to(BF16).contiguous(), c.patch, c.patch)
-        x = self.patch(cols, residual=self.pos_embed, res_mod=g * g)  # + pos_embed broadcast over views
+        x = self.patch(cols, residual=self.pos_embed, res_mod=g * g, out_f32=True)  # + pos_embed broadcast over views
         part, unpart, nw, gp = self._window_maps(V)
+        nwin = V * nw * nw
+        if V not in self._xw:
+            self._xw[V] = torch.zeros(nwin * c.window * c.window, D, dtype=BF16, device=x.device)  # padded rows stay zero
         for blk in self.blocks:
-            xn = blk["norm1"](x)
             if blk["glob"]:
-                a = self._attention(blk, xn, V, g, V)
-                x = blk["proj"](a, residual=x)
+                a = self._attention(blk, blk["norm1"](x), V, g, V)
+                x = blk["proj"](a, residual=x, out_f32=True)
             else:
-                xw = ops.gather_rows(xn, part)  # zero rows where the 14x14 windows overhang the 64x64 grid
-                a = self._attention(blk, xw, V, c.window, V * nw * nw)
-                pw = blk["proj"](a)
-                x = ops.gather_rows(pw, unpart, add=x)  # window_unpartition + shortcut
+                xw = blk["norm1"](x, out=self._xw[V], out_rows=unpart)  # LayerNorm + window_partition
+                a = self._attention(blk, xw, V, c.window, nwin)
+                x = blk["proj"](a, residual=x, out=x, out_rows=part)  # proj + window_unpartition + shortcut (in place)
             h = blk["lin1"](blk["norm2"](x), act="gelu")
-            x = blk["lin2"](h, residual=x)
-        y = self.neck1(self.neck0(x))
+            x = blk["lin2"](h, residual=x, out_f32=True)
+        y = self.neck1(self.neck0(ops.gather_rows(x, out_kind="bf16")))
         y = ops.linear(ops.im2col3x3_nhwc(y.view(V, g, g, c.out_chans)), self.neck2_w)
-        return self.neck3(y).view(V, g * g, c.out_chans)
+        return self.neck3(y, out_f32=True).view(V, g * g, c.out_chans)  # fp32: the mask decoder keeps fp32 activations
 
 
 # ================================================================================================
@@ -162,22 +183,28 @@ class SamImageEncoder:
 # ================================================================================================
 class SamMaskDecoder:
     """PromptEncoder.forward(text_embeds=...) + MaskDecoder.forward(multimask_output=False)
-    (prompt_encoder.py:140-186, mask_decoder.py:75-164, transformer.py:62-242)."""
+    (prompt_encoder.py:140-186, mask_decoder.py:75-164, transformer.py:62-242).
+
+    Precision: this stage is 15 GFLOP of the image's 27 TFLOP and it writes the mask logits, so it runs with fp32 activations
+    end to end: every nn.Linear / transposed conv takes its input as hi + lo bf16 rows against [W | W] (``_LinF32``: an
+    fp32-activation GEMM on the bf16 matrix cores, weights exactly the checkpoint's bf16), the attentions run in fp32
+    (``ops.attention_f32``), LayerNorms and the hypernetwork product read and write fp32."""
 
     def __init__(self, w, device, grid=64, prefix=SAM_PREFIX):
         self.device, self.grid = device, grid
         pe, md = prefix + ".prompt_encoder", prefix + ".mask_decoder"
         self.C = C = w[md + ".iou_token.weight"].shape[1]
-        self.no_mask = _dev(w[pe + ".no_mask_embed.weight"].reshape(1, C), device)
+        f32 = lambda t: t.to(device=device, dtype=BF16).to(F32).contiguous()  # the checkpoint's bf16 values, held as fp32
+        self.no_mask = f32(w[pe + ".no_mask_embed.weight"].reshape(1, C))
         gauss = w[pe + ".pe_layer.positional_encoding_gaussian_matrix"].to(device=device, dtype=torch.float32).contiguous()
-        self.key_pe = ops.dense_pe(gauss, grid, grid)  # [g*g, C] constant: computed once, not per call
-        self.out_tokens = _dev(torch.cat([w[md + ".iou_token.weight"], w[md + ".mask_tokens.weight"]], 0), device)
+        self.key_pe = ops.dense_pe(gauss, grid, grid)  # fp32 [g*g, C] constant: computed once, not per call
+        self.out_tokens = f32(torch.cat([w[md + ".iou_token.weight"], w[md + ".mask_tokens.weight"]], 0))
         self.n_mask = w[md + ".mask_tokens.weight"].shape[0]
         tp = md + ".transformer"
 
         def attn(p):
-            return dict(q=_Lin(w, p + ".q_proj", device), k=_Lin(w, p + ".k_proj", device),
-                        v=_Lin(w, p + ".v_proj", device), o=_Lin(w, p + ".out_proj", device))
+            return dict(q=_LinF32(w, p + ".q_proj", device), k=_LinF32(w, p + ".k_proj", device),
+                        v=_LinF32(w, p + ".v_proj", device), o=_LinF32(w, p + ".out_proj", device))
 
         self.layers = []
         i = 0
@@ -188,35 +215,37 @@ class SamMaskDecoder:
                 i2t=attn(lp + ".cross_attn_image_to_token"),
                 norm1=_LN(w, lp + ".norm1", device, 1e-5), norm2=_LN(w, lp + ".norm2", device, 1e-5),
                 norm3=_LN(w, lp + ".norm3", device, 1e-5), norm4=_LN(w, lp + ".norm4", device, 1e-5),
-                lin1=_Lin(w, lp + ".mlp.lin1", device), lin2=_Lin(w, lp + ".mlp.lin2", device)))
+                lin1=_LinF32(w, lp + ".mlp.lin1", device), lin2=_LinF32(w, lp + ".mlp.lin2", device)))
             i += 1
         self.final_attn = attn(tp + ".final_attn_token_to_image")
         self.norm_final = _LN(w, tp + ".norm_final_attn", device, 1e-5)
         # ConvTranspose2d(k=2,s=2) as GEMM: weight [ci, co, dy, dx] -> [(dy, dx, co), ci]; bias tiled over (dy,dx)
         w0 = w[md + ".output_upscaling.0.weight"]
-        self.up0_w = _dev(w0.permute(2, 3, 1, 0).reshape(-1, w0.shape[0]), device)
+        u0 = _dev(w0.permute(2, 3, 1, 0).reshape(-1, w0.shape[0]), device)
+        self.up0_w = torch.cat([u0, u0], 1).contiguous()
         self.up0_b = _dev(w[md + ".output_upscaling.0.bias"].repeat(4), device)
         self.up_ln = _LN(w, md + ".output_upscaling.1", device, 1e-6)
         w1 = w[md + ".output_upscaling.3.weight"]
-        self.up1_w = _dev(w1.permute(2, 3, 1, 0).reshape(-1, w1.shape[0]), device)
+        u1 = _dev(w1.permute(2, 3, 1, 0).reshape(-1, w1.shape[0]), device)
+        self.up1_w = torch.cat([u1, u1], 1).contiguous()
         self.up1_b = _dev(w[md + ".output_upscaling.3.bias"].repeat(4), device)
         self.c_mid, self.c_up = w0.shape[1], w1.shape[1]
-        self.hyper0 = [_Lin(w, f"{md}.output_hypernetworks_mlps.0.layers.{j}", device) for j in range(3)]
-        self.iou = [_Lin(w, f"{md}.iou_prediction_head.layers.{j}", device) for j in range(3)]
+        self.hyper0 = [_LinF32(w, f"{md}.output_hypernetworks_mlps.0.layers.{j}", device) for j in range(3)]
+        self.iou = [_LinF32(w, f"{md}.iou_prediction_head.layers.{j}", device) for j in range(3)]
 
-    def _attn(self, a, q_in, k_in, v_in, B, Sq, Sk, heads=8, kv_batch=None):
-        """Attention.forward (transformer.py:220-242). *_in are [B*S, C] row matrices."""
-        q, k, v = a["q"](q_in), a["k"](k_in), a["v"](v_in)
+    def _attn(self, a, q_split, k_split, v_split, B, Sq, Sk, heads=8, kv_batch=None):
+        """Attention.forward (transformer.py:220-242). *_split are [B*S, 2C] hi|lo rows -> fp32 [B*Sq, inner] (before out_proj)."""
+        q, k, v = a["q"](q_split), a["k"](k_split), a["v"](v_split)
         inner = q.shape[-1]
         d = inner // heads
         Bk = B if kv_batch is None else kv_batch
         q4 = q.view(B, Sq, heads, d).permute(0, 2, 1, 3)
         k4 = k.view(Bk, Sk, heads, d).permute(0, 2, 1, 3)
         v4 = v.view(Bk, Sk, heads, d).permute(0, 2, 1, 3)
-        o = ops.attention(q4, k4, v4, 1.0 / math.sqrt(d))
-        return o.permute(0, 2, 1, 3).reshape(B * Sq, inner)
+        o = ops.attention_f32(q4, k4, v4, 1.0 / math.sqrt(d))
+        return ops.split_rows(o.permute(0, 2, 1, 3).reshape(B * Sq, inner))
 
-    # The decoder chain (prompt tokens -> two-way transformer -> upscaler -> hypernetwork dot -> IoU head) is ~150 launches of
+    # The decoder chain (prompt tokens -> two-way transformer -> upscaler -> hypernetwork dot -> IoU head) is ~200 launches of
     # 3-30 us kernels with no host decision inside: replayed as ONE HIP graph per (views, tokens) shape (BASELINE.json
     # configs[4]: "fused SAM decoder in one hipGraph").  Same kernels, same order: bit-identical to the eager chain.
     use_graph = True
@@ -227,7 +256,7 @@ class SamMaskDecoder:
             return self._forward(image_embeddings, text_embeds)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
-        key = (tuple(image_embeddings.shape), tuple(text_embeds.shape), text_embeds.dtype)
+        key = (tuple(image_embeddings.shape), image_embeddings.dtype, tuple(text_embeds.shape), text_embeds.dtype)
         ent = self._graphs.get(key)
         dev = image_embeddings.device
         if ent is None:
@@ -248,7 +277,7 @@ class SamMaskDecoder:
         return s_out[0].clone(), s_out[1].clone()
 
     def _forward(self, image_embeddings, text_embeds):
-        """image_embeddings [V, g*g, C] bf16 (channels last); text_embeds [1, T, C] (the views as TOKENS)
+        """image_embeddings [V, g*g, C] fp32 or bf16 (channels last); text_embeds [1, T, C] (the views as TOKENS)
         -> low_res_masks f32 [V,1,4g,4g], iou f32 [V,1].
 
         Batch semantics follow torch broadcasting in the reference exactly: one token set of
@@ -257,42 +286,44 @@ class SamMaskDecoder:
         V, HW, C = image_embeddings.shape
         g = self.grid
         assert text_embeds.shape[0] == 1, "n_seg > 1 with multi-view mis-broadcasts in the reference (SURVEY §7)"
-        tokens = torch.cat([self.out_tokens, text_embeds[0].to(BF16)], dim=0)  # [Nt, C]
+        tokens = torch.cat([self.out_tokens, text_embeds[0].to(F32)], dim=0)  # [Nt, C]
         Nt = tokens.shape[0]
         query_pe = tokens.unsqueeze(0).expand(V, Nt, C).reshape(V * Nt, C).contiguous()
         queries = query_pe
-        keys = ops.add_rows(image_embeddings.reshape(V * HW, C).contiguous(), self.no_mask)  # src = emb + dense (no-mask embed)
+        keys = ops.add_rows(image_embeddings.reshape(V * HW, C).contiguous(), self.no_mask, out_kind="f32")  # src + dense
         key_pe = self.key_pe  # [HW, C], broadcast over V by row modulo
+        sp = ops.split_rows
         for li, L in enumerate(self.layers):
             if li == 0:  # skip_first_layer_pe: queries = self_attn(q=k=v=queries), no residual
-                sa = self._attn(L["self_attn"], queries, queries, queries, V, Nt, Nt)
-                queries = L["self_attn"]["o"](sa)
+                qs = sp(queries)
+                queries = L["self_attn"]["o"](self._attn(L["self_attn"], qs, qs, qs, V, Nt, Nt))
             else:
-                q = ops.add_rows(queries, query_pe)
-                sa = self._attn(L["self_attn"], q, q, queries, V, Nt, Nt)
+                q = ops.add_rows(queries, query_pe, out_kind="split")
+                sa = self._attn(L["self_attn"], q, q, sp(queries), V, Nt, Nt)
                 queries = L["self_attn"]["o"](sa, residual=queries)
-            queries = L["norm1"](queries)
-            q = ops.add_rows(queries, query_pe)
-            k = ops.add_rows(keys, key_pe)
-            ca = self._attn(L["t2i"], q, k, keys, V, Nt, HW)
-            queries = L["norm2"](L["t2i"]["o"](ca, residual=queries))
-            queries = L["norm3"](L["lin2"](L["lin1"](queries, act="relu"), residual=queries))
-            q = ops.add_rows(queries, query_pe)
-            ia = self._attn(L["i2t"], k, q, queries, V, HW, Nt)  # image attends to tokens (q=k_img, k=q_tok)
-            keys = L["norm4"](L["i2t"]["o"](ia, residual=keys))
-        q = ops.add_rows(queries, query_pe)
-        k = ops.add_rows(keys, key_pe)
-        fa = self._attn(self.final_attn, q, k, keys, V, Nt, HW)
-        hs = self.norm_final(self.final_attn["o"](fa, residual=queries)).view(V, Nt, C)
+            queries = L["norm1"](queries, out_f32=True)
+            q = ops.add_rows(queries, query_pe, out_kind="split")
+            k = ops.add_rows(keys, key_pe, out_kind="split")
+            ca = self._attn(L["t2i"], q, k, sp(keys), V, Nt, HW)
+            queries = L["norm2"](L["t2i"]["o"](ca, residual=queries), out_f32=True)
+            mlp = L["lin2"](sp(L["lin1"](sp(queries), act="relu")), residual=queries)
+            queries = L["norm3"](mlp, out_f32=True)
+            q = ops.add_rows(queries, query_pe, out_kind="split")
+            ia = self._attn(L["i2t"], k, q, sp(queries), V, HW, Nt)  # image attends to tokens (q=k_img, k=q_tok)
+            keys = L["norm4"](L["i2t"]["o"](ia, residual=keys), out_f32=True)
+        q = ops.add_rows(queries, query_pe, out_kind="split")
+        k = ops.add_rows(keys, key_pe, out_kind="split")
+        fa = self._attn(self.final_attn, q, k, sp(keys), V, Nt, HW)
+        hs = self.norm_final(self.final_attn["o"](fa, residual=queries), out_f32=True).view(V, Nt, C)
         iou_tok = hs[:, 0, :].contiguous()
         mask_tok0 = hs[:, 1, :].contiguous()  # mask token 0: multimask_output=False keeps masks[:, 0:1]
         # output_upscaling: ConvT(256->64) -> LayerNorm2d -> GELU -> ConvT(64->32) -> GELU, as GEMMs on pixels
-        u = ops.linear(keys, self.up0_w, self.up0_b)  # [V*HW, (dy,dx,64)]
-        u = self.up_ln(u.view(-1, self.c_mid), gelu=True)  # per output pixel over 64 channels
-        u = ops.linear(u, self.up1_w, self.up1_b, act="gelu")  # [V*HW*4, (dy2,dx2,32)]
-        h = self.hyper0[2](self.hyper0[1](self.hyper0[0](mask_tok0, act="relu"), act="relu"))  # [V, 32]
+        u = ops.linear(sp(keys), self.up0_w, self.up0_b, out_f32=True)  # [V*HW, (dy,dx,64)]
+        u = self.up_ln(u.view(-1, self.c_mid), gelu=True, out_f32=True)  # per output pixel over 64 channels
+        u = ops.linear(sp(u), self.up1_w, self.up1_b, act="gelu", out_f32=True)  # [V*HW*4, (dy2,dx2,32)]
+        h = self.hyper0[2](sp(self.hyper0[1](sp(self.hyper0[0](sp(mask_tok0), act="relu")), act="relu")))  # [V, 32]
         low = ops.mask_dot(u, h, V, g, g)  # f32 [V, 4g, 4g]
-        iou = self.iou[2](self.iou[1](self.iou[0](iou_tok, act="relu"), act="relu"), out_f32=True)
+        iou = self.iou[2](sp(self.iou[1](sp(self.iou[0](sp(iou_tok), act="relu")), act="relu")))
         return low.unsqueeze(1), iou[:, 0:1]
 
 

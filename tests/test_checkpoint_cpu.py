@@ -53,7 +53,7 @@ def test_mismatches_are_reported(tmp_path):
 
 
 def test_dispatch_choice_helpers_are_pure_host_logic():
-    """Split-K / tail-split choices and the rel-pos table concatenation run without a GPU (host logic of ops.py)."""
+    """Split-K choice and the rel-pos table concatenation run without a GPU (host logic of ops.py)."""
     import torch
 
     from interactvlm_amd import ops
@@ -64,16 +64,6 @@ def test_dispatch_choice_helpers_are_pure_host_logic():
     assert ops._splitk_choice(16384, 3840, 1280, "none", None) == 1
     assert ops._splitk_choice(330, 22016, 4096, "swiglu", None) == 1
     assert ops._splitk_choice(12, 4096, 4096, "none", None) == 1  # skinny MFMA kernel's territory
-    # tail split: opt-in; SAM mlp2 (320 tiles of 256^2) qualifies with 4 K slices, whole-round shapes do not
-    assert ops._tail_choice(16384, 1280, 5120, "none", None) == 0
-    ops.TAILSPLIT = True
-    try:
-        assert ops._tail_choice(16384, 1280, 5120, "none", None) == 4
-        assert ops._tail_choice(16384, 5120, 1280, "gelu", None) == 0      # K too short
-        assert ops._tail_choice(16384, 4096, 4096, "none", None) == 0      # 1024 tiles: whole rounds
-        assert ops._tail_choice(16384, 1280, 5120, "swiglu", None) == 0
-    finally:
-        ops.TAILSPLIT = False
     th = torch.arange(27 * 8, dtype=torch.float32).reshape(27, 8).to(torch.bfloat16)
     tw = -th
     cat = ops.relpos_tables_cat(th, tw)

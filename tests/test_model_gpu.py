@@ -1,10 +1,11 @@
 """GPU parity of the model stages (SAM encoder / decoder, CLIP, LLaMA, the InteractVLM facade) against the
 reference-generated goldens and the fp32 CPU oracle, on synthetic weights rounded to bf16.
 
-Tolerances: the HIP path stores activations in bf16 (like the reference's bf16 model), the oracle is fp32 with
-the SAME bf16-rounded weights.  A bf16 activation carries 2^-9 relative rounding per op, so stage outputs are
-compared at a few 1e-2 of their dynamic range; the final per-vertex contact probabilities are compared at the
-north star's 1e-3 (they average thousands of pixels through a sigmoid)."""
+Precision policy of the HIP path: bf16 weights (the checkpoint's dtype), fp32 residual streams, bf16 MFMA
+operands in the three big transformers (CLIP / LLaMA prefill / SAM encoder), fp32 activations with exact products on the
+weight-streaming decode kernels, and an fp32-activation SAM mask decoder (hi + lo operand split).  The oracle is fp32 with
+the SAME bf16-rounded weights.  Stage outputs that pass through bf16 MFMA operands are compared at ~1e-2 of their dynamic
+range; the final per-vertex contact probabilities at the north star's 1e-3."""
 import json
 import os
 
@@ -45,14 +46,14 @@ def test_sam_decoder_vs_reference_golden(hip_lib, cuda, golden_dir):
         emb = torch.from_numpy(synth.synth_normal(f"samdec/image_emb/{V}", (V, 256, 64, 64), 1.0, 0))
         text = torch.from_numpy(synth.synth_normal(f"samdec/text/{V}", (1, V, 256), 1.0, 0))
         emb_cl = emb.permute(0, 2, 3, 1).reshape(V, 4096, 256).to(torch.bfloat16).to(cuda)
-        low, iou = dec(emb_cl, text.to(torch.bfloat16).to(cuda))
+        low, iou = dec(emb_cl, text.to(torch.bfloat16).to(cuda).float())
         assert low.shape == (V, 1, 256, 256) and low.dtype == torch.float32 and iou.shape == (V, 1)
         # the call above replayed the chain as one HIP graph (configs[4]); the eager chain and a second replay with other
         # inputs in between give the same bits
         assert dec.use_graph and len(dec._graphs) >= 1
-        low_e, iou_e = dec._forward(emb_cl, text.to(torch.bfloat16).to(cuda))
-        dec(emb_cl.flip(0).contiguous(), text.to(torch.bfloat16).to(cuda) * 0.5)
-        low_r, iou_r = dec(emb_cl, text.to(torch.bfloat16).to(cuda))
+        low_e, iou_e = dec._forward(emb_cl, text.to(torch.bfloat16).to(cuda).float())
+        dec(emb_cl.flip(0).contiguous(), text.to(torch.bfloat16).to(cuda).float() * 0.5)
+        low_r, iou_r = dec(emb_cl, text.to(torch.bfloat16).to(cuda).float())
         assert torch.equal(low, low_e) and torch.equal(iou, iou_e) and torch.equal(low_r, low) and torch.equal(iou_r, iou)
         ref = torch.from_numpy(d["low_res"])
         assert _rel_err(low, ref) < 4e-2, _rel_err(low, ref)
@@ -60,7 +61,19 @@ def test_sam_decoder_vs_reference_golden(hip_lib, cuda, golden_dir):
         full = sam.postprocess_masks(low, (1024, 1024), (1024, 1024))
         assert _rel_err(full[..., ::16, ::16], torch.from_numpy(d["post_sub"])) < 4e-2
         pe = dec.key_pe.float().cpu().view(64, 64, 256).permute(2, 0, 1)[None]
-        assert float((pe[..., ::8, ::8] - torch.from_numpy(d["dense_pe_sub"])).abs().max()) < 2e-2
+        assert float((pe[..., ::8, ::8] - torch.from_numpy(d["dense_pe_sub"])).abs().max()) < 1e-4
+        # against the fp32 oracle on the SAME bf16-rounded weights and inputs: the decoder keeps fp32 activations (hi + lo
+        # operand split on the matrix cores, fp32 attention), so only fp32 summation-order noise is left
+        from oracle import nn as O
+        wb = {k: (v.to(torch.bfloat16).float() if "gaussian" not in k else v) for k, v in w.items()}
+        embf, textf = emb.to(torch.bfloat16).float(), text.to(torch.bfloat16).float()
+        sp_, de_ = O.prompt_encoder_text(wb, Wt.SAM_PREFIX + ".prompt_encoder", textf, (64, 64))
+        pe_ = O.dense_pe(wb, Wt.SAM_PREFIX + ".prompt_encoder", (64, 64))
+        low_o, iou_o = O.mask_decoder(wb, Wt.SAM_PREFIX + ".mask_decoder", embf, pe_, sp_, de_)
+        e_low = float((low.cpu() - low_o).abs().max() / low_o.abs().max())
+        print(f"\n[SAM decoder V={V}] vs fp32 oracle on identical weights: rel max err low_res {e_low:.2e}, "
+              f"iou {float((iou.cpu() - iou_o).abs().max()):.2e}")
+        assert e_low < 2e-4 and float((iou.cpu() - iou_o).abs().max()) < 2e-4
 
 
 def test_sam_encoder_small_vs_reference_golden(hip_lib, cuda, golden_dir):
@@ -138,9 +151,10 @@ def test_clip_and_llama_vs_oracle(hip_lib, cuda):
     lc = Wt.LlamaCfg(hidden=512, layers=3, heads=4, inter=1024, vocab=1000)  # head dim 128 like LLaMA-2
     w = _bf16_weights(Wt.llama_spec(lc))
     llm = llava.Llama(w, lc, cuda, max_len=128)
-    emb = (torch.randn(70, 512, generator=g) * 0.5).to(torch.bfloat16)
-    ref = O.llama(w, "model", emb.float()[None], 3, 4)[0]
+    emb = (torch.randn(70, 512, generator=g) * 0.5).to(torch.bfloat16).float()  # the fp32 stream starts at bf16 embeddings
+    ref = O.llama(w, "model", emb[None], 3, 4)[0]
     full = llm.forward(emb.to(cuda), 0)
+    assert full.dtype == torch.float32
     assert _rel_err(full, ref) < 4e-2, _rel_err(full, ref)
     # prefill 50 + 20 single-token decode steps through the KV cache == one 70-token pass
     llm2 = llava.Llama(w, lc, cuda, max_len=128)
@@ -149,7 +163,11 @@ def test_clip_and_llama_vs_oracle(hip_lib, cuda):
         h.append(llm2.forward(emb[t: t + 1].to(cuda), t))
     inc = torch.cat(h, 0)
     assert _rel_err(inc, ref) < 4e-2
-    assert _rel_err(inc, full) < 2e-2  # GEMV vs MFMA accumulation order only
+    assert _rel_err(inc, full) < 2e-2  # decode rows: fp32 activations, exact products; prefill rows: bf16 MFMA operands
+    # the decode rows (fp32 activations end to end) sit closer to the fp32 oracle than the bf16-operand prefill rows do
+    e_dec, e_pre = _rel_err(inc[50:], ref[50:]), _rel_err(full[50:], ref[50:])
+    print(f"\n[llama] decode rows vs oracle {e_dec:.2e}, the same rows through the MFMA prefill {e_pre:.2e}")
+    assert e_dec < 1.5 * e_pre + 1e-3
     lg = llm.logits(full[-1:]).cpu()
     ref_lg = ref[-1:] @ w["lm_head.weight"].T
     assert _rel_err(lg, ref_lg) < 4e-2
@@ -157,72 +175,8 @@ def test_clip_and_llama_vs_oracle(hip_lib, cuda):
     assert int(ops.argmax(llm.logits(full[-1:]))[0]) == int(lg.argmax())
 
 
-@pytest.mark.parametrize("hidden,heads,inter,vocab", [(1024, 8, 1376, 1003), (512, 4, 1024, 1000)])
-def test_persistent_generate_vs_per_op_and_oracle(hip_lib, cuda, hidden, heads, inter, vocab):
-    """ivlm_llama_generate (one persistent launch: all layers of all new tokens, device-side argmax / EOS) against
-    (a) the per-op decode path token by token and (b) the fp32 oracle run teacher-forced over the same ids.
-    inter = 1376 makes rows 172 chunks long: not a whole number of waves (the 'straddle' reduction, like 11008)."""
-    import torch
-
-    from interactvlm_amd import llava
-    from interactvlm_amd import weights as Wt
-    from oracle import nn as O
-
-    lc = Wt.LlamaCfg(hidden=hidden, layers=3, heads=heads, inter=inter, vocab=vocab)
-    w = _bf16_weights(Wt.llama_spec(lc))
-    g = torch.Generator().manual_seed(7)
-    T0, n_new = 37, 12
-    emb = (torch.randn(T0, hidden, generator=g) * 0.5).to(torch.bfloat16)
-
-    def prefill():
-        llm = llava.Llama(w, lc, cuda, max_len=64)
-        hid = torch.zeros(T0 + n_new, hidden, dtype=torch.bfloat16, device=cuda)
-        hid[:T0] = llm.forward(emb.to(cuda), 0)
-        return llm, hid
-
-    # (a) free-running greedy: per-op loop vs persistent kernel
-    llm_a, hid_a = prefill()
-    ids_a, last = [], hid_a[T0 - 1: T0]
-    from interactvlm_amd import ops
-    for step in range(n_new):
-        tok = int(ops.argmax(llm_a.logits(last))[0])
-        ids_a.append(tok)
-        if step == n_new - 1:
-            break
-        last = llm_a.forward(llm_a.embed_ids(torch.tensor([tok], dtype=torch.int32, device=cuda)), T0 + step)
-        hid_a[T0 + step] = last[0]
-    llm_b, hid_b = prefill()
-    new_ids, arg_ids, status = llm_b.generate_fused(hid_b, T0, n_new, eos=-1)
-    st = status.cpu().tolist()
-    assert st == [n_new, 0], st
-    assert new_ids.cpu().tolist() == ids_a and arg_ids.cpu().tolist() == ids_a
-    assert _rel_err(hid_b[: T0 + n_new - 1], hid_a[: T0 + n_new - 1].float().cpu()) < 2e-2
-    assert _rel_err(llm_b.kcache[:, : T0 + n_new - 1], llm_a.kcache[:, : T0 + n_new - 1].float().cpu()) < 2e-2
-    # run-to-run bit reproducibility (fixed summation order, no atomics on data)
-    llm_c, hid_c = prefill()
-    llm_c.generate_fused(hid_c, T0, n_new, eos=-1)
-    assert torch.equal(hid_c, hid_b)
-
-    # (b) teacher-forced ids + EOS stop, against the fp32 oracle over the whole sequence
-    forced = [5, 17, 900, 3, 44, 2, 8, 9]  # EOS (2) at index 5: generation must stop there
-    llm_d, hid_d = prefill()
-    f_t = torch.tensor(forced, dtype=torch.int32, device=cuda)
-    new_ids, arg_ids, status = llm_d.generate_fused(hid_d, T0, len(forced), eos=2, forced=f_t)
-    assert status.cpu().tolist() == [6, 0]
-    assert new_ids.cpu().tolist()[:6] == forced[:6]
-    seq = torch.cat([emb.float(), w["model.embed_tokens.weight"][forced[:5]].float()])
-    ref = O.llama(w, "model", seq[None], lc.layers, heads)[0]
-    assert _rel_err(hid_d[: T0 + 5], ref) < 4e-2
-    # the argmax the kernel reports at each step == argmax of lm_head over ITS OWN hidden state of that step
-    lg = hid_d[T0 - 1: T0 + 5].float().cpu() @ w["lm_head.weight"].float().T
-    top2 = lg.topk(2, dim=-1).values
-    clear = (top2[:, 0] - top2[:, 1]) > 1e-2
-    assert (arg_ids.cpu()[:6][clear] == lg.argmax(-1)[clear].to(torch.int32)).all()
-
-
-@pytest.mark.parametrize("dataflow", [True, False])
 @pytest.mark.parametrize("hidden,heads,inter", [(1024, 8, 1376), (512, 4, 1024)])
-def test_graph_decode_with_fused_attn_oproj_matches_eager(hip_lib, cuda, hidden, heads, inter, dataflow):
+def test_graph_decode_with_fused_attn_oproj_matches_eager(hip_lib, cuda, hidden, heads, inter):
     """The replayed HIP graph of a decode step (position from device memory; attention + o_proj fused into one launch whose
     GEMV blocks wait on a device counter) against the eager per-op steps: same argmax ids, hidden states and KV cache."""
     import torch
@@ -234,7 +188,7 @@ def test_graph_decode_with_fused_attn_oproj_matches_eager(hip_lib, cuda, hidden,
     w = _bf16_weights(Wt.llama_spec(lc))
     g = torch.Generator().manual_seed(11)
     T0, n_new = 29, 14
-    emb = (torch.randn(T0, hidden, generator=g) * 0.5).to(torch.bfloat16).to(cuda)
+    emb = (torch.randn(T0, hidden, generator=g) * 0.5).to(torch.bfloat16).float().to(cuda)
     toks = torch.randint(3, 1000, (n_new,), generator=g).to(torch.int32).to(cuda)
 
     llm_a = llava.Llama(w, lc, cuda, max_len=64)
@@ -245,27 +199,24 @@ def test_graph_decode_with_fused_attn_oproj_matches_eager(hip_lib, cuda, hidden,
         hid_a.append(h)
         arg_a.append(int(ops.argmax(llm_a.logits(h))[0]))
     llm_b = llava.Llama(w, lc, cuda, max_len=64)
-    llm_b.dataflow_layers = dataflow  # True: all layers in ONE dataflow launch; False: attention + o_proj fused per layer
     llm_b.forward(emb, 0)
     dg = llm_b.decode_graph()
-    assert dg.get("fused") is not None and (dg.get("dataflow") is not None) == dataflow
+    assert dg.get("fused") is not None
     for rep in range(2):  # a second generation re-uses the graph: counters / step / position are reset by the caller
         dg["pos"].fill_(T0)
         dg["pos64"].fill_(T0)
         for k in ("step", "counters", "status"):
             dg["fused"][k].zero_()
-        if dataflow:
-            llm_b.reset_dataflow()
         hid_b, arg_b = [], []
         for s in range(n_new):
             dg["tok"].copy_(toks[s: s + 1])
             dg["graph"].replay()
             hid_b.append(dg["hidden"].clone())
             arg_b.append(int(dg["nxt"][0]))
-        assert int(dg["fused"]["status"][0]) == 0 and (not dataflow or llm_b.dataflow_status() == 0)
+        assert int(dg["fused"]["status"][0]) == 0
         assert int(dg["pos"][0]) == T0 + n_new and int(dg["fused"]["step"][0]) == n_new
-        assert _rel_err(torch.cat(hid_b), torch.cat(hid_a).float().cpu()) < 2e-2
-        assert _rel_err(llm_b.kcache[:, : T0 + n_new], llm_a.kcache[:, : T0 + n_new].float().cpu()) < 2e-2
+        assert _rel_err(torch.cat(hid_b), torch.cat(hid_a).float().cpu()) < 1e-4  # same fp32 arithmetic, other launch shape
+        assert _rel_err(llm_b.kcache[:, : T0 + n_new], llm_a.kcache[:, : T0 + n_new].float().cpu()) < 1e-2
         lg = torch.cat(hid_b).float().cpu() @ w["lm_head.weight"].float().T
         top2 = lg.topk(2, dim=-1).values
         clear = (top2[:, 0] - top2[:, 1]) > 1e-2
@@ -329,11 +280,16 @@ def test_model_forward_vs_reference_golden(hip_lib, cuda, golden_dir):
     e_floor = float((o["pred_contact"] - ref_c).abs().max())
     print(f"[model_forward toy] vs fp32 oracle on identical bf16 weights: max|dp| = {e_same:.2e}; "
           f"bf16-checkpoint rounding floor vs fp32-weight reference: {e_floor:.2e}")
-    assert e_same < 4e-3
-    # North-star tolerance is 1e-3 on per-vertex probabilities vs the fp32 reference.  The bf16 pipeline (bf16
-    # weights AND activations, like the reference's own bf16 model) measures 2.6e-3 max / 8.7e-4 rms here; the
-    # bound below is the measured bf16 level, the 1e-3 claim is NOT made for bf16 (DESIGN.md "Parity status").
-    assert e_c < 5e-3, e_c
+    # North-star tolerance: 1e-3 on per-vertex probabilities against the reference path on the same inputs = the fp32
+    # oracle on the weights the GPU holds (bf16-representable).
+    assert e_same < 1e-3, e_same
+    # thresholded vertex sets equal to the oracle's off a 1e-6 band around the threshold
+    oc = o["pred_contact"]
+    for thr, op in ((0.5, torch.ge), (0.3, torch.gt)):
+        away = (oc - thr).abs() > max(1e-6, e_same)
+        assert torch.equal(op(contact, thr)[away], op(oc, thr)[away])
+    # against the reference's own fp32-weight run the difference is dominated by rounding the checkpoint to bf16 (e_floor)
+    assert e_c < e_floor + 1e-3, (e_c, e_floor)
 
     # evaluate(): KV-cached generation with the forced answer == teacher-forced pass (same [SEG] row)
     L0 = 40
@@ -342,20 +298,16 @@ def test_model_forward_vs_reference_golden(hip_lib, cuda, golden_dir):
     assert ev["output_ids"].shape == (1, len(ids)) and torch.equal(ev["output_ids"][0], ids)
     e2 = float((ev["pred_contact_3d"].float().cpu() - contact).abs().max())
     print(f"[evaluate vs model_forward] max|dp| = {e2:.2e}")
-    assert e2 < 2e-3  # same arithmetic, different GEMM path (GEMV decode vs MFMA prefill) for the answer tokens
+    assert e2 < 1e-3  # the answer tokens take the fp32-activation decode kernels instead of the bf16-operand MFMA prefill
+    e2o = float((ev["pred_contact_3d"].float().cpu() - o["pred_contact"]).abs().max())
+    print(f"[evaluate vs fp32 oracle] max|dp| = {e2o:.2e}")
+    assert e2o < 1e-3
     assert float((ev["pred_masks"][0] - pm).abs().max()) < 0.08 * float(ref_pm.abs().max())
     # cached SAM embeddings give bit-identical results
     emb = m.precompute_visual_embs(images[0].to(bf).to(cuda))
     ev2 = m.evaluate(images_clip.to(bf).to(cuda), images.to(bf).to(cuda), ids[None, :L0], cams, [(1024, 1024)],
                      [(1024, 1024)], contact_type="hcontact", forced_new_tokens=ids[L0:].tolist(), image_embeddings=emb)
     assert torch.equal(ev2["pred_contact_3d"], ev["pred_contact_3d"])
-    if m.llm.can_fuse_generate:  # opt-in persistent decode kernel: same ids, same contacts up to GEMV summation order
-        m.fused_generate = True
-        ev3 = m.evaluate(images_clip.to(bf).to(cuda), images.to(bf).to(cuda), ids[None, :L0], cams, [(1024, 1024)],
-                         [(1024, 1024)], contact_type="hcontact", forced_new_tokens=ids[L0:].tolist())
-        m.fused_generate = False
-        assert torch.equal(ev3["output_ids"], ev["output_ids"])
-        assert float((ev3["pred_contact_3d"] - ev["pred_contact_3d"]).abs().max()) < 2e-3
 
 
 def test_model_forward_oafford_vs_reference_golden(hip_lib, cuda, golden_dir, tmp_path):
@@ -405,7 +357,7 @@ def test_model_forward_oafford_vs_reference_golden(hip_lib, cuda, golden_dir, tm
     aff = out["pred_object_3d_afford"].float().cpu()
     e = float((aff - torch.from_numpy(d["pred_afford"])).abs().max())
     print(f"\n[model_forward oafford] max|dp_afford| = {e:.2e}")
-    assert aff.shape == (1, 2048) and e < 5e-3
+    assert aff.shape == (1, 2048) and e < 2e-3
     assert tuple(out["pred_object_3d_contact"].shape) == tuple(d["pred_ocontact"].shape)
     assert float(out["pred_human_3d_contact"].abs().max()) == 0.0
 
@@ -504,7 +456,7 @@ def test_object_render_localize_lift_flow(hip_lib, cuda, tmp_path):
     assert both[0]["pred_contact_3d"].shape == (1, 6890) and both[1]["pred_contact_3d"].shape == (1, nv)
     for got, ref in ((both[0], h1), (both[1], o1)):
         assert torch.equal(got["output_ids"], ref["output_ids"])
-        assert float((got["pred_contact_3d"] - ref["pred_contact_3d"]).abs().max()) < 2e-3
+        assert float((got["pred_contact_3d"] - ref["pred_contact_3d"]).abs().max()) < 1e-3
         assert float((got["pred_masks"][0] - ref["pred_masks"][0]).abs().max()) < 0.05
 
 
@@ -529,6 +481,28 @@ def test_decode_attn_batch_equals_per_sequence(hip_lib, cuda):
     assert torch.equal(got, exp) and torch.equal(kc, kc1) and torch.equal(vc, vc1)
     with pytest.raises(AssertionError):
         ops.llama_decode_attn_batch(qkv, kc, vc, H, D, pos[:3], 10000.0, D ** -0.5, table=tab)
+    # fp32 I/O (the decode path proper): against torch fp64 on the bf16 cache + the exact new row; a sequence whose position
+    # has reached the end of its slab is skipped (nothing appended, its neighbour's slab untouched)
+    q32 = torch.randn(B, 3 * H * D, generator=g).to(cuda)
+    pos2 = torch.tensor([0, 17, 63, 64, Tmax], dtype=torch.int32, device=cuda)
+    kc2, vc2 = kc.clone(), vc.clone()
+    got32 = ops.llama_decode_attn_batch(q32, kc2, vc2, H, D, pos2, 10000.0, D ** -0.5, table=tab)
+    assert got32.dtype == torch.float32 and torch.equal(kc2[4], kc[4]) and torch.equal(vc2[4], vc[4])
+    assert float(got32[4].abs().max()) == 0.0
+    cos, sin = tab[0].double().cpu(), tab[1].double().cpu()
+    for b in range(4):
+        p = int(pos2[b])
+        x = q32[b].double().cpu().view(3, H, D)
+        c, s_ = torch.cat([cos[p], cos[p]]), torch.cat([sin[p], sin[p]])
+        rot = lambda t: torch.cat([-t[..., D // 2:], t[..., : D // 2]], -1)
+        qr, kr = x[0] * c + rot(x[0]) * s_, x[1] * c + rot(x[1]) * s_
+        K_ = torch.cat([kc[b, :p].double().cpu(), kr[None]], 0)  # [p+1, H, D]: bf16 history + exact new row
+        V_ = torch.cat([vc[b, :p].double().cpu(), x[2][None]], 0)
+        a = torch.softmax(torch.einsum("hd,thd->ht", qr, K_) * D ** -0.5, -1)
+        ref = torch.einsum("ht,thd->hd", a, V_).reshape(-1)
+        assert float((got32[b].double().cpu() - ref).abs().max()) < 2e-5, b
+        assert torch.equal(kc2[b, p], kr.to(torch.bfloat16).to(cuda)) or \
+            float((kc2[b, p].double().cpu() - kr).abs().max()) < 2.0 ** -7 * float(kr.abs().max())
 
 
 @pytest.mark.parametrize("graph", [True, False])
@@ -570,7 +544,7 @@ def test_evaluate_batch_equals_per_image_evaluate(hip_lib, cuda, golden_dir, gra
         em = float((outs[b]["pred_masks"][0] - single[b]["pred_masks"][0]).abs().max())
         print(f"\n[evaluate_batch graph={graph}] image {b}: max|dp| = {e:.2e}, max|dmask| = {em:.3e}")
         assert outs[b]["pred_contact_3d"].shape == (1, 6890)
-        assert e < 2e-3
+        assert e < 1e-3
     # free-running greedy search: every sequence stops at its own EOS / length, ids equal the per-image runs
     free1 = [m.evaluate(ic[b: b + 1], im[b: b + 1], prompts[b][None], cams, [(1024, 1024)], [(1024, 1024)],
                         max_new_tokens=6 + b, eos_token_id=-1)["output_ids"] for b in range(B)]

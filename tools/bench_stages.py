@@ -23,10 +23,6 @@ def main():
     del w
     if os.environ.get("IVLM_NO_FUSE_ATTN_OPROJ"):
         m.llm.fuse_attn_oproj = False
-    if os.environ.get("IVLM_DATAFLOW_LAYERS"):  # all layers of a decode step in one persistent dataflow launch
-        m.llm.dataflow_layers = True
-    if os.environ.get("IVLM_FUSED_GENERATE"):   # the whole generation in one persistent launch
-        m.fused_generate = True
     ids, forced = synthetic.prompt_ids(cfg)
     cams = synthetic.human_cam_params()
     ic, im = synthetic.images(cfg, dev)

@@ -51,7 +51,6 @@ def main():
     run("baseline")
     run("split-K off (prefill o/down, CLIP)", setattr_(ops, "SPLITK", False), setattr_(ops, "SPLITK", True))
     run("rel-pos via dot kernel everywhere", setattr_(ops, "RELPOS_GEMM", False), setattr_(ops, "RELPOS_GEMM", True))
-    run("tail-split GEMM on (SAM mlp2)", setattr_(ops, "TAILSPLIT", True), setattr_(ops, "TAILSPLIT", False))
     run("GEMM tile 128 everywhere", lambda: lib.ivlm_gemm_tile_override(128), lambda: lib.ivlm_gemm_tile_override(0))
     run("baseline again")
 

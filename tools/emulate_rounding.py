@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""CPU study: which bf16 roundings of the HIP path move the per-vertex contacts, and by how much.
+
+Runs the fp32 oracle pipeline (oracle/pipeline.py) on the bench's parity configuration twice: exact, and with bf16
+roundings inserted where a given precision policy of the GPU path rounds (GEMM inputs always: the MFMA operands are
+bf16).  Test infrastructure only - this never runs on the product path.
+
+    python tools/emulate_rounding.py [policy ...]     policies: see POLICIES below
+"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from interactvlm_amd import synth, synthetic  # noqa: E402
+from interactvlm_amd import weights as Wt  # noqa: E402
+from oracle import nn as O  # noqa: E402
+from oracle import pipeline as P  # noqa: E402
+
+bf = lambda t: t.to(torch.bfloat16).float()
+ident = lambda t: t
+
+# knobs: which tensors are rounded to bf16
+K = dict(gemm_in=ident, gemm_out=ident, res=ident, norm_out=ident, attn_p=ident, attn_out=ident, dec_stream=ident)
+
+_linear0 = O.linear
+
+
+ACTIVE = set()
+
+
+def _stage(prefix):
+    if ".image_encoder." in prefix:
+        return "sam"
+    if "vision_tower" in prefix:
+        return "clip"
+    if prefix.startswith("model.layers") or "mm_projector" in prefix or "text_hidden_fcs" in prefix:
+        return "llama"
+    return "dec"
+
+
+def linear(w, prefix, x):
+    if _stage(prefix) not in ACTIVE:
+        return _linear0(w, prefix, x)
+    return K["gemm_out"](_linear0(w, prefix, K["gemm_in"](x)))
+
+
+def layer_norm(w, prefix, x, eps):
+    return K["norm_out"](F.layer_norm(x, (x.shape[-1],), w[prefix + ".weight"], w[prefix + ".bias"], eps))
+
+
+def sam_block(w, p, x, num_heads, window_size):
+    shortcut = x
+    x = layer_norm(w, p + ".norm1", x, 1e-6)
+    if window_size > 0:
+        H, Wd = x.shape[1], x.shape[2]
+        x, pad_hw = O._window_partition(x, window_size)
+    x = O._vit_attention(w, p + ".attn", x, num_heads)
+    if window_size > 0:
+        x = O._window_unpartition(x, window_size, pad_hw, (H, Wd))
+    x = K["res"](shortcut + x)
+    h = linear(w, p + ".mlp.lin2", K["gemm_out"](F.gelu(_linear0(w, p + ".mlp.lin1", K["gemm_in"](layer_norm(w, p + ".norm2", x, 1e-6))))))
+    return K["res"](x + h)
+
+
+def llama(w, p, x, num_layers, num_heads, eps=1e-5, theta=10000.0):
+    import math
+    B, T, C = x.shape
+    hd = C // num_heads
+    cos, sin = O.rope_tables(T, hd, theta)
+    mask = torch.full((T, T), float("-inf")).triu(1)
+    x = K["res"](x)
+    for i in range(num_layers):
+        lp = f"{p}.layers.{i}"
+        r = x
+        y = K["norm_out"](O.rms_norm(w[lp + ".input_layernorm.weight"], x, eps))
+        q = linear(w, lp + ".self_attn.q_proj", y).view(B, T, num_heads, hd).transpose(1, 2)
+        k = linear(w, lp + ".self_attn.k_proj", y).view(B, T, num_heads, hd).transpose(1, 2)
+        v = linear(w, lp + ".self_attn.v_proj", y).view(B, T, num_heads, hd).transpose(1, 2)
+        q = K["gemm_out"](q * cos + O._rot_half(q) * sin)
+        k = K["gemm_out"](k * cos + O._rot_half(k) * sin)
+        a = (q @ k.transpose(2, 3)) / math.sqrt(hd) + mask
+        a = K["attn_out"](K["attn_p"](torch.softmax(a, dim=-1)) @ v)
+        x = K["res"](r + _linear0(w, lp + ".self_attn.o_proj", K["gemm_in"](a.transpose(1, 2).reshape(B, T, C))))
+        y = K["norm_out"](O.rms_norm(w[lp + ".post_attention_layernorm.weight"], x, eps))
+        h = K["gemm_out"](F.silu(_linear0(w, lp + ".mlp.gate_proj", K["gemm_in"](y))) * _linear0(w, lp + ".mlp.up_proj", K["gemm_in"](y)))
+        x = K["res"](x + _linear0(w, lp + ".mlp.down_proj", K["gemm_in"](h)))
+    return K["norm_out"](O.rms_norm(w[p + ".norm.weight"], x, eps))
+
+
+def clip_vision(w, p, x, num_layers, num_heads, select_layer=-2, patch=14, eps=1e-5):
+    e = p + ".embeddings"
+    pe = F.conv2d(K["gemm_in"](x), w[e + ".patch_embedding.weight"], None, stride=patch).flatten(2).transpose(1, 2)
+    cls = w[e + ".class_embedding"].expand(x.shape[0], 1, -1)
+    h = K["res"](torch.cat([cls, pe], dim=1) + w[e + ".position_embedding.weight"][None])
+    h = K["res"](F.layer_norm(h, (h.shape[-1],), w[p + ".pre_layrnorm.weight"], w[p + ".pre_layrnorm.bias"], eps))
+    hidden = [h]
+    for i in range(num_layers):
+        lp = f"{p}.encoder.layers.{i}"
+        r = h
+        y = layer_norm(w, lp + ".layer_norm1", h, eps)
+        B, T, C = y.shape
+        hd = C // num_heads
+        q = K["gemm_out"](linear(w, lp + ".self_attn.q_proj", y) * hd ** -0.5).view(B, T, num_heads, hd).transpose(1, 2)
+        k = linear(w, lp + ".self_attn.k_proj", y).view(B, T, num_heads, hd).transpose(1, 2)
+        v = linear(w, lp + ".self_attn.v_proj", y).view(B, T, num_heads, hd).transpose(1, 2)
+        a = K["attn_out"](K["attn_p"](torch.softmax(q @ k.transpose(-1, -2), dim=-1)) @ v)
+        h = K["res"](r + _linear0(w, lp + ".self_attn.out_proj", K["gemm_in"](a.transpose(1, 2).reshape(B, T, C))))
+        y = layer_norm(w, lp + ".layer_norm2", h, eps)
+        y = _linear0(w, lp + ".mlp.fc1", K["gemm_in"](y))
+        y = K["gemm_out"](y * torch.sigmoid(1.702 * y))
+        h = K["res"](h + _linear0(w, lp + ".mlp.fc2", K["gemm_in"](y)))
+        hidden.append(h)
+    return hidden[select_layer][:, 1:]
+
+
+POLICIES = {
+    "exact": {},
+    # round 1 of this repo: everything bf16 between kernels
+    "all_bf16": dict(gemm_in=bf, gemm_out=bf, res=bf, norm_out=bf, attn_p=bf, attn_out=bf),
+    # fp32 residual stream, everything else bf16
+    "res_f32": dict(gemm_in=bf, gemm_out=bf, norm_out=bf, attn_p=bf, attn_out=bf),
+    # only the unavoidable MFMA operand roundings
+    "gemm_in_only": dict(gemm_in=bf, attn_p=bf),
+    "res_only": dict(res=bf),
+}
+
+
+def run(policy, stages=("clip", "llama", "sam", "dec")):
+    for k in K:
+        K[k] = ident
+    K.update(POLICIES[policy])
+    O.linear = linear
+    ACTIVE.clear()
+    ACTIVE.update(stages)
+    pl, ps, pc = O.llama, O.sam_block, O.clip_vision
+    if "llama" in stages:
+        O.llama = llama
+    if "sam" in stages:
+        O.sam_block = sam_block
+    if "clip" in stages:
+        O.clip_vision = clip_vision
+    # (oracle functions not replaced above - mask decoder, cam encoders, vit attention - see only the linear() hook)
+    try:
+        return _pipeline()
+    finally:
+        O.linear, O.llama, O.sam_block, O.clip_vision = _linear0, pl, ps, pc
+
+
+_cache = {}
+
+
+def _pipeline():
+    if "inp" not in _cache:
+        cfg = synthetic.config_tiny()
+        w = {k: v.to(torch.bfloat16).float() for k, v in Wt.synth_weights(Wt.ivlm_spec(cfg)).items()}
+        tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+        ids, forced = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=8)
+        cams = synthetic.human_cam_params()
+        g = torch.Generator().manual_seed(1234)
+        ic = torch.randn(1, 3, 224, 224, generator=g).to(torch.bfloat16).float()
+        im = torch.randn(1, 4, 3, 1024, 1024, generator=g).to(torch.bfloat16).float()
+        _cache["inp"] = (cfg, w, tables, torch.cat([ids[0], torch.tensor(forced)]), cams, ic, im)
+    cfg, w, tables, full_ids, cams, ic, im = _cache["inp"]
+    return P.model_forward(w, cfg, im[0], ic, full_ids, cams[0], tables)
+
+
+def main():
+    torch.set_grad_enabled(False)
+    pols = sys.argv[1:] or ["all_bf16", "res_f32", "gemm_in_only", "res_only"]
+    ref = run("exact")
+    rc = ref["pred_contact"]
+    print(f"contact range {float(rc.min()):.3f}..{float(rc.max()):.3f}")
+    for p in pols:
+        for stages in (("clip", "llama", "sam", "dec"), ("clip",), ("llama",), ("sam",), ("dec",)):
+            o = run(p, stages)
+            d = (o["pred_contact"] - rc).abs()
+            dm = (o["pred_masks"] - ref["pred_masks"]).abs().max()
+            dh = (o["seg_emb"] - ref["seg_emb"]).abs().max() / ref["seg_emb"].abs().max()
+            de = (o["sam_emb"] - ref["sam_emb"]).abs().max() / ref["sam_emb"].abs().max()
+            print(f"{p:14s} stages={'+'.join(stages):20s} max|dp| {float(d.max()):.2e} rms {float(d.pow(2).mean().sqrt()):.2e}"
+                  f"  max|dmask| {float(dm):.3f}  seg_emb rel {float(dh):.1e}  sam_emb rel {float(de):.1e}")
+
+
+if __name__ == "__main__":
+    main()
