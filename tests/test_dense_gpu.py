@@ -480,7 +480,7 @@ def test_skinny_mfma_gemm_vs_fp32(hip_lib, cuda, M, N, K, act, rms, res, f32, bi
         y = y + r.float()
     tol = dict(atol=2e-3, rtol=1e-3) if f32 else dict(atol=2e-2, rtol=1.6e-2)
     assert got.shape == (M, n_out) and torch.allclose(got.float(), y, **tol)
-    if M <= 8:
+    if M <= 8 and not (rms and M * K * 2 > 48 * 1024):  # (RMS-fused rows that do not fit LDS exist on the skinny kernel only)
         lib.ivlm_gemv_mfma_min_m(17)  # never: the wave-per-row kernel
         try:
             roww = ops.linear(x, w, **kw)
