@@ -3,12 +3,18 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
 
-One step = one pass of the hot path over one synthetic image per rank (BASELINE.json configs[1]:
-LLaVA-1.5-7B + CLIP ViT-L/14 + SAM ViT-H dims, bf16, 4 views of 1024x1024, 6890 vertices):
-  InteractVLMForCausalLM.evaluate = CLIP encode -> LLaMA prefill (330 positions) -> 24 greedy decode steps
-  (KV cache, lm_head + argmax every step, forced [SEG] answer) -> text_hidden_fcs -> SAM ViT-H encoder on the 4
-  views -> prompt encoder + two-way mask decoder -> postprocess to 4 x 1024^2 fp32 -> lift to 6890 vertices,
-then ONE all-gather of the per-vertex contacts across ranks (RCCL) and the D2H copy on rank 0.
+Workloads (``--workload``, default ``auto``):
+  b1    BASELINE.json configs[1] - the configuration the metric is quoted on.  One step = one pass of the hot path over ONE
+        synthetic image per rank (LLaVA-1.5-7B + CLIP ViT-L/14 + SAM ViT-H dims, bf16 weights, 4 views of 1024x1024, 6890
+        vertices): InteractVLMForCausalLM.evaluate = CLIP encode -> LLaMA prefill (330 positions) -> 24 greedy decode steps
+        (KV cache, lm_head + argmax every step, forced [SEG] answer) -> text_hidden_fcs -> SAM ViT-H encoder on the 4 views
+        -> prompt encoder + two-way mask decoder -> postprocess to 4 x 1024^2 fp32 -> lift to 6890 vertices, then ONE
+        all-gather of the per-vertex contacts across ranks (RCCL) and the D2H copy on rank 0.  Weak scaling.
+  dp64  BASELINE.json configs[2] (reference: evaluate.py:202-210, 346).  One step = the whole job of 64 seeded images:
+        contiguous shards of 64 / N per rank, ``evaluate_batch`` with 8 images per call, ONE all-gather -> [64, 6890],
+        rank-0 D2H.  Strong scaling; ``value`` = 64 * K / time.
+  auto  N == 1: b1 (the headline, with a dp64 pass reported under ``dp64_one_gpu``: the strong-scaling baseline);
+        N > 1: dp64 (with the same 64 images on rank 0 alone measured after the timed region: ``one_gpu_same_workload``).
 Inputs are resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -46,46 +52,72 @@ def flops_per_image(cfg, T0, n_new, V):
     return {"clip": clip, "llm": llm, "sam_encoder": sam, "total": clip + llm + sam + 14.6e9}
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, T0, n_new, V, tables):
-    """The CPU oracle ("port" of the reference's PyTorch path, pinned to reference goldens) timed on this box's
-    host cores on a bounded sample: one layer of each repeated stage at full width, scaled by the layer count."""
+    """The CPU oracle ("port" of the reference's PyTorch path, pinned to reference goldens) timed on this box's host cores:
+    every stage of ONE image at full depth and full width, >= 3 warm-ups and the median of 5 repetitions per stage
+    (IVLM_CPU_REPS / IVLM_CPU_WARMUPS override).  The SAM encoder is timed on ONE view at full depth and multiplied by V
+    (the views are independent); the repeated blocks / layers share one set of weights (same FLOPs and operand sizes; a 7B
+    fp32 weight set would need 27 GB of host RAM and minutes of random draws)."""
     import numpy as np
 
-    from interactvlm_amd import synth
     from interactvlm_amd import weights as Wt
     from oracle import cref
     from oracle import nn as O
 
     torch.set_grad_enabled(False)
     cores = torch.get_num_threads()
+    reps = int(os.environ.get("IVLM_CPU_REPS", "5"))
+    warm = int(os.environ.get("IVLM_CPU_WARMUPS", "3"))
     t = {}
 
-    def clock(fn, reps=1):
-        fn()
-        t0 = time.perf_counter()
-        for _ in range(reps):
+    def clock(fn):
+        for _ in range(warm):
             fn()
-        return (time.perf_counter() - t0) / reps
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
 
-    # --- SAM ViT-H: one windowed + one global block on ONE view
+    # --- SAM ViT-H, ONE view, all 32 blocks (the global blocks at their real positions) + patch embed + neck
     sc = Wt.SamEncCfg(depth=2, global_attn_indexes=(1,))
-    w = Wt.synth_weights({k: v for k, v in Wt.sam_encoder_spec(sc).items() if ".blocks." in k})
-    x = torch.randn(1, 64, 64, 1280)
+    w = Wt.synth_weights(Wt.sam_encoder_spec(sc))
     p = Wt.SAM_PREFIX + ".image_encoder"
-    t_win = clock(lambda: O.sam_block(w, p + ".blocks.0", x, 16, 14))
-    t_glob = clock(lambda: O.sam_block(w, p + ".blocks.1", x, 16, 0))
-    n_glob = len(cfg.sam.global_attn_indexes)
-    t["sam_encoder"] = V * ((cfg.sam.depth - n_glob) * t_win + n_glob * t_glob)
-    # --- LLaMA: one layer over the teacher-forced sequence (the reference's own uncached loop costs ~n_new x this)
+    for i in range(2, cfg.sam.depth):  # alias the two real blocks' weights for the remaining depth
+        src = 1 if i in cfg.sam.global_attn_indexes else 0
+        for k in [k for k in w if f".blocks.{src}." in k]:
+            w[k.replace(f".blocks.{src}.", f".blocks.{i}.")] = w[k]
+    xi = torch.randn(1, 3, cfg.sam.img_size, cfg.sam.img_size)
+    t_view = clock(lambda: O.sam_image_encoder(w, p, xi, cfg.sam.depth, cfg.sam.num_heads, cfg.sam.global_attn_indexes,
+                                               cfg.sam.window, cfg.sam.patch))
+    t["sam_encoder"] = V * t_view
+    # --- LLaMA: all layers over the teacher-forced sequence (the reference's own uncached loop costs ~n_new x this)
     lc = Wt.LlamaCfg(hidden=cfg.llama.hidden, layers=1, heads=cfg.llama.heads, inter=cfg.llama.inter, vocab=8)
     w = Wt.synth_weights({k: v for k, v in Wt.llama_spec(lc).items() if "layers.0" in k or k == "model.norm.weight"})
+    for i in range(1, cfg.llama.layers):
+        for k in [k for k in w if ".layers.0." in k]:
+            w[k.replace(".layers.0.", f".layers.{i}.")] = w[k]
     e = torch.randn(1, T0 + n_new - 1, cfg.llama.hidden)
-    t["llm"] = cfg.llama.layers * clock(lambda: O.llama(w, "model", e, 1, cfg.llama.heads))
-    # --- CLIP: one layer
+    t["llm"] = clock(lambda: O.llama(w, "model", e, cfg.llama.layers, cfg.llama.heads))
+    # --- CLIP: the 23 layers that are run
     cc = Wt.ClipCfg(layers=1)
     w = Wt.synth_weights(Wt.clip_spec(cc))
-    xi = torch.randn(1, 3, 224, 224)
-    t["clip"] = (cfg.clip.layers - 1) * clock(lambda: O.clip_vision(w, Wt.CLIP_PREFIX, xi, 1, 16, select_layer=-1))
+    for i in range(1, cfg.clip.layers - 1):
+        for k in [k for k in w if ".layers.0." in k]:
+            w[k.replace(".layers.0.", f".layers.{i}.")] = w[k]
+    xc = torch.randn(1, 3, 224, 224)
+    t["clip"] = clock(lambda: O.clip_vision(w, Wt.CLIP_PREFIX, xc, cfg.clip.layers - 1, cfg.clip.heads, select_layer=-1))
     # --- SAM decoder + postprocess + lift at full size
     w = Wt.synth_weights({**Wt.prompt_encoder_spec(), **Wt.mask_decoder_spec()})
     emb, text = torch.randn(V, 256, 64, 64), torch.randn(1, V, 256)
@@ -102,12 +134,13 @@ def cpu_baseline(cfg, T0, n_new, V, tables):
         masks[0] = cref.postprocess_masks(low[0].numpy(), (1024, 1024), (1024, 1024))
     t["postprocess"] = clock(post)
     vid32, bary = tables[0].cpu().numpy().astype(np.int32), tables[1].cpu().numpy()
-    t["lift"] = clock(lambda: cref.lift_mesh_soft(masks[0][:, 0][None], vid32, bary, 6890), reps=3)
+    t["lift"] = clock(lambda: cref.lift_mesh_soft(masks[0][:, 0][None], vid32, bary, 6890))
     total = sum(t.values())
-    return {"value": 1.0 / total, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "PyTorch-CPU fp32 oracle (oracle/nn.py, pinned to reference goldens) + C lift oracle: one "
-                      "SAM windowed + one global block on 1 view, one LLaMA layer over the teacher-forced sequence, "
-                      "one CLIP layer, full SAM decoder / postprocess / lift; scaled by layer and view counts",
+    return {"value": 1.0 / total, "unit": "images/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
+            "warmups": warm, "repetitions_median_of": reps,
+            "sample": "PyTorch-CPU fp32 oracle (oracle/nn.py, pinned to reference goldens) + C lift oracle, one image: SAM "
+                      "ViT-H on ONE view at full depth (x 4 views), LLaMA all layers over the teacher-forced sequence, "
+                      "CLIP 23 layers, full SAM decoder / postprocess / lift; repeated layers share one weight set",
             "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
 
 
@@ -133,16 +166,28 @@ def parity_vs_oracle(dev):
     ref = P.model_forward(w, cfg, im[0].float().cpu(), ic.float().cpu(), full_ids, cams[0], tables)
     got = out["pred_contact_3d"].float()
     refc = ref["pred_contact"].float()
+    err = float((got.cpu() - refc).abs().max())
     thr = float(refc.median())  # random weights put every contact near 0.5: threshold at the oracle's median
     f1 = ops.contact_prf((refc >= thr).float().to(dev), got, thr).cpu()[0]
     f1_cpu = OM.h_contact_metrics((refc >= thr).float(), got.cpu(), thr)[0]
+    # the device's own visibility set (view_count > 0 of the lift kernel on the GPU's masks) against the oracle's
+    plan = m.human_3d_contact_predictor._get_plan(dev)
+    _, nv_dev = ops.lift_mesh_plan(out["pred_masks"][0][None].contiguous(), plan, want_nviews=True)
+    vis_equal = bool(torch.equal(nv_dev[0].cpu() > 0, torch.from_numpy(ref["nviews"][0] > 0)))
+    # thresholded vertex sets: equal to the oracle's wherever the oracle's probability is further from the threshold than
+    # the measured max error (a vertex inside that band can legitimately fall on either side)
+    sets = {}
+    for name, t, op in (("ge_0.5", 0.5, torch.ge), ("gt_0.3", 0.3, torch.gt), ("ge_median", thr, torch.ge)):
+        band = (refc - t).abs() <= max(err, 1e-6)
+        same = op(got.cpu(), t) == op(refc, t)
+        sets[name] = {"equal_outside_error_band": bool(same[~band].all()), "vertices_in_band": int(band.sum()),
+                      "mismatches_in_band": int((~same[band]).sum())}
     return {"config": "tiny (2-layer LLaMA hd128, 3-layer CLIP, 2-block SAM ViT hd80, full SAM decoder, 4x1024^2, 6890 v)",
-            "max_abs_dp": round(float((got.cpu() - refc).abs().max()), 6),
-            "rms_dp": round(float((got.cpu() - refc).pow(2).mean().sqrt()), 6),
+            "max_abs_dp": round(err, 6), "rms_dp": round(float((got.cpu() - refc).pow(2).mean().sqrt()), 6),
+            "within_1e-3": bool(err <= 1e-3),
             "f1_vs_oracle": round(float(f1[0]), 5), "precision": round(float(f1[1]), 5), "recall": round(float(f1[2]), 5),
             "f1_device_equals_cpu_metric": bool(abs(float(f1[0]) - float(f1_cpu[0])) < 1e-6),
-            "threshold": round(thr, 4), "visibility_set_equal": bool(torch.equal(
-                torch.from_numpy(ref["nviews"] > 0), (got.cpu() > -1) & torch.from_numpy(ref["nviews"] > 0)))}
+            "threshold": round(thr, 4), "visibility_set_equal": vis_equal, "threshold_sets": sets}
 
 
 def main():
@@ -151,9 +196,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "b1", "dp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-variants", action="store_true", help="skip the cached-SAM and batch-8 variant legs (profiling runs)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the cached-SAM and dp64 variant legs (profiling runs)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -174,8 +220,9 @@ def main():
 
     from interactvlm_amd import model as M
     from interactvlm_amd import ops, synth, synthetic
-    from interactvlm_amd.dist import gather_contacts
+    from interactvlm_amd.dist import evaluate_sharded, gather_contacts
 
+    workload = args.workload if args.workload != "auto" else ("b1" if world == 1 else "dp64")
     cfg = {"7b": synthetic.config_7b, "13b": synthetic.config_13b, "tiny": synthetic.config_tiny}[args.model]()
     V = cfg.multiview_channels
     weights = synthetic.device_weights(cfg, dev, seed=0)
@@ -191,17 +238,46 @@ def main():
     S = cfg.sam.img_size
     T0 = ids.shape[1] + cfg.img_emb_len
 
-    def step():
+    def step_b1():
         out = model.evaluate(images_clip, images, ids, cams, [(S, S)], [(S, S)], contact_type="hcontact",
                              forced_new_tokens=forced)
         allc = gather_contacts(out["pred_contact_3d"])  # ONE all-gather of [1,6890] fp32 per rank
         return allc.cpu() if rank == 0 else allc
+
+    # ---- configs[2]: 64 seeded images, contiguous shards, 8 per evaluate_batch call, ONE all-gather of the shard results
+    N_IMG, PER_CALL = 64, 8
+    dp_inputs = {}
+
+    def dp_image(i):  # image i is the same tensor whatever rank / world size evaluates it
+        if i not in dp_inputs:
+            dp_inputs[i] = synthetic.images(cfg, dev, seed=1000 + i)
+        return dp_inputs[i]
+
+    def dp_chunk(idx):
+        if not idx:
+            return torch.zeros(0, 6890, device=dev)
+        icb = torch.cat([dp_image(i)[0] for i in idx])
+        imb = torch.cat([dp_image(i)[1] for i in idx])
+        outs = model.evaluate_batch(icb, imb, [ids[0]] * len(idx), [cams[0]] * len(idx), [(S, S)] * len(idx),
+                                    [(S, S)] * len(idx), contact_type="hcontact", forced_new_tokens=forced)
+        return torch.cat([o["pred_contact_3d"] for o in outs])
+
+    def step_dp64(r=None, w=None):
+        allc = evaluate_sharded(N_IMG, PER_CALL, dp_chunk, rank=r, world=w)
+        return allc.cpu() if rank == 0 else allc
+
+    step = step_b1 if workload == "b1" else step_dp64
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if workload == "dp64":  # inputs resident in HBM before the timed region
+        from interactvlm_amd.dist import shard_range
+        lo, hi = shard_range(N_IMG, rank, world)
+        for i in range(lo, hi):
+            dp_image(i)
     for _ in range(args.warmup):
         res = step()
     sync()
@@ -214,11 +290,30 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert res.shape == (world, 6890)
+    items_per_step = world if workload == "b1" else N_IMG
+    assert res.shape == (items_per_step, 6890)
+
+    # ---- dp64 at N > 1: the SAME 64 images on rank 0 alone (the strong-scaling denominator, measured in the same run)
+    one_gpu = None
+    if workload == "dp64" and world > 1:
+        if rank == 0:
+            for i in range(N_IMG):
+                dp_image(i)
+            evaluate_sharded(N_IMG, PER_CALL, dp_chunk, rank=0, world=1)  # (world 1: no collective is entered)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ref1 = evaluate_sharded(N_IMG, PER_CALL, dp_chunk, rank=0, world=1).cpu()
+            torch.cuda.synchronize()
+            t_one = time.perf_counter() - t1
+            one_gpu = {"images_per_s": round(N_IMG / t_one, 4), "seconds": round(t_one, 3),
+                       "speedup_of_this_run": round((N_IMG * args.steps / dt) / (N_IMG / t_one), 3),
+                       "max_abs_dp_sharded_vs_one_gpu": float((res - ref1).abs().max()),
+                       "note": "the same 64 images evaluated by rank 0 alone after the timed region (other ranks idle)"}
+        sync()
 
     # ---- variant (reported separately, never the headline): SAM embeddings of the 4 canonical body renders cached
     cached = None
-    if not args.no_roofline and not args.no_variants:
+    if workload == "b1" and not args.no_roofline and not args.no_variants:
         emb = model.precompute_visual_embs(images[0])
 
         def step_cached():
@@ -236,50 +331,41 @@ def main():
                   "note": "SAM ViT-H embeddings of the input-independent hcontact renders pre-computed (SURVEY 8f-1); "
                           "NOT the headline metric"}
 
-    # ---- variant (reported separately, never the headline): BASELINE.json configs[2]'s per-GPU share, 8 images per call.
-    # One decode step streams the LLaMA weights once for all 8 sequences; the 8 x 4 SAM views run on the side stream.
-    batch8 = None
-    if not args.no_roofline and not args.no_variants and world == 1:
-        Bv = 8
-        icb, imb = synthetic.images(cfg, dev, seed=100 + rank, batch=Bv)
-        prompts = [ids[0]] * Bv
-
-        def step_batch():
-            outs = model.evaluate_batch(icb, imb, prompts, [cams[0]] * Bv, [(S, S)] * Bv, [(S, S)] * Bv,
-                                        contact_type="hcontact", forced_new_tokens=forced)
-            return torch.cat([o["pred_contact_3d"] for o in outs]).cpu()
-        rb = step_batch()
+    # ---- variant at N = 1: the configs[2] job (64 images, 8 per call) on this one GPU = the strong-scaling baseline of the
+    # dp64 lines at N > 1; and the batched results against the same images one at a time
+    dp64_one = None
+    if workload == "b1" and world == 1 and not args.no_roofline and not args.no_variants:
+        step_dp64()
         sync()
         t1 = time.perf_counter()
-        nb = max(1, args.steps // 2)
-        for _ in range(nb):
-            rb = step_batch()
+        rb = step_dp64()
         sync()
         tb = time.perf_counter() - t1
-        assert rb.shape == (Bv, 6890)
-        # the same images one at a time through evaluate(): the batched step (split-K MFMA skinny GEMM, M = 8) against the
-        # batch-1 step (wave-per-row GEMV) - same arithmetic, different summation order
-        one = torch.cat([model.evaluate(icb[b: b + 1], imb[b: b + 1], ids, cams, [(S, S)], [(S, S)], contact_type="hcontact",
+        assert rb.shape == (N_IMG, 6890)
+        one = torch.cat([model.evaluate(dp_image(b)[0], dp_image(b)[1], ids, cams, [(S, S)], [(S, S)], contact_type="hcontact",
                                         forced_new_tokens=forced)["pred_contact_3d"] for b in range(2)]).cpu()
-        # ... and with the SAM embeddings of the (input-independent) hcontact renders cached: the language path alone
-        embc = model.precompute_visual_embs(imb[0])
+        embc = model.precompute_visual_embs(dp_image(0)[1][0])
 
         def step_batch_cached():
-            outs = model.evaluate_batch(icb, imb, prompts, [cams[0]] * Bv, [(S, S)] * Bv, [(S, S)] * Bv,
-                                        contact_type="hcontact", forced_new_tokens=forced, image_embeddings=embc)
+            idx = list(range(PER_CALL))
+            icb = torch.cat([dp_image(i)[0] for i in idx])
+            outs = model.evaluate_batch(icb, None, [ids[0]] * PER_CALL, [cams[0]] * PER_CALL, [(S, S)] * PER_CALL,
+                                        [(S, S)] * PER_CALL, contact_type="hcontact", forced_new_tokens=forced,
+                                        image_embeddings=embc)
             return torch.cat([o["pred_contact_3d"] for o in outs]).cpu()
         step_batch_cached()
         sync()
         t1 = time.perf_counter()
-        for _ in range(nb):
+        for _ in range(2):
             step_batch_cached()
         sync()
-        tbc = time.perf_counter() - t1
-        batch8 = {"images_per_s": round(Bv * nb / tb, 4), "batch": Bv, "ms_per_batch": round(1e3 * tb / nb, 2),
-                  "images_per_s_cached_sam_embeddings": round(Bv * nb / tbc, 4),
-                  "max_abs_dp_vs_batch1": float((rb[:2] - one).abs().max()),
-                  "note": "evaluate_batch: 8 images per call on one GPU (configs[2] per-GPU share); NOT the headline metric"}
-        del icb, imb
+        tbc = (time.perf_counter() - t1) / 2
+        dp64_one = {"images_per_s": round(N_IMG / tb, 4), "images": N_IMG, "per_call": PER_CALL, "seconds": round(tb, 3),
+                    "images_per_s_cached_sam_embeddings": round(PER_CALL / tbc, 4),
+                    "max_abs_dp_vs_batch1": float((rb[:2] - one).abs().max()),
+                    "note": "BASELINE configs[2] job on ONE GPU (64 images, evaluate_batch 8 per call): the strong-scaling "
+                            "baseline of the dp64 lines at N > 1; NOT the headline metric"}
+        dp_inputs.clear()
 
     roof = roof_lift = roof_serial = None
 
@@ -287,7 +373,7 @@ def main():
         """per-launch HIP events (on the launch stream) around every GEMM / GEMV / lift launch of `nsteps` steps"""
         ops.TIMER.start()
         for _ in range(nsteps):
-            step()
+            step_b1()
         ops.TIMER.stop()
         sm = ops.TIMER.summary()
         g, l, gv = sm["gemm_bf16_mfma"], sm["lift_mesh_plan"], sm["gemv_bf16"]
@@ -295,26 +381,20 @@ def main():
         rg = {"bound": "mfma", "kernel": "gemm_bf16_kernel + gemm256_kernel (all MFMA-path launches)",
               "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
               "traffic": None, "launches_per_image": g["launches"] // nsteps, "avg_us": round(g["avg_us"], 2),
-              "avg_us_events_raw": round(g["avg_us_events_raw"], 2),
-              "event_pair_overhead_us": round(g["event_pair_overhead_us"], 2),
               "ms_per_image": round(g["total_s"] / nsteps * 1e3, 2)}
         la = l["work"] / l["total_s"] / 1e9
         rl = {"bound": "hbm", "kernel": "lift_plan_kernel", "achieved": round(la, 1), "peak": PEAK_HBM_GBPS,
               "unit": "GB/s", "frac": round(la / PEAK_HBM_GBPS, 4), "traffic": None,
-              "algorithmic_bytes": int(l["work"] / l["launches"]), "avg_us": round(l["avg_us"], 2),
-              "avg_us_events_raw": round(l["avg_us_events_raw"], 2),
-              "event_pair_overhead_us": round(l["event_pair_overhead_us"], 2)}
+              "algorithmic_bytes": int(l["work"] / l["launches"]), "avg_us": round(l["avg_us"], 2)}
         va = gv["work"] / gv["total_s"] / 1e9
         rv = {"bound": "hbm", "kernel": "gemv_kernel (decode linears: weight streaming)", "achieved": round(va, 1),
               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(va / PEAK_HBM_GBPS, 4), "traffic": None,
               "algorithmic_bytes": int(gv["work"] / gv["launches"]), "launches_per_image": gv["launches"] // nsteps,
-              "avg_us": round(gv["avg_us"], 2), "avg_us_events_raw": round(gv["avg_us_events_raw"], 2),
-              "event_pair_overhead_us": round(gv["event_pair_overhead_us"], 2),
-              "ms_per_image": round(gv["total_s"] / nsteps * 1e3, 2)}
+              "avg_us": round(gv["avg_us"], 2), "ms_per_image": round(gv["total_s"] / nsteps * 1e3, 2)}
         return rg, rl, rv
 
     roof_gemv = None
-    if not args.no_roofline:  # the same steps again with per-launch HIP events on the launch stream(s)
+    if not args.no_roofline:  # the b1 steps again with per-launch HIP events on the launch stream(s)
         ns = max(1, min(args.steps, 3))
         roof, roof_lift, roof_gemv = timed_pass(ns)  # as timed: SAM encoder overlapped with the LLM on a 2nd stream
         model.overlap_sam_encoder = False
@@ -322,22 +402,37 @@ def main():
         model.overlap_sam_encoder = True
         roof_serial = {"note": "same steps with the two-stream overlap disabled (kernels run alone)", "gemm": rs,
                        "lift": rls, "gemv": rvs}
-        # the lift kernel is a single ~19 us launch per image: one event pair around it carries 6-9 us of record overhead
-        # (rocprofv3 measures 18.6 us for the same launch).  20 back-to-back launches on the masks of the last step between
-        # ONE event pair bound the kernel time from below (inputs warm in the Infinity Cache) - reported next to the in-situ figure
+        # The lift kernel is a single ~19 us launch per image.  HEADLINE = the in-situ figure above (one event pair around the
+        # one launch of each step: cold tables, 6-9 us of event-record overhead included).  Next to it, as bounds: 20
+        # back-to-back launches between one event pair (warm Infinity Cache), and SURVEY 8d's adversarial table (random
+        # pixel->vertex map, 40 % foreground: no locality for the CSR plan to exploit).
         o_last = model.evaluate(images_clip, images, ids, cams, [(S, S)], [(S, S)], contact_type="hcontact", forced_new_tokens=forced)
         logits = o_last["pred_masks"][0][None].contiguous()
         plan = model.human_3d_contact_predictor._get_plan(dev)
-        ops.lift_mesh_plan(logits, plan)
-        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ea.record()
-        for _ in range(20):
-            ops.lift_mesh_plan(logits, plan)
-        eb.record()
-        torch.cuda.synchronize()
-        us20 = ea.elapsed_time(eb) * 1e3 / 20
-        roof_lift["avg_us_20_back_to_back"] = round(us20, 2)
-        roof_lift["frac_20_back_to_back"] = round(roof_lift["algorithmic_bytes"] / us20 * 1e-3 / PEAK_HBM_GBPS, 4)
+
+        def b2b(pl, n=20):
+            ops.lift_mesh_plan(logits, pl)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            for _ in range(n):
+                ops.lift_mesh_plan(logits, pl)
+            eb.record()
+            torch.cuda.synchronize()
+            return ea.elapsed_time(eb) * 1e3 / n
+        us20 = b2b(plan)
+        alg = roof_lift["algorithmic_bytes"]
+        roof_lift["headline"] = "in situ (frac): one launch per image inside the pipeline, cold tables"
+        roof_lift["plan_bytes_moved"] = plan.bytes() + 4 * V * S * S  # CSR entries + row pointers + the logits it gathers from
+        roof_lift["back_to_back_20"] = {"avg_us": round(us20, 2), "frac_of_algorithmic": round(alg / us20 * 1e-3 / PEAK_HBM_GBPS, 4),
+                                        "frac_of_bytes_moved": round(roof_lift["plan_bytes_moved"] / us20 * 1e-3 / PEAK_HBM_GBPS, 4)}
+        rv_, rb_ = synth.synth_mesh_tables(V, S, S, 6890, fg=0.4, seed=0)
+        rplan = ops.LiftPlan(torch.from_numpy(rv_).to(dev, torch.int32), torch.from_numpy(rb_).to(dev), 6890)
+        usr = b2b(rplan)
+        moved = rplan.bytes() + 4 * V * S * S
+        roof_lift["adversarial_random_table_fg40"] = {
+            "avg_us_back_to_back": round(usr, 2), "frac_of_algorithmic": round(alg / usr * 1e-3 / PEAK_HBM_GBPS, 4),
+            "plan_bytes_moved": moved, "frac_of_bytes_moved": round(moved / usr * 1e-3 / PEAK_HBM_GBPS, 4)}
+        del rplan
         pj = os.path.join(REPO, "profiles", "pmc_traffic.json")
         pm = {}
         if os.path.exists(pj):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
@@ -360,18 +455,24 @@ def main():
 
     if rank == 0:
         fl = flops_per_image(cfg, T0, len(forced), V)
+        shape = ("interactvlm-3d-hcontact-damon shape: LLaVA-1.5-7B + CLIP ViT-L/14 + SAM ViT-H, 75-id prompt (330 positions) + "
+                 "24 KV-cached greedy steps, 4 views 1024x1024, 6890 vertices" if args.model == "7b" else args.model)
+        if workload == "b1":
+            wl = {"workload": "b1 = BASELINE configs[1]: " + shape + ", evaluate() batch 1 per GPU", "images_per_gpu_per_step": 1,
+                  "collective": "one all_gather of [1,6890] f32 contacts per step"}
+        else:
+            wl = {"workload": "dp64 = BASELINE configs[2]: " + shape + f"; {N_IMG} seeded images per step in contiguous shards of "
+                              f"{-(-N_IMG // world)} per rank, evaluate_batch {PER_CALL} per call",
+                  "images_per_step": N_IMG, "collective": f"one all_gather of [{-(-N_IMG // world)},6890] f32 contacts per step"}
+        wl.update({"lift_tables": f"6890-vertex/13776-face stand-in body rasterised under the 4 hcontact cameras "
+                                  f"(foreground {fg_frac:.2f})", "parallelism": f"dp{world}"})
         line = {
-            "metric": "images/sec end-to-end contact inference", "value": round(world * args.steps / dt, 4),
+            "metric": "images/sec end-to-end contact inference", "value": round(items_per_step * args.steps / dt, 4),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "interactvlm-3d-hcontact-damon shape: LLaVA-1.5-7B + CLIP ViT-L/14 + SAM ViT-H, "
-                                   "evaluate() with 75-id prompt (330 positions) + 24 KV-cached greedy steps, 4 views "
-                                   "1024x1024, 6890 vertices, batch 1 per GPU" if args.model == "7b" else args.model,
-                       "lift_tables": f"6890-vertex/13776-face stand-in body rasterised under the 4 hcontact cameras "
-                                      f"(foreground {fg_frac:.2f})",
-                       "images_per_gpu_per_step": 1, "parallelism": f"dp{world}",
-                       "collective": "one all_gather of [1,6890] f32 contacts per step"},
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if workload == "b1" else "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "config": wl,
+            "precision": "bf16 weights and MFMA operands, fp32 residual streams, fp32 activations on the decode and mask-decoder paths",
             "algorithmic_tflop_per_image": round(fl["total"] / 1e12, 2),
             # `roofline` = the kernel family with the largest share of GPU time (decode GEMV: HBM-bound);
             # the MFMA GEMMs and the mask-to-vertex lift (the two north-star targets) follow under their own keys
@@ -379,7 +480,8 @@ def main():
             "roofline": (roof_gemv if (roof_serial and roof_serial["gemv"]["ms_per_image"] >= roof_serial["gemm"]["ms_per_image"])
                          else roof),
             "roofline_mfma": roof, "roofline_gemv": roof_gemv, "roofline_lift": roof_lift, "cpu_baseline": cpu,
-            "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "variant_batch8": batch8, "parity_vs_oracle": parity,
+            "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "dp64_one_gpu": dp64_one,
+            "one_gpu_same_workload": one_gpu, "parity_vs_oracle": parity,
         }
         print(json.dumps(line))
     if world > 1:

@@ -2,6 +2,7 @@
 needs exactly one collective per batch — the all-gather of per-vertex contacts (reference: evaluate.py:202-222,
 torch.distributed.all_gather of [N_local, 6890] predictions).  On MI355X this is RCCL over xGMI; the message is
 27.5 KB per image, i.e. latency-bound, so a single fused all_gather_into_tensor is used, never a per-sample loop.
+Shards may be uneven: the collective always moves ceil(n / world) rows per rank (padding on the tail ranks).
 """
 from __future__ import annotations
 
@@ -17,15 +18,49 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, min(lo + per, n_items)
 
 
-def gather_contacts(local: torch.Tensor, group=None) -> torch.Tensor:
-    """local [B_local, Nv] fp32 -> [world * B_local, Nv] on every rank (single all-gather)."""
+def gather_contacts(local: torch.Tensor, n_items: int | None = None, group=None) -> torch.Tensor:
+    """local [B_local, Nv] fp32 (this rank's contiguous shard, ``shard_range`` order) -> [n_items, Nv] on every rank with
+    ONE all-gather.  Shards may be uneven (n_items % world != 0, even empty on the last ranks): every rank pads its block
+    to ceil(n_items / world) rows - the collective then has equal contributions - and the padding is trimmed afterwards.
+    n_items None: every rank holds the same number of rows (world * B_local results)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
-    local = local.contiguous()
     world = dist.get_world_size(group)
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local, group=group)
-    return out
+    rank = dist.get_rank(group)
+    if n_items is None:
+        per = local.shape[0]
+        n_items = per * world
+    else:
+        per = (n_items + world - 1) // world
+        lo, hi = shard_range(n_items, rank, world)
+        if local.shape[0] != hi - lo:
+            raise ValueError(f"rank {rank}: {local.shape[0]} rows, its shard of {n_items} items has {hi - lo}")
+    send = local.contiguous()
+    if send.shape[0] != per:  # pad the short (or empty) tail shard
+        send = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]].copy_(local)
+    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, send, group=group)
+    return out[:n_items]  # contiguous shards + tail padding: the real rows are exactly the first n_items
+
+
+def evaluate_sharded(n_items: int, per_call: int, eval_chunk, rank: int | None = None, world: int | None = None, group=None):
+    """The data-parallel job of BASELINE.json configs[2] (reference: evaluate.py:202-210, 346): this rank's contiguous shard
+    of the items [0, n_items) is evaluated ``per_call`` items at a time by ``eval_chunk(indices) -> [len(indices), Nv]``,
+    then ONE all-gather brings every rank the [n_items, Nv] result in input order."""
+    ini = dist.is_available() and dist.is_initialized()
+    rank = (dist.get_rank(group) if ini else 0) if rank is None else rank
+    world = (dist.get_world_size(group) if ini else 1) if world is None else world
+    lo, hi = shard_range(n_items, rank, world)
+    parts = [eval_chunk(list(range(i, min(i + per_call, hi)))) for i in range(lo, hi, per_call)]
+    if parts:
+        local = torch.cat(parts, 0)
+    else:  # an empty tail shard still takes part in the collective
+        probe = eval_chunk([])
+        local = probe if probe is not None else torch.zeros(0)
+    if world == 1:  # (also when a multi-rank job asks one rank for the whole job: no collective is entered)
+        return local
+    return gather_contacts(local, n_items, group=group)
 
 
 def reduce_meters(values: torch.Tensor, group=None) -> torch.Tensor:

@@ -23,24 +23,35 @@ def _worker(rank, world, port, n_items, q):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from interactvlm_amd.dist import gather_contacts, reduce_meters, shard_range
+    from interactvlm_amd.dist import evaluate_sharded, gather_contacts, reduce_meters, shard_range
 
     lo, hi = shard_range(n_items, rank, world)
     # each "image" i yields a deterministic contact row; ranks own contiguous shards
-    local = torch.stack([torch.full((6890,), float(i)) + torch.arange(6890) * 1e-4 for i in range(lo, hi)])
-    allc = gather_contacts(local)
+    rows = [torch.full((6890,), float(i)) + torch.arange(6890) * 1e-4 for i in range(lo, hi)]
+    local = torch.stack(rows) if rows else torch.zeros(0, 6890)
+    allc = gather_contacts(local, n_items)
     meters = reduce_meters(torch.tensor([float(hi - lo), float(local.sum())]))
+    # the bench's configs[2] job: shard, evaluate in chunks of 3, one gather
+    calls = []
+
+    def chunk(idx):
+        calls.append(len(idx))
+        return torch.stack([torch.full((6890,), float(i)) for i in idx]) if idx else torch.zeros(0, 6890)
+    job = evaluate_sharded(n_items, 3, chunk)
+    assert tuple(job.shape) == (n_items, 6890) and job[:, 0].tolist() == [float(i) for i in range(n_items)]
+    assert all(c <= 3 for c in calls)
     if rank == 0:
         q.put((allc[:, 0].tolist(), allc.shape, meters.tolist()))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_items", [4, 8])
-def test_gloo_world2_shard_and_gather(n_items):
+@pytest.mark.parametrize("n_items,world", [(4, 2), (8, 2), (5, 2), (1, 2), (10, 3), (2, 3)])
+def test_gloo_shard_and_gather(n_items, world):
+    """Divisible and NON-divisible item counts (uneven and even empty tail shards) through the real gather_contacts."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
     for p in procs:
         p.start()
     first, shape, meters = q.get(timeout=120)
