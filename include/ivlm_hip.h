@@ -147,6 +147,9 @@ int ivlm_gemm_bf16_splitk(const void *A, int64_t lda, const void *W, int64_t ldw
                           const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
                           int act, int out_f32, int splits, void *workspace, size_t workspace_bytes, int flags,
                           ivlm_stream_t stream);
+/* Benchmark hook of the GEMV grid shaping: resident blocks per CU assumed (default 4) and the N above which a wave takes two
+ * weight rows per step (default 8192); 0 = default. */
+int ivlm_gemv_tuning(int max_blocks_per_cu, int rows2_min_n);
 /* Benchmark/test hook for the skinny-M dispatch: rows M in [min_m, 16] against matrices with K, N >= 1024 go to the
  * split-K MFMA kernel (csrc/gemv_mfma.hip) instead of the wave-per-row GEMV / tile GEMM; 0 restores the automatic choice. */
 int ivlm_gemv_mfma_min_m(int min_m);

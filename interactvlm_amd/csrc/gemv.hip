@@ -300,20 +300,51 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 
 }  // namespace
 
+// Grid shaping (measured on the LLaMA-7B decode shapes, tools/bench_gemv.py): every block must be resident at once (a second
+// dispatch round runs at a fraction of the occupancy) and every wave should own the SAME number of row groups (the launch
+// ends when the most loaded wave does): with `slots` = CUs x resident blocks per CU (LDS-limited: the fp32 x image of
+// down_proj is 44 KB), each wave takes g = ceil(groups / (4 * slots)) groups and the grid is ceil(groups / (4 g)) blocks.
+int g_gemv_max_blocks_per_cu = 0, g_gemv_rows2_min_n = 0;  // experiment hooks (0 = defaults)
+static int gemv_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0)
+            cus = 256;
+    }
+    return cus;
+}
+
 template <int M>
 static int launch_gemv(const GemmArgs& g, hipStream_t st) {
     const size_t xbytes = (size_t)M * g.K * (g.a_f32 ? 4 : 2);
     // (x staged in LDS also when the GEMV shares the CUs with the encoder's 128-KB-LDS GEMM blocks: never staging it costs
     //  12 ms end to end, staging only K = 4096 vectors 1 ms - LDS room is not what slows the decode next to the encoder)
-    const bool xlds = xbytes <= 48 * 1024;
+    const bool xlds = xbytes <= (g.a_f32 ? 60 : 48) * 1024;
     if (g.rms_w && !xlds) return IVLM_ERR_UNSUPPORTED;  // (such shapes take the skinny MFMA kernel)
-    const bool rows2 = g.act == ACT_SWIGLU || g.N > 8192;  // small N: one row per wave = twice the waves
+    const int rows2_min = g_gemv_rows2_min_n > 0 ? g_gemv_rows2_min_n : 8192;
+    const bool rows2 = g.act == ACT_SWIGLU || g.N > rows2_min;  // small N: one row per wave = twice the waves
     const int ngroups = rows2 ? (g.N + 1) / 2 : g.N;
-    int blocks = (ngroups + 3) / 4;
-    const int cap = 256 * 4;  // 4 resident blocks per CU; waves stride over the remaining rows
-    if (blocks > cap) blocks = cap;
     const size_t lds = xlds ? xbytes : 0;
-#define IVLM_GEMV_GO(ROWS, RMS, XL, AF) gemv_kernel<M, ROWS, RMS, XL, AF><<<blocks, 256, lds, st>>>(g)
+    int per_cu = g_gemv_max_blocks_per_cu > 0 ? g_gemv_max_blocks_per_cu : 4;
+    if (lds > 0) per_cu = std::min<int>(per_cu, std::max<int>(1, (int)((160 * 1024) / (lds + 512))));
+    const int slots = gemv_cu_count() * per_cu;
+    const int gpw = std::max(1, (ngroups + 4 * slots - 1) / (4 * slots));  // row groups per wave
+    const int blocks = (ngroups + 4 * gpw - 1) / (4 * gpw);
+#define IVLM_GEMV_GO(ROWS, RMS, XL, AF)                                                                               \
+    do {                                                                                                              \
+        auto kfn = gemv_kernel<M, ROWS, RMS, XL, AF>;                                                                 \
+        if (lds > 48 * 1024) {                                                                                        \
+            static bool set = false;                                                                                  \
+            if (!set) {                                                                                               \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          64 * 1024);                                                                 \
+                set = true;                                                                                           \
+            }                                                                                                         \
+        }                                                                                                             \
+        kfn<<<blocks, 256, lds, st>>>(g);                                                                             \
+    } while (0)
 #define IVLM_GEMV_ROWS(ROWS)                                                                   \
     if (g.a_f32) {                                                                             \
         if (g.rms_w) IVLM_GEMV_GO(ROWS, true, true, true);                                     \
@@ -353,6 +384,12 @@ int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st)
 }
 
 }  // namespace ivlm
+
+extern "C" int ivlm_gemv_tuning(int max_blocks_per_cu, int rows2_min_n) {  // benchmark hook: 0 = defaults
+    ivlm::g_gemv_max_blocks_per_cu = max_blocks_per_cu;
+    ivlm::g_gemv_rows2_min_n = rows2_min_n;
+    return 0;
+}
 
 extern "C" int ivlm_argmax_f32(const float* x, int rows, int cols, int32_t* out, ivlm_stream_t stream) {
     ivlm_enter();

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""ms/token of the LLaMA decode step alone (graph replay), 7B or 13B shapes: prefill 330 positions, then timed decode steps.
+    python tools/bench_decode.py [--model 13b] [--batch B]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="7b")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=23)
+    ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--nofuse", action="store_true")
+    a = ap.parse_args()
+    from interactvlm_amd import llava, synthetic
+    from interactvlm_amd import weights as Wt
+
+    dev = torch.device("cuda:0")
+    cfg = (synthetic.config_7b() if a.model == "7b" else synthetic.config_13b()).llama
+    spec = Wt.llama_spec(cfg)
+    w = {}
+    for k, shape in spec.items():
+        t = torch.randn(shape, device=dev, dtype=torch.float32)
+        w[k] = ((1.0 + 0.05 * t) if (len(shape) == 1) else t / float(shape[-1]) ** 0.5).to(torch.bfloat16)
+        del t
+    llm = llava.Llama(w, cfg, dev, max_len=1024)
+    llm.fuse_attn_oproj = not a.nofuse
+    del w
+    T0 = 330
+    x = (torch.randn(T0, cfg.hidden, device=dev) * 0.5)
+    nbytes = sum(L[k].numel() * 2 for L in llm.layers for k in ("qkv", "o", "gu", "down")) + llm.lm_head.numel() * 2
+    if a.batch == 1:
+        llm.forward(x, 0)
+        dg = llm.decode_graph()
+        def run():
+            dg["pos"].fill_(T0)
+            dg["pos64"].fill_(T0)
+            if dg.get("fused") is not None:
+                for k in ("step", "counters", "status"):
+                    dg["fused"][k].zero_()
+            for s in range(a.steps):
+                dg["graph"].replay()
+    else:
+        B = a.batch
+        kc, vc = llm.batch_cache(B)
+        for b in range(B):
+            llm.forward(x, 0, cache=(kc[:, b], vc[:, b]))
+        dg = llm.decode_graph_batch(B)
+        def run():
+            dg["pos"].fill_(T0)
+            for s in range(a.steps):
+                dg["graph"].replay()
+    run()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(a.reps):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / (a.reps * a.steps)
+    print(f"{a.model} batch {a.batch}: {ms:.3f} ms/token  ({nbytes / ms / 1e9:.2f} TB/s of weight bytes, "
+          f"{nbytes / 1e9:.2f} GB per token)", flush=True)
+    if dg.get("fused") is not None:
+        print("fused status", int(dg["fused"]["status"][0]))
+
+
+if __name__ == "__main__":
+    main()

@@ -14,16 +14,31 @@ SHAPES = [("qkv+rms", 12288, 4096, "none", True), ("o+res", 4096, 4096, "none", 
 
 
 def main():
+    from interactvlm_amd import _lib
     dev = torch.device("cuda:0")
     bf = torch.bfloat16
-    for name, N, K, act, rms in SHAPES:
+    f32x = "--bf16x" not in sys.argv
+    lib = _lib.load()
+    for per_cu, r2 in ((0, 0), (3, 0), (6, 0), (8, 0), (0, 1024), (3, 1024), (8, 1024)):
+      lib.ivlm_gemv_tuning(per_cu, r2)
+      print(f"--- blocks/CU {per_cu or 4}, rows2 above N = {r2 or 8192}, x {'fp32' if f32x else 'bf16'}")
+      for name, N, K, act, rms in SHAPES:
+        run_shape(dev, bf, f32x, name, N, K, act, rms)
+
+
+def run_shape(dev, bf, f32x, name, N, K, act, rms):
+    if True:
         # rotate over several weight copies so the 256 MB Infinity Cache cannot serve the stream
         ncopy = max(2, int(600e6 // (N * K * 2)) + 1)
         ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(bf) for _ in range(ncopy)]
-        x = torch.randn(1, K, device=dev).to(bf)
+        x = torch.randn(1, K, device=dev)
+        if not f32x:
+            x = x.to(bf)
         g = torch.ones(K, device=dev).to(bf)
-        res = torch.randn(1, N, device=dev).to(bf) if act == "none" and not rms and N == 4096 else None
-        out_f32 = name == "lm_head"
+        res = torch.randn(1, N, device=dev) if act == "none" and not rms and N == 4096 else None
+        if res is not None and not f32x:
+            res = res.to(bf)
+        out_f32 = f32x or name == "lm_head"
         kw = dict(act=act, residual=res, rms=(g, 1e-5) if rms else None, out_f32=out_f32)
         for w in ws:
             ops.linear(x, w, **kw)
