@@ -132,12 +132,13 @@ int ivlm_postprocess_masks(const void *low, int dtype, int n, int h, int w, int 
  * skinny MFMA kernel), IVLM_GEMM_RES_F32 (fp32 residual).
  * out_rows != NULL (tile GEMM path, M > 16): scatter epilogue - row m of the product is written to row out_rows[m] of C and
  * takes its residual from that row; rows with out_rows[m] < 0 are dropped (SAM window_unpartition + shortcut,
- * image_encoder.py:186-190, folded into the proj GEMM; C may alias the residual). */
+ * image_encoder.py:186-190, folded into the proj GEMM; C may alias the residual).
+ * a_rows != NULL (tile GEMM path): gather prologue - row m of the product reads row a_rows[m] of A (all entries valid). */
 int ivlm_gemm_bf16(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
                    const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
                    int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
                    int64_t strideR, const void *rms_w, float rms_eps, int flags, const int32_t *out_rows,
-                   ivlm_stream_t stream);
+                   const int32_t *a_rows, ivlm_stream_t stream);
 
 /* Split-K variant for small-M GEMMs (LLaMA prefill, CLIP: too few output tiles for 256 CUs): same result contract as
  * ivlm_gemm_bf16 (batch 1, act != SwiGLU, no RMS fusion); K % (8*splits) == 0, N % 4 == 0.  fp32 partial sums of the
@@ -154,6 +155,8 @@ int ivlm_gemv_tuning(int max_blocks_per_cu, int rows2_min_n);
  * split-K MFMA kernel (csrc/gemv_mfma.hip) instead of the wave-per-row GEMV / tile GEMM; 0 restores the automatic choice. */
 int ivlm_gemv_mfma_min_m(int min_m);
 
+/* Benchmark hook: column split of GEMMs whose 256 x 256 tile count under-fills its last round (default 1 = on). */
+int ivlm_gemm_nsplit(int on);
 /* Benchmark/test hook: force the GEMM block tile (64 = 128x64, 128, 256; 0 = automatic choice). Returns the previous value. */
 int ivlm_gemm_tile_override(int tile);
 
@@ -240,6 +243,10 @@ int ivlm_gather_rows(void *dst, int dst_kind, int64_t ldd, const void *src, int 
  * (dense rows of 2*cols). */
 int ivlm_add_rows(void *out, int out_kind, const void *a, int a_dtype, const void *b, int b_dtype, int64_t rows, int cols,
                   int64_t b_rows, int op, ivlm_stream_t stream);
+/* dst[idx[r]] = row for r < n_idx (bf16, cols % 8 == 0): the q|k|v rows of SAM's zero-padded window positions are the bias
+ * alone (image_encoder.py:179-183, 222-243), so the qkv GEMM computes the real rows only and these are filled. */
+int ivlm_fill_rows(void *dst, int64_t ldd, const int32_t *idx, int64_t n_idx, const void *row, int cols,
+                   ivlm_stream_t stream);
 /* PositionEmbeddingRandom.forward (prompt_encoder.py:219-229): gauss f32 [2,F] -> pe bf16 | fp32 [h*w, 2F]
  * (the table is a constant of the weights: computed once at load, in fp32) */
 int ivlm_dense_pe(const void *gauss, void *pe, int pe_dtype, int h, int w, int F, ivlm_stream_t stream);

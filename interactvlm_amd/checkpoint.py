@@ -145,13 +145,36 @@ def config_from_hf(folder: str, tokenizer_ids: Optional[dict] = None,
     return cfg
 
 
-def check_against_spec(state: Dict[str, torch.Tensor], cfg: Wt.IvlmCfg, ignore: Iterable[str] = ()) -> None:
+# Tensors a checkpoint written by merge_lora_weights_and_save_hf_model.py:152-161 may carry besides the inference path's own
+# (tests/golden/state_dict_keys.json is the reference's inventory): the '-DifDe' token types register the SAME mask decoder
+# under two more names (InteractVLM.py:30-32), older transformers saved the rotary inv_freq buffers, and the optional fusion /
+# uncertainty heads are off in every released configuration.
+TOLERATED_PREFIXES = ("model.visual_model.uncertainty", "model.fusion", "model.visual_model.human_mask_decoder.",
+                      "model.visual_model.object_mask_decoder.")
+TOLERATED_SUFFIXES = ("rotary_emb.inv_freq",)
+
+
+def check_against_spec(state: Dict[str, torch.Tensor], cfg: Wt.IvlmCfg, ignore: Iterable[str] = TOLERATED_PREFIXES,
+                       strict_extras: bool = False) -> None:
     """Every tensor of the inference path present with the right shape; raises CheckpointError listing what is wrong.
-    Extra tensors (training-only heads, LoRA leftovers) are tolerated only when they match an ``ignore`` prefix."""
+    Known extras (``ignore`` prefixes, TOLERATED_SUFFIXES) are skipped silently; the '-DifDe' duplicate decoders must equal
+    ``mask_decoder.*``; any other unknown tensor is a warning (an error with strict_extras)."""
+    import warnings
+
     spec = Wt.ivlm_spec(cfg)
     missing = [k for k in spec if k not in state]
     bad = [(k, tuple(state[k].shape), tuple(spec[k])) for k in spec if k in state and tuple(state[k].shape) != tuple(spec[k])]
-    extra = [k for k in state if k not in spec and not any(k.startswith(p) for p in ignore)]
+    extra = [k for k in state if k not in spec and not any(k.startswith(p) for p in ignore)
+             and not k.endswith(TOLERATED_SUFFIXES)]
+    for dup in ("human_mask_decoder", "object_mask_decoder"):  # registered aliases of one module: same values
+        for k in [k for k in state if k.startswith(f"model.visual_model.{dup}.")]:
+            base = k.replace(f".{dup}.", ".mask_decoder.")
+            if base in state and not torch.equal(state[k], state[base]):
+                bad.append((k, "differs from", base))
+    if extra and not strict_extras:
+        warnings.warn(f"checkpoint carries {len(extra)} tensors outside the inference path (ignored): {extra[:6]}"
+                      f"{' ...' if len(extra) > 6 else ''}")
+        extra = []
     if missing or bad or extra:
         msg = [f"checkpoint does not match the {cfg.llama.layers}-layer / {cfg.cam_encoder_type} configuration:"]
         if missing:
@@ -164,7 +187,7 @@ def check_against_spec(state: Dict[str, torch.Tensor], cfg: Wt.IvlmCfg, ignore: 
 
 
 def load_weights(version_dir: str, clip_dir: str, tokenizer_ids: Optional[dict] = None,
-                 ignore: Iterable[str] = ("model.visual_model.uncertainty", "model.fusion")):
+                 ignore: Iterable[str] = TOLERATED_PREFIXES):
     """(cfg, state) ready for ``InteractVLMForCausalLM(cfg, state, device)``."""
     state = read_hf_state_dict(version_dir)
     state = {k: v for k, v in state.items() if "vision_tower" not in k}  # (never stored; guard against older dumps)

@@ -13,6 +13,7 @@ What is different by design (MI355X-first):
 """
 from __future__ import annotations
 
+import collections
 import os
 from typing import List, Optional, Sequence
 
@@ -96,7 +97,12 @@ class ObjectMeshContact3DPredictor(torch.nn.Module):
         self.multiview_channels = multiview_channels
         self.view_names = view_names(OBJS_VIEW_DICT[oC_sam_view_type])
         self.threshold = threshold
-        self._plans = {}
+        # lift plans of lift2d_dict.pkl files seen at least TWICE, least-recently-used first (a dataset evaluation visits one
+        # pkl per object: a single-use table goes through the streaming dense kernel and is never inverted or kept; ~40 MB of
+        # HBM per cached plan, bounded)
+        self._plans = collections.OrderedDict()
+        self._seen_once = collections.OrderedDict()
+        self.max_plans = 8
 
     # -- table sources ---------------------------------------------------------------------
     @staticmethod
@@ -124,15 +130,23 @@ class ObjectMeshContact3DPredictor(torch.nn.Module):
         V = logits.shape[1]
         plan = self._plans.get(cache_key) if cache_key is not None else None
         if plan is not None:
+            self._plans.move_to_end(cache_key)
             out = ops.lift_mesh_plan(logits, plan, mode=1, param=self.threshold)
         else:
             vid = torch.as_tensor(vid_np[:V]).to(device=device, dtype=torch.int32).contiguous()
             bary = torch.as_tensor(bary_np[:V]).to(device=device, dtype=torch.float32).contiguous()
-            if cache_key is not None:  # tables backed by a file that may come back: invert once, reuse
+            if cache_key is not None and cache_key in self._seen_once:  # the file came back: invert once, reuse from now on
+                del self._seen_once[cache_key]
                 plan = ops.LiftPlan(vid, bary, nv)
                 self._plans[cache_key] = plan
+                while len(self._plans) > self.max_plans:
+                    self._plans.popitem(last=False)
                 out = ops.lift_mesh_plan(logits, plan, mode=1, param=self.threshold)
-            else:
+            else:  # first sight (or no file identity): stream the dense tables once, keep nothing on the device
+                if cache_key is not None:
+                    self._seen_once[cache_key] = True
+                    while len(self._seen_once) > 4096:
+                        self._seen_once.popitem(last=False)
                 out = ops.lift_mesh_dense(logits, vid, bary, nv, mode=1, param=self.threshold)
         return out.to(dtype)
 

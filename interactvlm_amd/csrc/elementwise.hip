@@ -124,6 +124,19 @@ __global__ __launch_bounds__(kT) void gather_rows_kernel(void* __restrict__ dst,
     }
 }
 
+// dst[idx[r]] = row (one bf16 row broadcast to a list of destination rows): the q|k|v rows of the zero-padded window positions
+// are the bias alone (image_encoder.py:179-183: padded tokens are zeros AFTER norm1), so they are filled, not computed
+__global__ __launch_bounds__(kT) void fill_rows_kernel(bf16_t* __restrict__ dst, int64_t ldd, const int32_t* __restrict__ idx,
+                                                       int64_t n_idx, const bf16_t* __restrict__ row, int cols) {
+    const int c8n = cols >> 3;
+    const int64_t total = n_idx * c8n;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+        const int c8 = (int)(i % c8n);
+        const int64_t r = idx[i / c8n];
+        *reinterpret_cast<uint4*>(dst + r * ldd + c8 * 8) = *reinterpret_cast<const uint4*>(row + c8 * 8);
+    }
+}
+
 // out[r] = a[r] (+|*) b[r % b_rows]
 __global__ __launch_bounds__(kT) void add_rows_kernel(void* __restrict__ out, int out_kind, const void* __restrict__ a,
                                                       int a_kind, const void* __restrict__ b, int b_kind, int64_t rows,
@@ -317,6 +330,12 @@ int add_rows(void* out, int out_kind, const void* a, int a_kind, const void* b, 
     add_rows_kernel<<<grid_for(rows * (cols >> 3)), kT, 0, st>>>(out, out_kind, a, a_kind, b, b_kind, rows, cols, b_rows, op);
     return ivlm_launch_status();
 }
+int fill_rows(bf16_t* dst, int64_t ldd, const int32_t* idx, int64_t n_idx, const bf16_t* row, int cols, hipStream_t st) {
+    if (!dst || !idx || !row || n_idx < 0 || (cols & 7) || (ldd & 7)) return IVLM_ERR_INVALID_ARG;
+    if (n_idx == 0) return IVLM_OK;
+    fill_rows_kernel<<<grid_for(n_idx * (cols >> 3)), kT, 0, st>>>(dst, ldd, idx, n_idx, row, cols);
+    return ivlm_launch_status();
+}
 int dense_pe(const float* gauss, void* pe, int pe_f32, int h, int w, int F, hipStream_t st) {
     if (!gauss || !pe) return IVLM_ERR_INVALID_ARG;
     dense_pe_kernel<<<grid_for((int64_t)h * w * 2 * F), kT, 0, st>>>(gauss, pe, pe_f32, h, w, F);
@@ -366,6 +385,10 @@ int ivlm_add_rows(void* out, int out_kind, const void* a, int a_dtype, const voi
     ivlm_enter();
     return ivlm::add_rows(out, out_kind == IVLM_F32 ? 1 : (out_kind == IVLM_BF16 ? 0 : (out_kind == IVLM_BF16_SPLIT ? 2 : -1)),
                           a, a_dtype == IVLM_F32, b, b_dtype == IVLM_F32, rows, cols, b_rows, ivlm_stream(s), op);
+}
+int ivlm_fill_rows(void* dst, int64_t ldd, const int32_t* idx, int64_t n_idx, const void* row, int cols, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::fill_rows(BF(dst), ldd, idx, n_idx, CBF(row), cols, ivlm_stream(s));
 }
 int ivlm_dense_pe(const void* gauss, void* pe, int pe_dtype, int h, int w, int F, ivlm_stream_t s) {
     ivlm_enter();

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
         kcolA[i] = chunk * 8;
         int ra = m0 + row;
         ra = ra < g.M ? ra : g.M - 1;
+        if (g.a_rows) ra = g.a_rows[ra];
         srcA[i] = A + (int64_t)ra * g.lda + chunk * 8;
     }
 #pragma unroll
@@ -200,8 +201,40 @@ int launch(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
+static int g_nsplit = 1;  // benchmark hook: 0 = never split N
+void gemm_set_nsplit(int on) { g_nsplit = on; }
+
+// Column split for the 256 x 256 path: a GEMM whose tile count is just over a whole number of rounds on the 256 CUs (SAM
+// proj / mlp2: 16384 x 1280 -> 64 x 5 = 320 tiles = one full round + a quarter-filled one, 62 % efficiency) runs as the
+// columns that DO fill whole rounds (4 x 256 = 1024 -> 256 tiles, 8-phase kernel) plus the remaining strip on 128 x 64 tiles
+// (512 small blocks, 2-3 per CU).  Two launches of the existing kernels; no partial sums, the epilogues are per column.
+static int nsplit_cols(const GemmArgs& g) {
+    if (!g_nsplit || g.tile != 0 || g.batch != 1 || g.act == ACT_SWIGLU || g.M < 4096 || (g.N & 255)) return 0;
+    const long tm = (g.M + 255) / 256, tn = g.N / 256;
+    const long tiles = tm * tn;
+    const double q = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+    if (q >= 0.8 || tn < 2 || g.K < 2048) return 0;  // (K = 1280: the split loses - 76.6 vs 70.4 us on SAM proj)
+    for (long c = tn - 1; c >= tn / 2; --c)
+        if ((tm * c) % 256 == 0 || (double)(tm * c) / (double)(((tm * c + 255) / 256) * 256) >= 0.97) return (int)(c * 256);
+    return 0;
+}
+
 int gemm_bf16(const GemmArgs& g, hipStream_t st) {
     if (!g.A || !g.W || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return IVLM_ERR_INVALID_ARG;
+    if (const int n1 = nsplit_cols(g)) {
+        GemmArgs a = g, b = g;
+        a.N = n1;
+        a.tile = 512;
+        int rc = gemm_bf16(a, st);
+        if (rc != IVLM_OK) return rc;
+        b.N = g.N - n1;
+        b.tile = 64;
+        b.W = g.W + (int64_t)n1 * g.ldw;
+        b.C = static_cast<char*>(g.C) + (size_t)n1 * (g.out_f32 ? 4 : 2);
+        if (g.bias) b.bias = g.bias + n1;
+        if (g.residual) b.residual = g.residual + (g.res_f32 ? 2 * n1 : n1);
+        return gemm_bf16(b, st);
+    }
     if (g.K % 8 != 0) return IVLM_ERR_UNSUPPORTED;  // 16-byte K granules; a K % 64 tail is zero-filled in LDS
     if ((g.lda & 7) || (g.ldw & 7)) return IVLM_ERR_UNSUPPORTED;  // 16-byte DMA granules
     if (g.act == ACT_SWIGLU && ((g.N & 3) || g.residual)) return IVLM_ERR_UNSUPPORTED;
@@ -256,7 +289,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }  // namespace
 
 int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st) {
-    if (splits < 2 || g.batch != 1 || g.act == ACT_SWIGLU || g.rms_w || g.out_rows || !workspace) return IVLM_ERR_INVALID_ARG;
+    if (splits < 2 || g.batch != 1 || g.act == ACT_SWIGLU || g.rms_w || g.out_rows || g.a_rows || !workspace) return IVLM_ERR_INVALID_ARG;
     if (g.K % (splits * 8) != 0 || (g.N & 3) || (g.ldc & 3)) return IVLM_ERR_UNSUPPORTED;
     if (ws_bytes < (size_t)splits * g.M * g.N * sizeof(float)) return IVLM_ERR_WORKSPACE;
     GemmArgs p = g;
@@ -295,9 +328,9 @@ int linear_bf16(const GemmArgs& g, hipStream_t st) {
         //  activation rows fit LDS - 5.0-5.7 TB/s at M = 1 - and falls to 0.9-2.5 TB/s at M = 8; this kernel holds
         //  3.4-4.4 TB/s for every M <= 8 and 2.9-3.4 TB/s at M = 16, where the 128x64 tile GEMM reaches 0.7-1.8 TB/s)
         // fp32 activations: exact in the GEMV (fp32 x in LDS) for one row, hi + lo bf16 operand split on the MFMA for more
-        if (!g.out_rows && (skinny || (g.a_f32 && g.M >= 2))) return gemv_mfma_bf16(g, st);
+        if (!g.out_rows && !g.a_rows && (skinny || (g.a_f32 && g.M >= 2))) return gemv_mfma_bf16(g, st);
     }
-    if (g.M <= 8 && g.batch == 1 && !g.out_rows) return gemv_bf16(g, st);
+    if (g.M <= 8 && g.batch == 1 && !g.out_rows && !g.a_rows) return gemv_bf16(g, st);
     if (g.a_f32) return IVLM_ERR_UNSUPPORTED;  // the tile kernels DMA bf16 operands (use ivlm_gather_rows split + K' = 2K)
     if (g.rms_w) return IVLM_ERR_UNSUPPORTED;  // the RMSNorm fusion exists on the decode (GEMV) path only
     return gemm_bf16(g, st);
@@ -312,6 +345,11 @@ extern "C" int ivlm_gemv_mfma_min_m(int min_m) {  // benchmark/test hook: 0 = au
     return 0;
 }
 
+extern "C" int ivlm_gemm_nsplit(int on) {  // benchmark hook: column split of under-filled 256 x 256 rounds (default on)
+    ivlm::gemm_set_nsplit(on);
+    return 0;
+}
+
 extern "C" int ivlm_gemm_tile_override(int tile) {
     const int prev = g_tile_override;
     if (tile == 0 || tile == 64 || tile == 96 || tile == 128 || tile == 256 || tile == 512) g_tile_override = tile;
@@ -322,10 +360,11 @@ extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                               const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N, int K,
                               int act, int out_f32, int batch, int64_t strideA, int64_t strideW, int64_t strideC,
                               int64_t strideR, const void* rms_w, float rms_eps, int flags, const int32_t* out_rows,
-                              ivlm_stream_t stream) {
+                              const int32_t* a_rows, ivlm_stream_t stream) {
     ivlm_enter();
     ivlm::GemmArgs g;
     g.out_rows = out_rows;
+    g.a_rows = a_rows;
     g.a_f32 = (flags & IVLM_GEMM_A_F32) ? 1 : 0;
     g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
     g.rms_w = static_cast<const bf16_t*>(rms_w);

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         for (int q = 0; q < 2; ++q) {
             int ra = m0 + i * 128 + q * 64 + lr0;            // A half q: local row i*64 + lr0 = wave row i, quadrant row lr0
             ra = ra < g.M ? ra : g.M - 1;
+            if (g.a_rows) ra = g.a_rows[ra];
             src[q == 0 ? 0 : 3][i] = A + (int64_t)ra * g.lda + kcol;
             int rn = n0 + (2 * i + (lr0 >> 5)) * 64 + q * 32 + (lr0 & 31);  // B half q: local row i*64+lr0 = wave col, col
             rn = rn < g.N ? rn : g.N - 1;

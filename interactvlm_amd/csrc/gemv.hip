@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     f32x4v_t* xf = reinterpret_cast<f32x4v_t*>(smem);    // fp32 image [M][2 planes][nchunk] float4 (XLDS && AF32)
     const float* Af = reinterpret_cast<const float*>(g.A);
 
-    constexpr int U = ROWS == 2 ? 4 : 8;  // 8 x 16-byte weight loads in flight per lane per step
+#ifndef IVLM_GEMV_UMUL
+#define IVLM_GEMV_UMUL 1
+#endif
+    constexpr int U = (ROWS == 2 ? 4 : 8) * IVLM_GEMV_UMUL;  // 8 x 16-byte weight loads in flight per lane per step
     const int wave_global = blockIdx.x * 4 + wave;
     const int nwaves = gridDim.x * 4;
     const int ngroups = (g.N + ROWS - 1) / ROWS;

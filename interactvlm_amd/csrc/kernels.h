@@ -21,6 +21,9 @@ struct GemmArgs {
     // scatter epilogue (tile GEMM only): row m of the product is written to row out_rows[m] of C (and takes its residual from
     // that row); rows with out_rows[m] < 0 are dropped.  SAM's window_unpartition + shortcut without a separate pass.
     const int32_t* out_rows = nullptr;
+    // gather prologue (tile GEMM only): row m of the product reads row a_rows[m] of A (all entries valid).  SAM's proj GEMM of
+    // a windowed block runs on the 16384 real rows only, reading them from their window positions.
+    const int32_t* a_rows = nullptr;
     int a_f32 = 0;     // 1: A is float (M <= 16 weight-streaming paths: the products are exact, no operand rounding)
     int res_f32 = 0;   // 1: residual is float (fp32 residual stream)
     // batched (strided) variant: blockIdx.z = batch
@@ -85,6 +88,7 @@ int gather_rows(void* dst, int dst_kind, int64_t ldd, const void* src, int src_k
                 const void* add, int add_kind, int64_t lda, int64_t rows, int cols, hipStream_t st);
 int add_rows(void* out, int out_kind, const void* a, int a_kind, const void* b, int b_kind, int64_t rows, int cols,
              int64_t b_rows, hipStream_t st, int op = 0);  // op 0: a + b, 1: a * b
+int fill_rows(bf16_t* dst, int64_t ldd, const int32_t* idx, int64_t n_idx, const bf16_t* row, int cols, hipStream_t st);
 int dense_pe(const float* gauss, void* pe, int pe_f32, int h, int w, int F, hipStream_t st);
 int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, bf16_t* kcache, bf16_t* vcache,
             hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr);

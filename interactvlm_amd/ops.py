@@ -274,7 +274,8 @@ GEMM_A_F32, GEMM_RES_F32 = 1, 2
 F32 = torch.float32
 
 
-def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False, rms=None, out_rows=None):
+def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False, rms=None, out_rows=None,
+           a_rows=None):
     """act(x @ weight.T + bias) + residual.  out_rows (int32 [M], tile GEMM path): scatter epilogue, see ivlm_hip.h.  x [..., K] bf16 - or fp32 for M <= 16 rows (weight-streaming kernels: exact
     products) - last dim contiguous, uniform row stride; weight [N, K] bf16; residual bf16 or fp32 (fp32 residual stream)."""
     lib = _lib.load()
@@ -284,7 +285,7 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     x2 = x.reshape(-1, K)
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
-    M = x2.shape[0]
+    M = x2.shape[0] if a_rows is None else a_rows.numel()  # a_rows (int32 [M]): product row m reads x2[a_rows[m]]
     flags = 0
     if x.dtype == F32:
         if M > 16:
@@ -292,7 +293,8 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
         flags |= GEMM_A_F32
     n_out = N // 2 if act == "swiglu" else N
     if out is None:
-        out = torch.empty(x.shape[:-1] + (n_out,), dtype=F32 if out_f32 else BF16, device=x.device)
+        lead = x.shape[:-1] if a_rows is None else (M,)
+        out = torch.empty(tuple(lead) + (n_out,), dtype=F32 if out_f32 else BF16, device=x.device)
     o2 = out.reshape(-1, n_out)
     assert o2.stride(-1) == 1 and weight.stride(-1) == 1
     r2, ldr = None, 0
@@ -307,8 +309,8 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     call = lambda: check(lib.ivlm_gemm_bf16(
         x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
         _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, 1, 0, 0, 0, 0,
-        _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, flags, _p(out_rows), _stream()), "gemm_bf16")
-    splits = _splitk_choice(M, N, K, act, rms) if (x.dtype == BF16 and out_rows is None) else 1
+        _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, flags, _p(out_rows), _p(a_rows), _stream()), "gemm_bf16")
+    splits = _splitk_choice(M, N, K, act, rms) if (x.dtype == BF16 and out_rows is None and a_rows is None) else 1
     if splits > 1 and o2.stride(0) % 4 == 0:
         ws = torch.empty(splits * M * N, dtype=F32, device=x.device)  # caching allocator: stream-safe
         call = lambda: check(lib.ivlm_gemm_bf16_splitk(
@@ -425,7 +427,7 @@ def relpos_bias(q, tab_h, tab_w, SH, SW, cat=None):
         npad, M = cat.shape[0], B * S
         G = torch.empty(H, M, npad, dtype=BF16, device=q.device)
         call = lambda: check(lib.ivlm_gemm_bf16(q.data_ptr(), q.stride(2), cat.data_ptr(), D, G.data_ptr(), npad, 0, 0, 0, 0,
-                                                M, npad, D, 0, 0, H, q.stride(1), 0, M * npad, 0, 0, 0.0, 0, 0, _stream()),
+                                                M, npad, D, 0, 0, H, q.stride(1), 0, M * npad, 0, 0, 0.0, 0, 0, 0, _stream()),
                              "relpos gemm")
         if TIMER.enabled:
             TIMER.time("gemm_bf16_mfma", 2.0 * H * M * npad * D, call, tag=("relpos", M, npad, D))
@@ -503,6 +505,16 @@ def gather_rows(src, idx=None, add=None, out=None, out_kind=None):
                                _p(idx), _p(add), _dtc(add) if add is not None else 0, lda, rows, cols, _stream()),
           "gather_rows")
     return out
+
+
+def fill_rows(dst, idx, row):
+    """dst[idx[r]] = row (bf16 [C] broadcast to the listed rows of dst [R, C])."""
+    lib = _lib.load()
+    assert dst.dtype == BF16 and row.dtype == BF16 and dst.stride(-1) == 1 and row.is_contiguous()
+    assert idx.dtype == torch.int32 and idx.is_contiguous() and row.numel() == dst.shape[-1]
+    check(lib.ivlm_fill_rows(dst.data_ptr(), dst.stride(0), idx.data_ptr(), idx.numel(), row.data_ptr(), dst.shape[-1],
+                             _stream()), "fill_rows")
+    return dst
 
 
 def split_rows(x):

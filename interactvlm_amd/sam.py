@@ -28,9 +28,9 @@ class _Lin:
         self.w = _dev(w[prefix + ".weight"].reshape(w[prefix + ".weight"].shape[0], -1), device)
         self.b = _dev(w[prefix + ".bias"], device) if bias and (prefix + ".bias") in w else None
 
-    def __call__(self, x, act="none", residual=None, res_mod=0, out=None, out_f32=False, out_rows=None):
+    def __call__(self, x, act="none", residual=None, res_mod=0, out=None, out_f32=False, out_rows=None, a_rows=None):
         return ops.linear(x, self.w, self.b, act=act, residual=residual, res_mod=res_mod, out=out, out_f32=out_f32,
-                          out_rows=out_rows)
+                          out_rows=out_rows, a_rows=a_rows)
 
 
 class _LinF32(_Lin):
@@ -82,7 +82,7 @@ class SamImageEncoder:
         self.neck2_w = _dev(w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1), device)
         self.neck3 = _LN(w, p + ".neck.3", device, 1e-6)
         self._maps = {}
-        self._xw = {}  # per view count: window-ordered norm1 output with permanently-zero padding rows
+        self._xw = {}  # per view count: the window-ordered q|k|v buffer of the windowed blocks
 
     def _window_maps(self, V):
         """Row maps of window_partition / window_unpartition (image_encoder.py:263-318) incl. zero padding."""
@@ -102,16 +102,25 @@ class SamImageEncoder:
             xx = torch.arange(g).view(1, 1, g)
             vv = torch.arange(V).view(V, 1, 1)
             unpart = (((vv * nw + yy // ws) * nw + xx // ws) * ws + yy % ws) * ws + xx % ws
+            pad = (part < 0).nonzero().flatten()  # window positions that overhang the grid (zero tokens)
             self._maps[V] = (part.to(torch.int32).to(self.device), unpart.reshape(-1).to(torch.int32).to(self.device),
-                             nw, gp)
+                             nw, gp, pad.to(torch.int32).to(self.device))
         return self._maps[V]
 
-    def _attention(self, blk, xn, V, side, nwin):
-        """Attention.forward (image_encoder.py:235-260) on rows laid out [nwin, side*side, D]."""
+    def _attention(self, blk, xn, V, side, nwin, win=None):
+        """Attention.forward (image_encoder.py:235-260) on rows laid out [nwin, side*side, D].  win = (unpart, pad, buffer):
+        xn is in IMAGE order and the block is windowed - the q|k|v GEMM runs on the real rows only and scatters them to their
+        window positions (window_partition folded into its epilogue); the rows of the padded window positions, whose input is
+        zero, are the bias: filled, not computed (16 % of the rows at 64x64 / 14)."""
         c = self.cfg
         H, hd = c.num_heads, c.embed_dim // c.num_heads
         S = side * side
-        qkv = blk["qkv"](xn)  # [nwin*S, 3*D] == [nwin, S, 3, H, hd]
+        if win is None:
+            qkv = blk["qkv"](xn)  # [nwin*S, 3*D] == [nwin, S, 3, H, hd]
+        else:
+            unpart, pad, qkv = win
+            blk["qkv"](xn, out=qkv, out_rows=unpart)
+            ops.fill_rows(qkv, pad, blk["qkv"].b)
         qkv5 = qkv.view(nwin, S, 3, H, hd)
         q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         if "rel_cat" not in blk:
@@ -151,26 +160,27 @@ class SamImageEncoder:
 
     def _forward(self, images):
         """The residual stream x is fp32 (GEMM residual epilogues write it, the LayerNorms read it); MFMA operands are bf16.
-        window_partition is folded into norm1 (its rows are written straight to their window positions; the zero rows of the
-        padded 5x5 window grid live in a buffer that is never written) and window_unpartition + shortcut into the proj GEMM's
-        scatter epilogue - no separate gather passes over the activations."""
+        window_partition is folded into the q|k|v GEMM's scatter epilogue and window_unpartition + shortcut into the proj GEMM's
+        gather prologue: both GEMMs of a windowed block run on the g*g real rows of every view only - no gather passes over the
+        activations, no work on the padded window positions (whose q|k|v rows are just the bias)."""
         c = self.cfg
         V = images.shape[0]
         g, D = c.grid, c.embed_dim
         cols = ops.im2col_nchw(images.to(BF16).contiguous(), c.patch, c.patch)
         x = self.patch(cols, residual=self.pos_embed, res_mod=g * g, out_f32=True)  # + pos_embed broadcast over views
-        part, unpart, nw, gp = self._window_maps(V)
+        part, unpart, nw, gp, pad = self._window_maps(V)
         nwin = V * nw * nw
-        if V not in self._xw:
-            self._xw[V] = torch.zeros(nwin * c.window * c.window, D, dtype=BF16, device=x.device)  # padded rows stay zero
+        if V not in self._xw:  # q|k|v in window order (one buffer for all windowed blocks of this view count)
+            self._xw[V] = torch.empty(nwin * c.window * c.window, 3 * D, dtype=BF16, device=x.device)
         for blk in self.blocks:
             if blk["glob"]:
                 a = self._attention(blk, blk["norm1"](x), V, g, V)
                 x = blk["proj"](a, residual=x, out_f32=True)
             else:
-                xw = blk["norm1"](x, out=self._xw[V], out_rows=unpart)  # LayerNorm + window_partition
-                a = self._attention(blk, xw, V, c.window, nwin)
-                x = blk["proj"](a, residual=x, out=x, out_rows=part)  # proj + window_unpartition + shortcut (in place)
+                a = self._attention(blk, blk["norm1"](x), V, c.window, nwin, win=(unpart, pad, self._xw[V]))
+                # proj + window_unpartition + shortcut, in place: the GEMM runs on the g*g real rows of every view only (its A
+                # rows are gathered from their window positions; the rows of the padded window grid are never computed)
+                x = blk["proj"](a, residual=x, out=x, a_rows=unpart)
             h = blk["lin1"](blk["norm2"](x), act="gelu")
             x = blk["lin2"](h, residual=x, out_f32=True)
         y = self.neck1(self.neck0(ops.gather_rows(x, out_kind="bf16")))

@@ -393,6 +393,107 @@ def gen_model_forward(batch2=False):
 
 
 # ------------------------------------------------------------------------------------------
+# a17: caller-side preprocessing - the reference's ResizeLongestSide (segment_anything/utils/transforms.py:17-34,102-113) and
+# HF CLIPImageProcessor with the openai/clip-vit-large-patch14 settings (run_demo.py:170,333-339), non-identity sizes
+# ------------------------------------------------------------------------------------------
+PREPROCESS_SIZES = [(600, 1500), (480, 640), (1024, 1024), (333, 500), (1500, 600)]
+
+
+def gen_preprocess():
+    import torch
+    from PIL import Image
+    _ref_shims.install()
+    # torchvision is absent: ResizeLongestSide.apply_image only needs two of its functions; on a PIL image they are
+    # Image.fromarray and Image.resize(..., BILINEAR) (torchvision.transforms.functional.resize's PIL branch)
+    tvf = sys.modules["torchvision.transforms.functional"]
+    tvf.to_pil_image = lambda a: Image.fromarray(a)
+    tvf.resize = lambda im, size: im.resize((size[1], size[0]), Image.BILINEAR)
+    import importlib
+    T = importlib.import_module("model.segment_anything.utils.transforms")
+    T.resize, T.to_pil_image = tvf.resize, tvf.to_pil_image
+    from transformers import CLIPImageProcessorPil
+    proc = CLIPImageProcessorPil(do_resize=True, size={"shortest_edge": 224}, resample=Image.BICUBIC, do_center_crop=True,
+                                 crop_size={"height": 224, "width": 224}, do_rescale=True, rescale_factor=1 / 255,
+                                 do_normalize=True, image_mean=[0.48145466, 0.4578275, 0.40821073],
+                                 image_std=[0.26862954, 0.26130258, 0.27577711], do_convert_rgb=True)
+    tr = T.ResizeLongestSide(1024)
+    mean = torch.tensor([123.675, 116.28, 103.53]).view(-1, 1, 1)
+    std = torch.tensor([58.395, 57.12, 57.375]).view(-1, 1, 1)
+    out = {"sizes": np.array(PREPROCESS_SIZES)}
+    for h, w in PREPROCESS_SIZES:
+        img = np.random.default_rng(h * 10000 + w).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        r = tr.apply_image(img)  # uint8 [h', w', 3]
+        x = torch.from_numpy(r).permute(2, 0, 1).contiguous().float()
+        x = (x - mean) / std  # run_demo.py:65-79 preprocess(): normalise, then zero-pad to 1024^2
+        x = torch.nn.functional.pad(x, (0, 1024 - x.shape[2], 0, 1024 - x.shape[1]))
+        out[f"sam/{h}x{w}/resize"] = np.array(r.shape[:2])
+        out[f"sam/{h}x{w}/sub"] = x[:, ::8, ::8].numpy()
+        out[f"sam/{h}x{w}/sum"] = np.float64(x.double().sum())
+        pv = proc(Image.fromarray(img), return_tensors="pt")["pixel_values"][0]
+        out[f"clip/{h}x{w}/sub"] = pv[:, ::2, ::2].numpy()
+        out[f"clip/{h}x{w}/sum"] = np.float64(pv.double().sum())
+    _save("preprocess.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------
+# f3: the state-dict key inventory of the reference's own module tree (what merge_lora_weights_and_save_hf_model.py:152-161
+# writes into a released checkpoint: everything except vision_tower.*), for the configurations the loader must accept
+# ------------------------------------------------------------------------------------------
+def gen_state_keys():
+    import json
+    import torch
+    _ref_shims.install(full_model=True)
+    import model.InteractVLM as RI
+    from model.segment_anything.build_sam import _build_sam
+    from transformers import CLIPVisionConfig
+    from interactvlm_amd.constants import HUMAN_VIEW_DICT, view_names
+    from interactvlm_amd.synth import synth_mesh_tables
+
+    t = TOY
+    RI.build_sam_vit_h = lambda ckpt=None: _build_sam(encoder_embed_dim=160, encoder_depth=2, encoder_num_heads=2,
+                                                     encoder_global_attn_indexes=[1], checkpoint=None)
+    out = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        clip_dir = os.path.join(td, "clip-toy")
+        os.makedirs(clip_dir)
+        CLIPVisionConfig(hidden_size=t["clip_hidden"], intermediate_size=t["clip_inter"], num_hidden_layers=t["clip_layers"],
+                         num_attention_heads=t["clip_heads"], image_size=t["clip_image"], patch_size=t["clip_patch"],
+                         hidden_act="quick_gelu").save_pretrained(clip_dir)
+        vid, bary = synth_mesh_tables(4, 64, 64, 6890, fg=0.4, seed=0, patch=8)
+        names = view_names(HUMAN_VIEW_DICT["4MV-Z_Vitru"])
+        d = os.path.join(td, "data", "hcontact_vitruvian")
+        os.makedirs(d)
+        np.savez(os.path.join(d, "pixel_to_vertex_map_1024.npz"), **{n: vid[i] for i, n in enumerate(names)})
+        np.savez(os.path.join(d, "bary_coords_map_1024.npz"), **{n: bary[i] for i, n in enumerate(names)})
+        for tag, token_type, cam, oc in (("Gen/vi_v1", "Gen", "vi_v1", 0.0), ("Gen/simple", "Gen", "simple", 0.0),
+                                         ("Gen-Hu-Obj/view_index", "Gen-Hu-Obj", "view_index", 1.0),
+                                         ("Gen-Hu-Obj-DifDe/vi_v1", "Gen-Hu-Obj-DifDe", "vi_v1", 1.0)):
+            cfg = RI.LlavaLlamaForCausalLM.config_class(
+                hidden_size=t["hidden"], intermediate_size=t["inter"], num_hidden_layers=t["layers"],
+                num_attention_heads=t["heads"], num_key_value_heads=t["heads"], vocab_size=t["vocab"], rms_norm_eps=1e-5,
+                max_position_embeddings=1024, attn_implementation="eager")
+            for k, v in dict(vision_tower=clip_dir, mm_vision_tower=clip_dir, mm_hidden_size=t["clip_hidden"],
+                             mm_use_im_start_end=True, mm_vision_select_layer=-2, use_fusion=False, use_uncertainty=False,
+                             img_emb_len=255, seg_token_idx=32000, hseg_token_idx=32003, oseg_token_idx=32004,
+                             token_type=token_type, hC_sam_view_type="4MV-Z_Vitru", oC_sam_view_type="4MV-Z_HM",
+                             hC_loss_weight=1.0, oC_loss_weight=oc, multiview_channels=4, multiview_cam_cond=True,
+                             cam_encoder_type=cam, train_mask_decoder=True, out_dim=256).items():
+                setattr(cfg, k, v)
+            os.chdir(td)
+            try:
+                m = RI.InteractVLMForCausalLM(cfg)
+            finally:
+                os.chdir(cwd)
+            out[tag] = {k: list(v.shape) for k, v in m.state_dict().items() if "vision_tower" not in k}
+            del m
+    path = os.path.join(HERE, "state_dict_keys.json")
+    with open(path, "w") as f:
+        json.dump({"toy": TOY, "configs": out}, f, indent=0, sort_keys=True)
+    print(f"  wrote state_dict_keys.json ({os.path.getsize(path) / 1024:.1f} KiB, {', '.join(f'{k}: {len(v)}' for k, v in out.items())})")
+
+
+# ------------------------------------------------------------------------------------------
 # metrics right after the path (utils/eval_utils.py:63-151): get_h_contact_metrics, get_h_geo_metric
 # ------------------------------------------------------------------------------------------
 def gen_metrics():
@@ -435,7 +536,8 @@ def gen_metrics():
 
 GENERATORS = {"lift": gen_lift, "lift_points": gen_lift_points, "sam_decoder": gen_sam_decoder, "cam": gen_cam,
               "sam_encoder": gen_sam_encoder, "sam_encoder_full": gen_sam_encoder_full, "model_forward": gen_model_forward,
-              "model_forward_oafford": lambda: gen_model_forward(batch2=True), "metrics": gen_metrics}
+              "model_forward_oafford": lambda: gen_model_forward(batch2=True), "metrics": gen_metrics,
+              "state_keys": gen_state_keys, "preprocess": gen_preprocess}
 
 
 def main():

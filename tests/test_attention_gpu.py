@@ -152,7 +152,7 @@ def test_relpos_gemm_formulation_matches_dot_kernel(hip_lib, cuda, SH, SW, B, H)
     from interactvlm_amd import _lib
     lib = _lib.load()
     ops.check(lib.ivlm_gemm_bf16(q.data_ptr(), q.stride(2), cat.data_ptr(), D, G.data_ptr(), cat.shape[0], 0, 0, 0, 0, B * S,
-                                 cat.shape[0], D, 0, 0, H, q.stride(1), 0, B * S * cat.shape[0], 0, 0, 0.0, 0, 0,
+                                 cat.shape[0], D, 0, 0, H, q.stride(1), 0, B * S * cat.shape[0], 0, 0, 0.0, 0, 0, 0,
                                  torch.cuda.current_stream().cuda_stream), "gemm")
     gh, gw = torch.empty_like(eh), torch.empty_like(ew)
     ops.check(lib.ivlm_relpos_gather(G.data_ptr(), B * S * cat.shape[0], cat.shape[0], B, H, SH, SW, gh.data_ptr(), gw.data_ptr(),

@@ -245,6 +245,48 @@ def test_gemm_fp32_residual_and_scatter_epilogue(hip_lib, cuda):
             exp[rows[m]] += y[m]
     out = ops.linear(x, w, residual=stream, out=stream, out_rows=rows.to(cuda))
     assert out.data_ptr() == stream.data_ptr() and torch.allclose(stream, exp, atol=1e-3, rtol=1e-4)
+    # gather prologue: product row r reads A row a_rows[r] (proj of a windowed SAM block on the real rows only), every tile
+    for tile, (M2, N2, K2) in ((0, (24, 64, 128)), (128, (300, 256, 192)), (512, (700, 512, 256)), (64, (500, 192, 64))):
+        src = _bf(torch.randn(M2 + 37, K2, generator=g)).to(cuda)
+        amap = torch.randperm(M2 + 37, generator=g)[:M2].to(torch.int32)
+        w2 = _bf(torch.randn(N2, K2, generator=g) / K2 ** 0.5).to(cuda)
+        res = torch.randn(M2, N2, generator=g).to(cuda)
+        from interactvlm_amd import _lib
+        prev = _lib.load().ivlm_gemm_tile_override(tile)
+        try:
+            got = ops.linear(src, w2, residual=res, out_f32=True, a_rows=amap.to(cuda))
+        finally:
+            _lib.load().ivlm_gemm_tile_override(prev)
+        ref = src.float()[amap.long().to(cuda)] @ w2.float().T + res
+        assert got.shape == (M2, N2) and torch.allclose(got, ref, atol=2e-3, rtol=1e-4), (tile, M2, N2, K2)
+
+
+@pytest.mark.parametrize("M,N,K,act,f32res", [(16384, 1280, 1280, "none", True), (16384, 1280, 5120, "none", True),
+                                              (8192, 768, 512, "gelu", False), (4096, 1536, 256, "none", False)])
+def test_gemm_column_split_matches_unsplit(hip_lib, cuda, M, N, K, act, f32res):
+    """The column split of under-filled 256 x 256 rounds (SAM proj / mlp2: 320 tiles -> 256 on the 8-phase kernel + a strip
+    on 128 x 64 tiles) against the unsplit launch: same K order per output element on every tile kernel, so the two agree to
+    fp32 rounding of different MFMA groupings; both against fp32 torch."""
+    import torch
+
+    from interactvlm_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(cuda)
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    b = _bf(0.1 * torch.randn(N, generator=g)).to(cuda)
+    r = torch.randn(M, N, generator=g).to(cuda) if f32res else _bf(torch.randn(M, N, generator=g)).to(cuda)
+    kw = dict(act=act, residual=r, out_f32=True)
+    got = ops.linear(x, w, b, **kw)
+    lib.ivlm_gemm_nsplit(0)
+    try:
+        one = ops.linear(x, w, b, **kw)
+    finally:
+        lib.ivlm_gemm_nsplit(1)
+    ref = _ref_act(x.float() @ w.float().T + b.float(), act) + r.float()
+    assert torch.allclose(got, ref, atol=3e-3, rtol=1e-4) and torch.allclose(one, ref, atol=3e-3, rtol=1e-4)
+    assert torch.allclose(got, one, atol=1e-4, rtol=1e-5)
 
 
 @pytest.mark.parametrize("cols", [256, 1280, 4096])

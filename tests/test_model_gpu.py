@@ -607,3 +607,42 @@ def test_full_depth_towers_vs_oracle(hip_lib, cuda):
     e_dec = float((got[140:] - ref[140:]).pow(2).mean().sqrt() / ref[140:].pow(2).mean().sqrt())
     print(f"[LLaMA 32 layers] rel rms err: prefill rows (bf16 MFMA operands) {e_pre:.4f}, decode rows (fp32 activations) {e_dec:.4f}")
     assert e_pre < 2e-2 and e_dec < 2e-2
+
+
+@pytest.mark.parametrize("kind", ["simple", "view_index", "vi_v1"])
+def test_cam_encoders_and_attention_splitter_vs_reference_golden(hip_lib, cuda, golden_dir, kind):
+    """process_embeddings on the HIP path for every conditioning branch of the reference (components.py:491-571 CamPoseEncoder
+    / ViewIndexCamPoseEncoder / VIv1CamPoseEncoder; AttentionSplitter :155-193 for token_type 'Gen-Hu-Obj' with the human and
+    the object [SEG] tokens; InteractVLM.py:268-294) against the goldens produced by the reference's own classes.  The
+    activations are fp32 on this path, the weights the golden's fp32 values rounded to bf16."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth
+    from interactvlm_amd import weights as Wt
+
+    d = np.load(os.path.join(golden_dir, "cam_encoders.npz"))
+    cams = torch.from_numpy(d["cam_params"])
+    emb = torch.from_numpy(synth.synth_normal("cam/seg_emb", (1, 1, 256), 1.0, 0)).repeat(1, 4, 1)
+    w = Wt.synth_weights({**Wt.cam_encoder_spec(kind), **Wt.attention_splitter_spec()})
+    for tt in ("Gen", "Gen-Hu-Obj"):
+        m = M.InteractVLMForCausalLM.__new__(M.InteractVLMForCausalLM)  # only the conditioning sub-modules
+        m.device = cuda
+        m.multiview_cam_cond, m.cam_encoder_type, m.base_token_type = True, kind, tt
+        m.hseg_token_idx, m.oseg_token_idx = 32003, 32004
+        m.cam_pose_encoder = M._CamPoseEncoder(w, kind, 4, cuda)
+        m.attention_splitter = {n: M._Lin(w, "attention_splitter." + n, cuda) for n in
+                                ("input_proj", "query_human", "query_object", "key", "value", "output_proj")}
+        for token in ((32000,) if tt == "Gen" else (32000, 32003, 32004)):
+            got = m.process_embeddings(emb.to(cuda), cams, token).float().cpu()
+            ref = torch.from_numpy(d[f"{kind}/{tt}/{token}"])
+            err = float((got - ref).abs().max())
+            print(f"\n[process_embeddings {kind}/{tt}/{token}] max abs err {err:.2e} (range {float(ref.abs().max()):.2f})")
+            assert got.shape == ref.shape and err < 1.5e-2 * float(ref.abs().max())  # bf16-rounded weights vs fp32 weights
+            # against the fp32 oracle on the SAME bf16-rounded weights: fp32 activations, exact products
+            from oracle import nn as O
+            wb = {k: v.to(torch.bfloat16).float() for k, v in w.items()}
+            cfg = dict(multiview_cam_cond=True, cam_encoder_type=kind, multiview_channels=4, base_token_type=tt,
+                       hseg_token_idx=32003, oseg_token_idx=32004)
+            o = O.process_embeddings(wb, emb.clone(), cams, token, cfg)
+            assert float((got - o).abs().max()) < 2e-5 * max(1.0, float(o.abs().max())), (kind, tt, token)

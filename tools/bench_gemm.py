@@ -22,9 +22,10 @@ def main():
     from interactvlm_amd import _lib
     dev = torch.device("cuda:0")
     res = {}
-    tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    tile = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 0
     _lib.load().ivlm_gemm_tile_override(tile)
-    print("tile override:", tile)
+    _lib.load().ivlm_gemm_nsplit(0 if "--nosplit" in sys.argv else 1)
+    print("tile override:", tile, "nsplit:", "--nosplit" not in sys.argv)
     for name, M, N, K in SHAPES:
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
