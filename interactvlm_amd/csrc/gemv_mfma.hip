@@ -24,7 +24,7 @@ namespace ivlm {
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-constexpr int kWaves = 8, kThreads = kWaves * 64, kU = 8;
+constexpr int kWaves = 8, kThreads = kWaves * 64;
 
 __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
@@ -35,6 +35,13 @@ __device__ __forceinline__ float act_apply(float x, int act) {
         case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
         default: return x;
     }
+}
+
+// fp32 pair -> packed bf16 (hardware RNE) and the packed bf16 of the remainders: x = hi + lo to 2^-17
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16x2(a, b);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    lo = pack_bf16x2(ra, rb);
 }
 
 template <bool RMS, bool AF32>
@@ -56,6 +63,7 @@ __global__ __launch_bounds__(kThreads, 2) void skinny_mfma_kernel(GemmArgs g) {
     const u32x4_t zero = {0u, 0u, 0u, 0u};
     f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
     float ssq = 0.0f;
+    constexpr int kU = AF32 ? 4 : 8;  // fp32 rows: 4 k-steps in flight keeps two blocks per CU resident
     for (int s = s0; s < s1; s += kU) {
         u32x4_t w[kU], x[kU], x2[kU], gm[kU];
 #pragma unroll
@@ -92,9 +100,10 @@ __global__ __launch_bounds__(kThreads, 2) void skinny_mfma_kernel(GemmArgs g) {
                 u32x4_t hi, lo;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bf16_t h0 = f32_to_bf16(f[2 * j]), h1 = f32_to_bf16(f[2 * j + 1]);
-                    hi[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                    lo[j] = pack_bf16x2(f[2 * j] - bf16_to_f32(h0), f[2 * j + 1] - bf16_to_f32(h1));
+                    uint32_t h, l;
+                    split_pair(f[2 * j], f[2 * j + 1], h, l);
+                    hi[j] = h;
+                    lo[j] = l;
                 }
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[u]), __builtin_bit_cast(bf16x8_t, hi),
                                                               acc, 0, 0, 0);

@@ -49,16 +49,19 @@ typedef uint16_t bf16_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16 through the hardware converter of gfx950 (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN): one VALU
+// op per PAIR instead of ~6 per value for the integer add-and-shift formulation - the bf16 epilogues of the GEMMs, the norm
+// outputs and the hi + lo operand split of the fp32-activation kernels were VALU-bound on the conversion.
+typedef __attribute__((ext_vector_type(2))) __bf16 ivlm_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float ivlm_f32x2_t;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    // (a compiler-visible conversion, not inline asm: the hazard recognizer must see it - after a v_dot2c accumulation chain an
+    //  opaque asm read the accumulator too early)
+    const ivlm_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ivlm_bf16x2_t));
 }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 // ---- wave64 reductions (fixed butterfly order => deterministic) ------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
