@@ -377,6 +377,47 @@ def main():
                             "baseline of the dp64 lines at N > 1; NOT the headline metric"}
         dp_inputs.clear()
 
+    # ---- variant (BASELINE.json configs[4]; never the headline): e4m3 operands for the four big GEMMs of every SAM ViT-H block
+    # (75 % of the image's FLOPs) on the MX matrix instruction; error reported against the bf16 path, its own MFMA roofline
+    fp8v = None
+    if workload == "b1" and world == 1 and not args.no_roofline and not args.no_variants:
+        ref_c = step_b1()
+        enc = model.model.visual_model.image_encoder
+        enc.enable_fp8(images[0])
+        got_c = step_b1()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_b1()
+        sync()
+        t_fp8 = (time.perf_counter() - t1) / args.steps
+        # micro-benchmark of the mlp1 GEMM (16384 x 5120 x 1280, GELU, e4m3 in and out) for the fp8 roofline
+        xq = torch.randint(0, 120, (16384, 1280), dtype=torch.uint8, device=dev)
+        wq = torch.randint(0, 120, (5120, 1280), dtype=torch.uint8, device=dev)
+        one = torch.ones(1, device=dev)
+        o8 = torch.empty(16384, 5120, dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            ops.linear_fp8(xq, wq, one, one, act="gelu", out=o8, scale_out=one)
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(20):
+            ops.linear_fp8(xq, wq, one, one, act="gelu", out=o8, scale_out=one)
+        eb.record()
+        torch.cuda.synchronize()
+        us = ea.elapsed_time(eb) * 1e3 / 20
+        tf = 2.0 * 16384 * 5120 * 1280 / us * 1e-6
+        fp8v = {"images_per_s": round(1.0 / t_fp8, 4), "ms_per_image": round(t_fp8 * 1e3, 2),
+                "max_abs_dp_vs_bf16_path": float((got_c - ref_c).abs().max()),
+                "rms_dp_vs_bf16_path": float((got_c - ref_c).pow(2).mean().sqrt()),
+                "roofline_fp8": {"bound": "mfma", "kernel": "gemm256_kernel<GELU, fp8> (SAM mlp1 16384x5120x1280, warm, alone)",
+                                 "achieved": round(tf, 1), "peak": 5000.0, "unit": "TFLOP/s", "frac": round(tf / 5000.0, 4),
+                                 "avg_us": round(us, 1)},
+                "note": "SAM ViT-H qkv / proj / mlp GEMMs with OCP e4m3 operands (per-tensor scales calibrated on this image, "
+                        "fp32 accumulate, v_mfma_scale_f32_16x16x128_f8f6f4); CLIP / LLaMA / attention stay bf16. NOT the "
+                        "headline metric: fp8 cannot meet the 1e-3 parity target"}
+        enc.fp8 = False
+        del xq, wq, o8
+
     roof = roof_lift = roof_serial = None
 
     def timed_pass(nsteps):
@@ -490,7 +531,8 @@ def main():
             "roofline": (roof_gemv if (roof_serial and roof_serial["gemv"]["ms_per_image"] >= roof_serial["gemm"]["ms_per_image"])
                          else roof),
             "roofline_mfma": roof, "roofline_gemv": roof_gemv, "roofline_lift": roof_lift, "cpu_baseline": cpu,
-            "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "dp64_one_gpu": dp64_one,
+            "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "variant_fp8_sam_encoder": fp8v,
+            "dp64_one_gpu": dp64_one,
             "one_gpu_same_workload": one_gpu, "parity_vs_oracle": parity,
         }
         print(json.dumps(line))

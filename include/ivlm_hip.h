@@ -37,6 +37,7 @@ extern "C" {
 #define IVLM_F32 0
 #define IVLM_BF16 1
 #define IVLM_BF16_SPLIT 2
+#define IVLM_FP8 3 /* OCP e4m3 bytes (BASELINE configs[4]: fp8 operands for the big GEMMs); always with a per-tensor scale */
 
 /* flags of ivlm_gemm_bf16 / ivlm_gemm_bf16_splitk */
 #define IVLM_GEMM_A_F32 1   /* A is fp32 [M,K] (M <= 16 weight-streaming paths only; lda % 4 == 0) */
@@ -140,6 +141,17 @@ int ivlm_gemm_bf16(const void *A, int64_t lda, const void *W, int64_t ldw, void 
                    int64_t strideR, const void *rms_w, float rms_eps, int flags, const int32_t *out_rows,
                    const int32_t *a_rows, ivlm_stream_t stream);
 
+/* fp8 (OCP e4m3) operands for the big GEMMs (BASELINE.json configs[4]): C = act((A8 . W8^T) * *scale_a *
+ * *scale_w + bias) + residual on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, fp32 accumulation, the tile kernels
+ * of ivlm_gemm_bf16 (same tiles, DMA and epilogues; half the K tiles).  A [M,K] / W [N,K] are byte matrices (K, lda, ldw in
+ * bytes, multiples of 16; K % 128 != 0 tails are zero-filled); per-tensor scales are device scalars (x = q * scale).
+ * out_kind: IVLM_BF16, IVLM_F32, or 2 = e4m3 output act(...) / *scale_out (mlp1 -> mlp2).  act: none | GELU.  M > 16.
+ * The reference has no counterpart (it is a bf16 model): an opt-in variant whose error is reported against the bf16 path. */
+int ivlm_gemm_fp8(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc, const void *bias,
+                  const void *residual, int64_t ldr, int M, int N, int K, int act, int out_kind, const float *scale_a,
+                  const float *scale_w, const float *scale_out, int flags, const int32_t *out_rows, const int32_t *a_rows,
+                  ivlm_stream_t stream);
+
 /* Split-K variant for small-M GEMMs (LLaMA prefill, CLIP: too few output tiles for 256 CUs): same result contract as
  * ivlm_gemm_bf16 (batch 1, act != SwiGLU, no RMS fusion); K % (8*splits) == 0, N % 4 == 0.  fp32 partial sums of the
  * `splits` K-slices go to the caller's workspace (ivlm_gemm_splitk_workspace_bytes) and are summed in slice order. */
@@ -164,9 +176,9 @@ int ivlm_gemm_tile_override(int tile);
  * x / y bf16 or fp32 (dtype codes), fp32 statistics, cols % 8 == 0, cols <= 8192.  gelu_after != 0 fuses the exact-erf GELU
  * that follows LayerNorm2d in the mask decoder's upscaler (mask_decoder.py:53-63).  out_rows != NULL: row r is written to
  * row out_rows[r] of y (SAM window_partition, image_encoder.py:263-288, folded into norm1; the caller keeps the padded rows
- * of y zero). */
+ * of y zero).  y_dtype IVLM_FP8 (cols <= 2048, no GELU): y = e4m3(norm / *fp8_scale), the operand of ivlm_gemm_fp8. */
 int ivlm_layernorm(const void *x, int x_dtype, const void *w, const void *b, void *y, int y_dtype, int64_t rows, int cols,
-                   float eps, int gelu_after, const int32_t *out_rows, ivlm_stream_t stream);
+                   float eps, int gelu_after, const int32_t *out_rows, const float *fp8_scale, ivlm_stream_t stream);
 /* HF LlamaRMSNorm: y = w * (x * rsqrt(mean(x^2) + eps)); a bf16 x is cast back to bf16 before the weight multiply as HF
  * does, an fp32 x (fp32 residual stream) is not. */
 int ivlm_rmsnorm(const void *x, int x_dtype, const void *w, void *y, int y_dtype, int64_t rows, int cols, float eps,
@@ -235,9 +247,13 @@ int ivlm_im2col_nchw(const void *x, void *out, int B, int C, int H, int W, int k
 int ivlm_im2col3x3_nhwc(const void *x, void *out, int B, int H, int W, int C, ivlm_stream_t stream);
 /* dst[r] = (idx ? (idx[r] >= 0 ? src[idx[r]] : 0) : src[r]) + (add ? add[r] : 0): window_partition / window_unpartition +
  * shortcut (image_encoder.py:263-318, 177-193), embed_tokens gather (llava_arch.py:185-208), dtype conversion.  src / add
- * bf16 or fp32, dst bf16, fp32 or IVLM_BF16_SPLIT (row stride ldd >= 2*cols). */
+ * bf16 or fp32, dst bf16, fp32, IVLM_BF16_SPLIT (row stride ldd >= 2*cols) or IVLM_FP8 (bytes of x / *fp8_scale, clamped to
+ * +-448; ldd in bytes). */
 int ivlm_gather_rows(void *dst, int dst_kind, int64_t ldd, const void *src, int src_dtype, int64_t lds, const int32_t *idx,
-                     const void *add, int add_dtype, int64_t lda, int64_t rows, int cols, ivlm_stream_t stream);
+                     const void *add, int add_dtype, int64_t lda, int64_t rows, int cols, const float *fp8_scale,
+                     ivlm_stream_t stream);
+/* *out = max(*out, max |x|) over n elements (n % 8 == 0; *out >= 0 set by the caller): calibration of per-tensor fp8 scales */
+int ivlm_amax(const void *x, int dtype, int64_t n, float *out, ivlm_stream_t stream);
 /* out[r] = a[r] (op 0: +, op 1: *) b[r % b_rows]  (queries + query_pe, keys + key_pe: transformer.py:160-176;
  * [SEG] embedding * view encoding: InteractVLM.py:275-282); a / b bf16 or fp32, out bf16, fp32 or IVLM_BF16_SPLIT
  * (dense rows of 2*cols). */

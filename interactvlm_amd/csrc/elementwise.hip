@@ -82,7 +82,24 @@ __device__ __forceinline__ void load8(const void* base, int kind, int64_t elem, 
         f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
     }
 }
-__device__ __forceinline__ void store8(void* base, int kind, int64_t elem, int cols, const float* f) {
+// 8 fp32 values -> 8 e4m3 bytes of x / scale, clamped to the format's +-448
+__device__ __forceinline__ uint2 pack_fp8x8(const float* f, float inv_scale) {
+    float c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = fminf(fmaxf(f[j] * inv_scale, -448.0f), 448.0f);
+    uint32_t a = 0, b = 0;
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], a, false);
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], a, true);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], b, false);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], b, true);
+    return make_uint2(a, b);
+}
+
+__device__ __forceinline__ void store8(void* base, int kind, int64_t elem, int cols, const float* f, float inv_scale = 1.0f) {
+    if (kind == 3) {  // e4m3 bytes
+        *reinterpret_cast<uint2*>(static_cast<uint8_t*>(base) + elem) = pack_fp8x8(f, inv_scale);
+        return;
+    }
     if (kind == 1) {
         float4* p = reinterpret_cast<float4*>(static_cast<float*>(base) + elem);
         p[0] = make_float4(f[0], f[1], f[2], f[3]);
@@ -105,9 +122,11 @@ __device__ __forceinline__ void store8(void* base, int kind, int64_t elem, int c
 __global__ __launch_bounds__(kT) void gather_rows_kernel(void* __restrict__ dst, int dst_kind, int64_t ldd,
                                                          const void* __restrict__ src, int src_kind, int64_t lds_,
                                                          const int32_t* __restrict__ idx, const void* __restrict__ add,
-                                                         int add_kind, int64_t lda, int64_t rows, int cols) {
+                                                         int add_kind, int64_t lda, int64_t rows, int cols,
+                                                         const float* __restrict__ scale) {
     const int c8n = cols >> 3;
     const int64_t total = rows * c8n;
+    const float inv_scale = scale ? 1.0f / *scale : 1.0f;
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
         const int c8 = (int)(i % c8n);
         const int64_t r = i / c8n;
@@ -120,8 +139,21 @@ __global__ __launch_bounds__(kT) void gather_rows_kernel(void* __restrict__ dst,
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += a[j];
         }
-        store8(dst, dst_kind, r * ldd + c8 * 8, cols, v);
+        store8(dst, dst_kind, r * ldd + c8 * 8, cols, v, inv_scale);
     }
+}
+
+// max |x| of a tensor into *out (fp32 bits; *out >= 0 initialised by the caller): per-tensor fp8 scale calibration
+__global__ __launch_bounds__(kT) void amax_kernel(const void* __restrict__ x, int kind, int64_t n8, float* __restrict__ out) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n8; i += (int64_t)gridDim.x * kT) {
+        float v[8];
+        load8(x, kind, i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));  // m >= 0: bit order = value order
 }
 
 // dst[idx[r]] = row (one bf16 row broadcast to a list of destination rows): the q|k|v rows of the zero-padded window positions
@@ -315,12 +347,18 @@ int im2col3x3_nhwc(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hip
     return ivlm_launch_status();
 }
 int gather_rows(void* dst, int dst_kind, int64_t ldd, const void* src, int src_kind, int64_t lds_, const int32_t* idx,
-                const void* add, int add_kind, int64_t lda, int64_t rows, int cols, hipStream_t st) {
+                const void* add, int add_kind, int64_t lda, int64_t rows, int cols, hipStream_t st, const float* scale) {
     if (!dst || !src || rows <= 0 || (cols & 7) || (ldd & 7) || (lds_ & 7) || (lda & 7)) return IVLM_ERR_INVALID_ARG;
-    if (dst_kind < 0 || dst_kind > 2 || (src_kind & ~1) || (add_kind & ~1)) return IVLM_ERR_INVALID_ARG;
+    if (dst_kind < 0 || dst_kind > 3 || (src_kind & ~1) || (add_kind & ~1)) return IVLM_ERR_INVALID_ARG;
     if (dst_kind == 2 && ldd < 2 * (int64_t)cols) return IVLM_ERR_INVALID_ARG;
+    if (dst_kind == 3 && !scale) return IVLM_ERR_INVALID_ARG;
     gather_rows_kernel<<<grid_for(rows * (cols >> 3)), kT, 0, st>>>(dst, dst_kind, ldd, src, src_kind, lds_, idx, add,
-                                                                    add_kind, lda, rows, cols);
+                                                                    add_kind, lda, rows, cols, scale);
+    return ivlm_launch_status();
+}
+int amax(const void* x, int kind, int64_t n, float* out, hipStream_t st) {
+    if (!x || !out || n <= 0 || (n & 7) || (kind & ~1)) return IVLM_ERR_INVALID_ARG;
+    amax_kernel<<<grid_for(n >> 3, 2048), kT, 0, st>>>(x, kind, n >> 3, out);
     return ivlm_launch_status();
 }
 int add_rows(void* out, int out_kind, const void* a, int a_kind, const void* b, int b_kind, int64_t rows, int cols,
@@ -374,11 +412,16 @@ int ivlm_im2col3x3_nhwc(const void* x, void* out, int B, int H, int W, int C, iv
     return ivlm::im2col3x3_nhwc(CBF(x), BF(out), B, H, W, C, ivlm_stream(s));
 }
 int ivlm_gather_rows(void* dst, int dst_kind, int64_t ldd, const void* src, int src_dtype, int64_t lds_, const int32_t* idx,
-                     const void* add, int add_dtype, int64_t lda, int64_t rows, int cols, ivlm_stream_t s) {
+                     const void* add, int add_dtype, int64_t lda, int64_t rows, int cols, const float* fp8_scale,
+                     ivlm_stream_t s) {
     ivlm_enter();
-    return ivlm::gather_rows(dst, dst_kind == IVLM_F32 ? 1 : (dst_kind == IVLM_BF16 ? 0 : (dst_kind == IVLM_BF16_SPLIT ? 2 : -1)),
-                             ldd, src, src_dtype == IVLM_F32, lds_, idx, add, add_dtype == IVLM_F32, lda, rows, cols,
-                             ivlm_stream(s));
+    const int k = dst_kind == IVLM_F32 ? 1 : (dst_kind == IVLM_BF16 ? 0 : (dst_kind == IVLM_BF16_SPLIT ? 2 : (dst_kind == IVLM_FP8 ? 3 : -1)));
+    return ivlm::gather_rows(dst, k, ldd, src, src_dtype == IVLM_F32, lds_, idx, add, add_dtype == IVLM_F32, lda, rows, cols,
+                             ivlm_stream(s), fp8_scale);
+}
+int ivlm_amax(const void* x, int dtype, int64_t n, float* out, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::amax(x, dtype == IVLM_F32, n, out, ivlm_stream(s));
 }
 int ivlm_add_rows(void* out, int out_kind, const void* a, int a_dtype, const void* b, int b_dtype, int64_t rows, int cols,
                   int64_t b_rows, int op, ivlm_stream_t s) {

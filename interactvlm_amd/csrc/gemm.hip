@@ -40,7 +40,7 @@ struct TileCfg {
     static constexpr int PA = BM / 8 / kWaves, PW = BN / 8 / kWaves;  // 1-KiB DMA pieces per wave per tile
 };
 
-template <int ACT, bool OUT_F32, typename CFG>
+template <int ACT, bool OUT_F32, typename CFG, bool FP8 = false>
 __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NI = CFG::NI, PA = CFG::PA, PW = CFG::PW;
     constexpr int kTileBytesA = CFG::kTileBytesA, kStageBytes = CFG::kStageBytes;
@@ -118,6 +118,22 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
         if (t + 1 < nt) stage((t + 1) & 1, t + 1);
         const unsigned char* ta = smem + (t & 1) * kStageBytes;
         const unsigned char* tw = ta + kTileBytesA;
+        if (FP8) {  // one e4m3 16x16x128 step per K tile: the two bf16 k-step fragments of a lane, taken as 32 bytes
+            bf16x8_t fa[MI][2], fw[NI][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fw[i][kk] = *reinterpret_cast<const bf16x8_t*>(tw + (offW[i] ^ (kk << 6)));
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i][kk] = *reinterpret_cast<const bf16x8_t*>(ta + (offA[i] ^ (kk << 6)));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = mfma_fp8_128(fw[ni][0], fw[ni][1], fa[mi][0], fa[mi][1], acc[ni][mi]);
+            continue;
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t fa[MI], fw[NI];
@@ -148,11 +164,11 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
 using Cfg128 = TileCfg<2, 2, 4, 4>;
 using Cfg256 = TileCfg<2, 4, 8, 4>;
 
-template <int ACT, bool OUT_F32, typename CFG>
+template <int ACT, bool OUT_F32, typename CFG, bool FP8 = false>
 int launch_cfg(const GemmArgs& g, hipStream_t st) {
     const int tiles = ((g.M + CFG::BM - 1) / CFG::BM) * ((g.N + CFG::BN - 1) / CFG::BN);
     dim3 grid(tiles, 1, g.batch);
-    auto kfn = gemm_bf16_kernel<ACT, OUT_F32, CFG>;
+    auto kfn = gemm_bf16_kernel<ACT, OUT_F32, CFG, FP8>;
     if (CFG::kLdsBytes > 64 * 1024) {
         static bool attr_set = false;  // per instantiation
         if (!attr_set) {
@@ -190,6 +206,12 @@ inline int choose_tile(const GemmArgs& g) {
 
 template <int ACT>
 int launch(const GemmArgs& g, hipStream_t st) {
+    if (g.fp8) {  // fp8 operands: the 8-phase 256^2 kernel, or 128x128 / 128x64 tiles for what it does not fit
+        const int t = choose_tile(g);
+        if (t == 512 || t == 256) return gemm_bf16_256p(g, st);
+        if (t == 64) return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64, true>(g, st) : launch_cfg<ACT, false, Cfg128x64, true>(g, st);
+        return g.out_f32 ? launch_cfg<ACT, true, Cfg128, true>(g, st) : launch_cfg<ACT, false, Cfg128, true>(g, st);
+    }
     switch (choose_tile(g)) {
         case 512: return gemm_bf16_256p(g, st);  // 256^2, 8-phase ping-pong pipeline (gemm256.hip)
         case 256: return g.out_f32 ? launch_cfg<ACT, true, Cfg256>(g, st) : launch_cfg<ACT, false, Cfg256>(g, st);
@@ -230,7 +252,7 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
         b.N = g.N - n1;
         b.tile = 64;
         b.W = g.W + (int64_t)n1 * g.ldw;
-        b.C = static_cast<char*>(g.C) + (size_t)n1 * (g.out_f32 ? 4 : 2);
+        b.C = static_cast<char*>(g.C) + (size_t)n1 * (g.out_fp8 ? 1 : (g.out_f32 ? 4 : 2));
         if (g.bias) b.bias = g.bias + n1;
         if (g.residual) b.residual = g.residual + (g.res_f32 ? 2 * n1 : n1);
         return gemm_bf16(b, st);
@@ -240,6 +262,14 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
     if (g.act == ACT_SWIGLU && ((g.N & 3) || g.residual)) return IVLM_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) return IVLM_ERR_INVALID_ARG;
     if (g.a_f32) return IVLM_ERR_UNSUPPORTED;
+    if (g.fp8) {
+        if (!g.scale_a || !g.scale_w || (g.out_fp8 && (!g.scale_out || g.out_f32 || (g.ldc & 3)))) return IVLM_ERR_INVALID_ARG;
+        // (only the epilogues the SAM encoder uses are instantiated for fp8 operands)
+        if (g.act == ACT_NONE) return launch<ACT_NONE>(g, st);
+        if (g.act == ACT_GELU) return launch<ACT_GELU>(g, st);
+        return IVLM_ERR_UNSUPPORTED;
+    }
+    if (g.out_fp8) return IVLM_ERR_UNSUPPORTED;
     switch (g.act) {
         case ACT_NONE: return launch<ACT_NONE>(g, st);
         case ACT_GELU: return launch<ACT_GELU>(g, st);
@@ -383,6 +413,32 @@ extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     g.batch = batch < 1 ? 1 : batch;
     g.strideA = strideA; g.strideW = strideW; g.strideC = strideC; g.strideR = strideR;
     return ivlm::linear_bf16(g, ivlm_stream(stream));
+}
+
+extern "C" int ivlm_gemm_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias,
+                             const void* residual, int64_t ldr, int M, int N, int K, int act, int out_kind, const float* scale_a,
+                             const float* scale_w, const float* scale_out, int flags, const int32_t* out_rows,
+                             const int32_t* a_rows, ivlm_stream_t stream) {
+    ivlm_enter();
+    if ((K & 15) || (lda & 15) || (ldw & 15) || M <= 16) return IVLM_ERR_UNSUPPORTED;  // 16-byte granules; tile GEMM only
+    ivlm::GemmArgs g;
+    g.fp8 = 1;
+    g.out_fp8 = out_kind == 2 ? 1 : 0;
+    g.out_f32 = out_kind == IVLM_F32 ? 1 : 0;
+    g.scale_a = scale_a; g.scale_w = scale_w; g.scale_out = scale_out;
+    g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
+    g.out_rows = out_rows;
+    g.a_rows = a_rows;
+    g.A = static_cast<const bf16_t*>(A);
+    g.W = static_cast<const bf16_t*>(W);
+    g.C = C;
+    g.bias = static_cast<const bf16_t*>(bias);
+    g.residual = static_cast<const bf16_t*>(residual);
+    g.lda = lda / 2; g.ldw = ldw / 2; g.ldc = ldc; g.ldr = ldr;  // byte matrices seen as 2-byte matrices of half the width
+    g.M = M; g.N = N; g.K = K / 2;
+    g.act = act;
+    g.tile = g_tile_override;
+    return ivlm::gemm_bf16(g, ivlm_stream(stream));
 }
 
 extern "C" size_t ivlm_gemm_splitk_workspace_bytes(int M, int N, int splits) {

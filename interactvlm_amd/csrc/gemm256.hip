@@ -30,7 +30,7 @@ constexpr int kTileLds = 4 * kHalfBytes;         // 64 KiB per K tile
 constexpr int kLds256 = 2 * kTileLds;            // 128 KiB
 // slot order inside a tile buffer == kind index: 0 A0, 1 B0, 2 B1, 3 A1 (also the issue order)
 
-template <int ACT, bool OUT_F32>
+template <int ACT, bool OUT_F32, bool FP8>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -102,6 +102,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                 fb[nq][j][kk] = *reinterpret_cast<const bf16x8_t*>(slot + ((offB + j * 2048) ^ (kk << 6)));
     };
     auto mfma_quadrant = [&](int mq, int nq) {
+        if (FP8) {  // the same fragments as bytes: one 16x16x128 e4m3 step instead of two 16x16x32 bf16 steps
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[nq * 2 + j][mq * 4 + i] =
+                        mfma_fp8_128(fb[nq][j][0], fb[nq][j][1], fa[i][0], fa[i][1], acc[nq * 2 + j][mq * 4 + i]);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -173,9 +182,9 @@ template <int ACT>
 int launch256(const GemmArgs& g, hipStream_t st) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     dim3 grid(tiles, 1, g.batch);
-#define IVLM_GO(F32)                                                                                             \
+#define IVLM_GO(F32, F8)                                                                                         \
     do {                                                                                                         \
-        auto kfn = gemm256_kernel<ACT, F32>;                                                                     \
+        auto kfn = gemm256_kernel<ACT, F32, F8>;                                                                 \
         static bool attr_set = false;                                                                            \
         if (!attr_set) {                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -184,7 +193,11 @@ int launch256(const GemmArgs& g, hipStream_t st) {
         }                                                                                                        \
         kfn<<<grid, 512, kLds256, st>>>(g);                                                                      \
     } while (0)
-    if (g.out_f32) IVLM_GO(true); else IVLM_GO(false);
+    if (g.fp8) {
+        if (g.out_f32) IVLM_GO(true, true); else IVLM_GO(false, true);
+    } else {
+        if (g.out_f32) IVLM_GO(true, false); else IVLM_GO(false, false);
+    }
 #undef IVLM_GO
     return ivlm_launch_status();
 }

@@ -8,6 +8,17 @@ namespace ivlm {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
+// one MX fp8 step: the two 16-byte fragments a lane holds for the two bf16 k-steps of a 128-byte K tile are, as bytes, 32 e4m3
+// values of ONE 16x16x128 step (both operands use the same lane -> k-subset map, so the sum over k is the same sum)
+__device__ __forceinline__ f32x4_t mfma_fp8_128(const bf16x8_t& a0, const bf16x8_t& a1, const bf16x8_t& b0, const bf16x8_t& b1,
+                                                const f32x4_t& c) {
+    struct P { bf16x8_t lo, hi; };
+    const P pa{a0, a1}, pb{b0, b1};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_bit_cast(i32x8_t, pa), __builtin_bit_cast(i32x8_t, pb), c,
+                                                            0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);  // e4m3 x e4m3, scales 2^0
+}
 
 // exact-GELU x * Phi(x) with Phi through erfc (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7, no cancellation for x < 0):
 // ~14 VALU ops instead of ~45 for ocml erff - the GELU epilogue of the 16384x5120x1280 SAM MLP GEMM was 30 % of its time
@@ -76,6 +87,11 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
     const bf16_t* __restrict__ R = g.residual ? g.residual + (int64_t)bz * g.strideR * (g.res_f32 ? 2 : 1) : nullptr;
     const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
     float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (g.fp8) {  // per-tensor dequantisation scales (device scalars)
+        const float alpha = (*g.scale_a) * (*g.scale_w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= alpha;
+    }
     if ((g.N & 3) == 0) {
         if (bias) {
             const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
@@ -113,7 +129,13 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
             }
         }
         const int64_t o = (int64_t)m * g.ldc + n;
-        if (OUT_F32) {
+        if (g.out_fp8) {  // e4m3 output with the consumer's calibrated per-tensor scale (mlp1 -> mlp2)
+            const float inv = 1.0f / (*g.scale_out);
+            uint32_t w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, w, true);
+            *reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(g.C) + (int64_t)bz * g.strideC + o) = w;
+        } else if (OUT_F32) {
             float* C = static_cast<float*>(g.C) + (int64_t)bz * g.strideC;
             *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {

@@ -24,6 +24,12 @@ struct GemmArgs {
     // gather prologue (tile GEMM only): row m of the product reads row a_rows[m] of A (all entries valid).  SAM's proj GEMM of
     // a windowed block runs on the 16384 real rows only, reading them from their window positions.
     const int32_t* a_rows = nullptr;
+    // fp8 (OCP e4m3) operands on the MX matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales): A and W are
+    // BYTE matrices [M,K] / [N,K]; K, lda, ldw are then given in 2-byte units (K_fp8 / 2) so that tiles, DMA and LDS images
+    // are byte-identical to the bf16 path.  The fp32 accumulator is multiplied by *scale_a * *scale_w (per-tensor scales in
+    // device memory) before the epilogue.  out_fp8: C is e4m3, written as act(...) / *scale_out.
+    int fp8 = 0, out_fp8 = 0;
+    const float *scale_a = nullptr, *scale_w = nullptr, *scale_out = nullptr;
     int a_f32 = 0;     // 1: A is float (M <= 16 weight-streaming paths: the products are exact, no operand rounding)
     int res_f32 = 0;   // 1: residual is float (fp32 residual stream)
     // batched (strided) variant: blockIdx.z = batch
@@ -48,7 +54,7 @@ int linear_bf16(const GemmArgs& g, hipStream_t st);
 // y = (x-mean)/sqrt(var+eps)*w+b over the last dim (rows x cols); x / y bf16 or fp32, fp32 statistics.
 // out_rows != null: row r is written to row out_rows[r] of y (SAM's window_partition folded into norm1)
 int layernorm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols, float eps,
-              hipStream_t st, int gelu = 0, const int32_t* out_rows = nullptr);
+              hipStream_t st, int gelu = 0, const int32_t* out_rows = nullptr, const float* fp8_scale = nullptr);
 // y = x * rsqrt(mean(x^2)+eps) * w  (LLaMA RMSNorm; fp32 statistics; a bf16 input is cast back before the weight multiply as HF does)
 int rmsnorm(const void* x, int x_f32, const bf16_t* w, void* y, int y_f32, int64_t rows, int cols, float eps, hipStream_t st);
 
@@ -84,8 +90,10 @@ int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
 int im2col_nchw(const bf16_t* x, bf16_t* out, int B, int C, int H, int W, int ks, int stride, int Kpad, hipStream_t st);
 int im2col3x3_nhwc(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st);
 // kinds: 0 bf16, 1 fp32, 2 (outputs only) split [hi | lo] bf16 rows of width 2*cols
+// (kind 3, outputs only: e4m3 bytes of x / *scale)
 int gather_rows(void* dst, int dst_kind, int64_t ldd, const void* src, int src_kind, int64_t lds_, const int32_t* idx,
-                const void* add, int add_kind, int64_t lda, int64_t rows, int cols, hipStream_t st);
+                const void* add, int add_kind, int64_t lda, int64_t rows, int cols, hipStream_t st, const float* scale = nullptr);
+int amax(const void* x, int kind, int64_t n, float* out, hipStream_t st);
 int add_rows(void* out, int out_kind, const void* a, int a_kind, const void* b, int b_kind, int64_t rows, int cols,
              int64_t b_rows, hipStream_t st, int op = 0);  // op 0: a + b, 1: a * b
 int fill_rows(bf16_t* dst, int64_t ldd, const int32_t* idx, int64_t n_idx, const bf16_t* row, int cols, hipStream_t st);

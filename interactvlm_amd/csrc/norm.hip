@@ -26,7 +26,8 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 template <bool RMS, int MAXC, bool GELU, bool XF32, bool YF32>
 __global__ __launch_bounds__(256) void norm_kernel(const void* __restrict__ xv, const bf16_t* __restrict__ w,
                                                    const bf16_t* __restrict__ b, void* __restrict__ yv, int64_t rows,
-                                                   int cols, float eps, const int32_t* __restrict__ out_rows) {
+                                                   int cols, float eps, const int32_t* __restrict__ out_rows,
+                                                   const float* __restrict__ fp8_scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -94,7 +95,18 @@ __global__ __launch_bounds__(256) void norm_kernel(const void* __restrict__ xv, 
                     if (GELU) o[j] = 0.5f * o[j] * (1.0f + erff(o[j] * 0.70710678118654752f));
                 }
             }
-            if (YF32) {
+            if (!YF32 && fp8_scale) {  // e4m3 operand of an fp8 GEMM, calibrated per-tensor scale
+                const float inv = 1.0f / *fp8_scale;
+                float cl[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cl[j] = fminf(fmaxf(o[j] * inv, -448.0f), 448.0f);
+                uint32_t a = 0, bq = 0;
+                a = __builtin_amdgcn_cvt_pk_fp8_f32(cl[0], cl[1], a, false);
+                a = __builtin_amdgcn_cvt_pk_fp8_f32(cl[2], cl[3], a, true);
+                bq = __builtin_amdgcn_cvt_pk_fp8_f32(cl[4], cl[5], bq, false);
+                bq = __builtin_amdgcn_cvt_pk_fp8_f32(cl[6], cl[7], bq, true);
+                reinterpret_cast<uint2*>(static_cast<uint8_t*>(yv) + orow * cols)[idx] = make_uint2(a, bq);
+            } else if (YF32) {
                 yr4[2 * idx] = make_float4(o[0], o[1], o[2], o[3]);
                 yr4[2 * idx + 1] = make_float4(o[4], o[5], o[6], o[7]);
             } else {
@@ -108,23 +120,23 @@ __global__ __launch_bounds__(256) void norm_kernel(const void* __restrict__ xv, 
 
 template <bool RMS, int MAXC, bool GELU>
 static void launch_norm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols,
-                        float eps, hipStream_t st, const int32_t* out_rows = nullptr) {
+                        float eps, hipStream_t st, const int32_t* out_rows = nullptr, const float* fp8_scale = nullptr) {
     const unsigned grid = (unsigned)((rows + 3) / 4);
-    if (x_f32 && y_f32) norm_kernel<RMS, MAXC, GELU, true, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows);
-    else if (x_f32) norm_kernel<RMS, MAXC, GELU, true, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows);
-    else if (y_f32) norm_kernel<RMS, MAXC, GELU, false, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows);
-    else norm_kernel<RMS, MAXC, GELU, false, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows);
+    if (x_f32 && y_f32) norm_kernel<RMS, MAXC, GELU, true, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale);
+    else if (x_f32) norm_kernel<RMS, MAXC, GELU, true, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale);
+    else if (y_f32) norm_kernel<RMS, MAXC, GELU, false, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale);
+    else norm_kernel<RMS, MAXC, GELU, false, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale);
 }
 
 int layernorm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols, float eps,
-              hipStream_t st, int gelu, const int32_t* out_rows) {
+              hipStream_t st, int gelu, const int32_t* out_rows, const float* fp8_scale) {
     if (!x || !w || !b || !y || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
     if ((cols & 7) || cols > kMaxChunks * 512) return IVLM_ERR_UNSUPPORTED;
     if (gelu) {
         if (cols > 4 * 512) return IVLM_ERR_UNSUPPORTED;
         launch_norm<false, 4, true>(x, x_f32, w, b, y, y_f32, rows, cols, eps, st, out_rows);
     } else if (cols <= 4 * 512) {
-        launch_norm<false, 4, false>(x, x_f32, w, b, y, y_f32, rows, cols, eps, st, out_rows);
+        launch_norm<false, 4, false>(x, x_f32, w, b, y, y_f32, rows, cols, eps, st, out_rows, fp8_scale);
     } else {
         launch_norm<false, kMaxChunks, false>(x, x_f32, w, b, y, y_f32, rows, cols, eps, st, out_rows);
     }
@@ -144,10 +156,12 @@ int rmsnorm(const void* x, int x_f32, const bf16_t* w, void* y, int y_f32, int64
 extern "C" {
 
 int ivlm_layernorm(const void* x, int x_dtype, const void* w, const void* b, void* y, int y_dtype, int64_t rows, int cols,
-                   float eps, int gelu, const int32_t* out_rows, ivlm_stream_t stream) {
+                   float eps, int gelu, const int32_t* out_rows, const float* fp8_scale, ivlm_stream_t stream) {
     ivlm_enter();
+    if ((y_dtype == IVLM_FP8) != (fp8_scale != nullptr)) return IVLM_ERR_INVALID_ARG;
+    if (y_dtype == IVLM_FP8 && (gelu || cols > 2048)) return IVLM_ERR_UNSUPPORTED;
     return ivlm::layernorm(x, x_dtype == IVLM_F32, static_cast<const bf16_t*>(w), static_cast<const bf16_t*>(b), y,
-                           y_dtype == IVLM_F32, rows, cols, eps, ivlm_stream(stream), gelu, out_rows);
+                           y_dtype == IVLM_F32, rows, cols, eps, ivlm_stream(stream), gelu, out_rows, fp8_scale);
 }
 
 int ivlm_rmsnorm(const void* x, int x_dtype, const void* w, void* y, int y_dtype, int64_t rows, int cols, float eps,

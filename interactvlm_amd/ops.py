@@ -331,15 +331,79 @@ def _dtc(t):
     return IVLM_F32 if t.dtype == F32 else IVLM_BF16
 
 
-def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None, out_f32=False, out_rows=None):
-    """x bf16 or fp32 [..., cols] -> bf16 (the next GEMM's operand) or fp32 (out_f32: the row is itself a stream)."""
+IVLM_FP8 = 3
+U8 = torch.uint8
+
+
+def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None, out_f32=False, out_rows=None, fp8_scale=None):
+    """x bf16 or fp32 [..., cols] -> bf16 (the next GEMM's operand), fp32 (out_f32: the row is itself a stream) or, with
+    fp8_scale (device fp32 scalar), e4m3 bytes of y / scale (uint8 tensor: the operand of linear_fp8)."""
     lib = _lib.load()
     x = _req(x, None, "x")
-    y = torch.empty(x.shape, dtype=F32 if out_f32 else BF16, device=x.device) if out is None else out
+    if out is None:
+        out = torch.empty(x.shape, dtype=U8 if fp8_scale is not None else (F32 if out_f32 else BF16), device=x.device)
+    y = out
     cols = x.shape[-1]
-    check(lib.ivlm_layernorm(x.data_ptr(), _dtc(x), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), _dtc(y),
-                             x.numel() // cols, cols, float(eps), 1 if gelu else 0, _p(out_rows), _stream()), "layernorm")
+    ydt = IVLM_FP8 if fp8_scale is not None else _dtc(y)
+    check(lib.ivlm_layernorm(x.data_ptr(), _dtc(x), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), ydt,
+                             x.numel() // cols, cols, float(eps), 1 if gelu else 0, _p(out_rows), _p(fp8_scale), _stream()),
+          "layernorm")
     return y
+
+
+def amax(x, out=None):
+    """max |x| as a device fp32 scalar [1] (accumulates into ``out`` if given): per-tensor fp8 scale calibration."""
+    lib = _lib.load()
+    x = _req(x, None, "x")
+    assert x.numel() % 8 == 0
+    if out is None:
+        out = torch.zeros(1, dtype=F32, device=x.device)
+    check(lib.ivlm_amax(x.data_ptr(), _dtc(x), x.numel(), out.data_ptr(), _stream()), "amax")
+    return out
+
+
+def quantize_fp8(x, scale=None):
+    """bf16 | fp32 [..., C] -> (e4m3 bytes uint8 [..., C], scale fp32 [1]) with x ~ q * scale; scale None: amax(x) / 448."""
+    if scale is None:
+        scale = amax(x) / 448.0  # (weights, once at load: a torch op on a device scalar)
+        scale.clamp_(min=1e-12)
+    C = x.shape[-1]
+    q = gather_rows(x.reshape(-1, C), out_kind="fp8", scale=scale).view(x.shape)
+    return q, scale
+
+
+def linear_fp8(xq, wq, scale_a, scale_w, bias=None, act="none", residual=None, out=None, out_kind="bf16", scale_out=None,
+               out_rows=None, a_rows=None):
+    """act((xq . wq^T) * scale_a * scale_w + bias) + residual with e4m3 operands (uint8 tensors [M,K] / [N,K]) on the MX
+    matrix instruction; out_kind 'bf16' | 'f32' | 'fp8' (act(...) / scale_out as e4m3).  Tile GEMM path only (M > 16)."""
+    lib = _lib.load()
+    K = xq.shape[-1]
+    N = wq.shape[0]
+    assert xq.dtype == U8 and wq.dtype == U8 and wq.shape[1] == K
+    x2 = xq.reshape(-1, K)
+    M = x2.shape[0] if a_rows is None else a_rows.numel()
+    if out is None:
+        dt = {"bf16": BF16, "f32": F32, "fp8": U8}[out_kind]
+        out = torch.empty((M, N), dtype=dt, device=xq.device)
+    else:
+        out_kind = {BF16: "bf16", F32: "f32", U8: "fp8"}[out.dtype]
+    o2 = out.reshape(-1, N)
+    r2, ldr, flags = None, 0, 0
+    if residual is not None:
+        r2 = residual.reshape(-1, N)
+        ldr = r2.stride(0)
+        if r2.dtype == F32:
+            flags |= GEMM_RES_F32
+    kind = {"bf16": IVLM_BF16, "f32": IVLM_F32, "fp8": 2}[out_kind]
+    call = lambda: check(lib.ivlm_gemm_fp8(
+        x2.data_ptr(), x2.stride(0), wq.data_ptr(), wq.stride(0), o2.data_ptr(), o2.stride(0), _p(bias), _p(r2), ldr, M, N, K,
+        ACT[act], kind, scale_a.data_ptr(), scale_w.data_ptr(), _p(scale_out), flags, _p(out_rows), _p(a_rows), _stream()),
+        "gemm_fp8")
+    if TIMER.enabled:
+        TIMER.time("gemm_fp8_mfma", 2.0 * M * N * K, call, tag=(M, N, K, act))
+    else:
+        call()
+    return out
 
 
 def rmsnorm(x, weight, eps=1e-5, out_f32=False):
@@ -474,10 +538,10 @@ def im2col3x3_nhwc(x):
     return out
 
 
-_KIND = {"bf16": IVLM_BF16, "f32": IVLM_F32, "split": 2}
+_KIND = {"bf16": IVLM_BF16, "f32": IVLM_F32, "split": 2, "fp8": 3}
 
 
-def gather_rows(src, idx=None, add=None, out=None, out_kind=None):
+def gather_rows(src, idx=None, add=None, out=None, out_kind=None, scale=None):
     """out[r] = src[idx[r]] (zeros where idx < 0; idx None: out[r] = src[r]) (+ add[r]); src [R,C] / add [n,C] rows may be
     strided, bf16 or fp32.  out_kind 'bf16' | 'f32' | 'split' ([hi | lo] bf16 rows of width 2C, see split_rows); default: the
     dtype of ``out`` if given, else of ``add`` if given, else of ``src``."""
@@ -495,14 +559,15 @@ def gather_rows(src, idx=None, add=None, out=None, out_kind=None):
         out_kind = "f32" if ref.dtype == F32 else "bf16"
     if out is None:
         out = (torch.empty(rows, 2 * cols, dtype=BF16, device=src.device) if out_kind == "split"
-               else torch.empty(rows, cols, dtype=F32 if out_kind == "f32" else BF16, device=src.device))
-    assert out.stride(-1) == 1 and out.dtype == (F32 if out_kind == "f32" else BF16)
+               else torch.empty(rows, cols, dtype={"f32": F32, "fp8": torch.uint8}.get(out_kind, BF16), device=src.device))
+    assert out.stride(-1) == 1 and out.dtype == {"f32": F32, "fp8": torch.uint8}.get(out_kind, BF16)
+    assert (out_kind == "fp8") == (scale is not None)
     lda = 0
     if add is not None:
         assert add.dtype in (BF16, F32) and add.stride(-1) == 1
         lda = add.stride(0)
     check(lib.ivlm_gather_rows(out.data_ptr(), _KIND[out_kind], out.stride(0), src.data_ptr(), _dtc(src), src.stride(0),
-                               _p(idx), _p(add), _dtc(add) if add is not None else 0, lda, rows, cols, _stream()),
+                               _p(idx), _p(add), _dtc(add) if add is not None else 0, lda, rows, cols, _p(scale), _stream()),
           "gather_rows")
     return out
 

@@ -50,8 +50,9 @@ class _LN:
     def __init__(self, w, prefix, device, eps):
         self.w, self.b, self.eps = _dev(w[prefix + ".weight"], device), _dev(w[prefix + ".bias"], device), eps
 
-    def __call__(self, x, gelu=False, out_f32=False, out=None, out_rows=None):
-        return ops.layernorm(x, self.w, self.b, self.eps, gelu=gelu, out_f32=out_f32, out=out, out_rows=out_rows)
+    def __call__(self, x, gelu=False, out_f32=False, out=None, out_rows=None, fp8_scale=None):
+        return ops.layernorm(x, self.w, self.b, self.eps, gelu=gelu, out_f32=out_f32, out=out, out_rows=out_rows,
+                             fp8_scale=fp8_scale)
 
 
 # ================================================================================================
@@ -107,6 +108,35 @@ class SamImageEncoder:
                              nw, gp, pad.to(torch.int32).to(self.device))
         return self._maps[V]
 
+    # ---- fp8 (OCP e4m3) operands for the four big GEMMs of every block (BASELINE.json configs[4]; opt-in) -------------------
+    # Per-tensor scales: the weights are quantised once (amax / 448); the activation scales (norm1 / attention / norm2 / GELU
+    # outputs of every block) are calibrated on one bf16 pass over sample images and then FIXED (values beyond them saturate).
+    # The quantisation is fused into the producers: the LayerNorms and the mlp1 GEMM's GELU epilogue write e4m3 directly; only
+    # the attention output (bf16 kernel) takes one conversion pass.  Patch embedding, attention and neck stay bf16; the residual
+    # stream stays fp32.
+    fp8 = False
+
+    def enable_fp8(self, calib_images):
+        """calib_images [V,3,S,S]: one bf16 pass records the activation ranges, then the fp8 path is switched on."""
+        dev = self.device
+        for blk in self.blocks:
+            for n in ("qkv", "proj", "lin1", "lin2"):
+                q, sc = ops.quantize_fp8(blk[n].w)
+                blk[n + "_q"], blk[n + "_s"] = q, sc
+            blk["amax"] = {k: torch.zeros(1, dtype=F32, device=dev) for k in ("n1", "att", "n2", "h")}
+        self._calibrating = True
+        try:
+            self._forward(calib_images.to(dev))
+        finally:
+            self._calibrating = False
+        for blk in self.blocks:
+            blk["s"] = {k: (v / 448.0).clamp_(min=1e-12) for k, v in blk["amax"].items()}
+        self.fp8 = True
+        if hasattr(self, "_graphs"):
+            self._graphs.clear()
+
+    _calibrating = False
+
     def _attention(self, blk, xn, V, side, nwin, win=None):
         """Attention.forward (image_encoder.py:235-260) on rows laid out [nwin, side*side, D].  win = (unpart, pad, buffer):
         xn is in IMAGE order and the block is windowed - the q|k|v GEMM runs on the real rows only and scatters them to their
@@ -129,6 +159,36 @@ class SamImageEncoder:
         o = ops.attention(q, k, v, hd ** -0.5, rel=rel)  # view of a [nwin, S, H, hd] buffer
         return o.permute(0, 2, 1, 3).reshape(nwin * S, H * hd)
 
+    def _block_fp8(self, blk, x, V, nwin, unpart, pad):
+        """One block with e4m3 operands for qkv / proj / mlp1 / mlp2 (same dataflow as the bf16 block)."""
+        c = self.cfg
+        H, hd = c.num_heads, c.embed_dim // c.num_heads
+        sc = blk["s"]
+        xq = blk["norm1"](x, fp8_scale=sc["n1"])
+        glob = blk["glob"]
+        side = c.grid if glob else c.window
+        S = side * side
+        nw_ = V if glob else nwin
+        if glob:
+            qkv = ops.linear_fp8(xq, blk["qkv_q"], sc["n1"], blk["qkv_s"], blk["qkv"].b)
+        else:
+            qkv = self._xw[V]
+            ops.linear_fp8(xq, blk["qkv_q"], sc["n1"], blk["qkv_s"], blk["qkv"].b, out=qkv, out_rows=unpart)
+            ops.fill_rows(qkv, pad, blk["qkv"].b)
+        qkv5 = qkv.view(nw_, S, 3, H, hd)
+        q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        if "rel_cat" not in blk:
+            blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
+        rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat"])
+        a = ops.attention(q, k, v, hd ** -0.5, rel=rel).permute(0, 2, 1, 3).reshape(nw_ * S, H * hd)
+        aq = ops.gather_rows(a, out_kind="fp8", scale=sc["att"])
+        x = ops.linear_fp8(aq, blk["proj_q"], sc["att"], blk["proj_s"], blk["proj"].b, residual=x, out=x,
+                           a_rows=None if glob else unpart)
+        hq = blk["norm2"](x, fp8_scale=sc["n2"])
+        h8 = ops.linear_fp8(hq, blk["lin1_q"], sc["n2"], blk["lin1_s"], blk["lin1"].b, act="gelu", out_kind="fp8",
+                            scale_out=sc["h"])
+        return ops.linear_fp8(h8, blk["lin2_q"], sc["h"], blk["lin2_s"], blk["lin2"].b, residual=x, out=x)
+
     # The encoder is ~320 launches (ViT-H, 4 views).  Issued one by one they cost the host ~22 ms - during which the language
     # path, launched after it by the same thread, has not even started (measured: the first 21.9 ms of evaluate() had an idle
     # main stream).  Replayed as ONE HIP graph per input shape the host is free after ~20 us.  Same kernels, same order.
@@ -139,7 +199,7 @@ class SamImageEncoder:
             return self._forward(images)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
-        key = tuple(images.shape)
+        key = tuple(images.shape) + (self.fp8,)
         ent = self._graphs.get(key)
         dev = images.device
         if ent is None:
@@ -173,15 +233,30 @@ class SamImageEncoder:
         if V not in self._xw:  # q|k|v in window order (one buffer for all windowed blocks of this view count)
             self._xw[V] = torch.empty(nwin * c.window * c.window, 3 * D, dtype=BF16, device=x.device)
         for blk in self.blocks:
+            if self.fp8:
+                x = self._block_fp8(blk, x, V, nwin, unpart, pad)
+                continue
+            cal = blk.get("amax") if self._calibrating else None
+            xn = blk["norm1"](x)
+            if cal:
+                ops.amax(xn, cal["n1"])
             if blk["glob"]:
-                a = self._attention(blk, blk["norm1"](x), V, g, V)
+                a = self._attention(blk, xn, V, g, V)
+                if cal:
+                    ops.amax(a, cal["att"])
                 x = blk["proj"](a, residual=x, out_f32=True)
             else:
-                a = self._attention(blk, blk["norm1"](x), V, c.window, nwin, win=(unpart, pad, self._xw[V]))
+                a = self._attention(blk, xn, V, c.window, nwin, win=(unpart, pad, self._xw[V]))
+                if cal:
+                    ops.amax(a.contiguous(), cal["att"])
                 # proj + window_unpartition + shortcut, in place: the GEMM runs on the g*g real rows of every view only (its A
                 # rows are gathered from their window positions; the rows of the padded window grid are never computed)
                 x = blk["proj"](a, residual=x, out=x, a_rows=unpart)
-            h = blk["lin1"](blk["norm2"](x), act="gelu")
+            xn2 = blk["norm2"](x)
+            h = blk["lin1"](xn2, act="gelu")
+            if cal:
+                ops.amax(xn2, cal["n2"])
+                ops.amax(h, cal["h"])
             x = blk["lin2"](h, residual=x, out_f32=True)
         y = self.neck1(self.neck0(ops.gather_rows(x, out_kind="bf16")))
         y = ops.linear(ops.im2col3x3_nhwc(y.view(V, g, g, c.out_chans)), self.neck2_w)
