@@ -26,6 +26,26 @@ def main():
     _lib.load().ivlm_gemm_tile_override(tile)
     _lib.load().ivlm_gemm_nsplit(0 if "--nosplit" in sys.argv else 1)
     print("tile override:", tile, "nsplit:", "--nosplit" not in sys.argv)
+    if "--fp8" in sys.argv:  # the same shapes with e4m3 operands (K elements = K bytes)
+        one = torch.ones(1, device=dev)
+        for name, M, N, K in SHAPES:
+            if M <= 16:
+                continue
+            xq = torch.randint(0, 100, (M, K), dtype=torch.uint8, device=dev)
+            wq = torch.randint(0, 100, (N, K), dtype=torch.uint8, device=dev)
+            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            for _ in range(3):
+                ops.linear_fp8(xq, wq, one, one, out=out)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(20):
+                ops.linear_fp8(xq, wq, one, one, out=out)
+            e.record()
+            torch.cuda.synchronize()
+            t = s.elapsed_time(e) / 20 * 1e-3
+            print(name, "fp8", {"us": round(t * 1e6, 1), "TFLOPs": round(2 * M * N * K / t / 1e12, 1)}, flush=True)
+        return
     for name, M, N, K in SHAPES:
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
