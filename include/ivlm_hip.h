@@ -233,6 +233,38 @@ int ivlm_llama_decode_attn_batch(const void *qkv, int io_dtype, int64_t ldq, voi
                                  int tmax, void *o, int64_t ldo, int B, int H, int D, const int32_t *pos_dev, float theta,
                                  float scale, const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Stage-level entry points of the language path: C++ sequencers over the ops above, the same kernels in the same
+ * order as interactvlm_amd/llava.py (bit-identical results).  Weights: a HOST array of per-layer DEVICE pointers, bf16, in the
+ * layouts of the loader (qkv = q|k|v rows concatenated [3*hidden, hidden]; gu = gate/up rows interleaved [2*inter, hidden]).
+ * kcache / vcache bf16 [layers, max_len, heads, head_dim]; cos / sin fp32 [max_len, head_dim/2] (ivlm_rope_table).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int layers, hidden, heads, inter, max_len;
+    float eps, theta;
+} ivlm_llama_cfg;
+typedef struct {
+    const void *ln1, *qkv, *o, *ln2, *gu, *down;
+} ivlm_llama_layer;
+/* HF LlamaModel.forward over T new positions pos0..pos0+T-1 with the KV cache (llava_llama.py:93-102): x_in fp32
+ * [T, hidden] input embeddings -> hidden_out fp32 [T, hidden] after the final RMSNorm; appends K/V.  fp32 residual stream,
+ * bf16 MFMA operands. */
+size_t ivlm_llama_prefill_workspace_bytes(const ivlm_llama_cfg *cfg, int T);
+int ivlm_llama_prefill(const ivlm_llama_cfg *cfg, const ivlm_llama_layer *layers_host, const void *final_norm, void *kcache,
+                       void *vcache, const float *cos_tab, const float *sin_tab, const float *x_in, int T, int pos0,
+                       float *hidden_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* One decode step (HF greedy search under InteractVLM.evaluate, model/InteractVLM.py:524-531): x_in fp32 [hidden] = embedding of
+ * the newest token at position *pos_dev (device int32) -> hidden_out fp32 [hidden]; fp32 activations, exact products.
+ * workspace: ivlm_llama_decode_workspace_bytes, ZEROED by the caller at the start of every generation (arrival counters and
+ * the tokens-decoded word of the fused attention + o_proj launch; its int32 word [activations..] status stays 0 unless a bounded
+ * device-side wait expired).  advance != 0: *pos_dev += 1 at the end of the step (graph-replay friendly). */
+size_t ivlm_llama_decode_workspace_bytes(const ivlm_llama_cfg *cfg);
+int ivlm_llama_decode_step(const ivlm_llama_cfg *cfg, const ivlm_llama_layer *layers_host, const void *final_norm, void *kcache,
+                           void *vcache, const float *cos_tab, const float *sin_tab, const float *x_in, int32_t *pos_dev,
+                           int advance, float *hidden_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* The split-K rule of the small-M tile GEMMs (number of K slices, 1 = none): shared by the sequencers and the Python host. */
+int ivlm_gemm_splitk_choice(int M, int N, int K, int act, int has_rms);
+
 /* torch.argmax(logits, -1) of HF greedy search (first maximal index); x f32 [rows, cols] -> out i32 [rows]. */
 int ivlm_argmax_f32(const float *x, int rows, int cols, int32_t *out, ivlm_stream_t stream);
 

@@ -132,6 +132,13 @@ int llama_decode_attn_batch(const void* qkv, int io_f32, int64_t ldq, bf16_t* kc
                             int tmax, void* o, int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta, float scale,
                             const float* cos_tab, const float* sin_tab, hipStream_t st);
 
+// fused decode attention + o_proj (decode_fused.hip)
+int llama_attn_oproj(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* attn_scratch, const bf16_t* wo,
+                     const float* x, float* x_out, int H, int D, float theta, float scale, const float* cos_tab,
+                     const float* sin_tab, const int32_t* pos_dev, const int32_t* step_dev, int32_t* counter, int32_t* status,
+                     hipStream_t st);
+int gemm_splitk_choice(int M, int N, int K, int act, int has_rms);
+
 // ---- skinny GEMM (gemv.hip): M <= 8 rows of activations against streamed weights -------------------
 int gemv_bf16(const GemmArgs& g, hipStream_t st);
 // skinny GEMM on MFMA (gemv_mfma.hip): M <= 16 activation rows, split-K inside the block, RMSNorm prologue optional
