@@ -1,9 +1,9 @@
 set -x
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r1b; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2; mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
-timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
+timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 timeout 300 python tools/bench_lift.py > $O/lift.json 2>&1
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-variants > $O/bench_kt.json 2> $O/kt.err
