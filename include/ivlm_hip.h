@@ -52,6 +52,12 @@ const char *ivlm_build_arch(void); /* "gfx950" */
 /* detail of the most recent IVLM_ERR_LAUNCH on this thread: HIP error text + source location */
 const char *ivlm_last_hip_error(void);
 
+/* Measurement hook (bench.py's roofline legs): arm kernel-attached timing for the GEMM / GEMV / lift launches issued by the
+ * following calls on THIS thread - start_event (hipEvent_t) is recorded by the command processor when the first of them starts,
+ * stop_event when the last one ends (hipExtLaunchKernelGGL); pass NULL, NULL to disarm.  Returns the number of launches that
+ * were instrumented since the previous call.  Not for use during stream capture. */
+int ivlm_profile_launches(void *start_event, void *stop_event);
+
 /* ---------------------------------------------------------------------------------------------
  * Render-Localize-Lift: 2D multi-view masks -> per-vertex / per-point contact
  * ------------------------------------------------------------------------------------------- */

@@ -2,6 +2,19 @@
 #include "ivlm_common.h"
 
 static thread_local char g_last_hip_error[512] = "";
+// kernel-attached timing events for the launches of the NEXT calls on this thread (ivlm_profile_launches): the start event
+// goes to the first instrumented launch, the stop event to every one (it ends up holding the completion of the last)
+static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+static thread_local int g_prof_launches = 0;
+
+bool ivlm_profile_events(hipEvent_t* start, hipEvent_t* stop) {
+    if (!g_prof_stop) return false;
+    *start = g_prof_start;  // (null after the first launch)
+    *stop = g_prof_stop;
+    g_prof_start = nullptr;
+    ++g_prof_launches;
+    return true;
+}
 
 extern "C" {
 
@@ -11,6 +24,14 @@ void ivlm_set_last_hip_error(int code, const char* where) {
 }
 
 const char* ivlm_last_hip_error(void) { return g_last_hip_error; }
+
+int ivlm_profile_launches(void* start_event, void* stop_event) {
+    const int n = g_prof_launches;
+    g_prof_start = static_cast<hipEvent_t>(start_event);
+    g_prof_stop = static_cast<hipEvent_t>(stop_event);
+    g_prof_launches = 0;
+    return n;
+}
 
 int ivlm_abi_version(void) { return 2; }  // 2: fp32 residual streams / fp32 activation flags (round 2)
 

@@ -177,7 +177,7 @@ int launch_cfg(const GemmArgs& g, hipStream_t st) {
             attr_set = true;
         }
     }
-    kfn<<<grid, CFG::kThreads, CFG::kLdsBytes, st>>>(g);
+    ivlm_launch(kfn, grid, dim3(CFG::kThreads), CFG::kLdsBytes, st, g);
     return ivlm_launch_status();
 }
 
@@ -339,8 +339,8 @@ int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_
     if (rc != IVLM_OK) return rc;
     const int64_t total = (int64_t)g.M * (g.N >> 2);
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
-    if (g.out_f32) splitk_reduce_kernel<true><<<blocks, 256, 0, st>>>(workspace, splits, g);
-    else splitk_reduce_kernel<false><<<blocks, 256, 0, st>>>(workspace, splits, g);
+    if (g.out_f32) ivlm_launch(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, splits, g);
+    else ivlm_launch(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, splits, g);
     return ivlm_launch_status();
 }
 

@@ -191,7 +191,7 @@ int launch256(const GemmArgs& g, hipStream_t st) {
                                       kLds256);                                                                  \
             attr_set = true;                                                                                     \
         }                                                                                                        \
-        kfn<<<grid, 512, kLds256, st>>>(g);                                                                      \
+        ivlm_launch(kfn, grid, dim3(512), kLds256, st, g);                                                       \
     } while (0)
     if (g.fp8) {
         if (g.out_f32) IVLM_GO(true, true); else IVLM_GO(false, true);

@@ -346,7 +346,7 @@ static int launch_gemv(const GemmArgs& g, hipStream_t st) {
                 set = true;                                                                                           \
             }                                                                                                         \
         }                                                                                                             \
-        kfn<<<blocks, 256, lds, st>>>(g);                                                                             \
+        ivlm_launch(kfn, dim3(blocks), dim3(256), lds, st, g);                                                        \
     } while (0)
 #define IVLM_GEMV_ROWS(ROWS)                                                                   \
     if (g.a_f32) {                                                                             \

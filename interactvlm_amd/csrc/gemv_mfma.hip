@@ -175,11 +175,11 @@ int gemv_mfma_bf16(const GemmArgs& g, hipStream_t st) {
     if (g.act == ACT_SWIGLU && ((g.N & 1) || g.residual)) return IVLM_ERR_UNSUPPORTED;
     const int blocks = (g.N + 15) / 16;
     if (g.a_f32) {
-        if (g.rms_w) skinny_mfma_kernel<true, true><<<blocks, kThreads, 0, st>>>(g);
-        else skinny_mfma_kernel<false, true><<<blocks, kThreads, 0, st>>>(g);
+        if (g.rms_w) ivlm_launch(skinny_mfma_kernel<true, true>, dim3(blocks), dim3(kThreads), 0, st, g);
+        else ivlm_launch(skinny_mfma_kernel<false, true>, dim3(blocks), dim3(kThreads), 0, st, g);
     } else {
-        if (g.rms_w) skinny_mfma_kernel<true, false><<<blocks, kThreads, 0, st>>>(g);
-        else skinny_mfma_kernel<false, false><<<blocks, kThreads, 0, st>>>(g);
+        if (g.rms_w) ivlm_launch(skinny_mfma_kernel<true, false>, dim3(blocks), dim3(kThreads), 0, st, g);
+        else ivlm_launch(skinny_mfma_kernel<false, false>, dim3(blocks), dim3(kThreads), 0, st, g);
     }
     return ivlm_launch_status();
 }

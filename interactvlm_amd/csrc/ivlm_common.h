@@ -1,6 +1,7 @@
 // Shared device/host helpers for libivlm_hip.so (gfx950 only; wave = 64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -43,6 +44,18 @@ static inline int ivlm_launch_status_at(const char* file, int line) {
     } while (0)
 
 static inline hipStream_t ivlm_stream(ivlm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Launch helper of the kernels whose duration bench.py reports (GEMM / GEMV / lift families): when the caller armed
+// ivlm_profile_launches(start, stop), the HIP events are attached to the KERNEL (hipExtLaunchKernelGGL: recorded by the command
+// processor at its first / last wave) instead of being separate records around it - an event pair around one ~17 us launch reads
+// 5-12 us too long.
+bool ivlm_profile_events(hipEvent_t* start, hipEvent_t* stop);
+template <typename K, typename... A>
+static inline void ivlm_launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+    hipEvent_t ev0, ev1;
+    if (ivlm_profile_events(&ev0, &ev1)) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, ev0, ev1, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, args...);
+}
 
 // ---- bf16 <-> f32 (round-to-nearest-even), raw 16-bit storage -------------------------------
 typedef uint16_t bf16_t;

@@ -461,9 +461,9 @@ int ivlm_lift_mesh_plan(const float* logits, const int32_t* row_ptr, const int32
     hipStream_t st = ivlm_stream(stream);
     ivlm_enter();
     if (mode == 0)
-        lift_plan_kernel<0><<<grid, kBlock, 0, st>>>(logits, row_ptr, ent_pix, ent_w, V, HW, Nv, param, out, nviews);
+        ivlm_launch(lift_plan_kernel<0>, dim3(grid), dim3(kBlock), 0, st, logits, row_ptr, ent_pix, ent_w, V, HW, Nv, param, out, nviews);
     else
-        lift_plan_kernel<1><<<grid, kBlock, 0, st>>>(logits, row_ptr, ent_pix, ent_w, V, HW, Nv, param, out, nviews);
+        ivlm_launch(lift_plan_kernel<1>, dim3(grid), dim3(kBlock), 0, st, logits, row_ptr, ent_pix, ent_w, V, HW, Nv, param, out, nviews);
     return ivlm_launch_status();
 }
 

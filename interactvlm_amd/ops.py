@@ -18,26 +18,68 @@ def _stream() -> int:
 
 
 class KernelTimer:
-    """HIP-event timing of individual kernel launches (bench.py's roofline leg).  Events are recorded on the
-    stream the kernels are launched on (torch's current stream).  Off by default: zero overhead."""
+    """Per-launch kernel durations for bench.py's roofline legs.  The HIP events are ATTACHED to the kernels
+    (``ivlm_profile_launches`` -> hipExtLaunchKernelGGL: the command processor records the start event when the first kernel of
+    the call begins and the stop event when its last kernel ends, on the stream the kernels run on) - an event pair recorded
+    around a single ~17 us launch reads 5-12 us too long, which is why round 1's brackets sat below the rocprofv3 durations.
+    Off by default: zero overhead."""
 
     def __init__(self):
         self.enabled = False
-        self.records = {}  # name -> list[(start_event, end_event, work)]
+        self.records = {}  # name -> list[(start_event, end_event, work, tag)]
+        self._hip = None
+
+    def _rt(self):
+        if self._hip is None:
+            import ctypes
+            import os
+            self._hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+            self._hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        return self._hip
+
+    def _event(self):
+        import ctypes
+        ev = ctypes.c_void_p()
+        rc = self._rt().hipEventCreate(ctypes.byref(ev))
+        if rc != 0:
+            raise IvlmError(f"hipEventCreate failed ({rc})")
+        return ev
+
+    def _elapsed_ms(self, a, b):
+        import ctypes
+        ms = ctypes.c_float()
+        rc = self._rt().hipEventElapsedTime(ctypes.byref(ms), a, b)
+        if rc != 0:
+            raise IvlmError(f"hipEventElapsedTime failed ({rc})")
+        return ms.value
 
     def start(self):
+        self._free()
         self.enabled, self.records = True, {}
 
     def stop(self):
         self.enabled = False
 
+    def _free(self):
+        if self._hip is not None:
+            for rec in self.records.values():
+                for a, b, _, _ in rec:
+                    self._hip.hipEventDestroy(a)
+                    self._hip.hipEventDestroy(b)
+        self.records = {}
+
     def time(self, name, work, fn, tag=None):
         if not self.enabled:
             return fn()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        r = fn()
-        b.record()
+        lib = _lib.load()
+        a, b = self._event(), self._event()
+        lib.ivlm_profile_launches(a, b)
+        try:
+            r = fn()
+        finally:
+            n = lib.ivlm_profile_launches(None, None)
+        if n <= 0:
+            raise IvlmError(f"{name}: no instrumented kernel launch inside the timed call")
         self.records.setdefault(name, []).append((a, b, work, tag))
         return r
 
@@ -48,34 +90,16 @@ class KernelTimer:
         for a, b, w, tag in self.records.get(name, []):
             d = out.setdefault(tag, {"launches": 0, "total_s": 0.0, "work": 0.0})
             d["launches"] += 1
-            d["total_s"] += a.elapsed_time(b) * 1e-3
+            d["total_s"] += self._elapsed_ms(a, b) * 1e-3
             d["work"] += w
         return out
 
-    def event_pair_overhead_ms(self, n=64):
-        """Elapsed time an EMPTY event pair reports on the current stream (median).  Reported next to the timings for
-        information only: it varies run to run (5-12 us measured) and over-corrects when subtracted - rocprofv3 durations
-        (profiles/) are 2.5-6.5 us below the raw event brackets for the 15-25 us kernels."""
+    def summary(self):
         torch.cuda.synchronize()
-        pairs = []
-        for _ in range(n):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            b.record()
-            pairs.append((a, b))
-        torch.cuda.synchronize()
-        v = sorted(a.elapsed_time(b) for a, b in pairs)
-        return v[len(v) // 2]
-
-    def summary(self, subtract_event_overhead=False):
-        torch.cuda.synchronize()
-        ovh = self.event_pair_overhead_ms() if subtract_event_overhead else 0.0
         out = {}
         for name, rec in self.records.items():
-            raw = [a.elapsed_time(b) for a, b, _, _ in rec]
-            ms = [max(x - ovh, 0.2 * x) for x in raw]
+            ms = [self._elapsed_ms(a, b) for a, b, _, _ in rec]
             out[name] = {"launches": len(rec), "total_s": sum(ms) * 1e-3, "avg_us": sum(ms) / len(ms) * 1e3,
-                         "avg_us_events_raw": sum(raw) / len(raw) * 1e3, "event_pair_overhead_us": ovh * 1e3,
                          "work": float(sum(r[2] for r in rec))}
         return out
 
