@@ -253,9 +253,11 @@ TOY = dict(hidden=128, layers=2, heads=4, inter=256, vocab=32003, clip_hidden=64
            clip_inter=128, clip_image=224, clip_patch=14)
 
 
-def gen_model_forward(batch2=False):
+def gen_model_forward(batch2=False, huobj=False):
     """batch2: second scenario - an oafford sample with the object predictors enabled
-    (oC_loss_weight > 0, 'HM' view type: sigmoid on the valid pixels, per-view p2pmap files for the point lift)."""
+    (oC_loss_weight > 0, 'HM' view type: sigmoid on the valid pixels, per-view p2pmap files for the point lift).
+    huobj: third scenario - token_type 'Gen-Hu-Obj' with a [HSEG] answer token and the 'view_index' camera encoder: the
+    AttentionSplitter branch of process_embeddings (InteractVLM.py:284-292) inside the whole path."""
     import json
     import torch
     _ref_shims.install(full_model=True)
@@ -290,9 +292,11 @@ def gen_model_forward(batch2=False):
             max_position_embeddings=1024, attn_implementation="eager")
         for k, v in dict(vision_tower=clip_dir, mm_vision_tower=clip_dir, mm_hidden_size=t["clip_hidden"],
                          mm_use_im_start_end=True, mm_vision_select_layer=-2, use_fusion=False, use_uncertainty=False,
-                         img_emb_len=255, seg_token_idx=32000, hseg_token_idx=None, oseg_token_idx=None, token_type="Gen",
+                         img_emb_len=255, seg_token_idx=32000, hseg_token_idx=31999 if huobj else None,
+                         oseg_token_idx=31998 if huobj else None, token_type="Gen-Hu-Obj" if huobj else "Gen",
                          hC_sam_view_type="4MV-Z_Vitru", oC_sam_view_type="4MV-Z_HM", hC_loss_weight=1.0,
-                         oC_loss_weight=1.0 if batch2 else 0.0, multiview_channels=4, multiview_cam_cond=True, cam_encoder_type="vi_v1",
+                         oC_loss_weight=1.0 if batch2 else 0.0, multiview_channels=4, multiview_cam_cond=True,
+                         cam_encoder_type="view_index" if huobj else "vi_v1",
                          train_mask_decoder=True, out_dim=256).items():
             setattr(cfg, k, v)
         os.chdir(td)
@@ -353,7 +357,7 @@ def gen_model_forward(batch2=False):
         rng = np.random.default_rng(0)
         ids = rng.integers(3, 31000, size=52)
         ids[10], ids[11], ids[12] = 32001, -200, 32002
-        ids[47] = 32000
+        ids[47] = 31999 if huobj else 32000
         ids[51] = 2
         input_ids = torch.from_numpy(ids)[None]
         images_clip = torch.from_numpy(synth.synth_normal("mf/images_clip", (1, 3, 224, 224), 1.0, 0))
@@ -385,7 +389,7 @@ def gen_model_forward(batch2=False):
             h.remove()
         clip_feat, hid, img_emb = taps["clip_feat"], taps["hidden_last"], taps["sam_emb"]
     pm = out["pred_masks"][0].numpy()
-    _save("model_forward_toy.npz", input_ids=ids, cam_params=cams.numpy(), toy=json.dumps(TOY),
+    _save("model_forward_huobj.npz" if huobj else "model_forward_toy.npz", input_ids=ids, cam_params=cams.numpy(), toy=json.dumps(TOY),
           clip_feat=clip_feat.numpy(), hidden_last=hid.numpy(), sam_emb_sub=_sub(img_emb.numpy(), 4),
           seg_fcs=taps["fcs"].numpy(), low_res=taps["low_res"].numpy(),
           pred_masks_sub=_sub(pm), pred_masks_sum=np.float64(pm.astype(np.float64).sum()),
@@ -536,7 +540,8 @@ def gen_metrics():
 
 GENERATORS = {"lift": gen_lift, "lift_points": gen_lift_points, "sam_decoder": gen_sam_decoder, "cam": gen_cam,
               "sam_encoder": gen_sam_encoder, "sam_encoder_full": gen_sam_encoder_full, "model_forward": gen_model_forward,
-              "model_forward_oafford": lambda: gen_model_forward(batch2=True), "metrics": gen_metrics,
+              "model_forward_oafford": lambda: gen_model_forward(batch2=True),
+              "model_forward_huobj": lambda: gen_model_forward(huobj=True), "metrics": gen_metrics,
               "state_keys": gen_state_keys, "preprocess": gen_preprocess}
 
 

@@ -646,3 +646,49 @@ def test_cam_encoders_and_attention_splitter_vs_reference_golden(hip_lib, cuda, 
                        hseg_token_idx=32003, oseg_token_idx=32004)
             o = O.process_embeddings(wb, emb.clone(), cams, token, cfg)
             assert float((got - o).abs().max()) < 2e-5 * max(1.0, float(o.abs().max())), (kind, tt, token)
+
+
+def test_model_forward_gen_hu_obj_vs_reference_golden(hip_lib, cuda, golden_dir):
+    """The facade with token_type 'Gen-Hu-Obj' ([HSEG] answer token -> AttentionSplitter human branch, 'view_index' camera
+    encoder) against the reference's own model_forward(inference=True) output and the fp32 oracle on identical weights."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth
+    from interactvlm_amd import weights as Wt
+    from oracle import pipeline as P
+
+    d = np.load(os.path.join(golden_dir, "model_forward_huobj.npz"))
+    t = json.loads(str(d["toy"]))
+    cfg = Wt.IvlmCfg(
+        llama=Wt.LlamaCfg(hidden=t["hidden"], layers=t["layers"], heads=t["heads"], inter=t["inter"], vocab=t["vocab"]),
+        clip=Wt.ClipCfg(hidden=t["clip_hidden"], layers=t["clip_layers"], heads=t["clip_heads"], inter=t["clip_inter"]),
+        sam=Wt.SamEncCfg(embed_dim=160, depth=2, num_heads=2, global_attn_indexes=(1,)), token_type="Gen-Hu-Obj",
+        cam_encoder_type="view_index", hseg_token_idx=31999, oseg_token_idx=31998)
+    ids = torch.from_numpy(d["input_ids"])
+    images_clip = torch.from_numpy(synth.synth_normal("mf/images_clip", (1, 3, 224, 224), 1.0, 0))
+    images = torch.from_numpy(synth.synth_normal("mf/images", (1, 4, 3, 1024, 1024), 1.0, 0))
+    cams = torch.from_numpy(d["cam_params"])
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    assert m.attention_splitter is not None
+    bf = torch.bfloat16
+    out = m.model_forward(images=images.to(bf).to(cuda), images_clip=images_clip.to(bf).to(cuda), input_ids=ids[None],
+                          offset=torch.tensor([0, 1]), masks_list=[torch.zeros(4, 1, 1024, 1024)],
+                          label_list=[torch.zeros(1024, 1024)], cam_params=cams, resize_list=[(1024, 1024)],
+                          ds_name_list=["hcontact"], mask_paths_list=[None], inference=True)
+    contact = out["pred_human_3d_contact"].float().cpu()
+    wb = {k: (v.to(bf).float() if "gaussian" not in k else v) for k, v in w.items()}
+    o = P.model_forward(wb, cfg, images[0].to(bf).float(), images_clip.to(bf).float(), ids, cams[0], tables)
+    e_same = float((contact - o["pred_contact"]).abs().max())
+    e_ref = float((contact - torch.from_numpy(d["pred_contact"])).abs().max())
+    e_floor = float((o["pred_contact"] - torch.from_numpy(d["pred_contact"])).abs().max())
+    print(f"\n[model_forward Gen-Hu-Obj] vs fp32 oracle on identical weights {e_same:.2e}; vs reference golden {e_ref:.2e} "
+          f"(bf16-checkpoint floor {e_floor:.2e})")
+    assert e_same < 1e-3 and e_ref < e_floor + 1e-3
+    # evaluate(): the [HSEG] token arrives through generation, same branch
+    L0 = 40
+    ev = m.evaluate(images_clip.to(bf).to(cuda), images.to(bf).to(cuda), ids[None, :L0], cams, [(1024, 1024)], [(1024, 1024)],
+                    contact_type="hcontact", forced_new_tokens=ids[L0:].tolist())
+    assert float((ev["pred_contact_3d"].float().cpu() - o["pred_contact"]).abs().max()) < 1e-3

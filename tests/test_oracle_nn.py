@@ -152,3 +152,24 @@ def test_metrics_oracle_vs_reference_golden(golden_dir):
     np.testing.assert_allclose(per.numpy(), d["geo_per_sample"], rtol=1e-6)
     np.testing.assert_allclose([fp, fn], d["geo_batch"], rtol=1e-6)
     np.testing.assert_allclose(OM.h_contact_metrics(gt, pred).numpy(), d["prf_per_sample"], atol=1e-7)
+
+
+def _huobj_cfg(t):
+    return Wt.IvlmCfg(
+        llama=Wt.LlamaCfg(hidden=t["hidden"], layers=t["layers"], heads=t["heads"], inter=t["inter"], vocab=t["vocab"]),
+        clip=Wt.ClipCfg(hidden=t["clip_hidden"], layers=t["clip_layers"], heads=t["clip_heads"], inter=t["clip_inter"]),
+        sam=Wt.SamEncCfg(embed_dim=160, depth=2, num_heads=2, global_attn_indexes=(1,)), token_type="Gen-Hu-Obj",
+        cam_encoder_type="view_index", hseg_token_idx=31999, oseg_token_idx=31998)
+
+
+def test_model_forward_gen_hu_obj_end_to_end(golden_dir):
+    """token_type 'Gen-Hu-Obj' with a [HSEG] answer token and the 'view_index' camera encoder: the AttentionSplitter branch of
+    process_embeddings (InteractVLM.py:284-292) inside the reference's whole model_forward(inference=True) vs the oracle."""
+    d = _g(golden_dir, "model_forward_huobj.npz")
+    cfg = _huobj_cfg(json.loads(str(d["toy"])))
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    ids, images_clip, images, cams, tables = toy_inputs(d)
+    assert int(ids[47]) == 31999
+    o = P.model_forward(w, cfg, images, images_clip, ids, cams, tables)
+    np.testing.assert_allclose(o["low_res"].numpy(), d["low_res"], atol=5e-5)
+    np.testing.assert_allclose(o["pred_contact"].numpy(), d["pred_contact"], atol=1e-5)
