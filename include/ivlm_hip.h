@@ -268,6 +268,75 @@ size_t ivlm_llama_decode_workspace_bytes(const ivlm_llama_cfg *cfg);
 int ivlm_llama_decode_step(const ivlm_llama_cfg *cfg, const ivlm_llama_layer *layers_host, const void *final_norm, void *kcache,
                            void *vcache, const float *cos_tab, const float *sin_tab, const float *x_in, int32_t *pos_dev,
                            int advance, float *hidden_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* CLIPVisionTower.forward + feature_select('patch', layer -2) (clip_encoder.py:31-60): images bf16 [B,3,S,S] -> bf16
+ * [B, tokens-1, hidden] (the mm_projector's operand).  layers_run = the encoder layers actually needed (23 of 24 for layer -2);
+ * patch_w bf16 [hidden, kpad] (conv weight as GEMM rows, K zero-padded to kpad % 64 == 0), pos bf16 [tokens, hidden], cls_row
+ * fp32 [hidden] = class_embedding + position_embedding[0].  qkv_w / qkv_b: q|k|v rows concatenated. */
+typedef struct {
+    int layers_run, hidden, heads, inter, image_size, patch, kpad, tokens;
+    float eps;
+} ivlm_clip_cfg;
+typedef struct {
+    const void *patch_w, *pos, *cls_row, *pre_ln_w, *pre_ln_b;
+} ivlm_clip_head;
+typedef struct {
+    const void *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} ivlm_clip_layer;
+size_t ivlm_clip_encode_workspace_bytes(const ivlm_clip_cfg *cfg, int B);
+int ivlm_clip_encode(const ivlm_clip_cfg *cfg, const ivlm_clip_head *head, const ivlm_clip_layer *layers_host, const void *images,
+                     int B, void *features_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+
+/* ImageEncoderViT.forward (image_encoder.py:110-125; Block :177-193, Attention :235-260, window partition :263-318, decomposed
+ * rel-pos :354-392, neck :92-108): images bf16 [V,3,img,img] -> embeddings fp32 [V, grid*grid, out_chans] (channels last).
+ * Conv weights in GEMM layout: patch_w [D, 3*p*p], neck0_w [OC, D], neck2_w [OC, (ky,kx,OC)]; rel_cat = [rel_pos_h ; rel_pos_w]
+ * zero-padded to a multiple of 8 rows (the rel-pos GEMM of the global blocks). */
+typedef struct {
+    int embed_dim, depth, heads, grid, window, patch, img_size, out_chans, mlp_dim;
+} ivlm_sam_cfg;
+typedef struct {
+    const void *patch_w, *patch_b, *pos_embed, *neck0_w, *neck1_w, *neck1_b, *neck2_w, *neck3_w, *neck3_b;
+} ivlm_sam_head;
+typedef struct {
+    const void *norm1_w, *norm1_b, *qkv_w, *qkv_b, *rel_h, *rel_w, *rel_cat, *proj_w, *proj_b, *norm2_w, *norm2_b, *lin1_w, *lin1_b,
+        *lin2_w, *lin2_b;
+    int global_attn;
+} ivlm_sam_block;
+size_t ivlm_sam_encode_workspace_bytes(const ivlm_sam_cfg *cfg, int V);
+int ivlm_sam_encode(const ivlm_sam_cfg *cfg, const ivlm_sam_head *head, const ivlm_sam_block *blocks_host, const void *images, int V,
+                    float *embeddings_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+
+/* PromptEncoder.forward(text_embeds) + MaskDecoder.forward(multimask_output=False) (prompt_encoder.py:140-186,
+ * mask_decoder.py:75-164, transformer.py:62-242) with fp32 activations end to end: image_embeddings fp32 [V, grid*grid, C]
+ * (ivlm_sam_encode's output), text_embeds fp32 [n_text, C] (the view-conditioned [SEG] embeddings, one token per view) ->
+ * low_res fp32 [V, 4*grid, 4*grid] (mask token 0), iou fp32 [V, n_mask] (column 0 belongs to that mask).
+ * Every linear is an ivlm_lin: w2 = [W | W] bf16 [n, 2k] (the fp32 input arrives as hi | lo bf16 rows), b bf16 [n].
+ * Transposed convs as GEMMs: up0 = [(dy,dx,co), ci | same], bias tiled over (dy,dx).  no_mask fp32 [C], key_pe fp32
+ * [grid*grid, C] (ivlm_dense_pe), out_tokens fp32 [5, C] = [iou_token ; mask_tokens]. */
+typedef struct {
+    const void *w2, *b;
+    int n, k;
+} ivlm_lin;
+typedef struct {
+    ivlm_lin q, k, v, o;
+} ivlm_dec_attn;
+typedef struct {
+    ivlm_dec_attn self_attn, t2i, i2t;
+    const void *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b, *norm4_w, *norm4_b;
+    ivlm_lin lin1, lin2;
+} ivlm_dec_layer;
+typedef struct {
+    int C, heads, depth;
+    const void *no_mask, *key_pe, *out_tokens;
+    ivlm_dec_layer layers[4];
+    ivlm_dec_attn final_attn;
+    const void *norm_final_w, *norm_final_b, *up_ln_w, *up_ln_b;
+    ivlm_lin up0, up1, hyper[3], iou[3];
+} ivlm_sam_dec;
+size_t ivlm_sam_decode_workspace_bytes(int V, int grid, int C, int n_text, int mlp_dim);
+int ivlm_sam_decode(const ivlm_sam_dec *weights, int V, int grid, int n_text, const float *image_embeddings,
+                    const float *text_embeds, float *low_res_out, float *iou_out, void *workspace, size_t workspace_bytes,
+                    ivlm_stream_t stream);
+
 /* The split-K rule of the small-M tile GEMMs (number of K slices, 1 = none): shared by the sequencers and the Python host. */
 int ivlm_gemm_splitk_choice(int M, int N, int K, int act, int has_rms);
 

@@ -215,3 +215,373 @@ extern "C" int ivlm_llama_decode_step(const ivlm_llama_cfg* c, const ivlm_llama_
     bump_kernel<<<1, 1, 0, st>>>(fuse ? words + 1 : nullptr, advance ? pos_dev : nullptr);  // tokens decoded += 1 (position += 1)
     return ivlm_launch_status();
 }
+
+// =====================================================================================================================
+// Vision stages: ivlm_clip_encode (CLIPVisionTower.forward + feature_select, clip_encoder.py:31-60) and ivlm_sam_encode
+// (ImageEncoderViT.forward, image_encoder.py:110-125) as C++ sequencers - the launch order of interactvlm_amd/llava.py
+// ClipTower._forward and interactvlm_amd/sam.py SamImageEncoder._forward (bf16 operands, fp32 residual stream).
+// =====================================================================================================================
+namespace ivlm {
+namespace {
+
+// window_partition / window_unpartition row maps of SAM's ViT on the device (image_encoder.py:263-318): part[w] = image row
+// of window position w (-1 = zero padding), unpart[r] = window position of image row r
+__global__ void sam_window_maps_kernel(int V, int g, int ws, int nw, int32_t* __restrict__ part, int32_t* __restrict__ unpart) {
+    const int S = ws * ws;
+    const int64_t total = (int64_t)V * nw * nw * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % ws), iy = (int)((i / ws) % ws);
+        const int wx = (int)((i / S) % nw), wy = (int)((i / ((int64_t)S * nw)) % nw), v = (int)(i / ((int64_t)S * nw * nw));
+        const int y = wy * ws + iy, x = wx * ws + ix;
+        const bool ok = y < g && x < g;
+        const int src = (v * g + y) * g + x;
+        part[i] = ok ? src : -1;
+        if (ok) unpart[src] = (int32_t)i;
+    }
+}
+
+// dst[r] = row wherever part[r] < 0 (the zero-padded window positions: their q|k|v rows are the bias)
+__global__ void fill_pad_rows_kernel(bf16_t* __restrict__ dst, int64_t ldd, const int32_t* __restrict__ part, int64_t rows,
+                                     const bf16_t* __restrict__ row, int cols) {
+    const int c8n = cols >> 3;
+    const int64_t total = rows * c8n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c8n;
+        if (part[r] >= 0) continue;
+        const int c8 = (int)(i % c8n);
+        *reinterpret_cast<uint4*>(dst + r * ldd + c8 * 8) = *reinterpret_cast<const uint4*>(row + c8 * 8);
+    }
+}
+
+// generic tile-GEMM call of the sequencers (bias, activation, bf16 / fp32 residual with row modulo, row maps, split-K rule)
+int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int out_f32, int64_t ldc, const void* bias,
+         const void* res, int res_f32, int64_t ldr, int res_mod, int M, int N, int K, int act, const int32_t* out_rows,
+         const int32_t* a_rows, float* sk, size_t skb, hipStream_t st) {
+    GemmArgs g;
+    g.A = static_cast<const bf16_t*>(A);
+    g.W = static_cast<const bf16_t*>(W);
+    g.C = C;
+    g.bias = static_cast<const bf16_t*>(bias);
+    g.residual = static_cast<const bf16_t*>(res);
+    g.res_f32 = res_f32;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr;
+    g.res_mod = res_mod;
+    g.M = M; g.N = N; g.K = K;
+    g.act = act;
+    g.out_f32 = out_f32;
+    g.out_rows = out_rows;
+    g.a_rows = a_rows;
+    const int sp = (out_rows || a_rows) ? 1 : gemm_splitk_choice(M, N, K, act, 0);
+    if (sp > 1 && (ldc & 3) == 0 && sk && skb >= (size_t)sp * M * N * 4) return gemm_bf16_splitk(g, sp, sk, skb, st);
+    return linear_bf16(g, st);
+}
+
+}  // namespace
+}  // namespace ivlm
+
+extern "C" size_t ivlm_clip_encode_workspace_bytes(const ivlm_clip_cfg* c, int B) {
+    if (!c || B <= 0) return 0;
+    const size_t T = c->tokens, h = c->hidden, rows = (size_t)B * T;
+    return al((size_t)B * (T - 1) * c->kpad * 2) + 2 * al(rows * h * 4) + al(rows * h * 2) + al(rows * 3 * h * 2) + al(rows * h * 2) +
+           al(rows * c->inter * 2) + al(8 * rows * std::max<size_t>(3 * h, c->inter) * 4) + al(rows * 4) + 512;
+}
+
+extern "C" int ivlm_clip_encode(const ivlm_clip_cfg* c, const ivlm_clip_head* hd, const ivlm_clip_layer* layers_host,
+                                const void* images, int B, void* features_out, void* workspace, size_t workspace_bytes,
+                                ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!c || !hd || !layers_host || !images || !features_out || !workspace || B <= 0) return IVLM_ERR_INVALID_ARG;
+    if (workspace_bytes < ivlm_clip_encode_workspace_bytes(c, B)) return IVLM_ERR_WORKSPACE;
+    hipStream_t st = ivlm_stream(stream);
+    const int T = c->tokens, Hd = c->hidden, H = c->heads, D = Hd / H, I = c->inter, R = B * T;
+    Carver cv{static_cast<char*>(workspace), workspace_bytes};
+    bf16_t* cols = static_cast<bf16_t*>(cv.take((size_t)B * (T - 1) * c->kpad * 2));
+    float* xa = static_cast<float*>(cv.take((size_t)R * Hd * 4));
+    float* xb = static_cast<float*>(cv.take((size_t)R * Hd * 4));
+    bf16_t* y = static_cast<bf16_t*>(cv.take((size_t)R * Hd * 2));
+    bf16_t* qkv = static_cast<bf16_t*>(cv.take((size_t)R * 3 * Hd * 2));
+    bf16_t* att = static_cast<bf16_t*>(cv.take((size_t)R * Hd * 2));
+    bf16_t* hh = static_cast<bf16_t*>(cv.take((size_t)R * I * 2));
+    const size_t skb = (size_t)8 * R * std::max(3 * Hd, I) * 4;
+    float* sk = static_cast<float*>(cv.take(skb));
+    int32_t* prow = static_cast<int32_t*>(cv.take((size_t)R * 4));
+    if (!cv.ok) return IVLM_ERR_WORKSPACE;
+    int rc;
+    if ((rc = im2col_nchw(static_cast<const bf16_t*>(images), cols, B, 3, c->image_size, c->image_size, c->patch, c->patch, c->kpad, st))) return rc;
+    for (int b = 0; b < B; ++b) {  // patch GEMM writes rows 1..T-1 (+ their position embeddings); row 0 = class + position 0
+        float* xrow = xa + (size_t)b * T * Hd;
+        if ((rc = gemm(cols + (size_t)b * (T - 1) * c->kpad, c->kpad, hd->patch_w, c->kpad, xrow + Hd, 1, Hd, nullptr,
+                       static_cast<const bf16_t*>(hd->pos) + Hd, 0, Hd, 0, T - 1, Hd, c->kpad, ACT_NONE, nullptr, nullptr, sk, skb, st)))
+            return rc;
+        if ((rc = gather_rows(xrow, 1, Hd, hd->cls_row, 1, Hd, nullptr, nullptr, 0, 0, 1, Hd, st))) return rc;
+    }
+    if ((rc = layernorm(xa, 1, static_cast<const bf16_t*>(hd->pre_ln_w), static_cast<const bf16_t*>(hd->pre_ln_b), xb, 1, R, Hd, c->eps, st))) return rc;
+    float* x = xb;
+    const int64_t strides[12] = {(int64_t)T * 3 * Hd, D, 3 * Hd, (int64_t)T * 3 * Hd, D, 3 * Hd, (int64_t)T * 3 * Hd, D, 3 * Hd,
+                                 (int64_t)T * Hd, D, Hd};
+    for (int l = 0; l < c->layers_run; ++l) {
+        const ivlm_clip_layer& L = layers_host[l];
+        if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(L.ln1_w), static_cast<const bf16_t*>(L.ln1_b), y, 0, R, Hd, c->eps, st))) return rc;
+        if ((rc = gemm(y, Hd, L.qkv_w, Hd, qkv, 0, 3 * Hd, L.qkv_b, nullptr, 0, 0, 0, R, 3 * Hd, Hd, ACT_NONE, nullptr, nullptr, sk, skb, st))) return rc;
+        if ((rc = ivlm_attention_bf16(qkv, qkv + Hd, qkv + 2 * Hd, att, strides, B, H, T, T, D, 1.0f / sqrtf((float)D), 0, 0, nullptr,
+                                      nullptr, 0, 0, 1, 1, stream)))
+            return rc;
+        float* x1 = (x == xa) ? xb : xa;
+        if ((rc = gemm(att, Hd, L.out_w, Hd, x1, 1, Hd, L.out_b, x, 1, Hd, 0, R, Hd, Hd, ACT_NONE, nullptr, nullptr, sk, skb, st))) return rc;
+        if ((rc = layernorm(x1, 1, static_cast<const bf16_t*>(L.ln2_w), static_cast<const bf16_t*>(L.ln2_b), y, 0, R, Hd, c->eps, st))) return rc;
+        if ((rc = gemm(y, Hd, L.fc1_w, Hd, hh, 0, I, L.fc1_b, nullptr, 0, 0, 0, R, I, Hd, ACT_QUICK_GELU, nullptr, nullptr, sk, skb, st))) return rc;
+        float* x2 = (x1 == xa) ? xb : xa;
+        if ((rc = gemm(hh, I, L.fc2_w, I, x2, 1, Hd, L.fc2_b, x1, 1, Hd, 0, R, Hd, I, ACT_NONE, nullptr, nullptr, sk, skb, st))) return rc;
+        x = x2;
+    }
+    // drop the CLS row of every image, fp32 stream -> bf16 features (the mm_projector's operand)
+    for (int b = 0; b < B; ++b)
+        if ((rc = gather_rows(static_cast<bf16_t*>(features_out) + (size_t)b * (T - 1) * Hd, 0, Hd, x + ((size_t)b * T + 1) * Hd, 1, Hd,
+                              nullptr, nullptr, 0, 0, T - 1, Hd, st)))
+            return rc;
+    (void)prow;
+    return IVLM_OK;
+}
+
+extern "C" size_t ivlm_sam_encode_workspace_bytes(const ivlm_sam_cfg* c, int V) {
+    if (!c || V <= 0) return 0;
+    const size_t g2 = (size_t)c->grid * c->grid, rows = (size_t)V * g2, D = c->embed_dim;
+    const int nw = (c->grid + c->window - 1) / c->window;
+    const size_t wrows = (size_t)V * nw * nw * c->window * c->window, qrows = std::max(rows, wrows);
+    const size_t npad = (((size_t)2 * (2 * c->grid - 1)) + 7) / 8 * 8;
+    size_t b = al(rows * 3 * c->patch * c->patch * 2) + al(rows * D * 4) + al(rows * D * 2) + al(qrows * 3 * D * 2) + al(qrows * D * 2) +
+               al(rows * c->mlp_dim * 2);
+    b += 2 * al((size_t)V * c->heads * g2 * c->grid * 4);          // rel_h / rel_w of a global block (the larger case)
+    b += 2 * al(wrows * c->heads * c->window * 4);                  // ... of a windowed block
+    b += al((size_t)c->heads * rows * npad * 2);                    // G of the rel-pos GEMM
+    b += al(wrows * 4) + al(rows * 4);                              // part / unpart maps
+    b += al(rows * c->out_chans * 2) * 2 + al(rows * 9 * c->out_chans * 2) + al(rows * D * 2);
+    return b + 1024;
+}
+
+extern "C" int ivlm_sam_encode(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, const ivlm_sam_block* blocks_host, const void* images,
+                               int V, float* embeddings_out, void* workspace, size_t workspace_bytes, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!c || !hd || !blocks_host || !images || !embeddings_out || !workspace || V <= 0) return IVLM_ERR_INVALID_ARG;
+    if (workspace_bytes < ivlm_sam_encode_workspace_bytes(c, V)) return IVLM_ERR_WORKSPACE;
+    hipStream_t st = ivlm_stream(stream);
+    const int g = c->grid, D = c->embed_dim, H = c->heads, hdim = D / H, wsz = c->window, OC = c->out_chans;
+    const int nw = (g + wsz - 1) / wsz, g2 = g * g, R = V * g2, nwin = V * nw * nw, WS = wsz * wsz, WR = nwin * WS;
+    const int Kp = 3 * c->patch * c->patch;
+    Carver cv{static_cast<char*>(workspace), workspace_bytes};
+    bf16_t* cols = static_cast<bf16_t*>(cv.take((size_t)R * Kp * 2));
+    float* x = static_cast<float*>(cv.take((size_t)R * D * 4));
+    bf16_t* xn = static_cast<bf16_t*>(cv.take((size_t)R * D * 2));
+    const size_t qrows = std::max(R, WR);
+    bf16_t* qkv = static_cast<bf16_t*>(cv.take(qrows * 3 * D * 2));
+    bf16_t* att = static_cast<bf16_t*>(cv.take(qrows * D * 2));
+    bf16_t* hh = static_cast<bf16_t*>(cv.take((size_t)R * c->mlp_dim * 2));
+    float* relh_g = static_cast<float*>(cv.take((size_t)V * H * g2 * g * 4));
+    float* relw_g = static_cast<float*>(cv.take((size_t)V * H * g2 * g * 4));
+    float* relh_w = static_cast<float*>(cv.take((size_t)WR * H * wsz * 4));
+    float* relw_w = static_cast<float*>(cv.take((size_t)WR * H * wsz * 4));
+    const int npad = (2 * (2 * g - 1) + 7) / 8 * 8;
+    bf16_t* G = static_cast<bf16_t*>(cv.take((size_t)H * R * npad * 2));
+    int32_t* part = static_cast<int32_t*>(cv.take((size_t)WR * 4));
+    int32_t* unpart = static_cast<int32_t*>(cv.take((size_t)R * 4));
+    bf16_t* n0 = static_cast<bf16_t*>(cv.take((size_t)R * OC * 2));
+    bf16_t* n1 = static_cast<bf16_t*>(cv.take((size_t)R * OC * 2));
+    bf16_t* c3 = static_cast<bf16_t*>(cv.take((size_t)R * 9 * OC * 2));
+    bf16_t* xb16 = static_cast<bf16_t*>(cv.take((size_t)R * D * 2));
+    if (!cv.ok) return IVLM_ERR_WORKSPACE;
+    int rc;
+    sam_window_maps_kernel<<<256, 256, 0, st>>>(V, g, wsz, nw, part, unpart);
+    if ((rc = ivlm_launch_status())) return rc;
+    if ((rc = im2col_nchw(static_cast<const bf16_t*>(images), cols, V, 3, c->img_size, c->img_size, c->patch, c->patch, Kp, st))) return rc;
+    if ((rc = gemm(cols, Kp, hd->patch_w, Kp, x, 1, D, hd->patch_b, hd->pos_embed, 0, D, g2, R, D, Kp, ACT_NONE, nullptr, nullptr, nullptr, 0, st))) return rc;
+    const float scale = 1.0f / sqrtf((float)hdim);
+    for (int l = 0; l < c->depth; ++l) {
+        const ivlm_sam_block& Bk = blocks_host[l];
+        if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(Bk.norm1_w), static_cast<const bf16_t*>(Bk.norm1_b), xn, 0, R, D, 1e-6f, st))) return rc;
+        const int side = Bk.global_attn ? g : wsz, S = side * side, nb = Bk.global_attn ? V : nwin;
+        if (Bk.global_attn) {
+            if ((rc = gemm(xn, D, Bk.qkv_w, D, qkv, 0, 3 * D, Bk.qkv_b, nullptr, 0, 0, 0, R, 3 * D, D, ACT_NONE, nullptr, nullptr, nullptr, 0, st))) return rc;
+        } else {  // real rows only, scattered to their window positions; the padded positions get the bias
+            if ((rc = gemm(xn, D, Bk.qkv_w, D, qkv, 0, 3 * D, Bk.qkv_b, nullptr, 0, 0, 0, R, 3 * D, D, ACT_NONE, unpart, nullptr, nullptr, 0, st))) return rc;
+            fill_pad_rows_kernel<<<2048, 256, 0, st>>>(qkv, 3 * D, part, WR, static_cast<const bf16_t*>(Bk.qkv_b), 3 * D);
+            if ((rc = ivlm_launch_status())) return rc;
+        }
+        float *rh, *rw;
+        if (side >= 32) {  // rel-pos operands through one batched GEMM over the heads + Toeplitz gather
+            rh = relh_g; rw = relw_g;
+            const int M = nb * S;
+            GemmArgs gg;
+            gg.A = qkv; gg.lda = 3 * D; gg.W = static_cast<const bf16_t*>(Bk.rel_cat); gg.ldw = hdim; gg.C = G; gg.ldc = npad;
+            gg.M = M; gg.N = npad; gg.K = hdim; gg.batch = H; gg.strideA = hdim; gg.strideW = 0; gg.strideC = (int64_t)M * npad;
+            if ((rc = linear_bf16(gg, st))) return rc;
+            if ((rc = ivlm_relpos_gather(G, (int64_t)M * npad, npad, nb, H, side, side, rh, rw, stream))) return rc;
+        } else {
+            rh = relh_w; rw = relw_w;
+            if ((rc = relpos_bias(qkv, (int64_t)S * 3 * D, hdim, 3 * D, static_cast<const bf16_t*>(Bk.rel_h), static_cast<const bf16_t*>(Bk.rel_w),
+                                  nb, H, side, side, hdim, rh, rw, st)))
+                return rc;
+        }
+        const int64_t strides[12] = {(int64_t)S * 3 * D, hdim, 3 * D, (int64_t)S * 3 * D, hdim, 3 * D, (int64_t)S * 3 * D, hdim, 3 * D,
+                                     (int64_t)S * D, hdim, D};
+        if ((rc = ivlm_attention_bf16(qkv, qkv + D, qkv + 2 * D, att, strides, nb, H, S, S, hdim, scale, 0, 0, rh, rw, side, side, 1, 1, stream)))
+            return rc;
+        // proj (+ window_unpartition via the gather prologue) + shortcut, in place on the fp32 stream
+        if ((rc = gemm(att, D, Bk.proj_w, D, x, 1, D, Bk.proj_b, x, 1, D, 0, R, D, D, ACT_NONE, nullptr, Bk.global_attn ? nullptr : unpart, nullptr, 0, st)))
+            return rc;
+        if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(Bk.norm2_w), static_cast<const bf16_t*>(Bk.norm2_b), xn, 0, R, D, 1e-6f, st))) return rc;
+        if ((rc = gemm(xn, D, Bk.lin1_w, D, hh, 0, c->mlp_dim, Bk.lin1_b, nullptr, 0, 0, 0, R, c->mlp_dim, D, ACT_GELU, nullptr, nullptr, nullptr, 0, st))) return rc;
+        if ((rc = gemm(hh, c->mlp_dim, Bk.lin2_w, c->mlp_dim, x, 1, D, Bk.lin2_b, x, 1, D, 0, R, D, c->mlp_dim, ACT_NONE, nullptr, nullptr, nullptr, 0, st))) return rc;
+    }
+    if ((rc = gather_rows(xb16, 0, D, x, 1, D, nullptr, nullptr, 0, 0, R, D, st))) return rc;
+    if ((rc = gemm(xb16, D, hd->neck0_w, D, n0, 0, OC, nullptr, nullptr, 0, 0, 0, R, OC, D, ACT_NONE, nullptr, nullptr, nullptr, 0, st))) return rc;
+    if ((rc = layernorm(n0, 0, static_cast<const bf16_t*>(hd->neck1_w), static_cast<const bf16_t*>(hd->neck1_b), n1, 0, R, OC, 1e-6f, st))) return rc;
+    if ((rc = im2col3x3_nhwc(n1, c3, V, g, g, OC, st))) return rc;
+    if ((rc = gemm(c3, 9 * OC, hd->neck2_w, 9 * OC, n0, 0, OC, nullptr, nullptr, 0, 0, 0, R, OC, 9 * OC, ACT_NONE, nullptr, nullptr, nullptr, 0, st))) return rc;
+    return layernorm(n0, 0, static_cast<const bf16_t*>(hd->neck3_w), static_cast<const bf16_t*>(hd->neck3_b), embeddings_out, 1, R, OC, 1e-6f, st);
+}
+
+// =====================================================================================================================
+// ivlm_sam_decode: PromptEncoder.forward(text_embeds) + MaskDecoder.forward(multimask_output=False) (prompt_encoder.py:140-186,
+// mask_decoder.py:75-164, transformer.py:62-242) with fp32 activations end to end - the launch order of
+// interactvlm_amd/sam.py SamMaskDecoder._forward.  Every linear takes [hi | lo] bf16 rows against [W | W] weights.
+// =====================================================================================================================
+namespace ivlm {
+namespace {
+
+struct DecCtx {
+    hipStream_t st;
+    ivlm_stream_t stream;
+    Carver* cv;
+    float* sk;
+    size_t skb;
+    int rc = 0;
+    void* take(size_t b) {
+        void* p = cv->take(b);
+        if (!p && !rc) rc = IVLM_ERR_WORKSPACE;
+        return p;
+    }
+    // fp32 rows -> [hi | lo] bf16 rows
+    bf16_t* split(const float* x, int64_t rows, int cols) {
+        bf16_t* o = static_cast<bf16_t*>(take((size_t)rows * 2 * cols * 2));
+        if (o && !rc) rc = gather_rows(o, 2, 2 * cols, x, 1, cols, nullptr, nullptr, 0, 0, rows, cols, st);
+        return o;
+    }
+    // (a + b[r % b_rows]) as fp32 rows or as split rows
+    void* add(const float* a, const float* b, int64_t rows, int cols, int64_t b_rows, bool as_split) {
+        void* o = take((size_t)rows * cols * 4);  // (split rows: 2 * cols bf16 = the same bytes)
+        if (o && !rc) rc = add_rows(o, as_split ? 2 : 1, a, 1, b, 1, rows, cols, b_rows, st, 0);
+        return o;
+    }
+    // act(x_split . [W|W]^T + bias) + residual -> fp32 [M, N]
+    float* lin(const bf16_t* xs, const ivlm_lin& L, int M, int act, const float* res, float* dst = nullptr) {
+        float* o = dst ? dst : static_cast<float*>(take((size_t)M * L.n * 4));
+        if (o && !rc) rc = gemm(xs, 2 * L.k, L.w2, 2 * L.k, o, 1, L.n, L.b, res, 1, L.n, 0, M, L.n, 2 * L.k, act, nullptr, nullptr, sk, skb, st);
+        return o;
+    }
+    float* norm(const float* x, const void* w, const void* b, int64_t rows, int cols, float eps, int gelu = 0) {
+        float* o = static_cast<float*>(take((size_t)rows * cols * 4));
+        if (o && !rc) rc = layernorm(x, 1, static_cast<const bf16_t*>(w), static_cast<const bf16_t*>(b), o, 1, rows, cols, eps, st, gelu);
+        return o;
+    }
+    // Attention.forward (transformer.py:220-242) up to, not including, out_proj; returns the split rows of its output
+    bf16_t* attn(const ivlm_dec_attn& a, const bf16_t* qs, const bf16_t* ks, const bf16_t* vs, int B, int Sq, int Sk, int heads) {
+        float* q = lin(qs, a.q, B * Sq, ACT_NONE, nullptr);
+        float* k = lin(ks, a.k, B * Sk, ACT_NONE, nullptr);
+        float* v = lin(vs, a.v, B * Sk, ACT_NONE, nullptr);
+        const int inner = a.q.n, d = inner / heads;
+        float* o = static_cast<float*>(take((size_t)B * Sq * inner * 4));
+        if (rc) return nullptr;
+        const int64_t s12[12] = {(int64_t)Sq * inner, d, inner, (int64_t)Sk * inner, d, inner, (int64_t)Sk * inner, d, inner,
+                                 (int64_t)Sq * inner, d, inner};
+        rc = attention_f32(q, k, v, o, s12, B, heads, Sq, Sk, d, 1.0f / sqrtf((float)d), 1, st);
+        return split(o, (int64_t)B * Sq, inner);
+    }
+};
+
+}  // namespace
+}  // namespace ivlm
+
+extern "C" size_t ivlm_sam_decode_workspace_bytes(int V, int grid, int C, int n_text, int mlp_dim) {
+    if (V <= 0 || grid <= 0 || C <= 0 || n_text <= 0) return 0;
+    const size_t HW = (size_t)grid * grid, rows = (size_t)V * HW;
+    // every intermediate has its own slot (one call = one carve, nothing is reused): ~40 image-sized fp32 / split buffers of
+    // [V*HW, C], the upscaler's [V*HW*4, 128] pair, and the token-sized ones
+    return 48 * al(rows * C * 4) + 3 * al(rows * 4 * 128 * 4) + 64 * al((size_t)V * (5 + n_text) * std::max(mlp_dim, 2 * C) * 4) +
+           al((size_t)8 * V * (5 + n_text) * std::max(mlp_dim, C) * 4) + (1 << 20);
+}
+
+extern "C" int ivlm_sam_decode(const ivlm_sam_dec* w, int V, int grid, int n_text, const float* image_embeddings,
+                               const float* text_embeds, float* low_res_out, float* iou_out, void* workspace, size_t workspace_bytes,
+                               ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!w || !image_embeddings || !text_embeds || !low_res_out || !iou_out || !workspace || V <= 0 || grid <= 0 || n_text <= 0 ||
+        w->depth <= 0 || w->depth > 4)
+        return IVLM_ERR_INVALID_ARG;
+    const int C = w->C, HW = grid * grid, Nt = 5 + n_text, heads = w->heads;
+    if (workspace_bytes < ivlm_sam_decode_workspace_bytes(V, grid, C, n_text, w->layers[0].lin1.n)) return IVLM_ERR_WORKSPACE;
+    hipStream_t st = ivlm_stream(stream);
+    Carver cv{static_cast<char*>(workspace), workspace_bytes};
+    DecCtx x;
+    x.st = st; x.stream = stream; x.cv = &cv;
+    x.skb = (size_t)8 * V * Nt * std::max(w->layers[0].lin1.n, C) * 4;
+    x.sk = static_cast<float*>(x.take(x.skb));
+    // tokens = [iou token ; mask tokens ; text embeds], the same set for every view
+    float* tokens = static_cast<float*>(x.take((size_t)Nt * C * 4));
+    float* query_pe = static_cast<float*>(x.take((size_t)V * Nt * C * 4));
+    if (x.rc) return x.rc;
+    int rc;
+    if ((rc = gather_rows(tokens, 1, C, w->out_tokens, 1, C, nullptr, nullptr, 0, 0, 5, C, st))) return rc;
+    if ((rc = gather_rows(tokens + 5 * C, 1, C, text_embeds, 1, C, nullptr, nullptr, 0, 0, n_text, C, st))) return rc;
+    for (int v = 0; v < V; ++v)
+        if ((rc = gather_rows(query_pe + (size_t)v * Nt * C, 1, C, tokens, 1, C, nullptr, nullptr, 0, 0, Nt, C, st))) return rc;
+    const float* queries = query_pe;
+    const float* keys = static_cast<const float*>(x.add(image_embeddings, static_cast<const float*>(w->no_mask), (int64_t)V * HW, C, 1, false));
+    const float* key_pe = static_cast<const float*>(w->key_pe);
+    const bf16_t* k_split = nullptr;
+    for (int li = 0; li < w->depth && !x.rc; ++li) {
+        const ivlm_dec_layer& L = w->layers[li];
+        if (li == 0) {  // skip_first_layer_pe: queries = self_attn(q = k = v = queries), no residual
+            const bf16_t* qs = x.split(queries, (int64_t)V * Nt, C);
+            queries = x.lin(x.attn(L.self_attn, qs, qs, qs, V, Nt, Nt, heads), L.self_attn.o, V * Nt, ACT_NONE, nullptr);
+        } else {
+            const bf16_t* q = static_cast<const bf16_t*>(x.add(queries, query_pe, (int64_t)V * Nt, C, (int64_t)V * Nt, true));
+            const bf16_t* sa = x.attn(L.self_attn, q, q, x.split(queries, (int64_t)V * Nt, C), V, Nt, Nt, heads);
+            queries = x.lin(sa, L.self_attn.o, V * Nt, ACT_NONE, queries);
+        }
+        queries = x.norm(queries, L.norm1_w, L.norm1_b, (int64_t)V * Nt, C, 1e-5f);
+        const bf16_t* q = static_cast<const bf16_t*>(x.add(queries, query_pe, (int64_t)V * Nt, C, (int64_t)V * Nt, true));
+        k_split = static_cast<const bf16_t*>(x.add(keys, key_pe, (int64_t)V * HW, C, HW, true));
+        const bf16_t* ca = x.attn(L.t2i, q, k_split, x.split(keys, (int64_t)V * HW, C), V, Nt, HW, heads);
+        queries = x.norm(x.lin(ca, L.t2i.o, V * Nt, ACT_NONE, queries), L.norm2_w, L.norm2_b, (int64_t)V * Nt, C, 1e-5f);
+        const float* h1 = x.lin(x.split(queries, (int64_t)V * Nt, C), L.lin1, V * Nt, ACT_RELU, nullptr);
+        const float* mlp = x.lin(x.split(h1, (int64_t)V * Nt, L.lin1.n), L.lin2, V * Nt, ACT_NONE, queries);
+        queries = x.norm(mlp, L.norm3_w, L.norm3_b, (int64_t)V * Nt, C, 1e-5f);
+        q = static_cast<const bf16_t*>(x.add(queries, query_pe, (int64_t)V * Nt, C, (int64_t)V * Nt, true));
+        const bf16_t* ia = x.attn(L.i2t, k_split, q, x.split(queries, (int64_t)V * Nt, C), V, HW, Nt, heads);  // image attends to tokens
+        keys = x.norm(x.lin(ia, L.i2t.o, V * HW, ACT_NONE, keys), L.norm4_w, L.norm4_b, (int64_t)V * HW, C, 1e-5f);
+    }
+    if (x.rc) return x.rc;
+    const bf16_t* q = static_cast<const bf16_t*>(x.add(queries, query_pe, (int64_t)V * Nt, C, (int64_t)V * Nt, true));
+    const bf16_t* k = static_cast<const bf16_t*>(x.add(keys, key_pe, (int64_t)V * HW, C, HW, true));
+    const bf16_t* fa = x.attn(w->final_attn, q, k, x.split(keys, (int64_t)V * HW, C), V, Nt, HW, heads);
+    const float* hs = x.norm(x.lin(fa, w->final_attn.o, V * Nt, ACT_NONE, queries), w->norm_final_w, w->norm_final_b, (int64_t)V * Nt, C, 1e-5f);
+    float* iou_tok = static_cast<float*>(x.take((size_t)V * C * 4));
+    float* mask_tok = static_cast<float*>(x.take((size_t)V * C * 4));
+    if (x.rc) return x.rc;
+    if ((rc = gather_rows(iou_tok, 1, C, hs, 1, (int64_t)Nt * C, nullptr, nullptr, 0, 0, V, C, st))) return rc;       // hs[:, 0, :]
+    if ((rc = gather_rows(mask_tok, 1, C, hs + C, 1, (int64_t)Nt * C, nullptr, nullptr, 0, 0, V, C, st))) return rc;  // hs[:, 1, :]
+    // output_upscaling: ConvT(C -> C/4) -> LayerNorm2d -> GELU -> ConvT(C/4 -> C/8) -> GELU, as GEMMs on pixels
+    const float* u = x.lin(x.split(keys, (int64_t)V * HW, C), w->up0, V * HW, ACT_NONE, nullptr);  // [V*HW, (dy,dx,C/4)]
+    const int cm = w->up0.n / 4;
+    const float* un = x.norm(u, w->up_ln_w, w->up_ln_b, (int64_t)V * HW * 4, cm, 1e-6f, 1);
+    const float* u2 = x.lin(x.split(un, (int64_t)V * HW * 4, cm), w->up1, V * HW * 4, ACT_GELU, nullptr);  // [V*HW*4, (dy2,dx2,C/8)]
+    const float* h0 = x.lin(x.split(mask_tok, V, C), w->hyper[0], V, ACT_RELU, nullptr);
+    const float* h1 = x.lin(x.split(h0, V, w->hyper[0].n), w->hyper[1], V, ACT_RELU, nullptr);
+    const float* h2 = x.lin(x.split(h1, V, w->hyper[1].n), w->hyper[2], V, ACT_NONE, nullptr);  // [V, C/8]
+    if (x.rc) return x.rc;
+    if ((rc = mask_dot(u2, h2, 1, low_res_out, V, grid, grid, w->hyper[2].n, st))) return rc;
+    const float* i0 = x.lin(x.split(iou_tok, V, C), w->iou[0], V, ACT_RELU, nullptr);
+    const float* i1 = x.lin(x.split(i0, V, w->iou[0].n), w->iou[1], V, ACT_RELU, nullptr);
+    x.lin(x.split(i1, V, w->iou[1].n), w->iou[2], V, ACT_NONE, nullptr, iou_out);  // [V, n_mask]: column 0 is the kept mask's IoU
+    return x.rc;
+}

@@ -62,3 +62,154 @@ class LlamaStages:
                                          pos_dev.data_ptr(), 1 if advance else 0, out.data_ptr(), self._dws.data_ptr(),
                                          self._dws.numel(), self._stream()), "llama_decode_step")
         return out
+
+
+class ClipCfgC(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("layers_run", "hidden", "heads", "inter", "image_size", "patch", "kpad", "tokens")] + [
+        ("eps", C.c_float)]
+
+
+class ClipHeadC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("patch_w", "pos", "cls_row", "pre_ln_w", "pre_ln_b")]
+
+
+class ClipLayerC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b",
+                                          "fc2_w", "fc2_b")]
+
+
+class ClipStages:
+    """``ivlm_clip_encode`` over the weights of a ``llava.ClipTower``."""
+
+    def __init__(self, tower):
+        self.t = tower
+        c = tower.cfg
+        self.cfg = ClipCfgC(len(tower.layers), c.hidden, c.heads, c.inter, c.image_size, c.patch, tower.kpad, c.tokens, c.eps)
+        p = lambda t: t.data_ptr()
+        self.head = ClipHeadC(p(tower.patch_w), p(tower.pos), p(tower.cls_row), p(tower.pre_ln.w), p(tower.pre_ln.b))
+        self.layers = (ClipLayerC * len(tower.layers))(*[
+            ClipLayerC(p(L["ln1"].w), p(L["ln1"].b), p(L["qkv_w"]), p(L["qkv_b"]), p(L["out"].w), p(L["out"].b), p(L["ln2"].w),
+                       p(L["ln2"].b), p(L["fc1"].w), p(L["fc1"].b), p(L["fc2"].w), p(L["fc2"].b)) for L in tower.layers])
+
+    def __call__(self, images):
+        lib = _lib.load()
+        images = images.to(torch.bfloat16).contiguous()
+        B = images.shape[0]
+        c = self.t.cfg
+        out = torch.empty(B, c.tokens - 1, c.hidden, dtype=torch.bfloat16, device=images.device)
+        nbytes = lib.ivlm_clip_encode_workspace_bytes(C.byref(self.cfg), B)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device)
+        check(lib.ivlm_clip_encode(C.byref(self.cfg), C.byref(self.head), self.layers, images.data_ptr(), B, out.data_ptr(),
+                                   ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "clip_encode")
+        return out
+
+
+class SamCfgC(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("embed_dim", "depth", "heads", "grid", "window", "patch", "img_size", "out_chans", "mlp_dim")]
+
+
+class SamHeadC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("patch_w", "patch_b", "pos_embed", "neck0_w", "neck1_w", "neck1_b", "neck2_w", "neck3_w",
+                                          "neck3_b")]
+
+
+class SamBlockC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "rel_h", "rel_w", "rel_cat", "proj_w", "proj_b",
+                                          "norm2_w", "norm2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b")] + [("global_attn", C.c_int)]
+
+
+class SamEncodeStages:
+    """``ivlm_sam_encode`` over the weights of a ``sam.SamImageEncoder`` (bf16 operands, fp32 residual stream)."""
+
+    def __init__(self, enc):
+        from . import ops
+
+        self.e = enc
+        c = enc.cfg
+        self.cfg = SamCfgC(c.embed_dim, c.depth, c.num_heads, c.grid, c.window, c.patch, c.img_size, c.out_chans,
+                           enc.blocks[0]["lin1"].w.shape[0])
+        p = lambda t: t.data_ptr()
+        self.head = SamHeadC(p(enc.patch.w), p(enc.patch.b), p(enc.pos_embed), p(enc.neck0.w), p(enc.neck1.w), p(enc.neck1.b),
+                             p(enc.neck2_w), p(enc.neck3.w), p(enc.neck3.b))
+        for blk in enc.blocks:
+            if "rel_cat" not in blk:
+                blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
+        self.blocks = (SamBlockC * c.depth)(*[
+            SamBlockC(p(b["norm1"].w), p(b["norm1"].b), p(b["qkv"].w), p(b["qkv"].b), p(b["rel_h"]), p(b["rel_w"]), p(b["rel_cat"]),
+                      p(b["proj"].w), p(b["proj"].b), p(b["norm2"].w), p(b["norm2"].b), p(b["lin1"].w), p(b["lin1"].b),
+                      p(b["lin2"].w), p(b["lin2"].b), 1 if b["glob"] else 0) for b in enc.blocks])
+
+    def __call__(self, images):
+        lib = _lib.load()
+        images = images.to(torch.bfloat16).contiguous()
+        V = images.shape[0]
+        c = self.e.cfg
+        out = torch.empty(V, c.grid * c.grid, c.out_chans, dtype=torch.float32, device=images.device)
+        nbytes = lib.ivlm_sam_encode_workspace_bytes(C.byref(self.cfg), V)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device)
+        check(lib.ivlm_sam_encode(C.byref(self.cfg), C.byref(self.head), self.blocks, images.data_ptr(), V, out.data_ptr(),
+                                  ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "sam_encode")
+        return out
+
+
+class LinC(C.Structure):
+    _fields_ = [("w2", C.c_void_p), ("b", C.c_void_p), ("n", C.c_int), ("k", C.c_int)]
+
+
+class DecAttnC(C.Structure):
+    _fields_ = [(n, LinC) for n in ("q", "k", "v", "o")]
+
+
+class DecLayerC(C.Structure):
+    _fields_ = ([("self_attn", DecAttnC), ("t2i", DecAttnC), ("i2t", DecAttnC)]
+                + [(f"norm{i}_{p}", C.c_void_p) for i in (1, 2, 3, 4) for p in ("w", "b")] + [("lin1", LinC), ("lin2", LinC)])
+
+
+class SamDecC(C.Structure):
+    _fields_ = [("C", C.c_int), ("heads", C.c_int), ("depth", C.c_int), ("no_mask", C.c_void_p), ("key_pe", C.c_void_p),
+                ("out_tokens", C.c_void_p), ("layers", DecLayerC * 4), ("final_attn", DecAttnC), ("norm_final_w", C.c_void_p),
+                ("norm_final_b", C.c_void_p), ("up_ln_w", C.c_void_p), ("up_ln_b", C.c_void_p), ("up0", LinC), ("up1", LinC),
+                ("hyper", LinC * 3), ("iou", LinC * 3)]
+
+
+def _lin_c(w2, b):
+    return LinC(w2.data_ptr(), b.data_ptr() if b is not None else None, w2.shape[0], w2.shape[1] // 2)
+
+
+class SamDecodeStages:
+    """``ivlm_sam_decode`` over the weights of a ``sam.SamMaskDecoder``."""
+
+    def __init__(self, dec):
+        self.d = dec
+        attn = lambda a: DecAttnC(*[_lin_c(a[n].w, a[n].b) for n in ("q", "k", "v", "o")])
+        w = SamDecC()
+        w.C, w.heads, w.depth = dec.C, 8, len(dec.layers)
+        w.no_mask, w.key_pe, w.out_tokens = dec.no_mask.data_ptr(), dec.key_pe.data_ptr(), dec.out_tokens.data_ptr()
+        for i, L in enumerate(dec.layers):
+            norms = [t for k in ("norm1", "norm2", "norm3", "norm4") for t in (L[k].w.data_ptr(), L[k].b.data_ptr())]
+            w.layers[i] = DecLayerC(attn(L["self_attn"]), attn(L["t2i"]), attn(L["i2t"]), *norms, _lin_c(L["lin1"].w, L["lin1"].b),
+                                    _lin_c(L["lin2"].w, L["lin2"].b))
+        w.final_attn = attn(dec.final_attn)
+        w.norm_final_w, w.norm_final_b = dec.norm_final.w.data_ptr(), dec.norm_final.b.data_ptr()
+        w.up_ln_w, w.up_ln_b = dec.up_ln.w.data_ptr(), dec.up_ln.b.data_ptr()
+        w.up0, w.up1 = _lin_c(dec.up0_w, dec.up0_b), _lin_c(dec.up1_w, dec.up1_b)
+        for j in range(3):
+            w.hyper[j] = _lin_c(dec.hyper0[j].w, dec.hyper0[j].b)
+            w.iou[j] = _lin_c(dec.iou[j].w, dec.iou[j].b)
+        self.w = w
+        self.mlp_dim = dec.layers[0]["lin1"].w.shape[0]
+
+    def __call__(self, image_embeddings, text_embeds):
+        """image_embeddings fp32 [V, g*g, C], text_embeds fp32 [1, T, C] -> (low_res f32 [V,1,4g,4g], iou f32 [V,1])."""
+        lib = _lib.load()
+        V, HW, Cc = image_embeddings.shape
+        g = self.d.grid
+        emb = image_embeddings.to(torch.float32).contiguous()
+        txt = text_embeds[0].to(torch.float32).contiguous()
+        low = torch.empty(V, 4 * g, 4 * g, dtype=torch.float32, device=emb.device)
+        iou = torch.empty(V, self.w.iou[2].n, dtype=torch.float32, device=emb.device)
+        nbytes = lib.ivlm_sam_decode_workspace_bytes(V, g, Cc, txt.shape[0], self.mlp_dim)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)
+        check(lib.ivlm_sam_decode(C.byref(self.w), V, g, txt.shape[0], emb.data_ptr(), txt.data_ptr(), low.data_ptr(),
+                                  iou.data_ptr(), ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "sam_decode")
+        return low.unsqueeze(1), iou[:, 0:1]

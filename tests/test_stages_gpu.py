@@ -55,3 +55,61 @@ def test_llama_prefill_and_decode_step_equal_python_path(hip_lib, cuda, hidden, 
                                     b.rope[0].data_ptr(), b.rope[1].data_ptr(), emb.data_ptr(), posb.data_ptr(), 0,
                                     hb[0].data_ptr(), st._dws.data_ptr(), 1024, None)
     assert rc == -2
+
+
+def test_clip_encode_stage_equals_python_path(hip_lib, cuda):
+    import torch
+
+    from interactvlm_amd import llava, stages
+    from interactvlm_amd import weights as Wt
+
+    cc = Wt.ClipCfg(hidden=256, layers=4, heads=4, inter=512)
+    w = Wt.synth_weights(Wt.clip_spec(cc))
+    tower = llava.ClipTower(w, cc, cuda)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 3, 224, 224, generator=g).to(torch.bfloat16).to(cuda)
+    ref = tower._forward(x)
+    got = stages.ClipStages(tower)(x)
+    assert got.shape == ref.shape and torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+
+
+@pytest.mark.parametrize("V", [1, 4])
+def test_sam_encode_stage_equals_python_path(hip_lib, cuda, V):
+    """ivlm_sam_encode (device-built window maps, scatter / gather row maps in the q|k|v and proj GEMMs, rel-pos through the
+    batched GEMM for global blocks and the dot kernel for windows, neck) == SamImageEncoder._forward bit for bit, at the real
+    ViT-H layer dimensions (2 windowed + 2 global blocks)."""
+    import torch
+
+    from interactvlm_amd import sam, stages
+    from interactvlm_amd import weights as Wt
+
+    c = Wt.SamEncCfg(depth=4, global_attn_indexes=(1, 3))
+    w = Wt.synth_weights(Wt.sam_encoder_spec(c))
+    enc = sam.SamImageEncoder(w, c, cuda)
+    g = torch.Generator().manual_seed(V)
+    x = torch.randn(V, 3, 1024, 1024, generator=g).to(torch.bfloat16).to(cuda)
+    ref = enc._forward(x)
+    got = stages.SamEncodeStages(enc)(x)
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("V", [4, 1])
+def test_sam_decode_stage_equals_python_path(hip_lib, cuda, V):
+    """ivlm_sam_decode (the whole fp32-activation prompt-encoder / two-way-transformer / upscaler / hypernetwork chain as one C
+    call) == SamMaskDecoder._forward bit for bit."""
+    import torch
+
+    from interactvlm_amd import sam, stages, synth
+    from interactvlm_amd import weights as Wt
+
+    w = Wt.synth_weights({**Wt.prompt_encoder_spec(), **Wt.mask_decoder_spec()})
+    dec = sam.SamMaskDecoder(w, cuda)
+    emb = torch.from_numpy(synth.synth_normal(f"samdec/image_emb/{V}", (V, 256, 64, 64), 1.0, 0))
+    emb = emb.permute(0, 2, 3, 1).reshape(V, 4096, 256).contiguous().to(cuda)
+    text = torch.from_numpy(synth.synth_normal(f"samdec/text/{V}", (1, V, 256), 1.0, 0)).to(cuda)
+    low_r, iou_r = dec._forward(emb, text)
+    low, iou = stages.SamDecodeStages(dec)(emb, text)
+    assert low.shape == low_r.shape and iou.shape == iou_r.shape
+    assert torch.equal(low, low_r), float((low - low_r).abs().max())
+    assert torch.equal(iou, iou_r), float((iou - iou_r).abs().max())
