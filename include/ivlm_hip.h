@@ -172,6 +172,9 @@ int ivlm_gemv_tuning(int max_blocks_per_cu, int rows2_min_n);
 /* Benchmark/test hook for the skinny-M dispatch: rows M in [min_m, 16] against matrices with K, N >= 1024 go to the
  * split-K MFMA kernel (csrc/gemv_mfma.hip) instead of the wave-per-row GEMV / tile GEMM; 0 restores the automatic choice. */
 int ivlm_gemv_mfma_min_m(int min_m);
+/* Benchmark hook of the skinny MFMA kernel: 16-row weight tiles per block (1, 2, 3, 4 or 6); 0 = the automatic choice
+ * (fewest blocks-per-CU x tiles, then the most tiles: 3 for the 12288 fused qkv rows, 6 for 22016 gate-up rows). */
+void ivlm_skinny_tuning(int tiles_per_block);
 
 /* Benchmark hook: column split of GEMMs whose 256 x 256 tile count under-fills its last round (default 1 = on). */
 int ivlm_gemm_nsplit(int on);

@@ -17,10 +17,13 @@ def main():
     ap.add_argument("--steps", type=int, default=23)
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--nofuse", action="store_true")
+    ap.add_argument("--tiles", type=int, default=0, help="skinny MFMA tiles per block (0 = automatic)")
     a = ap.parse_args()
     from interactvlm_amd import llava, synthetic
     from interactvlm_amd import weights as Wt
+    from interactvlm_amd import _lib
 
+    _lib.load().ivlm_skinny_tuning(a.tiles)
     dev = torch.device("cuda:0")
     cfg = (synthetic.config_7b() if a.model == "7b" else synthetic.config_13b()).llama
     spec = Wt.llama_spec(cfg)
