@@ -451,7 +451,7 @@ def main():
               "unit": "GB/s", "frac": round(la / PEAK_HBM_GBPS, 4), "traffic": None,
               "algorithmic_bytes": int(l["work"] / l["launches"]), "avg_us": round(l["avg_us"], 2)}
         va = gv["work"] / gv["total_s"] / 1e9
-        rv = {"bound": "hbm", "kernel": "gemv_kernel (decode linears: weight streaming)", "achieved": round(va, 1),
+        rv = {"bound": "hbm", "kernel": "gemv1_kernel + gemv_kernel (decode linears: weight streaming)", "achieved": round(va, 1),
               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(va / PEAK_HBM_GBPS, 4), "traffic": None,
               "algorithmic_bytes": int(gv["work"] / gv["launches"]), "launches_per_image": gv["launches"] // nsteps,
               "avg_us": round(gv["avg_us"], 2), "ms_per_image": round(gv["total_s"] / nsteps * 1e3, 2)}

@@ -167,8 +167,11 @@ int ivlm_gemm_bf16_splitk(const void *A, int64_t lda, const void *W, int64_t ldw
                           int act, int out_f32, int splits, void *workspace, size_t workspace_bytes, int flags,
                           ivlm_stream_t stream);
 /* Benchmark hook of the GEMV grid shaping: resident blocks per CU assumed (default 4) and the N above which a wave takes two
- * weight rows per step (default 8192); 0 = default. */
+ * weight rows per step (default 8192); 0 = default.  max_blocks_per_cu < 0: the persistent kernel also serves M = 1 fp32 rows
+ * (which otherwise take gemv1_kernel: one row per wave, 1024-thread blocks, no persistence). */
 int ivlm_gemv_tuning(int max_blocks_per_cu, int rows2_min_n);
+/* Benchmark hook of the batch-1 decode GEMV (gemv1_kernel): waves per weight row (1 or 2); 0 = default (1). */
+void ivlm_gemv1_tuning(int ksplit);
 /* Benchmark/test hook for the skinny-M dispatch: rows M in [min_m, 16] against matrices with K, N >= 1024 go to the
  * split-K MFMA kernel (csrc/gemv_mfma.hip) instead of the wave-per-row GEMV / tile GEMM; 0 restores the automatic choice. */
 int ivlm_gemv_mfma_min_m(int min_m);
@@ -251,6 +254,8 @@ int ivlm_llama_decode_attn_batch(const void *qkv, int io_dtype, int64_t ldq, voi
 typedef struct {
     int layers, hidden, heads, inter, max_len;
     float eps, theta;
+    int fuse_attn_oproj; /* decode step: attention + o_proj in ONE launch (o_proj blocks wait on device counters) when the grid
+                          * fits the chip; 0 (default of the Python host) = separate launches - as fast since gemv1_kernel */
 } ivlm_llama_cfg;
 typedef struct {
     const void *ln1, *qkv, *o, *ln2, *gu, *down;

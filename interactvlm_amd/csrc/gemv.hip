@@ -59,6 +59,10 @@ __device__ __forceinline__ float dot8f(const u32x4_t& w, const f32x4v_t& xa, con
     return acc;
 }
 
+__device__ __forceinline__ float gemm_residual_f32_or_bf16(const GemmArgs& g, int64_t col) {  // row 0 (M = 1)
+    return g.res_f32 ? reinterpret_cast<const float*>(g.residual)[col] : bf16_to_f32(g.residual[col]);
+}
+
 template <int M, int ROWS, bool RMS, bool XLDS, bool AF32>
 __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -249,6 +253,130 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     }
 }
 
+// ---- batch-1 decode GEMV (M = 1, fp32 x): the kernel every generated token runs 4 x 32 + 1 times --------------------
+// Measured against pure streaming reads of the same matrices (tools/experiments/exp_access_pattern.hip: 6.4 TB/s for one
+// row per wave, 1 KB per wave instruction), the persistent software-pipelined kernel above reaches 80 %; the SIMPLEST
+// shape does better: 1024-thread blocks, ONE weight row per wave, one pass, no persistence - the hardware dispatcher
+// balances the CUs, 32 resident waves per CU hide the latency, and x is staged once per 16 rows (16 KB of L2 reads per
+// 128 KB of weights).  Same arithmetic as gemv_kernel<1, 1, RMS, true, true> (fp32 x in two LDS planes, exact products,
+// per-lane ascending chunk order), so results are identical up to the block-level sum(x^2) order of the RMS prologue.
+constexpr int kG1Waves = 16;
+
+// (KS = 2 waves per weight row - K halves, partial sums through LDS - was measured for the 4096-row matrices, which put only
+//  16 waves on each CU: 3-6 % slower on every shape.  KS stays a template parameter for that A/B: ivlm_gemv1_tuning.)
+template <bool RMS, int KS>
+__global__ __launch_bounds__(64 * kG1Waves, 8) void gemv1_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float s_red[kG1Waves];
+    __shared__ float s_val[kG1Waves];
+    constexpr int U = 8 / KS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = g.K >> 3;
+    f32x4v_t* xf = reinterpret_cast<f32x4v_t*>(smem);  // [2 planes][nchunk] float4
+    const int row = blockIdx.x * (kG1Waves / KS) + wave / KS;
+    const bool live = row < g.N;
+    const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(g.W + (int64_t)(live ? row : g.N - 1) * g.ldw);
+    // this wave's chunk range (multiples of 64 chunks = 1 KB of the row per wave instruction)
+    const int cpp = KS == 1 ? nchunk : ((nchunk + 64 * KS - 1) / (64 * KS)) * 64;
+    const int c_lo = (wave % KS) * cpp, c_hi = min(nchunk, c_lo + cpp);
+    u32x4_t w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wp + min(c_lo + lane + 64 * u, nchunk - 1));
+    // ---- stage x (x * gamma) in LDS, sum(x^2) ----
+    float ssq = 0.0f;
+    for (int c = threadIdx.x; c < nchunk; c += 64 * kG1Waves) {
+        const f32x4v_t* xp = reinterpret_cast<const f32x4v_t*>(g.A) + 2 * c;
+        f32x4v_t xa = xp[0], xb = xp[1];
+        if (RMS) {
+            const u32x4_t gv = *(reinterpret_cast<const u32x4_t*>(g.rms_w) + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ssq += xa[j] * xa[j] + xb[j] * xb[j];
+            xa[0] *= __uint_as_float(gv[0] << 16); xa[1] *= __uint_as_float(gv[0] & 0xffff0000u);
+            xa[2] *= __uint_as_float(gv[1] << 16); xa[3] *= __uint_as_float(gv[1] & 0xffff0000u);
+            xb[0] *= __uint_as_float(gv[2] << 16); xb[1] *= __uint_as_float(gv[2] & 0xffff0000u);
+            xb[2] *= __uint_as_float(gv[3] << 16); xb[3] *= __uint_as_float(gv[3] & 0xffff0000u);
+        }
+        xf[c] = xa;
+        xf[nchunk + c] = xb;
+    }
+    if (RMS) {
+        ssq = wave_sum(ssq);
+        if (lane == 0) s_red[wave] = ssq;
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    for (int c = c_lo + lane; c < c_hi; c += 64 * U) {
+        if (c != c_lo + lane) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c + 64 * u < c_hi) w[u] = __builtin_nontemporal_load(wp + c + 64 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cc = c + 64 * u;
+            if (cc < c_hi) acc += dot8f(w[u], xf[cc], xf[nchunk + cc]);
+        }
+    }
+    acc = wave_sum(acc);
+    if (KS > 1) {  // partial sums of the row's KS waves, added in part order
+        if (lane == 0) s_val[wave] = acc;
+        __syncthreads();
+        if (wave % KS) return;
+        acc = s_val[wave];
+#pragma unroll
+        for (int i = 1; i < KS; ++i) acc += s_val[wave + i];
+    }
+    if (RMS) {
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kG1Waves; ++i) q += s_red[i];
+        acc *= rsqrtf(q / (float)g.K + g.rms_eps);
+    }
+    float v = acc + ((g.bias && live) ? bf16_to_f32(g.bias[row]) : 0.0f);
+    if (KS == 1 && g.act == ACT_SWIGLU) {  // rows (gate_j, up_j) interleaved: the even wave finishes the pair
+        if (lane == 0) s_val[wave] = v;
+        __syncthreads();
+        if (lane != 0 || (wave & 1) || !live) return;
+        const float o = (v / (1.0f + __expf(-v))) * s_val[wave + 1];
+        const int64_t idx = row >> 1;
+        if (g.out_f32) static_cast<float*>(g.C)[idx] = o;
+        else static_cast<bf16_t*>(g.C)[idx] = f32_to_bf16(o);
+        return;
+    }
+    if (lane != 0 || !live) return;
+    v = act_apply(v, g.act);
+    if (g.residual) v += gemm_residual_f32_or_bf16(g, row);
+    if (g.out_f32) static_cast<float*>(g.C)[row] = v;
+    else static_cast<bf16_t*>(g.C)[row] = f32_to_bf16(v);
+}
+
+int g_gemv1_ksplit = 0;  // 0 = rule below (A/B hook: ivlm_gemv1_tuning)
+
+template <bool RMS, int KS>
+static void launch_gemv1_ks(const GemmArgs& g, hipStream_t st) {
+    static bool set = false;
+    auto kfn = gemv1_kernel<RMS, KS>;
+    if (!set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        set = true;
+    }
+    const int rows_per_block = kG1Waves / KS;
+    ivlm_launch(kfn, dim3((g.N + rows_per_block - 1) / rows_per_block), dim3(64 * kG1Waves), (size_t)g.K * 4, st, g);
+}
+
+static int launch_gemv1(const GemmArgs& g, hipStream_t st) {
+    int ks = g_gemv1_ksplit > 0 ? g_gemv1_ksplit : 1;
+    if (g.act == ACT_SWIGLU || g.K < 2048) ks = 1;
+    if (ks == 2) {
+        if (g.rms_w) launch_gemv1_ks<true, 2>(g, st);
+        else launch_gemv1_ks<false, 2>(g, st);
+    } else {
+        if (g.rms_w) launch_gemv1_ks<true, 1>(g, st);
+        else launch_gemv1_ks<false, 1>(g, st);
+    }
+    return ivlm_launch_status();
+}
+
 // first index of the row maximum (torch.argmax tie rule), one 1024-thread block per row, 16-byte loads
 // (the lm_head logits row is 128 KB: ~5 us instead of 38 us for the 256-thread scalar version)
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, int cols, int32_t* __restrict__ out) {
@@ -308,6 +436,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 // ends when the most loaded wave does): with `slots` = CUs x resident blocks per CU (LDS-limited: the fp32 x image of
 // down_proj is 44 KB), each wave takes g = ceil(groups / (4 * slots)) groups and the grid is ceil(groups / (4 g)) blocks.
 int g_gemv_max_blocks_per_cu = 0, g_gemv_rows2_min_n = 0;  // experiment hooks (0 = defaults)
+int g_gemv_legacy = 0;  // 1: M = 1 fp32 rows also take the persistent kernel (A/B hook of tools/bench_decode.py)
 static int gemv_cu_count() {
     static int cus = 0;
     if (cus == 0) {
@@ -368,6 +497,7 @@ int gemv_bf16(const GemmArgs& g, hipStream_t st) {
     if (!g.A || !g.W || !g.C || g.M <= 0 || g.M > kMaxM || g.N <= 0 || g.K <= 0) return IVLM_ERR_INVALID_ARG;
     if ((g.K & 7) || (g.lda & (g.a_f32 ? 3 : 7)) || (g.ldw & 7) || g.batch != 1) return IVLM_ERR_UNSUPPORTED;
     if (g.act == ACT_SWIGLU && ((g.N & 1) || g.residual)) return IVLM_ERR_UNSUPPORTED;
+    if (g.M == 1 && g.a_f32 && (size_t)g.K * 4 <= 60 * 1024 && !g_gemv_legacy) return launch_gemv1(g, st);
     switch (g.M) {
         case 1: return launch_gemv<1>(g, st);
         case 2: return launch_gemv<2>(g, st);
@@ -389,10 +519,13 @@ int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st)
 }  // namespace ivlm
 
 extern "C" int ivlm_gemv_tuning(int max_blocks_per_cu, int rows2_min_n) {  // benchmark hook: 0 = defaults
-    ivlm::g_gemv_max_blocks_per_cu = max_blocks_per_cu;
+    ivlm::g_gemv_legacy = max_blocks_per_cu < 0 ? 1 : 0;  // negative: the persistent kernel also for M = 1 fp32 rows
+    ivlm::g_gemv_max_blocks_per_cu = max_blocks_per_cu > 0 ? max_blocks_per_cu : 0;
     ivlm::g_gemv_rows2_min_n = rows2_min_n;
     return 0;
 }
+
+extern "C" void ivlm_gemv1_tuning(int ksplit) { ivlm::g_gemv1_ksplit = ksplit; }
 
 extern "C" int ivlm_argmax_f32(const float* x, int rows, int cols, int32_t* out, ivlm_stream_t stream) {
     ivlm_enter();

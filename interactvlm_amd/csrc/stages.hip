@@ -187,7 +187,7 @@ extern "C" int ivlm_llama_decode_step(const ivlm_llama_cfg* c, const ivlm_llama_
         IVLM_HIP_TRY(hipGetDevice(&dev));
         IVLM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const bool fuse = (Hd == 512 || Hd == 1024 || Hd == 4096 || Hd == 5120) && H + Hd / 32 <= cus;
+    const bool fuse = c->fuse_attn_oproj && (Hd == 512 || Hd == 1024 || Hd == 4096 || Hd == 5120) && H + Hd / 32 <= cus;
     const int64_t cache_layer = (int64_t)c->max_len * Hd;
     const float scale = 1.0f / sqrtf((float)D);
     const float* x = x_in;

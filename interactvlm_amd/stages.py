@@ -13,7 +13,7 @@ from ._lib import check
 
 class LlamaCfg(C.Structure):
     _fields_ = [("layers", C.c_int), ("hidden", C.c_int), ("heads", C.c_int), ("inter", C.c_int), ("max_len", C.c_int),
-                ("eps", C.c_float), ("theta", C.c_float)]
+                ("eps", C.c_float), ("theta", C.c_float), ("fuse_attn_oproj", C.c_int)]
 
 
 class LlamaLayer(C.Structure):
@@ -26,7 +26,7 @@ class LlamaStages:
     def __init__(self, llm):
         self.llm = llm
         c = llm.cfg
-        self.cfg = LlamaCfg(c.layers, c.hidden, c.heads, c.inter, llm.max_len, c.eps, c.theta)
+        self.cfg = LlamaCfg(c.layers, c.hidden, c.heads, c.inter, llm.max_len, c.eps, c.theta, 1 if llm.fuse_attn_oproj else 0)
         self.layers = (LlamaLayer * c.layers)(*[LlamaLayer(*[L[k].data_ptr() for k in ("ln1", "qkv", "o", "ln2", "gu", "down")])
                                                 for L in llm.layers])
         lib = _lib.load()

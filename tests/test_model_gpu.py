@@ -199,6 +199,7 @@ def test_graph_decode_with_fused_attn_oproj_matches_eager(hip_lib, cuda, hidden,
         hid_a.append(h)
         arg_a.append(int(ops.argmax(llm_a.logits(h))[0]))
     llm_b = llava.Llama(w, lc, cuda, max_len=64)
+    llm_b.fuse_attn_oproj = True  # (opt-in since round 2: the separate launches are as fast with gemv1_kernel)
     llm_b.forward(emb, 0)
     dg = llm_b.decode_graph()
     assert dg.get("fused") is not None

@@ -5,8 +5,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("hidden,heads,inter", [(1024, 8, 1376), (256, 2, 512)])
-def test_llama_prefill_and_decode_step_equal_python_path(hip_lib, cuda, hidden, heads, inter):
+@pytest.mark.parametrize("hidden,heads,inter,fuse", [(1024, 8, 1376, False), (1024, 8, 1376, True), (256, 2, 512, False)])
+def test_llama_prefill_and_decode_step_equal_python_path(hip_lib, cuda, hidden, heads, inter, fuse):
     import torch
 
     from interactvlm_amd import llava, stages
@@ -19,8 +19,10 @@ def test_llama_prefill_and_decode_step_equal_python_path(hip_lib, cuda, hidden, 
     emb = (torch.randn(T0 + n_new, hidden, generator=g) * 0.5).to(torch.bfloat16).float().to(cuda)
     # Python-sequenced reference: prefill, then decode steps through the captured graph (fused attention + o_proj where it applies)
     a = llava.Llama(w, lc, cuda, max_len=512)
+    a.fuse_attn_oproj = fuse  # (attention + o_proj in one launch: opt-in on both sides)
     ha = [a.forward(emb[:T0], 0)]
     dg = a.decode_graph()
+    assert (dg.get("fused") is not None) == fuse
     dg["pos"].fill_(T0)
     if dg.get("fused") is not None:
         for k in ("step", "counters", "status"):
@@ -35,6 +37,7 @@ def test_llama_prefill_and_decode_step_equal_python_path(hip_lib, cuda, hidden, 
             pos.add_(1)
     # C sequencers on a second instance (its own KV cache)
     b = llava.Llama(w, lc, cuda, max_len=512)
+    b.fuse_attn_oproj = fuse
     st = stages.LlamaStages(b)
     hb = [st.prefill(emb[:T0], 0)]
     st.start_generation()

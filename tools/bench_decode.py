@@ -16,7 +16,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--steps", type=int, default=23)
     ap.add_argument("--reps", type=int, default=8)
-    ap.add_argument("--nofuse", action="store_true")
+    ap.add_argument("--fuse", action="store_true", help="attention + o_proj in one launch (opt-in)")
+    ap.add_argument("--legacy", action="store_true", help="persistent GEMV kernel also for the M = 1 fp32 rows")
     ap.add_argument("--tiles", type=int, default=0, help="skinny MFMA tiles per block (0 = automatic)")
     a = ap.parse_args()
     from interactvlm_amd import llava, synthetic
@@ -24,6 +25,8 @@ def main():
     from interactvlm_amd import _lib
 
     _lib.load().ivlm_skinny_tuning(a.tiles)
+    if a.legacy:
+        _lib.load().ivlm_gemv_tuning(-1, 0)
     dev = torch.device("cuda:0")
     cfg = (synthetic.config_7b() if a.model == "7b" else synthetic.config_13b()).llama
     spec = Wt.llama_spec(cfg)
@@ -33,7 +36,7 @@ def main():
         w[k] = ((1.0 + 0.05 * t) if (len(shape) == 1) else t / float(shape[-1]) ** 0.5).to(torch.bfloat16)
         del t
     llm = llava.Llama(w, cfg, dev, max_len=1024)
-    llm.fuse_attn_oproj = not a.nofuse
+    llm.fuse_attn_oproj = a.fuse
     del w
     T0 = 330
     x = (torch.randn(T0, cfg.hidden, device=dev) * 0.5)

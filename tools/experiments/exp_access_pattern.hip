@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include "ivlm_hip.h"  // the library GEMV under the same conditions (link with -livlm_hip)
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 template <int U>
@@ -62,6 +63,134 @@ __global__ __launch_bounds__(512, 2) void rows16_interleaved(const u32x4_t* W, i
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// row1 + the GEMV's work: fp32 x staged in LDS per block (two float4 planes), exact products, wave reduce, store.
+// R rows per wave, one after the other; no software pipeline - occupancy (LDS: 4 K bytes per block) hides the row boundaries.
+typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+template <int U, int R>
+__global__ __launch_bounds__(256) void row1_dot(const u32x4_t* W, int64_t ldw16, int K, int N, const float* x, float* y) {
+    extern __shared__ f32x4v_t xf[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = K / 8;
+    const int row0 = (blockIdx.x * 4 + wave) * R;
+    u32x4_t w[U];
+    if (row0 < N) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(W + (int64_t)row0 * ldw16 + min(lane + 64 * u, nch - 1));
+    }
+    for (int c = threadIdx.x; c < nch; c += 256) {
+        const f32x4v_t* xp = reinterpret_cast<const f32x4v_t*>(x) + 2 * c;
+        xf[c] = xp[0];
+        xf[nch + c] = xp[1];
+    }
+    __syncthreads();
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        if (row >= N) return;
+        const u32x4_t* wp = W + (int64_t)row * ldw16;
+        float acc = 0.0f;
+        for (int c = lane; c < nch; c += 64 * U) {
+            if (c != lane || r != 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wp + min(c + 64 * u, nch - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cc = c + 64 * u;
+                if (cc < nch) {
+                    const f32x4v_t xa = xf[cc], xb = xf[nch + cc];
+                    acc = fmaf(__uint_as_float(w[u][0] << 16), xa[0], acc);
+                    acc = fmaf(__uint_as_float(w[u][0] & 0xffff0000u), xa[1], acc);
+                    acc = fmaf(__uint_as_float(w[u][1] << 16), xa[2], acc);
+                    acc = fmaf(__uint_as_float(w[u][1] & 0xffff0000u), xa[3], acc);
+                    acc = fmaf(__uint_as_float(w[u][2] << 16), xb[0], acc);
+                    acc = fmaf(__uint_as_float(w[u][2] & 0xffff0000u), xb[1], acc);
+                    acc = fmaf(__uint_as_float(w[u][3] << 16), xb[2], acc);
+                    acc = fmaf(__uint_as_float(w[u][3] & 0xffff0000u), xb[3], acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) y[row] = acc;
+    }
+}
+
+// v2: WAVES waves per block, each wave takes ROWS rows AT ONCE (x read from LDS once for all of them), single pass, no
+// persistence: the hardware dispatcher balances, occupancy hides latency
+template <int U, int ROWS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rowsN_dot(const u32x4_t* W, int64_t ldw16, int K, int N, const float* x, float* y) {
+    extern __shared__ f32x4v_t xf[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = K / 8;
+    const int row0 = (blockIdx.x * WAVES + wave) * ROWS;
+    const u32x4_t* wp[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) wp[r] = W + (int64_t)min(row0 + r, N - 1) * ldw16;
+    u32x4_t w[ROWS][U];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[r][u] = __builtin_nontemporal_load(wp[r] + min(lane + 64 * u, nch - 1));
+    for (int c = threadIdx.x; c < nch; c += 64 * WAVES) {
+        const f32x4v_t* xp = reinterpret_cast<const f32x4v_t*>(x) + 2 * c;
+        xf[c] = xp[0];
+        xf[nch + c] = xp[1];
+    }
+    __syncthreads();
+    if (row0 >= N) return;
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.0f;
+    for (int c = lane; c < nch; c += 64 * U) {
+        if (c != lane) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (c + 64 * u < nch) w[r][u] = __builtin_nontemporal_load(wp[r] + c + 64 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cc = c + 64 * u;
+            if (cc < nch) {
+                const f32x4v_t xa = xf[cc], xb = xf[nch + cc];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    float a = acc[r];
+                    a = fmaf(__uint_as_float(w[r][u][0] << 16), xa[0], a);
+                    a = fmaf(__uint_as_float(w[r][u][0] & 0xffff0000u), xa[1], a);
+                    a = fmaf(__uint_as_float(w[r][u][1] << 16), xa[2], a);
+                    a = fmaf(__uint_as_float(w[r][u][1] & 0xffff0000u), xa[3], a);
+                    a = fmaf(__uint_as_float(w[r][u][2] << 16), xb[0], a);
+                    a = fmaf(__uint_as_float(w[r][u][2] & 0xffff0000u), xb[1], a);
+                    a = fmaf(__uint_as_float(w[r][u][3] << 16), xb[2], a);
+                    a = fmaf(__uint_as_float(w[r][u][3] & 0xffff0000u), xb[3], a);
+                    acc[r] = a;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        float a = acc[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if (lane == 0 && row0 + r < N) y[row0 + r] = a;
+    }
+}
+
+template <int U, int ROWS, int WAVES>
+float run_rowsN(const u32x4_t* W, int64_t ld, int K, int N, const float* x, float* y, size_t lds) {
+    auto k = rowsN_dot<U, ROWS, WAVES>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    const int per = ROWS * WAVES;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    k<<<(N + per - 1) / per, 64 * WAVES, lds>>>(W, ld, K, N, x, y);
+    hipDeviceSynchronize();
+    return 0.f;
+}
+
 template <class F>
 float time_it(F f, int reps) {
     hipEvent_t a, b;
@@ -94,6 +223,43 @@ int main() {
         float i4 = time_it([&] { rows16_interleaved<4><<<sh.N / 16, 512>>>(W[it++ % nbuf], ld, sh.K, out); }, 30);
         float b4 = time_it([&] { row1<4><<<sh.N / 4, 256>>>(W[it++ % nbuf], ld, sh.K, sh.N, out); }, 30);
         float b8 = time_it([&] { row1<8><<<sh.N / 4, 256>>>(W[it++ % nbuf], ld, sh.K, sh.N, out); }, 30);
+        // the product GEMV (fp32 x, fp32 out; RMS prologue on the 12288 / 22016 shapes, SwiGLU on 22016, fp32 residual else)
+        float *x, *y, *res; void* gam;
+        hipMalloc(&x, sh.K * 4); hipMemset(x, 0, sh.K * 4);
+        hipMalloc(&y, sh.N * 4); hipMalloc(&res, sh.N * 4); hipMemset(res, 0, sh.N * 4);
+        hipMalloc(&gam, sh.K * 2); hipMemset(gam, 0, sh.K * 2);
+        const bool rms = sh.N > 4096, swiglu = sh.N == 22016;
+        for (int ks = 1; ks <= 2; ++ks) {
+        ivlm_gemv1_tuning(ks);
+        float gv = time_it([&] {
+            ivlm_gemm_bf16(x, sh.K, W[it++ % nbuf], sh.K, y, swiglu ? sh.N / 2 : sh.N, nullptr, rms ? nullptr : res, sh.N, 0, 1, sh.N,
+                           sh.K, swiglu ? 5 : 0, 1, 1, 0, 0, 0, 0, rms ? gam : nullptr, 1e-5f, rms ? 1 : 3, nullptr, nullptr, nullptr);
+        }, 30);
+        printf("    library GEMV (waves per row %d): %.2f TB/s (%.1f us)\n", ks, rate(gv), gv * 1e3);
+        }
+        ivlm_gemv1_tuning(0);
+        {
+            const size_t lds = (size_t)sh.K * 4;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(row1_dot<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(row1_dot<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(row1_dot<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(row1_dot<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(row1_dot<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            float d1 = time_it([&] { row1_dot<8, 1><<<(sh.N + 3) / 4, 256, lds>>>(W[it++ % nbuf], ld, sh.K, sh.N, x, y); }, 30);
+            float d2 = time_it([&] { row1_dot<8, 2><<<(sh.N + 7) / 8, 256, lds>>>(W[it++ % nbuf], ld, sh.K, sh.N, x, y); }, 30);
+            float d4 = time_it([&] { row1_dot<8, 4><<<(sh.N + 15) / 16, 256, lds>>>(W[it++ % nbuf], ld, sh.K, sh.N, x, y); }, 30);
+            float d8 = time_it([&] { row1_dot<8, 8><<<(sh.N + 31) / 32, 256, lds>>>(W[it++ % nbuf], ld, sh.K, sh.N, x, y); }, 30);
+            float e4 = time_it([&] { row1_dot<4, 4><<<(sh.N + 15) / 16, 256, lds>>>(W[it++ % nbuf], ld, sh.K, sh.N, x, y); }, 30);
+#define RUN(U, R, WV) { auto k = rowsN_dot<U, R, WV>; \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+            float t = time_it([&] { k<<<(sh.N + R * WV - 1) / (R * WV), 64 * WV, lds>>>(W[it++ % nbuf], ld, sh.K, sh.N, x, y); }, 30); \
+            printf(" U%d R%d W%d %.2f", U, R, WV, rate(t)); }
+            printf("    rowsN_dot:");
+            RUN(8, 1, 4) RUN(8, 1, 8) RUN(8, 1, 16) RUN(4, 2, 4) RUN(4, 2, 8) RUN(4, 2, 16) RUN(8, 2, 8) RUN(8, 2, 16) RUN(4, 4, 8) RUN(4, 4, 16) RUN(2, 4, 16)
+            printf(" TB/s\n");
+            printf("    row1_dot (x in LDS, dot, reduce) U8: R1 %.2f R2 %.2f R4 %.2f R8 %.2f | U4 R4 %.2f TB/s\n", rate(d1), rate(d2), rate(d4),
+                   rate(d8), rate(e4));
+        }
         printf("N %5d K %5d (%.0f MB): rows16 U4 %.2f U8 %.2f  interleaved U4 %.2f | row1 U4 %.2f U8 %.2f TB/s\n", sh.N, sh.K,
                bytes / 1e6, rate(a4), rate(a8), rate(i4), rate(b4), rate(b8));
         for (int i = 0; i < nbuf; ++i) hipFree(W[i]);
