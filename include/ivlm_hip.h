@@ -147,6 +147,17 @@ int ivlm_gemm_bf16(const void *A, int64_t lda, const void *W, int64_t ldw, void 
                    int64_t strideR, const void *rms_w, float rms_eps, int flags, const int32_t *out_rows,
                    const int32_t *a_rows, ivlm_stream_t stream);
 
+/* The tile GEMM (M > 16, bf16, batch 1, K % 64 == 0) with operands and / or output in the K-PANEL layout: a matrix [rows, K] stored
+ * as K/64 panels of [rows][64] elements, element (r, k) at (k/64) * kstep + r * 64 + (k % 64) (kstep >= 64 * rows, in elements).
+ * One wave DMA instruction of the kernels (8 rows x 128 B of a K tile) then reads 1 KB contiguous instead of eight lines a row
+ * stride apart: 78 instead of 52 GB/s of L2-hit feed per CU, the ceiling of the 256 x 256 kernel.  a_kstep / w_kstep
+ * = 0: that operand is row-major (lda / ldw).  c_panel != 0: bf16 C written in the panel layout (N % 64 == 0; ldc ignored) for
+ * the GEMM that consumes it; out_rows / a_rows only with row-major C / A.  The SAM encoder's weights are panelised once at
+ * load, norm1 / norm2 and the mlp lin1 epilogue write panels (image_encoder.py:150-260). */
+int ivlm_gemm_bf16_panel(const void *A, int64_t lda, int64_t a_kstep, const void *W, int64_t ldw, int64_t w_kstep, void *C,
+                         int64_t ldc, int64_t c_panel, const void *bias, const void *residual, int64_t ldr, int M, int N, int K,
+                         int act, int out_f32, int flags, const int32_t *out_rows, const int32_t *a_rows, ivlm_stream_t stream);
+
 /* fp8 (OCP e4m3) operands for the big GEMMs (BASELINE.json configs[4]): C = act((A8 . W8^T) * *scale_a *
  * *scale_w + bias) + residual on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, fp32 accumulation, the tile kernels
  * of ivlm_gemm_bf16 (same tiles, DMA and epilogues; half the K tiles).  A [M,K] / W [N,K] are byte matrices (K, lda, ldw in

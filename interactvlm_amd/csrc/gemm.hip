@@ -61,6 +61,9 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
     const bf16_t* srcA[PA];
     const bf16_t* srcW[PW];
     int kcolA[PA], kcolW[PW];  // first K index of the chunk this lane copies (per piece)
+    // row stride / K-tile step of each operand: (lda, 64) row-major, (64, kstep) in the K-panel layout
+    const int64_t a_rs = g.a_kstep ? 64 : g.lda, a_ks = g.a_kstep ? g.a_kstep : BK;
+    const int64_t w_rs = g.w_kstep ? 64 : g.ldw, w_ks = g.w_kstep ? g.w_kstep : BK;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         const int row = (wave * PA + i) * 8 + (lane >> 3);
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
         int ra = m0 + row;
         ra = ra < g.M ? ra : g.M - 1;
         if (g.a_rows) ra = g.a_rows[ra];
-        srcA[i] = A + (int64_t)ra * g.lda + chunk * 8;
+        srcA[i] = A + (int64_t)ra * a_rs + chunk * 8;
     }
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
         kcolW[i] = chunk * 8;
         int rw = n0 + row;
         rw = rw < g.N ? rw : g.N - 1;
-        srcW[i] = W + (int64_t)rw * g.ldw + chunk * 8;
+        srcW[i] = W + (int64_t)rw * w_rs + chunk * 8;
     }
     auto stage = [&](int buf, int kt) {
         unsigned char* baseA = smem + buf * kStageBytes + wave * PA * 1024;
@@ -86,9 +89,9 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
         const int koff = kt * BK;
         const bf16_t* zero = reinterpret_cast<const bf16_t*>(kGemmZeroChunk);
 #pragma unroll
-        for (int i = 0; i < PA; ++i) glds16(kcolA[i] + koff < g.K ? srcA[i] + koff : zero, baseA + i * 1024);
+        for (int i = 0; i < PA; ++i) glds16(kcolA[i] + koff < g.K ? srcA[i] + kt * a_ks : zero, baseA + i * 1024);
 #pragma unroll
-        for (int i = 0; i < PW; ++i) glds16(kcolW[i] + koff < g.K ? srcW[i] + koff : zero, baseW + i * 1024);
+        for (int i = 0; i < PW; ++i) glds16(kcolW[i] + koff < g.K ? srcW[i] + kt * w_ks : zero, baseW + i * 1024);
     };
 
     // ---- fragment read offsets (bytes within a tile), constant over the K loop ---------------
@@ -251,8 +254,9 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
         if (rc != IVLM_OK) return rc;
         b.N = g.N - n1;
         b.tile = 64;
-        b.W = g.W + (int64_t)n1 * g.ldw;
-        b.C = static_cast<char*>(g.C) + (size_t)n1 * (g.out_fp8 ? 1 : (g.out_f32 ? 4 : 2));
+        b.W = g.W + (int64_t)n1 * (g.w_kstep ? 64 : g.ldw);
+        b.C = g.c_panel ? static_cast<char*>(g.C) + (size_t)(n1 / 64) * g.c_panel * 2  // (n1 % 256 == 0: whole panels)
+                        : static_cast<char*>(g.C) + (size_t)n1 * (g.out_fp8 ? 1 : (g.out_f32 ? 4 : 2));
         if (g.bias) b.bias = g.bias + n1;
         if (g.residual) b.residual = g.residual + (g.res_f32 ? 2 * n1 : n1);
         return gemm_bf16(b, st);
@@ -262,6 +266,12 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
     if (g.act == ACT_SWIGLU && ((g.N & 3) || g.residual)) return IVLM_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) return IVLM_ERR_INVALID_ARG;
     if (g.a_f32) return IVLM_ERR_UNSUPPORTED;
+    if (g.a_kstep || g.w_kstep || g.c_panel) {  // K-panel layouts: bf16, whole 64-wide panels, plain epilogues
+        if (g.fp8 || g.out_fp8 || (g.K & 63) || g.batch != 1 || g.act == ACT_SWIGLU) return IVLM_ERR_UNSUPPORTED;
+        if ((g.a_kstep && (g.a_kstep < (int64_t)64 * g.M || (g.a_kstep & 7) || g.a_rows)) || (g.w_kstep && (g.w_kstep < (int64_t)64 * g.N || (g.w_kstep & 7))))
+            return IVLM_ERR_INVALID_ARG;
+        if (g.c_panel && (g.out_f32 || (g.N & 63) || g.c_panel < (int64_t)64 * g.M || g.out_rows)) return IVLM_ERR_UNSUPPORTED;
+    }
     if (g.fp8) {
         if (!g.scale_a || !g.scale_w || (g.out_fp8 && (!g.scale_out || g.out_f32 || (g.ldc & 3)))) return IVLM_ERR_INVALID_ARG;
         // (only the epilogues the SAM encoder uses are instantiated for fp8 operands)
@@ -413,6 +423,31 @@ extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     g.batch = batch < 1 ? 1 : batch;
     g.strideA = strideA; g.strideW = strideW; g.strideC = strideC; g.strideR = strideR;
     return ivlm::linear_bf16(g, ivlm_stream(stream));
+}
+
+extern "C" int ivlm_gemm_bf16_panel(const void* A, int64_t lda, int64_t a_kstep, const void* W, int64_t ldw, int64_t w_kstep, void* C,
+                                    int64_t ldc, int64_t c_panel, const void* bias, const void* residual, int64_t ldr, int M, int N,
+                                    int K, int act, int out_f32, int flags, const int32_t* out_rows, const int32_t* a_rows,
+                                    ivlm_stream_t stream) {
+    ivlm_enter();
+    if (M <= 16) return IVLM_ERR_UNSUPPORTED;  // tile GEMM only
+    ivlm::GemmArgs g;
+    g.out_rows = out_rows;
+    g.a_rows = a_rows;
+    g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
+    if (flags & IVLM_GEMM_A_F32) return IVLM_ERR_UNSUPPORTED;
+    g.tile = g_tile_override;
+    g.A = static_cast<const bf16_t*>(A);
+    g.W = static_cast<const bf16_t*>(W);
+    g.C = C;
+    g.bias = static_cast<const bf16_t*>(bias);
+    g.residual = static_cast<const bf16_t*>(residual);
+    g.lda = a_kstep ? 64 : lda; g.ldw = w_kstep ? 64 : ldw; g.ldc = ldc; g.ldr = ldr;
+    g.a_kstep = a_kstep; g.w_kstep = w_kstep; g.c_panel = c_panel;
+    g.M = M; g.N = N; g.K = K;
+    g.act = act;
+    g.out_f32 = out_f32;
+    return ivlm::gemm_bf16(g, ivlm_stream(stream));
 }
 
 extern "C" int ivlm_gemm_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias,

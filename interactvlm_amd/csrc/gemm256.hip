@@ -48,6 +48,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     const int chunk = (lane & 7) ^ ((lr0 >> 1) & 7);        // source chunk landing in LDS chunk lane & 7 (same for lr0+64)
     const int kcol = chunk * 8;
     const bf16_t* src[4][2];  // [kind][piece]
+    // row stride / K-tile step of each operand: (lda, 64) row-major, (64, kstep) in the K-panel layout (kernels.h)
+    const int64_t a_rs = g.a_kstep ? 64 : g.lda, a_ks = g.a_kstep ? g.a_kstep : kBK;
+    const int64_t w_rs = g.w_kstep ? 64 : g.ldw, w_ks = g.w_kstep ? g.w_kstep : kBK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -55,10 +58,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
             int ra = m0 + i * 128 + q * 64 + lr0;            // A half q: local row i*64 + lr0 = wave row i, quadrant row lr0
             ra = ra < g.M ? ra : g.M - 1;
             if (g.a_rows) ra = g.a_rows[ra];
-            src[q == 0 ? 0 : 3][i] = A + (int64_t)ra * g.lda + kcol;
+            src[q == 0 ? 0 : 3][i] = A + (int64_t)ra * a_rs + kcol;
             int rn = n0 + (2 * i + (lr0 >> 5)) * 64 + q * 32 + (lr0 & 31);  // B half q: local row i*64+lr0 = wave col, col
             rn = rn < g.N ? rn : g.N - 1;
-            src[q == 0 ? 1 : 2][i] = W + (int64_t)rn * g.ldw + kcol;
+            src[q == 0 ? 1 : 2][i] = W + (int64_t)rn * w_rs + kcol;
         }
     }
     const int nt = (g.K + kBK - 1) / kBK;
@@ -68,8 +71,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     // half-tile `kind` of K tile `tile` -> its slot (tiles past the end stream the zero chunk: keeps vmcnt uniform)
     auto stage = [&](int kind, int tile) {
         unsigned char* dst = dma_base + (tile & 1) * kTileLds + kind * kHalfBytes;
-        const int koff = tile * kBK;
-        const bool ok = tile < nt && kcol + koff < g.K;
+        const bool ok = tile < nt && kcol + tile * kBK < g.K;
+        const int64_t koff = tile * ((kind == 0 || kind == 3) ? a_ks : w_ks);
         glds16(ok ? src[kind][0] + koff : zero, dst);
         glds16(ok ? src[kind][1] + koff : zero, dst + 8192);
     };

@@ -128,7 +128,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
                 v[3] += bf16_to_f32((bf16_t)(r2.y >> 16));
             }
         }
-        const int64_t o = (int64_t)m * g.ldc + n;
+        const int64_t o = g.c_panel ? (int64_t)(n >> 6) * g.c_panel + (int64_t)m * 64 + (n & 63) : (int64_t)m * g.ldc + n;
         if (g.out_fp8) {  // e4m3 output with the consumer's calibrated per-tensor scale (mlp1 -> mlp2)
             const float inv = 1.0f / (*g.scale_out);
             uint32_t w = 0;

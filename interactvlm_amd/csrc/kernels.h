@@ -24,6 +24,14 @@ struct GemmArgs {
     // gather prologue (tile GEMM only): row m of the product reads row a_rows[m] of A (all entries valid).  SAM's proj GEMM of
     // a windowed block runs on the 16384 real rows only, reading them from their window positions.
     const int32_t* a_rows = nullptr;
+    // K-panel operand layouts (tile GEMM only, bf16, K % 64 == 0): the matrix is stored as K/64 panels of [rows][64] elements,
+    // element (r, k) at (k / 64) * kstep + r * 64 + (k % 64), kstep >= rows * 64.  One wave DMA instruction (8 rows x 128 B of a
+    // K tile) then reads 1 KB CONTIGUOUS instead of eight 128-byte lines one row stride apart - measured 78 instead of 52
+    // GB/s of L2-hit feed per CU (tools/experiments/exp_l2_feed.hip), the ceiling of the 256 x 256 kernel.  0 = row-major.
+    int64_t a_kstep = 0, w_kstep = 0;
+    // c_panel != 0: bf16 C written in the same K-panel layout (for the GEMM that consumes it): (m, n) at
+    // (n / 64) * c_panel + m * 64 + (n % 64); ldc is ignored.
+    int64_t c_panel = 0;
     // fp8 (OCP e4m3) operands on the MX matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales): A and W are
     // BYTE matrices [M,K] / [N,K]; K, lda, ldw are then given in 2-byte units (K_fp8 / 2) so that tiles, DMA and LDS images
     // are byte-identical to the bf16 path.  The fp32 accumulator is multiplied by *scale_a * *scale_w (per-tensor scales in
