@@ -152,7 +152,24 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
         }
     }
 
-    // ---- epilogue: lane holds C[m][n..n+3], m = l&15, n = (l>>4)*4 -----------------------------
+    // ---- epilogue: whole lines through LDS where the wave's rows are 128 / 256 bytes (gemm_common.h) ----------------
+    {
+        constexpr int kRowBytes = NI * 16 * (OUT_F32 ? 4 : 2);
+        if constexpr (kRowBytes == 128 || kRowBytes == 256) {
+            constexpr int kBudget = CFG::kLdsBytes / CFG::kWaves;  // this wave's slice of the (now free) tile buffers
+            constexpr int kFit = kBudget / (16 * kRowBytes);
+            constexpr int kPass = kFit >= MI ? MI : (kFit >= 4 ? 4 : (kFit >= 2 ? 2 : (kFit >= 1 ? 1 : 0)));
+            if constexpr (kPass > 0 && MI % kPass == 0) {
+                if (gemm_whole_lines_ok<OUT_F32>(g, ACT)) {
+                    __syncthreads();  // every wave is done with the last K tile
+                    gemm_store_lines<ACT, OUT_F32, MI, NI, kPass>(g, smem + wave * kBudget, m0 + wm * (MI * 16), n0 + wn * (NI * 16),
+                                                                  lane, acc);
+                    return;
+                }
+            }
+        }
+    }
+    // direct fragment stores: lane holds C[m][n..n+3], m = l&15, n = (l>>4)*4
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm * (MI * 16) + mi * 16 + (lane & 15);

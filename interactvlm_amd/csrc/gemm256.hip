@@ -169,7 +169,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #undef IVLM_PHASE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-chunk DMAs must not outlive the block's LDS
 
-    // ---- epilogue: lane holds C[m][n..n+3], m = lane & 15, n = (lane >> 4) * 4 --------------------------------------------
+    // ---- epilogue: whole lines through LDS (gemm_common.h), direct fragment stores for what that does not cover --------------
+    if (gemm_whole_lines_ok<OUT_F32>(g, ACT)) {
+        __syncthreads();  // every wave is done with the K tiles
+        // acc is [n fragment][m fragment]; 16 KB of LDS per wave: the bf16 sub-tile in one pass, the fp32 one in two halves
+        gemm_store_lines<ACT, OUT_F32, 8, 4, OUT_F32 ? 4 : 8>(g, smem + wave * 16384, m0 + wr * 128, n0 + wc * 64, lane, acc);
+        return;
+    }
+    // direct stores (SwiGLU, fp8 output, ragged N, bf16 residual with bf16 output)
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int m = m0 + wr * 128 + mi * 16 + (lane & 15);

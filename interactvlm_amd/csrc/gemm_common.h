@@ -29,8 +29,11 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
-    const float q = 0.5f * p * t * __expf(-z * z);  // 0.5 * erfc(z)
-    return x * (x < 0.0f ? q : 1.0f - q);
+    // (every multiply-add is an explicit fma: the result must not depend on which contractions the compiler picks in the
+    //  caller's context - the direct and the LDS-staged epilogues of the same GEMM are compared bit for bit)
+    const float a = 0.5f * p * t, e = __expf(-z * z);
+    const float q = a * e;  // 0.5 * erfc(z)
+    return x * (x < 0.0f ? q : fmaf(-a, e, 1.0f));
 }
 
 __device__ __forceinline__ float gemm_act(float x, int act) {
@@ -72,6 +75,109 @@ __device__ __forceinline__ void gemm_tile_origin(const GemmArgs& g, int BM, int 
 // one residual element (bf16 or fp32 stream)
 __device__ __forceinline__ float gemm_residual_at(const GemmArgs& g, const bf16_t* R, int64_t idx) {
     return g.res_f32 ? reinterpret_cast<const float*>(R)[idx] : bf16_to_f32(R[idx]);
+}
+
+// bias + activation of one accumulator fragment (the lane owns columns n .. n+3; N % 4 == 0, n < N): the value part of the
+// epilogue, for kernels that stage the tile through LDS and store whole lines (gemm256.hip)
+template <int ACT>
+__device__ __forceinline__ void gemm_value4(const GemmArgs& g, int n, const f32x4_t& acc, float (&v)[4]) {
+    v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2]; v[3] = acc[3];
+    if (g.fp8) {
+        const float alpha = (*g.scale_a) * (*g.scale_w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= alpha;
+    }
+    if (g.bias) {
+        const uint2 b2 = *reinterpret_cast<const uint2*>(g.bias + n);
+        v[0] += bf16_to_f32((bf16_t)(b2.x & 0xffff));
+        v[1] += bf16_to_f32((bf16_t)(b2.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(b2.y & 0xffff));
+        v[3] += bf16_to_f32((bf16_t)(b2.y >> 16));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = gemm_act(v[j], ACT);
+}
+
+// ---- whole-line epilogue ------------------------------------------------------------------------------------------
+// A lane holds C[m][n..n+3] (m = lane & 15, n = (lane >> 4) * 4) of each 16 x 16 fragment: stored directly, one wave instruction
+// touches 16 rows x 32 (bf16) / 64 (fp32) bytes - 16 PARTIAL cache lines - and the 32 fragments of a 128 x 64 wave tile cost
+// ~15 us per 256 x 256 block tile, a quarter to a third of the SAM GEMMs (ablation of gemm256_kernel at M = 65536: qkv 806 ->
+// 589 us, mlp1 1204 -> 680 us without the epilogue; tools/experiments/README.md).  After the K loop the tile buffers are free:
+// each wave transposes its sub-tile through its own slice of LDS (chunk swizzle: conflict-free both ways) and then writes - and
+// reads the residual as - WHOLE lines: 8 rows x 128 B or 4 rows x 256 B per wave instruction.  Same values, same order of
+// operations per element as gemm_epilogue4 (bit-identical results).
+template <bool OUT_F32>
+__device__ __forceinline__ bool gemm_whole_lines_ok(const GemmArgs& g, int act) {
+    return act != ACT_SWIGLU && !g.out_fp8 && g.batch == 1 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+           (OUT_F32 ? ((g.N & 3) == 0 && (g.ldc & 3) == 0 && (!g.residual || (g.ldr & 3) == 0))
+                    : ((g.N & 7) == 0 && !g.residual && (g.c_panel ? (g.c_panel & 7) == 0 : (g.ldc & 7) == 0)));
+}
+
+// wbuf: this wave's LDS slice (>= PASS_MI * 16 rows x NI * 16 elements); (mw, nw): origin of the wave's sub-tile
+template <int ACT, bool OUT_F32, int MI, int NI, int PASS_MI>
+__device__ __forceinline__ void gemm_store_lines(const GemmArgs& g, unsigned char* wbuf, int mw, int nw, int lane,
+                                                 const f32x4_t (&acc)[NI][MI]) {
+    constexpr int ES = OUT_F32 ? 4 : 2;
+    constexpr int RB = NI * 16 * ES;  // bytes per row of the sub-tile
+    constexpr int CH = RB / 16;       // 16-byte chunks per row
+    static_assert(CH == 8 || CH == 16, "rows of 128 or 256 bytes");
+    static_assert(MI % PASS_MI == 0, "whole passes");
+    constexpr int RPI = 64 / CH;      // rows per wave instruction
+    constexpr int ROWS = PASS_MI * 16;
+    const int cc = lane % CH, n = nw + cc * (16 / ES);
+#pragma unroll
+    for (int p = 0; p < MI / PASS_MI; ++p) {
+#pragma unroll
+        for (int mi = 0; mi < PASS_MI; ++mi) {
+            const int r = mi * 16 + (lane & 15);
+            const int sw = CH == 8 ? ((r >> 1) & 7) : (r & 15);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int nl = ni * 16 + (lane >> 4) * 4;  // local column
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (nw + nl < g.N) gemm_value4<ACT>(g, nw + nl, acc[ni][p * PASS_MI + mi], v);
+                unsigned char* dst = wbuf + r * RB + ((((nl * ES) >> 4) ^ sw) << 4) + ((nl * ES) & 15);
+                if (OUT_F32) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < ROWS / RPI; ++it) {
+            const int rr = it * RPI + lane / CH;
+            const int sw = CH == 8 ? ((rr >> 1) & 7) : (rr & 15);
+            const unsigned char* src = wbuf + rr * RB + ((cc ^ sw) << 4);
+            int m = mw + p * ROWS + rr;
+            if (m >= g.M || n >= g.N) continue;
+            if (g.out_rows) {  // scatter epilogue: destination (and residual) row from the map; negative = dropped
+                m = g.out_rows[m];
+                if (m < 0) continue;
+            }
+            if (OUT_F32) {
+                float4 q = *reinterpret_cast<const float4*>(src);
+                if (g.residual) {
+                    const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
+                    if (g.res_f32) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.residual) + rrow * g.ldr + n);
+                        q.x += r4.x; q.y += r4.y; q.z += r4.z; q.w += r4.w;
+                    } else {
+                        const uint2 r2 = *reinterpret_cast<const uint2*>(g.residual + rrow * g.ldr + n);
+                        q.x += bf16_to_f32((bf16_t)(r2.x & 0xffff));
+                        q.y += bf16_to_f32((bf16_t)(r2.x >> 16));
+                        q.z += bf16_to_f32((bf16_t)(r2.y & 0xffff));
+                        q.w += bf16_to_f32((bf16_t)(r2.y >> 16));
+                    }
+                }
+                *reinterpret_cast<float4*>(static_cast<float*>(g.C) + (int64_t)m * g.ldc + n) = q;
+            } else {
+                const int64_t o = g.c_panel ? (int64_t)(n >> 6) * g.c_panel + (int64_t)m * 64 + (n & 63) : (int64_t)m * g.ldc + n;
+                *reinterpret_cast<uint4*>(static_cast<bf16_t*>(g.C) + o) = *reinterpret_cast<const uint4*>(src);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // Epilogue for one accumulator fragment: the lane owns C[m][n .. n+3] (operands were swapped so that the four

@@ -22,6 +22,18 @@ def unpanel(p):
     return p.permute(1, 0, 2).reshape(r, kp * 64)
 
 
+def t(f, n=20):
+    for _ in range(3):
+        f()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        f()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
 def main():
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -46,22 +58,16 @@ def main():
             assert rc == 0, rc
 
         row(); pan(); torch.cuda.synchronize()
+        if os.environ.get("IVLM_GEMM_ABLATE"):
+            tp = t(pan)
+            print(f"{name:5s} ablate {os.environ['IVLM_GEMM_ABLATE']:>2s}: {tp:7.1f} us", flush=True)
+            continue
         assert torch.equal(out0, out1), float((out0.float() - out1.float()).abs().max())
         pan(True); torch.cuda.synchronize()
         assert torch.equal(unpanel(outp), out0)
         pan(False, False); torch.cuda.synchronize()
         assert torch.equal(out0, out1)
 
-        def t(f, n=20):
-            for _ in range(3):
-                f()
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(n):
-                f()
-            e.record()
-            torch.cuda.synchronize()
-            return s.elapsed_time(e) / n * 1e3
         tr, tp, tpc, tw = t(row), t(pan), t(lambda: pan(True)), t(lambda: pan(False, False))
         fl = 2.0 * M * N * K
         print(f"{name:5s} M={M} N={N} K={K}: row-major {tr:7.1f} us {fl / tr / 1e6:6.0f} TF | W panel only {tw:7.1f} us {fl / tw / 1e6:6.0f} TF | "
