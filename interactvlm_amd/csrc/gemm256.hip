@@ -13,10 +13,15 @@
 //     and every phase issues the direct-to-LDS DMA of ONE half-tile, five half-tiles ahead of its first use:
 //     half-tile s (issue order A0,B0,B1,A1 of tile 0, then tile 1, ...) is issued in global phase s-5 and first read in
 //     phase >= s.  `s_waitcnt vmcnt(8)` once per phase (never 0) therefore leaves four half-tiles in flight across the
-//     barriers, and a slot is only restaged >= 2 phases after its last read (reads retire after the mid-phase barrier).
-//   * The two wave rows run staggered by one barrier: while one row of waves executes its MFMA quadrant, the other
-//     issues its LDS reads and DMA - on every SIMD one wave of each row is resident, so the matrix pipe and the LDS /
-//     memory pipes overlap (s_setprio(1) around the MFMAs arbitrates in favour of the computing wave).
+//     barriers, and a slot is only restaged >= 2 phases after its last read (reads retire right after the phase's barrier).
+//   * ONE barrier per phase.  It publishes the half-tile whose DMA every wave has just waited for (vmcnt(8): half-tiles up to
+//     s+1 have landed in phase s) and, because a slot is restaged at least two phases after its last read, also orders the restaging
+//     DMA behind everybody's reads.  (Rounds 1-2 ran two barriers per phase with the two wave rows staggered by half a phase,
+//     one row computing while the other loads: same speed to the noise - 102.2 vs 102.4 ms end to end, 20.48 vs 20.52 img/s on
+//     the batched job - so the simpler schedule stays.  Ablation of this loop at M = 65536, SAM qkv: MFMAs alone 380 us (1.7
+//     PFLOP/s: the practical matrix ceiling at the sustained clock), DMA alone 233 us (82 GB/s per CU), barriers alone 25 us,
+//     everything 563 us + 31 us of epilogue: what is lost is overlap between a wave's LDS reads and its own MFMAs, with only
+//     two waves per SIMD to cover for each other.)
 //   * LDS image and swizzle as in gemm.hip: DMA destination is lane-linear, so 16-byte chunk c of local row r is fetched
 //     from source chunk c ^ ((r >> 1) & 7) and read back with the same XOR.
 #include "gemm_common.h"
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                     acc[nq * 2 + j][mq * 4 + i] =
                         __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nq][j][kk], fa[i][kk], acc[nq * 2 + j][mq * 4 + i], 0, 0, 0);
     };
-    // one phase: [LDS reads][DMA of one half-tile][counted wait] | barrier | retire reads, 16 MFMAs | barrier
+    // one phase: [LDS reads][DMA of one half-tile][counted wait] | barrier | retire reads, 16 MFMAs
 #define IVLM_PHASE(READS, KIND, TILE, MQ, NQ)                    \
     do {                                                         \
         READS;                                                   \
@@ -136,7 +141,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         mfma_quadrant(MQ, NQ);                                   \
         __builtin_amdgcn_s_setprio(0);                           \
         __builtin_amdgcn_sched_barrier(0);                       \
-        __builtin_amdgcn_s_barrier();                            \
     } while (0)
 #define IVLM_KTILE(T, BUF)                                                                                        \
     do {                                                                                                          \
@@ -156,7 +160,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     stage(1, 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A0, B0 of tile 0 landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: wave row 1 runs half a phase behind wave row 0
 
     int t = 0;
     for (; t + 1 < nt; t += 2) {
@@ -164,7 +167,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         IVLM_KTILE(t + 1, 1);
     }
     if (t < nt) IVLM_KTILE(t, 0);
-    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two wave rows
 #undef IVLM_KTILE
 #undef IVLM_PHASE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-chunk DMAs must not outlive the block's LDS

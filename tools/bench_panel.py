@@ -58,9 +58,9 @@ def main():
             assert rc == 0, rc
 
         row(); pan(); torch.cuda.synchronize()
-        if os.environ.get("IVLM_GEMM_ABLATE"):
+        if os.environ.get("IVLM_LIB_PATH"):
             tp = t(pan)
-            print(f"{name:5s} ablate {os.environ['IVLM_GEMM_ABLATE']:>2s}: {tp:7.1f} us", flush=True)
+            print(f"{name:5s} {os.path.basename(os.environ['IVLM_LIB_PATH'])}: {tp:7.1f} us", flush=True)
             continue
         assert torch.equal(out0, out1), float((out0.float() - out1.float()).abs().max())
         pan(True); torch.cuda.synchronize()

@@ -11,7 +11,10 @@
 #include <cstdint>
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-constexpr int kRowBytes = 2560;  // K = 1280 bf16
+#ifndef ROWBYTES
+#define ROWBYTES 2560
+#endif
+constexpr int kRowBytes = ROWBYTES;  // default: K = 1280 bf16
 #ifndef CONTIG
 #define CONTIG 0
 #endif
@@ -20,7 +23,7 @@ constexpr bool kContig = CONTIG;
 __device__ __forceinline__ const char* src_of(const char* base, size_t footprint, long long seg, int lane) {
     // segment = 8 rows x 128 B at row stride kRowBytes: 20 segments side by side cover 8 full rows (20 KB)
     if (kContig) return base + ((size_t)seg * 1024 + lane * 16) % footprint;  // 1 KB contiguous per wave instruction
-    const long long grp = seg / 20, col = seg % 20;
+    const long long grp = seg / (kRowBytes / 128), col = seg % (kRowBytes / 128);
     size_t off = (size_t)grp * (8 * kRowBytes) + (size_t)(lane >> 3) * kRowBytes + (size_t)col * 128 + (lane & 7) * 16;
     return base + off % footprint;
 }
