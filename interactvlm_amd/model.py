@@ -85,7 +85,7 @@ class InteractVLMForCausalLM:
         # HIP-graph replay of the decode step / CLIP tower (launch-bound on the host otherwise); IVLM_NO_GRAPHS=1 turns both
         # off (rocprofv3 --pmc passes crash on replayed graphs)
         self.graph_decode = not os.environ.get("IVLM_NO_GRAPHS")
-        self.sam_after_prefill = False  # measured: 107.6 vs 106.6 ms - overlapping the decode instead of the prefill is not better
+        self.sam_after_prefill = bool(os.environ.get("IVLM_SAM_AFTER_PREFILL"))  # measured: 107.6 vs 106.6 ms - overlapping the decode instead of the prefill is not better
         self.packed_prefill = True  # generate_batch: prefill all prompts of a batch as one packed pass (rows independent)
         self.fused_lowres_lift = False  # measured slower than lifting the (cache-resident) full-res masks
         self._side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None

@@ -529,3 +529,65 @@ def test_skinny_mfma_gemm_vs_fp32(hip_lib, cuda, M, N, K, act, rms, res, f32, bi
         finally:
             lib.ivlm_gemv_mfma_min_m(0)
         assert torch.allclose(got.float(), roww.float(), **tol)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(4096, 3840, 1280, "none"), (2048, 5120, 1280, "gelu"), (4096, 1280, 5120, "none"),
+                                       (330, 4096, 512, "none"), (1000, 576, 192, "gelu")])
+def test_gemm_k_panel_layouts_equal_row_major(hip_lib, cuda, M, N, K, act):
+    """ivlm_gemm_bf16_panel: operands and / or output stored as K/64 panels of [rows][64] (1 KB contiguous per wave DMA
+    instruction) - same kernels, same arithmetic: BIT-identical to the row-major call, for every combination of panelised A, W
+    and C, on the 8-phase 256^2 kernel, the column split (K = 5120) and the small-tile kernel (M = 330 - a shape the row-major call does not split over K -, ragged 1000 x 576)."""
+    import torch
+
+    from interactvlm_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g) * 0.5).to(cuda)
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    b = _bf(torch.randn(N, generator=g) * 0.1).to(cuda)
+    pan = lambda x: x.view(x.shape[0], x.shape[1] // 64, 64).permute(1, 0, 2).contiguous()
+    unpan = lambda p: p.permute(1, 0, 2).reshape(p.shape[1], p.shape[0] * 64)
+    ap, wp = pan(a), pan(w)
+    ref = ops.linear(a, w, b, act=act)
+    st = torch.cuda.current_stream().cuda_stream
+    for a_p, w_p, c_p in ((1, 1, 0), (0, 1, 0), (1, 0, 0), (1, 1, 1), (0, 0, 1)):
+        out = torch.empty(N // 64, M, 64, device=cuda, dtype=torch.bfloat16) if c_p else torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+        rc = lib.ivlm_gemm_bf16_panel((ap if a_p else a).data_ptr(), K, M * 64 if a_p else 0, (wp if w_p else w).data_ptr(), K,
+                                      N * 64 if w_p else 0, out.data_ptr(), N, M * 64 if c_p else 0, b.data_ptr(), None, 0, M, N, K,
+                                      ops.ACT[act], 0, 0, None, None, st)
+        assert rc == 0, (a_p, w_p, c_p, rc)
+        got = unpan(out) if c_p else out
+        assert torch.equal(got, ref), (a_p, w_p, c_p, float((got.float() - ref.float()).abs().max()))
+    # argument checks: K must be whole panels, panel strides must cover the rows, fp32 output has no panel form
+    out = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+    assert lib.ivlm_gemm_bf16_panel(ap.data_ptr(), K, M * 64 - 8, wp.data_ptr(), K, N * 64, out.data_ptr(), N, 0, None, None, 0, M, N, K,
+                                    0, 0, 0, None, None, st) == -1
+    assert lib.ivlm_gemm_bf16_panel(ap.data_ptr(), K, M * 64, wp.data_ptr(), K, N * 64, out.data_ptr(), N, M * 64, None, None, 0, M, N, K,
+                                    0, 1, 0, None, None, st) == -4
+
+
+@pytest.mark.parametrize("M,N,K,act,rms", [(8, 12288, 4096, "none", True), (8, 22016, 4096, "swiglu", True), (5, 4096, 11008, "none", False),
+                                           (16, 32003, 1024, "none", False)])
+def test_skinny_tiles_per_block_do_not_change_the_result(hip_lib, cuda, M, N, K, act, rms):
+    """gemv_mfma.hip: a block may own 1, 2, 3, 4 or 6 tiles of 16 weight rows (the automatic choice is 3 for the fused q|k|v rows
+    and 6 for gate|up); every tile is accumulated by the same waves in the same order, so the result is bit-identical."""
+    import torch
+
+    from interactvlm_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(M, K, generator=g).to(cuda)
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    gam = _bf(1 + 0.1 * torch.randn(K, generator=g)).to(cuda)
+    kw = dict(act=act, rms=(gam, 1e-5) if rms else None, out_f32=True)
+    lib.ivlm_gemv_mfma_min_m(1)
+    try:
+        base = ops.linear(x, w, **kw)  # automatic
+        for t in (1, 2, 3, 4, 6):
+            lib.ivlm_skinny_tuning(t)
+            assert torch.equal(ops.linear(x, w, **kw), base), t
+    finally:
+        lib.ivlm_skinny_tuning(0)
+        lib.ivlm_gemv_mfma_min_m(0)
