@@ -135,9 +135,10 @@ __device__ __forceinline__ bool gemm_whole_lines_ok(const GemmArgs& g, int act) 
 }
 
 // wbuf: this wave's LDS slice (>= PASS_MI * 16 rows x NI * 16 elements); (mw, nw): origin of the wave's sub-tile
-template <int ACT, bool OUT_F32, int MI, int NI, int PASS_MI>
+// (NI_ALL / NI0: the accumulator array may be wider than the NI fragments stored by this call - they start at fragment NI0)
+template <int ACT, bool OUT_F32, int MI, int NI, int PASS_MI, int NI_ALL = NI, int NI0 = 0>
 __device__ __forceinline__ void gemm_store_lines(const GemmArgs& g, unsigned char* wbuf, int mw, int nw, int lane,
-                                                 const f32x4_t (&acc)[NI][MI]) {
+                                                 const f32x4_t (&acc)[NI_ALL][MI]) {
     constexpr int ES = OUT_F32 ? 4 : 2;
     constexpr int RB = NI * 16 * ES;  // bytes per row of the sub-tile
     constexpr int CH = RB / 16;       // 16-byte chunks per row
@@ -156,7 +157,7 @@ __device__ __forceinline__ void gemm_store_lines(const GemmArgs& g, unsigned cha
             for (int ni = 0; ni < NI; ++ni) {
                 const int nl = ni * 16 + (lane >> 4) * 4;  // local column
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (nw + nl < g.N) gemm_value4<ACT>(g, nw + nl, acc[ni][p * PASS_MI + mi], v);
+                if (nw + nl < g.N) gemm_value4<ACT>(g, nw + nl, acc[NI0 + ni][p * PASS_MI + mi], v);
                 unsigned char* dst = wbuf + r * RB + ((((nl * ES) >> 4) ^ sw) << 4) + ((nl * ES) & 15);
                 if (OUT_F32) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));

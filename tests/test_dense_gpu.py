@@ -103,8 +103,9 @@ def test_gemm_forced_tiles(hip_lib, cuda, tile):
     assert torch.allclose(got.cpu(), ref, atol=3e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("tile", [512])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (4096, 1280, 1280), (1000, 520, 200), (2048, 3840, 1288)])
-def test_gemm_8phase_matches_simple_kernel_bitwise(hip_lib, cuda, M, N, K):
+def test_gemm_8phase_matches_simple_kernel_bitwise(hip_lib, cuda, M, N, K, tile):
     """The 8-phase ping-pong 256^2 kernel (tile code 512) accumulates in the same order as the plain double-buffered
     256^2 kernel, so the two must agree BIT FOR BIT; repeated launches screen for LDS races in the staggered pipeline
     (a late DMA / early read shows up as a few wrong tiles in some runs)."""
@@ -120,7 +121,9 @@ def test_gemm_8phase_matches_simple_kernel_bitwise(hip_lib, cuda, M, N, K):
     prev = lib.ivlm_gemm_tile_override(256)
     try:
         base = ops.linear(x, w, b, act="gelu", out_f32=True)
-        lib.ivlm_gemm_tile_override(512)
+        base_bf = ops.linear(x, w, b, act="none")
+        lib.ivlm_gemm_tile_override(tile)  # eight waves, 8-phase loop (gemm256.hip)
+        assert torch.equal(ops.linear(x, w, b, act="none"), base_bf)  # the bf16 store path of the same kernels
         filler = torch.randn(64 << 20, device=cuda)  # perturb memory timing between runs
         for it in range(30):
             got = ops.linear(x, w, b, act="gelu", out_f32=True)
