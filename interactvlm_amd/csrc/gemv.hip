@@ -1,11 +1,12 @@
 // Skinny GEMM / GEMV for gfx950: out[M<=8, N] = act(x[M,K] . W[N,K]^T + bias) + residual.
 //
 // Batch-1 autoregressive decode (HF greedy search driven by InteractVLM.evaluate, model/InteractVLM.py:524-531)
-// is pure weight streaming: 13.5 GB of bf16 weights per generated token for LLaMA-7B.  No LDS round trip
-// (nothing is shared between waves), no MFMA (M is 1): each wave owns two weight rows at a time, streams
-// them with non-temporal 16-byte loads (8 in flight per lane), dots them against the L1-resident
-// activation rows and reduces with a wave butterfly.  Two rows per wave also lets the SwiGLU epilogue
-// (row-interleaved gate/up weights) complete inside the wave.
+// is pure weight streaming: 13.5 GB of bf16 weights per generated token for LLaMA-7B.  No MFMA (M is 1): waves own whole
+// weight rows, stream them with non-temporal 16-byte loads (8 in flight per lane: 1 KB contiguous per wave instruction), dot
+// them against the activation row(s) staged once per block in LDS and reduce with a wave butterfly.  Two kernels:
+//   gemv1_kernel  M = 1, fp32 x (the decode path proper): 1024-thread blocks, ONE row per wave, no persistence - see below;
+//   gemv_kernel   M <= 8, bf16 or fp32 x: persistent blocks, two rows per wave (SwiGLU over the row-interleaved gate / up
+//                 weights completes inside the wave), software-pipelined over (row group, chunk batch) steps.
 #include <stdlib.h>
 
 #include <algorithm>
