@@ -187,7 +187,8 @@ void ivlm_gemv1_tuning(int ksplit);
  * split-K MFMA kernel (csrc/gemv_mfma.hip) instead of the wave-per-row GEMV / tile GEMM; 0 restores the automatic choice. */
 int ivlm_gemv_mfma_min_m(int min_m);
 /* Benchmark hook of the skinny MFMA kernel: 16-row weight tiles per block (1, 2, 3, 4 or 6); 0 = the automatic choice
- * (fewest blocks-per-CU x tiles, then the most tiles: 3 for the 12288 fused qkv rows, 6 for 22016 gate-up rows). */
+ * (fewest blocks-per-CU x tiles among 1 / 2 / 3, then the most tiles: 3 for the 12288 fused qkv rows and the 22016 gate-up rows);
+ * 10 q + g: q tiles for 8192 < N <= 16384, g tiles above, 1 below (sweeps). */
 void ivlm_skinny_tuning(int tiles_per_block);
 
 /* Benchmark hook: column split of GEMMs whose 256 x 256 tile count under-fills its last round (default 1 = on). */

@@ -8,7 +8,7 @@
 //
 //   * one block = T tiles of 16 weight rows, 8 waves; wave w owns the k-steps [w*per, (w+1)*per) of those rows (split-K
 //     inside the block), so N/(16 T) blocks x 8 waves stream the matrix (T = 1, 256 blocks for N = 4096; T = 3 for the
-//     fused qkv rows, 6 for gate-up: about one block per CU, each activation fragment loaded and split once for T tiles);
+//     fused qkv and the gate-up rows: one to two blocks per CU, each activation fragment loaded and split once for T tiles);
 //   * W fragment: lane (n = l & 15, kg = l >> 4) loads 16 bytes of row n at k = 32*step + 8*kg straight from HBM
 //     (non-temporal; 4 lanes cover 64 contiguous bytes, consecutive steps continue the row), 8 steps in flight per lane;
 //   * x fragment: lane (m = l & 15, kg) loads the same k of activation row m (L2 resident: M x K x 2 bytes), zero for
@@ -203,10 +203,11 @@ int g_skinny_tiles = 0;  // 0 = rule below; tools/bench_decode.py sweeps it
 
 // tiles per block: fewest (blocks per CU) x (tiles per block), then the most tiles (least activation re-reading)
 int skinny_tiles(int N) {
+    if (g_skinny_tiles >= 10) return N > 16384 ? g_skinny_tiles % 10 : (N > 8192 ? g_skinny_tiles / 10 : 1);  // sweep hook: 10 q + g
     if (g_skinny_tiles > 0) return g_skinny_tiles;
     const int tiles = (N + 15) / 16, cus = 256;
     int best = 1, best_cost = 1 << 30;
-    for (int t : {1, 2, 3, 4, 6}) {
+    for (int t : {1, 2, 3}) {  // (4 and 6 tiles per block measured slower: gate|up 230 blocks of 6 tiles 4.56 ms per step, 459 of 3: 4.44)
         const int blocks = (tiles + t - 1) / t;
         const int cost = ((blocks + cus - 1) / cus) * t;
         if (cost <= best_cost) { best = t; best_cost = cost; }
