@@ -251,8 +251,8 @@ int ivlm_llama_decode_attn(const void *qkv, int io_dtype, void *kcache, void *vc
                            ivlm_stream_t stream);
 
 /* B sequences in one launch (grid H x B): sequence b reads qkv + b*ldq, appends to kcache/vcache + b*cache_stride
- * ([tmax,H,D] each), writes o + b*ldo and sits at position pos_dev[b] (strides in elements, multiples of 8).  The
- * batched counterpart of the reference's padded-batch generate (model/InteractVLM.py:524-531 with B > 1 prompts). */
+ * ([tmax,H,D] each), writes o + b*ldo and sits at position pos_dev[b] (strides in elements, multiples of 8); a sequence with
+ * pos_dev[b] >= tmax is skipped (nothing appended) and its output row written as zeros.  The batched counterpart of the reference's padded-batch generate (model/InteractVLM.py:524-531 with B > 1 prompts). */
 int ivlm_llama_decode_attn_batch(const void *qkv, int io_dtype, int64_t ldq, void *kcache, void *vcache, int64_t cache_stride,
                                  int tmax, void *o, int64_t ldo, int B, int H, int D, const int32_t *pos_dev, float theta,
                                  float scale, const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);

@@ -31,6 +31,17 @@ __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_batch_kernel(
     const float* __restrict__ stab, const int32_t* __restrict__ pos_dev, int tmax) {
     const int b = blockIdx.y;
     constexpr int esz = F32IO ? 4 : 2;
+    // a sequence that has filled its cache slab is skipped: its output row is ZERO (written here, so that the caller does not
+    // have to clear the buffer with a launch of its own before every layer of every step)
+    const int pos_b = __builtin_amdgcn_readfirstlane(pos_dev[b]);
+    if (pos_b >= tmax || pos_b >= kMaxT) {
+        if ((int)threadIdx.x < D) {
+            const int64_t e = b * ldo + (int64_t)blockIdx.x * D + threadIdx.x;
+            if (F32IO) static_cast<float*>(o)[e] = 0.0f;
+            else static_cast<bf16_t*>(o)[e] = 0;
+        }
+        return;
+    }
     llama_decode_attn_body<false, F32IO>(blockIdx.x, static_cast<const char*>(qkv) + b * ldq * esz, kcache + b * cache_stride,
                                          vcache + b * cache_stride, static_cast<char*>(o) + b * ldo * esz, H, D, 0, theta, scale,
                                          ct, stab, pos_dev + b, tmax);

@@ -685,14 +685,15 @@ def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, ta
 
 def llama_decode_attn_batch(qkv, kcache, vcache, H, D, pos_dev, theta, scale, table=None, out=None):
     """One decode step of B sequences: qkv bf16 | fp32 [B, 3*H*D], kcache/vcache bf16 [B, Tmax, H, D] (one slab per
-    sequence), pos_dev int32 [B] on the device -> o [B, H*D].  A sequence whose position has reached Tmax is skipped."""
+    sequence), pos_dev int32 [B] on the device -> o [B, H*D].  A sequence whose position has reached Tmax is skipped: its
+    output row is zero (written by the kernel)."""
     lib = _lib.load()
     B = qkv.shape[0]
     assert qkv.dtype in (BF16, F32) and qkv.stride(1) == 1 and kcache.dim() == 4 and kcache.shape[0] == B
     assert kcache[0].is_contiguous() and vcache[0].is_contiguous() and kcache.stride(0) == vcache.stride(0)
     assert pos_dev.dtype == torch.int32 and pos_dev.is_cuda and pos_dev.numel() == B and pos_dev.is_contiguous()
     if out is None:
-        out = torch.zeros(B, H * D, dtype=qkv.dtype, device=qkv.device)
+        out = torch.empty(B, H * D, dtype=qkv.dtype, device=qkv.device)
     check(lib.ivlm_llama_decode_attn_batch(qkv.data_ptr(), _dtc(qkv), qkv.stride(0), kcache.data_ptr(), vcache.data_ptr(),
                                            kcache.stride(0), kcache.shape[1], out.data_ptr(), out.stride(0), B, H, D,
                                            pos_dev.data_ptr(), float(theta), float(scale), _p(table[0]) if table else 0,
