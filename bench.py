@@ -154,6 +154,98 @@ def cpu_baseline(cfg, T0, n_new, V, tables):
             "stage_seconds": {k: round(v, 4) for k, v in t.items()}}
 
 
+def full_depth_oracle(cfg, weights, ids, forced, cams, images_clip, images, tables):
+    """The fp32 CPU oracle (oracle/pipeline.py, pinned to the reference's goldens) on the HEADLINE configuration itself: the
+    benchmark model's own weights (every layer its own), copied to the host as fp32, one image: CLIP 23 layers, the LLaMA over
+    the teacher-forced sequence, SAM ViT-H at depth 32 on the four views (one at a time: the global-attention score matrix of
+    one view is 4.3 GB in fp32), the mask decoder, postprocess and the lift at full size.  Every stage is timed where it runs,
+    so this ONE pass is both the checker of the "per-vertex F1 vs ref" half of the metric at the real depth and the CPU
+    baseline (`cpu_baseline`).  -> (oracle outputs, cpu_baseline dict)."""
+    import numpy as np
+
+    from oracle import cref
+    from oracle import nn as O
+    from oracle import pipeline as P
+
+    torch.set_grad_enabled(False)
+    cores = torch.get_num_threads()
+    t = {}
+    t0 = time.perf_counter()
+    w = {k: v.detach().float().cpu() for k, v in weights.items()}
+    t_copy = time.perf_counter() - t0
+    ic = images_clip.float().cpu()
+    im = images[0].float().cpu()
+    full_ids = torch.cat([ids[0], torch.tensor(forced)])
+
+    def clock(name, fn, reps=1, warm=0):
+        for _ in range(warm):
+            fn()
+        ts, r = [], None
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t1)
+        t[name] = float(np.median(ts))
+        return r
+
+    feat = clock("clip", lambda: P.encode_images(w, cfg, ic)[0], reps=3, warm=1)
+    hidden = clock("llm", lambda: P.llm_hidden(w, cfg, full_ids, feat))
+    seg_ids = [cfg.seg_token_idx]
+    rows = O.seg_rows(full_ids, seg_ids, cfg.img_emb_len, model_forward=True)
+    seg_emb = O.text_hidden_fcs(w, hidden)[rows]
+    k = int(rows.nonzero()[0]) - cfg.img_emb_len + 1
+    token = int(full_ids[k]) if k > 0 else None
+    embs, tv = [], []
+    for v in range(im.shape[0]):  # the views are independent: one at a time bounds the host memory
+        t1 = time.perf_counter()
+        embs.append(P.sam_embed(w, cfg, im[v: v + 1]))
+        tv.append(time.perf_counter() - t1)
+    t["sam_encoder"] = float(sum(tv))
+    emb = torch.cat(embs, 0)
+    S = cfg.sam.img_size
+    res = clock("sam_decoder", lambda: P.decode_masks(w, cfg, seg_emb, token, cams[0], emb, (S, S), (S, S)), reps=3, warm=1)
+    masks, low, _ = res
+    clock("postprocess", lambda: cref.postprocess_masks(low.numpy(), (S, S), (S, S), S), reps=5, warm=1)
+    vid = tables[0].cpu().numpy().astype(np.int32)
+    bary = tables[1].cpu().numpy()
+    contact, nviews = clock("lift", lambda: cref.lift_mesh_soft(masks.numpy()[None], vid, bary, 6890), reps=5, warm=1)
+    t["sam_decoder"] -= t["postprocess"]  # (decode_masks runs the torch postprocess inside; the C one is the timed stage)
+    total = sum(t.values())
+    cpu = {"value": round(1.0 / total, 6), "unit": "images/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
+           "weights": "the benchmark model's own weights, every layer distinct (fp32 copies of the bf16 values)",
+           "sample": "ONE image through the fp32 PyTorch-CPU oracle (oracle/, pinned to reference goldens) at full depth and "
+                     "width: CLIP 23 layers (median of 3), LLaMA 32 layers over the teacher-forced 353-position sequence (one "
+                     "run), SAM ViT-H 32 blocks on each of the 4 views (one run each, summed), mask decoder (median of 3), C "
+                     "postprocess + lift (median of 5)",
+           "stage_seconds": {k_: round(v_, 4) for k_, v_ in t.items()}, "sam_view_seconds": [round(x, 2) for x in tv],
+           "weights_d2h_seconds": round(t_copy, 2)}
+    return {"contact": torch.from_numpy(contact), "nviews": nviews, "masks": masks, "low": low, "sam_emb": emb,
+            "hidden_seg": hidden[rows], "seg_emb": seg_emb}, cpu
+
+
+def compare_contacts(got, ref, nviews_dev=None, nviews_ref=None):
+    """per-vertex contact probabilities of the HIP path against the oracle's: max / rms |dp|, F1 at the oracle's median (random
+    weights put every contact near 0.5), threshold sets outside the error band, visibility set."""
+    from oracle import metrics as OM
+
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = float((got - ref).abs().max())
+    thr = float(ref.median())
+    f1 = OM.h_contact_metrics((ref >= thr).float(), got, thr)
+    sets = {}
+    for name, t_, op in (("ge_0.5", 0.5, torch.ge), ("gt_0.3", 0.3, torch.gt), ("ge_median", thr, torch.ge)):
+        band = (ref - t_).abs() <= max(err, 1e-6)
+        same = op(got, t_) == op(ref, t_)
+        sets[name] = {"equal_outside_error_band": bool(same[~band].all()), "vertices_in_band": int(band.sum()),
+                      "mismatches_in_band": int((~same[band]).sum()), "set_exactly_equal": bool(same.all())}
+    out = {"max_abs_dp": round(err, 6), "rms_dp": round(float((got - ref).pow(2).mean().sqrt()), 6),
+           "within_1e-3": bool(err <= 1e-3), "f1_vs_oracle": round(float(f1[0][0]), 5), "threshold": round(thr, 4),
+           "threshold_sets": sets}
+    if nviews_dev is not None:
+        out["visibility_set_equal"] = bool(torch.equal(nviews_dev.cpu() > 0, torch.from_numpy(nviews_ref > 0)))
+    return out
+
+
 def parity_vs_oracle(dev):
     """The "per-vertex F1 vs ref" half of the metric: run evaluate() of a small, structurally complete configuration
     (real head dims, 14x14 windows + global blocks, 1024^2 x 4 views, 6890 vertices) on the GPU and on the fp32 CPU
@@ -207,6 +299,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
     ap.add_argument("--workload", default="auto", choices=["auto", "b1", "dp64"])
+    ap.add_argument("--spawn", action="store_true", help="launch the ranks from this process even for --gpus 1 (world size 1 "
+                                                         "through torch.distributed.run: exercises the N > 1 launcher path)")
+    ap.add_argument("--dp-images", type=int, default=64, help="images of the dp64 job (64 = BASELINE configs[2]; tests use fewer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the cached-SAM and dp64 variant legs (profiling runs)")
@@ -214,10 +309,23 @@ def main():
 
     import torch.distributed as dist
 
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher - one rank per GPU through torch.distributed.run (the same
+        # launcher the driver uses), rendezvous on 127.0.0.1; rank 0 of the child job prints the JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        argv = [a for a in sys.argv[1:] if a != "--spawn"]
+        sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv,
+                                 env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # (a world of one launched by torch.distributed.run still initialises RCCL)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
@@ -241,7 +349,6 @@ def main():
     vid, bary = synthetic.body_lift_tables(dev)
     fg_frac = float((vid[..., 0] >= 0).float().mean())
     model = M.InteractVLMForCausalLM(cfg, weights, dev, lift_tables=(vid, bary))
-    del weights
     ids, forced = synthetic.prompt_ids(cfg)
     cams = synthetic.human_cam_params()
     images_clip, images = synthetic.images(cfg, dev, seed=rank)
@@ -255,7 +362,7 @@ def main():
         return allc.cpu() if rank == 0 else allc
 
     # ---- configs[2]: 64 seeded images, contiguous shards, 8 per evaluate_batch call, ONE all-gather of the shard results
-    N_IMG, PER_CALL = 64, 8
+    N_IMG, PER_CALL = args.dp_images, 8
     dp_inputs = {}
 
     def dp_image(i):  # image i is the same tensor whatever rank / world size evaluates it
@@ -511,13 +618,46 @@ def main():
             roof_lift["traffic"] = pm.get("lift_plan_kernel")
             roof_gemv["traffic"] = pm.get("gemv_kernel")
 
-    cpu = parity = None
+    cpu = parity = parity_full = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- parity at the REAL depth, on the headline configuration itself: the model that was just timed (its own weights, this
+        # rank's image) in every precision mode it offers against the fp32 CPU oracle, which is timed as the CPU baseline
+        gpu_modes = {}
+        for mode in getattr(model, "precision_modes", ("default",)):
+            if hasattr(model, "set_precision"):
+                model.set_precision(mode)
+            o = model.evaluate(images_clip, images, ids, cams, [(S, S)], [(S, S)], contact_type="hcontact", forced_new_tokens=forced)
+            plan_ = model.human_3d_contact_predictor._get_plan(dev)
+            _, nv_ = ops.lift_mesh_plan(o["pred_masks"][0][None].contiguous(), plan_, want_nviews=True)
+            step_b1()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step_b1()
+            sync()
+            gpu_modes[mode] = {"contact": o["pred_contact_3d"].float().cpu(), "nviews": nv_[0].cpu(),
+                               "masks": o["pred_masks"][0].float().cpu(),
+                               "images_per_s": round(args.steps / (time.perf_counter() - t1), 4)}
+        if hasattr(model, "set_precision"):
+            model.set_precision("default")
         del model
         torch.cuda.empty_cache()
         # the CPU leg: the oracle is used here only - as the timed baseline and as the checker of the "F1 vs ref" half of the metric
         parity = parity_vs_oracle(dev)
-        cpu = cpu_baseline(cfg, T0, len(forced), V, (vid, bary))
+        if os.environ.get("IVLM_OLD_CPU_BASELINE"):  # (round-2 procedure: shared weights per layer, medians of repeated runs)
+            cpu = cpu_baseline(cfg, T0, len(forced), V, (vid, bary))
+        else:
+            ref, cpu = full_depth_oracle(cfg, weights, ids, forced, cams, images_clip, images, (vid, bary))
+            parity_full = {"config": "the headline configuration itself (" + args.model + ": every layer of CLIP / LLaMA / SAM "
+                                     "ViT-H with its own weights, 4 x 1024^2 views, 6890 vertices), HIP path vs the fp32 CPU "
+                                     "oracle on identical bf16-valued weights and inputs",
+                           "oracle_contact_range": [round(float(ref["contact"].min()), 4), round(float(ref["contact"].max()), 4)]}
+            for mode, g_ in gpu_modes.items():
+                c_ = compare_contacts(g_["contact"], ref["contact"], g_["nviews"][None], ref["nviews"])
+                c_["images_per_s"] = g_["images_per_s"]
+                c_["max_abs_dmask_logit"] = round(float((g_["masks"] - ref["masks"]).abs().max()), 4)
+                c_["mask_logit_range"] = round(float(ref["masks"].abs().max()), 2)
+                parity_full[mode] = c_
 
     if rank == 0:
         fl = flops_per_image(cfg, T0, len(forced), V)
@@ -550,9 +690,10 @@ def main():
             "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "variant_fp8_sam_encoder": fp8v,
             "dp64_one_gpu": dp64_one,
             "one_gpu_same_workload": one_gpu, "parity_vs_oracle": parity,
+            "parity_vs_oracle_full_depth": parity_full,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -42,6 +42,9 @@ extern "C" {
 /* flags of ivlm_gemm_bf16 / ivlm_gemm_bf16_splitk */
 #define IVLM_GEMM_A_F32 1   /* A is fp32 [M,K] (M <= 16 weight-streaming paths only; lda % 4 == 0) */
 #define IVLM_GEMM_RES_F32 2 /* residual is fp32 (fp32 residual stream) */
+#define IVLM_GEMM_A_SPLIT 4 /* tile GEMM (M > 16): A rows are [hi(K) | lo(K)] bf16 (IVLM_BF16_SPLIT, lda >= 2K): an fp32-activation
+                               GEMM on the bf16 matrix cores against the plain [N,K] weight (each W tile is used twice) */
+#define IVLM_GEMM_OUT_SPLIT 8 /* tile GEMM: C is bf16 [M, >= 2 n_out], the fp32 result written as [hi(n_out) | lo(n_out)] */
 
 typedef void *ivlm_stream_t;
 
@@ -219,6 +222,14 @@ int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, co
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float *rel_h,
                         const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q,
                         ivlm_stream_t stream);
+/* "Parity" precision of the same operator (fp32-operand attention on the bf16 matrix cores): q / k / v / o are given as hi + lo
+ * bf16 planes (x = hi + lo to 2^-17: the [hi | lo] halves of IVLM_BF16_SPLIT rows; the *_lo tensors use the strides of the hi
+ * ones), both products run as three MFMAs per fragment (hi.hi + hi.lo + lo.hi), q * scale and the rel-pos bias stay fp32.
+ * Shapes of the path only: D = 64 (plain), D = 80 with rel_h / rel_w (prescale_q = 1), D = 128 causal. */
+int ivlm_attention_bf16_split(const void *q, const void *q_lo, const void *k, const void *k_lo, const void *v, const void *v_lo,
+                              void *o, void *o_lo, const int64_t *strides_host, int B, int H, int Sq, int Sk, int D, float scale,
+                              int causal, int q_pos0, const float *rel_h, const float *rel_w, int rel_kh, int rel_kw,
+                              int kv_batch_div, int prescale_q, ivlm_stream_t stream);
 /* The same operator with fp32 q / k / v / o and no operand rounding, for the SAM mask decoder's small attentions
  * (transformer.py:220-242: head dim 16 or 32; 9 tokens x 4096 image positions or the reverse) and the AttentionSplitter
  * (components.py:155-193: one head of 128 over V keys): scores = (q.k) * scale, fp32 softmax, fp32 P.V on the VALU.

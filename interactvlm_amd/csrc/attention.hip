@@ -69,8 +69,13 @@ __device__ __forceinline__ void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\
 // VALU, and they swap at every barrier.  Waves w and w + 4 share a SIMD, so the matrix unit and the VALU are both busy
 // instead of both groups queueing for the same unit (without PP the two co-resident blocks drift into the same phase:
 // measured time = MFMA time + VALU time).
-template <int DQK, int DV, bool CAUSAL, int REL, bool PP>
-__global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnArgs a) {
+// SPLIT ("parity" precision): q / k / v arrive as hi + lo bf16 planes (x = hi + lo to 2^-17: the [hi | lo] rows the GEMM's split
+// epilogue writes; the lo tensors have the strides of the hi ones) and both products run as three MFMAs per fragment,
+//     S^T = Kh.Qh^T + Kh.Ql^T + Kl.Qh^T,      O^T = Vh^T.Ph^T + Vh^T.Pl^T + Vl^T.Ph^T      (the lo.lo terms are below 2^-17),
+// i.e. fp32-operand attention on the bf16 matrix cores at 3x the MFMA work; the output is written as hi + lo planes again.
+// The LDS tiles double (dynamic LDS, one block per CU), one register set stages the next tile.
+template <int DQK, int DV, bool CAUSAL, int REL, bool PP, bool SPLIT = false>
+__global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_kernel(AttnArgs a) {
     constexpr int NT = PP ? 512 : 256;  // threads per block
     constexpr int kQBlk = PP ? 2 * kQPerBlock : kQPerBlock;
     constexpr int KS = DQK / 32;        // MFMA k-steps over the head dim
@@ -85,11 +90,19 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
     constexpr int VPL = kKV * 16 + 16;   // elements per d-tile plane  [key][16] (+ 32 B)
     constexpr int KBUF = KS * KPL;
     constexpr int VBUF = DT * VPL;
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KBUF];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[2][VBUF];
+    // (SPLIT: the tiles live in dynamic LDS - [hi planes | lo planes] per buffer, 2 x the bytes)
+    __shared__ __attribute__((aligned(16))) bf16_t Ks_[2][SPLIT ? 8 : KBUF];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs_[2][SPLIT ? 8 : VBUF];
     // REL 2: rel_h[query][key row] of the block's queries, one value per (query, key tile).  Read from global at its point of use it is a dependent load in every tile, and the s_waitcnt the
     // compiler puts in front of it also drains the K/V prefetches of the following tiles.
-    __shared__ __attribute__((aligned(16))) float Rh[REL == 2 ? kQBlk * kKV : 4];
+    __shared__ __attribute__((aligned(16))) float Rh_[(REL == 2 && !SPLIT) ? kQBlk * kKV : 4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_dyn[];
+    constexpr int KB2 = SPLIT ? 2 * KBUF : KBUF, VB2 = SPLIT ? 2 * VBUF : VBUF;  // elements per buffer
+    bf16_t* const Ks0 = SPLIT ? reinterpret_cast<bf16_t*>(attn_dyn) : &Ks_[0][0];
+    bf16_t* const Vs0 = SPLIT ? Ks0 + 2 * KB2 : &Vs_[0][0];
+    float* const Rh = SPLIT ? reinterpret_cast<float*>(Vs0 + 2 * VB2) : &Rh_[0];
+    auto Ks = [&](int buf) __attribute__((always_inline)) { return Ks0 + buf * KB2; };
+    auto Vs = [&](int buf) __attribute__((always_inline)) { return Vs0 + buf * VB2; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -100,6 +113,9 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
     const bf16_t* __restrict__ Q = a.q + b * a.q_bs + h * a.q_hs;
     const bf16_t* __restrict__ K = a.k + bkv * a.k_bs + h * a.k_hs;
     const bf16_t* __restrict__ V = a.v + bkv * a.v_bs + h * a.v_hs;
+    const bf16_t* __restrict__ Ql = SPLIT ? a.q_lo + b * a.q_bs + h * a.q_hs : nullptr;
+    const bf16_t* __restrict__ Kl = SPLIT ? a.k_lo + bkv * a.k_bs + h * a.k_hs : nullptr;
+    const bf16_t* __restrict__ Vl = SPLIT ? a.v_lo + bkv * a.v_bs + h * a.v_hs : nullptr;
 
     // ---- zero the pad chunks of K once (head dim < DQK), both buffers ------------------------------
     if (DCH < KS * 4) {
@@ -108,7 +124,8 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
             const int buf = i / (kKV * NPAD), r = i % (kKV * NPAD);
             const int key = r / NPAD, ch = DCH + r % NPAD;
             const int phys = (ch & 3) ^ (((key >> 3) & 1) << 1);
-            *reinterpret_cast<u32x4_t*>(&Ks[buf][(ch >> 2) * KPL + key * 32 + phys * 8]) = u32x4_t{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4_t*>(&Ks(buf)[(ch >> 2) * KPL + key * 32 + phys * 8]) = u32x4_t{0u, 0u, 0u, 0u};
+            if (SPLIT) *reinterpret_cast<u32x4_t*>(&Ks(buf)[KBUF + (ch >> 2) * KPL + key * 32 + phys * 8]) = u32x4_t{0u, 0u, 0u, 0u};
         }
     }
 
@@ -125,6 +142,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
 
     // ---- Q fragments (B operand): lane holds Q[q0 + qt*16 + l15][(s*4+g)*8 .. +8] ---------------
     bf16x8_t qf[2][KS];
+    bf16x8_t qfl[2][SPLIT ? KS : 1];  // SPLIT: the lo halves
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         int qi = q0 + qt * 16 + l15;
@@ -134,7 +152,24 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
             const int d0 = (s * 4 + g) * 8;
             uint4 u = make_uint4(0, 0, 0, 0);
             if (d0 < DV) u = *reinterpret_cast<const uint4*>(Q + (int64_t)qi * a.q_rs + d0);
-            if (a.prescale_q) {  // (q * scale) rounded to bf16 BEFORE the dot product, like SAM / HF-CLIP do
+            if (SPLIT) {
+                u32x4_t uh = u32x4_t{u.x, u.y, u.z, u.w}, ul = u32x4_t{0u, 0u, 0u, 0u};
+                if (d0 < DV) ul = *reinterpret_cast<const u32x4_t*>(Ql + (int64_t)qi * a.q_rs + d0);
+                if (a.prescale_q) {  // (q * scale) in fp32 on the hi + lo value, split again: no rounding to bf16
+                    const float sc = a.scale;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = (__uint_as_float(uh[e] << 16) + __uint_as_float(ul[e] << 16)) * sc;
+                        const float x1 = (__uint_as_float(uh[e] & 0xffff0000u) + __uint_as_float(ul[e] & 0xffff0000u)) * sc;
+                        uint32_t hh, ll;
+                        split_bf16x2(x0, x1, hh, ll);
+                        uh[e] = hh;
+                        ul[e] = ll;
+                    }
+                }
+                u = make_uint4(uh[0], uh[1], uh[2], uh[3]);
+                qfl[qt][s] = __builtin_bit_cast(bf16x8_t, ul);
+            } else if (a.prescale_q) {  // (q * scale) rounded to bf16 BEFORE the dot product, like SAM / HF-CLIP do
                 u.x = pack_bf16x2(__uint_as_float(u.x << 16) * a.scale, __uint_as_float(u.x & 0xffff0000u) * a.scale);
                 u.y = pack_bf16x2(__uint_as_float(u.y << 16) * a.scale, __uint_as_float(u.y & 0xffff0000u) * a.scale);
                 u.z = pack_bf16x2(__uint_as_float(u.z << 16) * a.scale, __uint_as_float(u.z & 0xffff0000u) * a.scale);
@@ -186,25 +221,33 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
             vreg[i] = *reinterpret_cast<const u32x4_t*>(V + (int64_t)key * a.v_rs + ld_d[i]);
         }
     };
-    auto store_k = [&](const u32x4_t (&kreg)[CPT], int buf) __attribute__((always_inline)) {
+    auto store_k = [&](const u32x4_t (&kreg)[CPT], int buf, int plane_off = 0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = tid + i * NT;
             if (c < NCH) {
                 const int key = c / DCH, dch = c % DCH;
                 const int phys = (dch & 3) ^ (((key >> 3) & 1) << 1);
-                *reinterpret_cast<u32x4_t*>(&Ks[buf][(dch >> 2) * KPL + key * 32 + phys * 8]) = kreg[i];
+                *reinterpret_cast<u32x4_t*>(&Ks(buf)[plane_off + (dch >> 2) * KPL + key * 32 + phys * 8]) = kreg[i];
             }
         }
     };
-    auto store_v = [&](const u32x4_t (&vreg)[CPT], int buf) __attribute__((always_inline)) {
+    auto store_v = [&](const u32x4_t (&vreg)[CPT], int buf, int plane_off = 0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = tid + i * NT;
             if (c < NCH) {
                 const int key = c / DCH, dch = c % DCH;
-                *reinterpret_cast<u32x4_t*>(&Vs[buf][(dch >> 1) * VPL + key * 16 + (dch & 1) * 8]) = vreg[i];
+                *reinterpret_cast<u32x4_t*>(&Vs(buf)[plane_off + (dch >> 1) * VPL + key * 16 + (dch & 1) * 8]) = vreg[i];
             }
+        }
+    };
+    auto gload_lo = [&](u32x4_t (&reg)[CPT], const bf16_t* base, int64_t rs, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            int key = t * kKV + ld_key[i];
+            key = key < last_key ? key : last_key;
+            reg[i] = *reinterpret_cast<const u32x4_t*>(base + (int64_t)key * rs + ld_d[i]);
         }
     };
     const int kswz = (g ^ ((l15 >> 3) << 1)) * 8;                       // this lane's K chunk inside a 64-byte row
@@ -212,6 +255,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
 
     // ---- rel-pos operands of this lane's two queries -------------------------------------------
     bf16x8_t qrel[2];       // REL 1: [rel_h(KH) | rel_w(KW) | 0] features g*8 .. g*8+7
+    bf16x8_t qrel_lo[2];    //        (SPLIT: the fp32 bias values as hi + lo operands: the one-hot MFMA adds them exactly)
     f32x4_t rwf[2][4];      // REL 2: rel_w[q][kt*16 + g*4 + r]: tile-invariant, SEEDS the score accumulators (no add later)
     const float* rhp[2] = {nullptr, nullptr};
     const float* rwg[2] = {nullptr, nullptr};  // REL 3
@@ -232,6 +276,14 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
                 }
                 uint4 u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
                                      pack_bf16x2(f[6], f[7]));
+                if (SPLIT) {
+                    uint4 ul;
+                    split_bf16x2(f[0], f[1], u.x, ul.x);
+                    split_bf16x2(f[2], f[3], u.y, ul.y);
+                    split_bf16x2(f[4], f[5], u.z, ul.z);
+                    split_bf16x2(f[6], f[7], u.w, ul.w);
+                    qrel_lo[qt] = *reinterpret_cast<bf16x8_t*>(&ul);
+                }
                 qrel[qt] = *reinterpret_cast<bf16x8_t*>(&u);
             } else if (REL == 3) {
                 rhp[qt] = rh;
@@ -251,12 +303,13 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
     // ---- the three phases of a key tile (state: s = scores then probabilities, pf = packed P^T fragments) ------------
     f32x4_t s[2][4];
     bf16x8_t pf[2][2];
+    bf16x8_t pfl[2][SPLIT ? 2 : 1];  // SPLIT: lo halves of the probabilities
     auto nkt_of = [&](int t) __attribute__((always_inline)) {
         int nkt = (a.Sk - t * kKV + 15) >> 4;  // 16-key sub-tiles that hold real keys (wave-uniform)
         return nkt < 4 ? nkt : 4;
     };
     auto phase_qk = [&](const int t) __attribute__((always_inline)) {
-        const bf16_t* Kb = Ks[t & 1];
+        const bf16_t* Kb = Ks(t & 1);
         const int nkt = nkt_of(t);
         // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query l15 ------------------
 #pragma unroll
@@ -273,6 +326,15 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
+                if (SPLIT) {
+                    const bf16x8_t kfl =
+                        *reinterpret_cast<const bf16x8_t*>(&Kb[KBUF + ks * KPL + (kt * 16 + l15) * 32 + kswz]);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[qt][ks], s[qt][kt], 0, 0, 0);
+                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qf[qt][ks], s[qt][kt], 0, 0, 0);
+                    }
+                }
             }
             if (REL == 1) {
                 const int key = t * kKV + kt * 16 + l15;
@@ -288,8 +350,10 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
                 uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
                 const bf16x8_t hot = *reinterpret_cast<bf16x8_t*>(&u);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < 2; ++qt) {
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel[qt], s[qt][kt], 0, 0, 0);
+                    if (SPLIT) s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo[qt], s[qt][kt], 0, 0, 0);
+                }
             }
         }
 
@@ -383,11 +447,21 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
                 asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.z) : "v"(s[qt][2 * s2 + 1][0]), "v"(s[qt][2 * s2 + 1][1]));
                 asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.w) : "v"(s[qt][2 * s2 + 1][2]), "v"(s[qt][2 * s2 + 1][3]));
                 pf[qt][s2] = *reinterpret_cast<bf16x8_t*>(&u);
+                if (SPLIT) {  // lo halves: p - bf16(p), exactly representable differences rounded once
+                    uint4 ul;
+                    const f32x4_t& sa = s[qt][2 * s2];
+                    const f32x4_t& sb = s[qt][2 * s2 + 1];
+                    ul.x = pack_bf16x2(sa[0] - __uint_as_float(u.x << 16), sa[1] - __uint_as_float(u.x & 0xffff0000u));
+                    ul.y = pack_bf16x2(sa[2] - __uint_as_float(u.y << 16), sa[3] - __uint_as_float(u.y & 0xffff0000u));
+                    ul.z = pack_bf16x2(sb[0] - __uint_as_float(u.z << 16), sb[1] - __uint_as_float(u.z & 0xffff0000u));
+                    ul.w = pack_bf16x2(sb[2] - __uint_as_float(u.w << 16), sb[3] - __uint_as_float(u.w & 0xffff0000u));
+                    pfl[qt][s2] = *reinterpret_cast<bf16x8_t*>(&ul);
+                }
             }
 
     };
     auto phase_pv = [&](const int t) __attribute__((always_inline)) {
-        const bf16_t* Vb = Vs[t & 1];
+        const bf16_t* Vb = Vs(t & 1);
         const int nkt = nkt_of(t);
         // ---- O^T += V^T . P^T  (key step outer: one uniform skip test per 32 keys, DT independent accumulators inner) ---
 #pragma unroll
@@ -406,11 +480,53 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                     o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s2], o[qt][dt], 0, 0, 0);
+                if (SPLIT) {
+                    const bf16_t* vpl = vp + VBUF;
+                    const s16x4_t lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vpl));
+                    const s16x4_t hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vpl + 16 * 16));
+                    const s16x8_t v8l = __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8_t vfl = __builtin_bit_cast(bf16x8_t, v8l);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl[qt][s2], o[qt][dt], 0, 0, 0);
+                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf[qt][s2], o[qt][dt], 0, 0, 0);
+                    }
+                }
             }
         }
     };
 
-    if (!PP) {
+    if (SPLIT) {
+        // one register set (hi + lo of K and V): tile t + 1 is loaded while tile t is computed and written to the other buffer
+        // at the end of the step; one barrier per tile (three MFMAs per fragment give the loads three times the cover)
+        u32x4_t kh[CPT], kl[CPT], vh[CPT], vl[CPT];
+        gload_k(kh, 0);
+        gload_lo(kl, Kl, a.k_rs, 0);
+        gload_v(vh, 0);
+        gload_lo(vl, Vl, a.v_rs, 0);
+        store_k(kh, 0);
+        store_k(kl, 0, KBUF);
+        store_v(vh, 0);
+        store_v(vl, 0, VBUF);
+        for (int t = 0; t < ntiles; ++t) {
+            sync_lds();
+            if (t + 1 < ntiles) {
+                gload_k(kh, t + 1);
+                gload_lo(kl, Kl, a.k_rs, t + 1);
+                gload_v(vh, t + 1);
+                gload_lo(vl, Vl, a.v_rs, t + 1);
+            }
+            phase_qk(t);
+            phase_softmax(t);
+            phase_pv(t);
+            if (t + 1 < ntiles) {
+                store_k(kh, (t + 1) & 1);
+                store_k(kl, (t + 1) & 1, KBUF);
+                store_v(vh, (t + 1) & 1);
+                store_v(vl, (t + 1) & 1, VBUF);
+            }
+        }
+    } else if (!PP) {
         // two register sets: the loads of tile t + 2 are issued while tile t is computed, tile t + 1 - loaded one step
         // earlier - is written to the free LDS buffer at the end of the step; one barrier per tile
         u32x4_t kregA[CPT], vregA[CPT], kregB[CPT], vregB[CPT];
@@ -482,6 +598,14 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
         const float inv = l_run[qt] > 0.0f ? 1.0f / l_run[qt] : 0.0f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
+            if (SPLIT) {
+                uint2 wh, wl;
+                split_bf16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv, wh.x, wl.x);
+                split_bf16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv, wh.y, wl.y);
+                *reinterpret_cast<uint2*>(O + (int64_t)qi * a.o_rs + dt * 16 + g * 4) = wh;
+                *reinterpret_cast<uint2*>(a.o_lo + b * a.o_bs + h * a.o_hs + (int64_t)qi * a.o_rs + dt * 16 + g * 4) = wl;
+                continue;
+            }
             const uint2 w = make_uint2(pack_bf16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv),
                                        pack_bf16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
             *reinterpret_cast<uint2*>(O + (int64_t)qi * a.o_rs + dt * 16 + g * 4) = w;
@@ -491,6 +615,41 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void attn_kernel(AttnAr
 
 static int g_attn_pp = -1;  // -1 automatic; 0 / 1 force the 4-wave / 8-wave ping-pong kernel (benchmark hook)
 void attn_set_pingpong(int mode) { g_attn_pp = mode; }
+
+// SPLIT kernels (dynamic LDS: K and V tiles as hi + lo planes, double-buffered, + the rel_h block of REL 2)
+template <int DQK, int DV, bool CAUSAL, int REL>
+int launch_split_k(const AttnArgs& a, hipStream_t st) {
+    constexpr int KS = DQK / 32, DT = DV / 16;
+    constexpr size_t lds = (size_t)(2 * 2 * KS * (kKV * 32 + 32) + 2 * 2 * DT * (kKV * 16 + 16)) * 2 +
+                           (REL == 2 ? (size_t)kQPerBlock * kKV * 4 : 0);
+    auto kfn = attn_kernel<DQK, DV, CAUSAL, REL, false, true>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B);
+    kfn<<<grid, 256, lds, st>>>(a);
+    return ivlm_launch_status();
+}
+
+// the shapes of the path only (keeps the build small): CLIP (64, plain), SAM ViT (80, rel-pos), LLaMA prefill (128, causal)
+template <int DQK, int DV>
+int launch_split(const AttnArgs& a, hipStream_t st) {
+    const bool rel = a.rel_h != nullptr;
+    if constexpr (DV == 128) {
+        if (a.causal && !rel) return launch_split_k<DQK, DV, true, 0>(a, st);
+    } else if constexpr (DV == 64) {
+        if (!a.causal && !rel) return launch_split_k<DQK, DV, false, 0>(a, st);
+    } else if constexpr (DV == 80) {
+        if (!a.causal && rel && a.prescale_q) {
+            if (a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw) return launch_split_k<DQK, DV, false, 2>(a, st);
+            if (a.rel_kh + a.rel_kw <= 32) return launch_split_k<DQK, DV, false, 1>(a, st);
+            return launch_split_k<DQK, DV, false, 3>(a, st);
+        }
+    }
+    return IVLM_ERR_UNSUPPORTED;
+}
 
 template <int DQK, int DV, bool PP>
 int launch_dp(const AttnArgs& a, hipStream_t st) {
@@ -520,6 +679,7 @@ int launch_d(const AttnArgs& a, hipStream_t st) {
     // the 8-wave ping-pong block (256 queries) is opt-in: measured 5-15 % SLOWER than two independent 4-wave blocks per CU on
     // every shape of the path (SAM global 634 vs 604 us, windows 151 vs 132 us) - the loop is bound by the issue latency of
     // the dependent softmax chain, not by the two waves of a SIMD contending for the same unit
+    if (a.q_lo) return launch_split<DQK, DV>(a, st);
     const bool pp = g_attn_pp > 0;
     return pp ? launch_dp<DQK, DV, true>(a, st) : launch_dp<DQK, DV, false>(a, st);
 }
@@ -686,6 +846,7 @@ int attention_bf16(const AttnArgs& a, hipStream_t st) {
         return IVLM_ERR_UNSUPPORTED;  // 16-byte row chunks
     if ((a.o_rs | a.o_hs | a.o_bs) & 3) return IVLM_ERR_UNSUPPORTED;
     if (a.rel_h && (!a.rel_w || a.rel_kh <= 0 || a.rel_kw <= 0)) return IVLM_ERR_INVALID_ARG;
+    if ((a.q_lo || a.k_lo || a.v_lo || a.o_lo) && !(a.q_lo && a.k_lo && a.v_lo && a.o_lo)) return IVLM_ERR_INVALID_ARG;
     switch (a.D) {
         case 16: return launch_d<32, 16>(a, st);
         case 32: return launch_d<32, 32>(a, st);
@@ -753,6 +914,40 @@ int ivlm_attention_bf16(const void* q, const void* k, const void* v, void* o, co
     a.rel_kw = rel_kw;
     a.kv_batch_div = kv_batch_div < 1 ? 1 : kv_batch_div;
     a.prescale_q = prescale_q;
+    return ivlm::attention_bf16(a, ivlm_stream(stream));
+}
+
+int ivlm_attention_bf16_split(const void* q, const void* q_lo, const void* k, const void* k_lo, const void* v, const void* v_lo,
+                              void* o, void* o_lo, const int64_t* strides /*[12]*/, int B, int H, int Sq, int Sk, int D, float scale,
+                              int causal, int q_pos0, const float* rel_h, const float* rel_w, int rel_kh, int rel_kw,
+                              int kv_batch_div, int prescale_q, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!strides || !q_lo || !k_lo || !v_lo || !o_lo) return IVLM_ERR_INVALID_ARG;
+    ivlm::AttnArgs a;
+    a.q = static_cast<const bf16_t*>(q);
+    a.k = static_cast<const bf16_t*>(k);
+    a.v = static_cast<const bf16_t*>(v);
+    a.o = static_cast<bf16_t*>(o);
+    a.q_lo = static_cast<const bf16_t*>(q_lo);
+    a.k_lo = static_cast<const bf16_t*>(k_lo);
+    a.v_lo = static_cast<const bf16_t*>(v_lo);
+    a.o_lo = static_cast<bf16_t*>(o_lo);
+    a.q_bs = strides[0]; a.q_hs = strides[1]; a.q_rs = strides[2];
+    a.k_bs = strides[3]; a.k_hs = strides[4]; a.k_rs = strides[5];
+    a.v_bs = strides[6]; a.v_hs = strides[7]; a.v_rs = strides[8];
+    a.o_bs = strides[9]; a.o_hs = strides[10]; a.o_rs = strides[11];
+    a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.D = D;
+    a.scale = scale;
+    a.causal = causal;
+    a.q_pos0 = q_pos0;
+    a.rel_h = rel_h;
+    a.rel_w = rel_w;
+    a.rel_kh = rel_kh;
+    a.rel_kw = rel_kw;
+    a.kv_batch_div = kv_batch_div < 1 ? 1 : kv_batch_div;
+    a.prescale_q = prescale_q;
+    if ((reinterpret_cast<uintptr_t>(q_lo) | reinterpret_cast<uintptr_t>(k_lo) | reinterpret_cast<uintptr_t>(v_lo)) & 15)
+        return IVLM_ERR_INVALID_ARG;
     return ivlm::attention_bf16(a, ivlm_stream(stream));
 }
 

@@ -86,12 +86,15 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
     auto stage = [&](int buf, int kt) {
         unsigned char* baseA = smem + buf * kStageBytes + wave * PA * 1024;
         unsigned char* baseW = smem + buf * kStageBytes + kTileBytesA + wave * PW * 1024;
-        const int koff = kt * BK;
+        // split A ([hi | lo] halves): K tile kt pairs W tile kt / 2 with the hi (even kt) or the lo (odd kt) tile of A
+        const int kw = g.a_split ? kt >> 1 : kt;
+        const int64_t alo = (g.a_split && (kt & 1)) ? g.a_lo : 0;
+        const int koff = kw * BK;
         const bf16_t* zero = reinterpret_cast<const bf16_t*>(kGemmZeroChunk);
 #pragma unroll
-        for (int i = 0; i < PA; ++i) glds16(kcolA[i] + koff < g.K ? srcA[i] + kt * a_ks : zero, baseA + i * 1024);
+        for (int i = 0; i < PA; ++i) glds16(kcolA[i] + koff < g.K ? srcA[i] + kw * a_ks + alo : zero, baseA + i * 1024);
 #pragma unroll
-        for (int i = 0; i < PW; ++i) glds16(kcolW[i] + koff < g.K ? srcW[i] + kt * w_ks : zero, baseW + i * 1024);
+        for (int i = 0; i < PW; ++i) glds16(kcolW[i] + koff < g.K ? srcW[i] + kw * w_ks : zero, baseW + i * 1024);
     };
 
     // ---- fragment read offsets (bytes within a tile), constant over the K loop ---------------
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (g.K + BK - 1) / BK;
+    const int nt = ((g.K + BK - 1) / BK) << (g.a_split ? 1 : 0);
     stage(0, 0);
     for (int t = 0; t < nt; ++t) {
         __syncthreads();  // tile t landed (vmcnt(0) + barrier); everyone is done with tile t-1
@@ -273,7 +276,7 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
         b.tile = 64;
         b.W = g.W + (int64_t)n1 * (g.w_kstep ? 64 : g.ldw);
         b.C = g.c_panel ? static_cast<char*>(g.C) + (size_t)(n1 / 64) * g.c_panel * 2  // (n1 % 256 == 0: whole panels)
-                        : static_cast<char*>(g.C) + (size_t)n1 * (g.out_fp8 ? 1 : (g.out_f32 ? 4 : 2));
+                        : static_cast<char*>(g.C) + (size_t)n1 * (g.out_fp8 ? 1 : ((g.out_f32 && !g.out_split) ? 4 : 2));
         if (g.bias) b.bias = g.bias + n1;
         if (g.residual) b.residual = g.residual + (g.res_f32 ? 2 * n1 : n1);
         return gemm_bf16(b, st);
@@ -283,6 +286,11 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
     if (g.act == ACT_SWIGLU && ((g.N & 3) || g.residual)) return IVLM_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) return IVLM_ERR_INVALID_ARG;
     if (g.a_f32) return IVLM_ERR_UNSUPPORTED;
+    if (g.a_split || g.out_split) {  // fp32-activation ("parity") operands / outputs: bf16 tile kernels only
+        if (g.fp8 || g.out_fp8 || g.a_kstep || g.w_kstep || g.c_panel) return IVLM_ERR_UNSUPPORTED;
+        if (g.a_split && ((g.a_lo & 7) || g.a_lo < g.K)) return IVLM_ERR_INVALID_ARG;
+        if (g.out_split && (!g.out_f32 || (g.c_lo & 1) || g.c_lo <= 0)) return IVLM_ERR_INVALID_ARG;
+    }
     if (g.a_kstep || g.w_kstep || g.c_panel) {  // K-panel layouts: bf16, whole 64-wide panels, plain epilogues
         if (g.fp8 || g.out_fp8 || (g.K & 63) || g.batch != 1 || g.act == ACT_SWIGLU) return IVLM_ERR_UNSUPPORTED;
         if ((g.a_kstep && (g.a_kstep < (int64_t)64 * g.M || (g.a_kstep & 7) || g.a_rows)) || (g.w_kstep && (g.w_kstep < (int64_t)64 * g.N || (g.w_kstep & 7))))
@@ -339,7 +347,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             }
         }
         const int64_t o = (int64_t)m * g.ldc + n;
-        if (OUT_F32) *reinterpret_cast<float4*>(static_cast<float*>(g.C) + o) = make_float4(v[0], v[1], v[2], v[3]);
+        if (OUT_F32 && g.out_split) {
+            uint32_t h0, l0, h1, l1;
+            split_bf16x2(v[0], v[1], h0, l0);
+            split_bf16x2(v[2], v[3], h1, l1);
+            *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o + g.c_lo) = make_uint2(l0, l1);
+        } else if (OUT_F32) *reinterpret_cast<float4*>(static_cast<float*>(g.C) + o) = make_float4(v[0], v[1], v[2], v[3]);
         else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     }
 }
@@ -359,6 +373,7 @@ int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_
     p.C = workspace;
     p.ldc = g.N;
     p.out_f32 = 1;
+    p.out_split = 0;  // (the partials are fp32; the reduce pass applies the epilogue, split output included; a_split / a_lo stay)
     p.bias = nullptr;
     p.residual = nullptr;
     p.act = ACT_NONE;
@@ -424,6 +439,9 @@ extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     g.a_rows = a_rows;
     g.a_f32 = (flags & IVLM_GEMM_A_F32) ? 1 : 0;
     g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
+    if (flags & IVLM_GEMM_A_SPLIT) { g.a_split = 1; g.a_lo = K; }
+    if (flags & IVLM_GEMM_OUT_SPLIT) { g.out_split = 1; g.c_lo = act == ivlm::ACT_SWIGLU ? N / 2 : N; out_f32 = 1; }
+    if ((g.a_split || g.out_split) && M <= 16) return IVLM_ERR_UNSUPPORTED;  // tile GEMM path only
     g.rms_w = static_cast<const bf16_t*>(rms_w);
     g.rms_eps = rms_eps;
     g.tile = g_tile_override;
@@ -505,6 +523,8 @@ extern "C" int ivlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     if (flags & IVLM_GEMM_A_F32) return IVLM_ERR_UNSUPPORTED;
     ivlm::GemmArgs g;
     g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
+    if (flags & IVLM_GEMM_A_SPLIT) { g.a_split = 1; g.a_lo = K; }
+    if (flags & IVLM_GEMM_OUT_SPLIT) { g.out_split = 1; g.c_lo = N; out_f32 = 1; }
     g.tile = g_tile_override;
     g.A = static_cast<const bf16_t*>(A);
     g.W = static_cast<const bf16_t*>(W);

@@ -69,15 +69,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
             src[q == 0 ? 1 : 2][i] = W + (int64_t)rn * w_rs + kcol;
         }
     }
-    const int nt = (g.K + kBK - 1) / kBK;
+    const int nt = ((g.K + kBK - 1) / kBK) << (g.a_split ? 1 : 0);  // split A: every W tile twice (hi then lo tile of A)
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(kGemmZeroChunk);
     unsigned char* dma_base = smem + wave * 1024;  // piece i of a slot: + i * 8192
 
     // half-tile `kind` of K tile `tile` -> its slot (tiles past the end stream the zero chunk: keeps vmcnt uniform)
     auto stage = [&](int kind, int tile) {
         unsigned char* dst = dma_base + (tile & 1) * kTileLds + kind * kHalfBytes;
-        const bool ok = tile < nt && kcol + tile * kBK < g.K;
-        const int64_t koff = tile * ((kind == 0 || kind == 3) ? a_ks : w_ks);
+        const int kw = g.a_split ? tile >> 1 : tile;
+        const bool ok = tile < nt && kcol + kw * kBK < g.K;
+        const bool isa = kind == 0 || kind == 3;
+        const int64_t koff = kw * (isa ? a_ks : w_ks) + ((isa && g.a_split && (tile & 1)) ? g.a_lo : 0);
         glds16(ok ? src[kind][0] + koff : zero, dst);
         glds16(ok ? src[kind][1] + koff : zero, dst + 8192);
     };

@@ -130,7 +130,7 @@ __device__ __forceinline__ void gemm_value4(const GemmArgs& g, int n, const f32x
 template <bool OUT_F32>
 __device__ __forceinline__ bool gemm_whole_lines_ok(const GemmArgs& g, int act) {
     return act != ACT_SWIGLU && !g.out_fp8 && g.batch == 1 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
-           (OUT_F32 ? ((g.N & 3) == 0 && (g.ldc & 3) == 0 && (!g.residual || (g.ldr & 3) == 0))
+           (OUT_F32 ? ((g.N & 3) == 0 && (g.ldc & 3) == 0 && (!g.residual || (g.ldr & 3) == 0) && (!g.out_split || (g.c_lo & 3) == 0))
                     : ((g.N & 7) == 0 && !g.residual && (g.c_panel ? (g.c_panel & 7) == 0 : (g.ldc & 7) == 0)));
 }
 
@@ -191,7 +191,16 @@ __device__ __forceinline__ void gemm_store_lines(const GemmArgs& g, unsigned cha
                         q.w += bf16_to_f32((bf16_t)(r2.y >> 16));
                     }
                 }
-                *reinterpret_cast<float4*>(static_cast<float*>(g.C) + (int64_t)m * g.ldc + n) = q;
+                if (g.out_split) {  // [hi | lo] bf16 halves of the fp32 value (16 lanes x 8 B = one 128-byte line each)
+                    uint32_t h0, l0, h1, l1;
+                    split_bf16x2(q.x, q.y, h0, l0);
+                    split_bf16x2(q.z, q.w, h1, l1);
+                    bf16_t* cb = static_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n;
+                    *reinterpret_cast<uint2*>(cb) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(cb + g.c_lo) = make_uint2(l0, l1);
+                } else {
+                    *reinterpret_cast<float4*>(static_cast<float*>(g.C) + (int64_t)m * g.ldc + n) = q;
+                }
             } else {
                 const int64_t o = g.c_panel ? (int64_t)(n >> 6) * g.c_panel + (int64_t)m * 64 + (n & 63) : (int64_t)m * g.ldc + n;
                 *reinterpret_cast<uint4*>(static_cast<bf16_t*>(g.C) + o) = *reinterpret_cast<const uint4*>(src);
@@ -233,7 +242,13 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
             const float o0 = (v[0] / (1.0f + __expf(-v[0]))) * v[1];
             const float o1 = (v[2] / (1.0f + __expf(-v[2]))) * v[3];
             const int64_t o = (int64_t)m * g.ldc + (n >> 1);
-            if (OUT_F32) {
+            if (OUT_F32 && g.out_split) {
+                bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
+                uint32_t hi, lo;
+                split_bf16x2(o0, o1, hi, lo);
+                *reinterpret_cast<uint32_t*>(C + o) = hi;
+                *reinterpret_cast<uint32_t*>(C + o + g.c_lo) = lo;
+            } else if (OUT_F32) {
                 float* C = static_cast<float*>(g.C) + (int64_t)bz * g.strideC;
                 *reinterpret_cast<float2*>(C + o) = make_float2(o0, o1);
             } else {
@@ -263,6 +278,13 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
             w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, w, false);
             w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, w, true);
             *reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(g.C) + (int64_t)bz * g.strideC + o) = w;
+        } else if (OUT_F32 && g.out_split) {
+            bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
+            uint32_t h0, l0, h1, l1;
+            split_bf16x2(v[0], v[1], h0, l0);
+            split_bf16x2(v[2], v[3], h1, l1);
+            *reinterpret_cast<uint2*>(C + o) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(C + o + g.c_lo) = make_uint2(l0, l1);
         } else if (OUT_F32) {
             float* C = static_cast<float*>(g.C) + (int64_t)bz * g.strideC;
             *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -278,7 +300,11 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
             x = gemm_act(x, ACT);
             if (R) x += gemm_residual_at(g, R, rrow * g.ldr + n + j);
             const int64_t o = (int64_t)m * g.ldc + n + j;
-            if (OUT_F32)
+            if (OUT_F32 && g.out_split) {
+                bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
+                C[o] = f32_to_bf16(x);
+                C[o + g.c_lo] = f32_to_bf16(x - bf16_to_f32(C[o]));
+            } else if (OUT_F32)
                 (static_cast<float*>(g.C) + (int64_t)bz * g.strideC)[o] = x;
             else
                 (static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC)[o] = f32_to_bf16(x);

@@ -76,6 +76,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
+// hi + lo bf16 split of fp32 values (x = hi + lo to 2^-17 relative): packed pairs, hi = RNE(x), lo = RNE(x - hi)
+__device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16x2(a, b);
+    lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+
 // ---- wave64 reductions (fixed butterfly order => deterministic) ------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

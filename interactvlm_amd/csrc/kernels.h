@@ -39,6 +39,16 @@ struct GemmArgs {
     int fp8 = 0, out_fp8 = 0;
     const float *scale_a = nullptr, *scale_w = nullptr, *scale_out = nullptr;
     int a_f32 = 0;     // 1: A is float (M <= 16 weight-streaming paths: the products are exact, no operand rounding)
+    // fp32-activation GEMM on the bf16 matrix cores ("parity" precision; tile GEMM path): A rows are [hi(K) | lo(K)] bf16 with
+    // x = hi + lo to 2^-17 (ivlm_gather_rows / norm / GEMM outputs of kind IVLM_BF16_SPLIT), the lo half a_lo elements after the
+    // hi half; K counts the columns of ONE half (= the columns of W).  The K loop visits every W tile twice in a row (against the
+    // hi tile, then the lo tile of A): 2x the MFMA work, the second W read hits L2.
+    int a_split = 0;
+    int64_t a_lo = 0;
+    // out_split: C is bf16, the fp32 result v of column n is written as hi = bf16(v) at column n and lo = bf16(v - hi) at column
+    // n + c_lo (the next GEMM's / attention's split operand).  Set together with out_f32 = 1 (fp32 epilogue arithmetic).
+    int out_split = 0;
+    int64_t c_lo = 0;
     int res_f32 = 0;   // 1: residual is float (fp32 residual stream)
     // batched (strided) variant: blockIdx.z = batch
     int batch = 1;
@@ -83,6 +93,9 @@ struct AttnArgs {
     int rel_kh, rel_kw;
     int kv_batch_div;    // key/value batch index = b / kv_batch_div (broadcast K/V over query batches)
     int prescale_q;      // 1: scores = bf16(q*scale).k (SAM, HF-CLIP); 0: scores = (q.k)*scale (HF-LLaMA)
+    // "parity" precision: lo planes of q / k / v / o (x = hi + lo; same strides as the hi tensors).  All four set or none.
+    const bf16_t *q_lo = nullptr, *k_lo = nullptr, *v_lo = nullptr;
+    bf16_t* o_lo = nullptr;
 };
 
 // softmax(scale * Q.K^T (+ rel-pos bias) (+ causal mask)) . V ; bf16 in/out, fp32 softmax. D in {16,32,64,80,128}.

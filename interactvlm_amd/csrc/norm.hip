@@ -27,7 +27,7 @@ template <bool RMS, int MAXC, bool GELU, bool XF32, bool YF32>
 __global__ __launch_bounds__(256) void norm_kernel(const void* __restrict__ xv, const bf16_t* __restrict__ w,
                                                    const bf16_t* __restrict__ b, void* __restrict__ yv, int64_t rows,
                                                    int cols, float eps, const int32_t* __restrict__ out_rows,
-                                                   const float* __restrict__ fp8_scale) {
+                                                   const float* __restrict__ fp8_scale, int y_split) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void norm_kernel(const void* __restrict__ xv, 
         rstd = rsqrtf(q / (float)cols + eps);
     }
     const int64_t orow = out_rows ? (int64_t)out_rows[row] : row;
-    uint4* yr = reinterpret_cast<uint4*>(static_cast<bf16_t*>(yv) + orow * cols);
+    // y_split (bf16 output only): the row is written as [hi(cols) | lo(cols)], the A operand of an fp32-activation GEMM
+    uint4* yr = reinterpret_cast<uint4*>(static_cast<bf16_t*>(yv) + orow * (y_split ? 2 * cols : cols));
     float4* yr4 = reinterpret_cast<float4*>(static_cast<float*>(yv) + orow * cols);
     const uint4* wr = reinterpret_cast<const uint4*>(w);
     const uint4* br = reinterpret_cast<const uint4*>(b);
@@ -109,6 +110,12 @@ __global__ __launch_bounds__(256) void norm_kernel(const void* __restrict__ xv, 
             } else if (YF32) {
                 yr4[2 * idx] = make_float4(o[0], o[1], o[2], o[3]);
                 yr4[2 * idx + 1] = make_float4(o[4], o[5], o[6], o[7]);
+            } else if (y_split) {
+                uint32_t h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split_bf16x2(o[2 * j], o[2 * j + 1], h[j], l[j]);
+                yr[idx] = make_uint4(h[0], h[1], h[2], h[3]);
+                yr[nchunk + idx] = make_uint4(l[0], l[1], l[2], l[3]);
             } else {
                 yr[idx] = pack8(o);
             }
@@ -122,10 +129,11 @@ template <bool RMS, int MAXC, bool GELU>
 static void launch_norm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols,
                         float eps, hipStream_t st, const int32_t* out_rows = nullptr, const float* fp8_scale = nullptr) {
     const unsigned grid = (unsigned)((rows + 3) / 4);
-    if (x_f32 && y_f32) norm_kernel<RMS, MAXC, GELU, true, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale);
-    else if (x_f32) norm_kernel<RMS, MAXC, GELU, true, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale);
-    else if (y_f32) norm_kernel<RMS, MAXC, GELU, false, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale);
-    else norm_kernel<RMS, MAXC, GELU, false, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale);
+    const int y_split = y_f32 == 2;  // (y kind: 0 bf16, 1 fp32, 2 split bf16 [hi | lo])
+    if (x_f32 && y_f32 == 1) norm_kernel<RMS, MAXC, GELU, true, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale, 0);
+    else if (x_f32) norm_kernel<RMS, MAXC, GELU, true, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale, y_split);
+    else if (y_f32 == 1) norm_kernel<RMS, MAXC, GELU, false, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale, 0);
+    else norm_kernel<RMS, MAXC, GELU, false, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale, y_split);
 }
 
 int layernorm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols, float eps,
@@ -161,14 +169,15 @@ int ivlm_layernorm(const void* x, int x_dtype, const void* w, const void* b, voi
     if ((y_dtype == IVLM_FP8) != (fp8_scale != nullptr)) return IVLM_ERR_INVALID_ARG;
     if (y_dtype == IVLM_FP8 && (gelu || cols > 2048)) return IVLM_ERR_UNSUPPORTED;
     return ivlm::layernorm(x, x_dtype == IVLM_F32, static_cast<const bf16_t*>(w), static_cast<const bf16_t*>(b), y,
-                           y_dtype == IVLM_F32, rows, cols, eps, ivlm_stream(stream), gelu, out_rows, fp8_scale);
+                           y_dtype == IVLM_F32 ? 1 : (y_dtype == IVLM_BF16_SPLIT ? 2 : 0), rows, cols, eps, ivlm_stream(stream), gelu,
+                           out_rows, fp8_scale);
 }
 
 int ivlm_rmsnorm(const void* x, int x_dtype, const void* w, void* y, int y_dtype, int64_t rows, int cols, float eps,
                  ivlm_stream_t stream) {
     ivlm_enter();
-    return ivlm::rmsnorm(x, x_dtype == IVLM_F32, static_cast<const bf16_t*>(w), y, y_dtype == IVLM_F32, rows, cols, eps,
-                         ivlm_stream(stream));
+    return ivlm::rmsnorm(x, x_dtype == IVLM_F32, static_cast<const bf16_t*>(w), y,
+                         y_dtype == IVLM_F32 ? 1 : (y_dtype == IVLM_BF16_SPLIT ? 2 : 0), rows, cols, eps, ivlm_stream(stream));
 }
 
 }  // extern "C"
