@@ -245,6 +245,10 @@ int ivlm_attention_pingpong(int mode);
  *   like the reference's model-dtype einsum, stored f32).  tab_h bf16 [2*SH-1,D], tab_w bf16 [2*SW-1,D]. */
 int ivlm_relpos_bias(const void *q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void *tab_h, const void *tab_w,
                      int B, int H, int SH, int SW, int D, float *rel_h, float *rel_w, ivlm_stream_t stream);
+/* "Parity" precision of the same operands: q as hi + lo bf16 planes (q_lo: same strides), results unrounded fp32 (D = 80). */
+int ivlm_relpos_bias_split(const void *q, const void *q_lo, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void *tab_h,
+                           const void *tab_w, int B, int H, int SH, int SW, int D, float *rel_h, float *rel_w,
+                           ivlm_stream_t stream);
 /* Second half of the GEMM formulation of the same operands: G bf16 [H][B*S][npad] = q . [rel_pos_h ; rel_pos_w]^T (one
  * batched ivlm_gemm_bf16 over the heads, K = head dim), g_head_stride = elements between heads; this gathers the Toeplitz
  * shifts rel_h[bh,s,kh] = G[qh-kh+SH-1], rel_w[bh,s,kw] = G[(2SH-1) + qw-kw+SW-1] into f32 [B*H,S,SH] / [B*H,S,SW]. */
@@ -256,7 +260,7 @@ int ivlm_relpos_gather(const void *G, int64_t g_head_stride, int npad, int B, in
  * qkv [3,H,D] (output of the fused q|k|v projection) and o [H,D] are bf16 or fp32 (io_dtype): with fp32 I/O q and the softmax
  * weights are not rounded (the decode path keeps fp32 activations), with bf16 they are rounded like the MFMA prefill path.
  * pos_dev != NULL: the position is read from device memory (one captured HIP graph then serves every decode step).
- * A position >= tmax (or >= 4096) is skipped: nothing is appended, o is left untouched.  D <= 128. */
+ * A position >= tmax (or >= 4096) is skipped: nothing is appended and o is written as zeros.  D <= 128. */
 int ivlm_llama_decode_attn(const void *qkv, int io_dtype, void *kcache, void *vcache, int tmax, void *o, int H, int D, int pos,
                            const int32_t *pos_dev, float theta, float scale, const float *cos_tab, const float *sin_tab,
                            ivlm_stream_t stream);
@@ -267,6 +271,16 @@ int ivlm_llama_decode_attn(const void *qkv, int io_dtype, void *kcache, void *vc
 int ivlm_llama_decode_attn_batch(const void *qkv, int io_dtype, int64_t ldq, void *kcache, void *vcache, int64_t cache_stride,
                                  int tmax, void *o, int64_t ldo, int B, int H, int D, const int32_t *pos_dev, float theta,
                                  float scale, const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
+
+/* "Parity" precision of the two kernels above: fp32 qkv / o, and the cache holds K / V as hi + lo bf16 planes (kcache_lo /
+ * vcache_lo: the layout of the hi caches) - the appended rows are not rounded to bf16, the cached ones are read as hi + lo. */
+int ivlm_llama_decode_attn_split(const void *qkv, void *kcache, void *kcache_lo, void *vcache, void *vcache_lo, int tmax, void *o,
+                                 int H, int D, int pos, const int32_t *pos_dev, float theta, float scale, const float *cos_tab,
+                                 const float *sin_tab, ivlm_stream_t stream);
+int ivlm_llama_decode_attn_batch_split(const void *qkv, int64_t ldq, void *kcache, void *kcache_lo, void *vcache, void *vcache_lo,
+                                       int64_t cache_stride, int tmax, void *o, int64_t ldo, int B, int H, int D,
+                                       const int32_t *pos_dev, float theta, float scale, const float *cos_tab,
+                                       const float *sin_tab, ivlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage-level entry points of the language path: C++ sequencers over the ops above, the same kernels in the same
@@ -383,6 +397,10 @@ int ivlm_im2col_nchw(const void *x, void *out, int B, int C, int H, int W, int k
                      ivlm_stream_t stream);
 /* 3x3 / pad 1 conv operand from channels-last x [B,H,W,C] -> [(b,y,x), (ky,kx,c)] (SAM neck, image_encoder.py:92-108) */
 int ivlm_im2col3x3_nhwc(const void *x, void *out, int B, int H, int W, int C, ivlm_stream_t stream);
+/* the same with pixel stride ldx >= C of x and row stride ldo >= 9C of out (elements, multiples of 8): the hi and the lo half of
+ * IVLM_BF16_SPLIT rows are unfolded separately into the two halves of a [rows, 2 * 9C] split operand */
+int ivlm_im2col3x3_nhwc_strided(const void *x, int64_t ldx, void *out, int64_t ldo, int B, int H, int W, int C,
+                                ivlm_stream_t stream);
 /* dst[r] = (idx ? (idx[r] >= 0 ? src[idx[r]] : 0) : src[r]) + (add ? add[r] : 0): window_partition / window_unpartition +
  * shortcut (image_encoder.py:263-318, 177-193), embed_tokens gather (llava_arch.py:185-208), dtype conversion.  src / add
  * bf16 or fp32, dst bf16, fp32, IVLM_BF16_SPLIT (row stride ldd >= 2*cols) or IVLM_FP8 (bytes of x / *fp8_scale, clamped to
@@ -408,6 +426,11 @@ int ivlm_dense_pe(const void *gauss, void *pe, int pe_dtype, int h, int w, int F
  * positions pos0+t, and KV-cache append (kcache/vcache [Tmax,H,D], may be NULL). */
 int ivlm_rope_kv(void *qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void *kcache, void *vcache,
                  const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
+/* "Parity" precision of ivlm_rope_kv: qkv rows are IVLM_BF16_SPLIT ([hi(3HD) | lo(3HD)], ld >= 6HD), rotated in fp32 on hi + lo
+ * and written back as hi + lo; K / V are appended to hi + lo cache planes ([Tmax,H,D] each; all four or none).  cos / sin tables
+ * are required. */
+int ivlm_rope_kv_split(void *qkv, int64_t ld, int T, int H, int D, int pos0, void *kcache, void *kcache_lo, void *vcache,
+                       void *vcache_lo, const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
 /* Decode attention (as ivlm_llama_decode_attn with fp32 I/O and a device position) and the o_proj GEMV + residual of the same
  * layer in ONE launch: x_out[hidden] = x + W_o . attention(qkv), qkv / x / x_out fp32 (fp32 residual stream), W_o bf16.  The
  * o_proj blocks stream their weight rows while the attention blocks run and wait for them on `counter` (int32, zeroed by the

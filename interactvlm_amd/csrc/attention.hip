@@ -255,7 +255,8 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
 
     // ---- rel-pos operands of this lane's two queries -------------------------------------------
     bf16x8_t qrel[2];       // REL 1: [rel_h(KH) | rel_w(KW) | 0] features g*8 .. g*8+7
-    bf16x8_t qrel_lo[2];    //        (SPLIT: the fp32 bias values as hi + lo operands: the one-hot MFMA adds them exactly)
+    bf16x8_t qrel_lo[2];    //        (SPLIT: the fp32 bias values as hi + lo + lo2 operands - three bf16 terms carry all 24 bits:
+    bf16x8_t qrel_lo2[2];   //         the one-hot MFMAs add them exactly; a bias of +-20 split in two would be off by 1e-4)
     f32x4_t rwf[2][4];      // REL 2: rel_w[q][kt*16 + g*4 + r]: tile-invariant, SEEDS the score accumulators (no add later)
     const float* rhp[2] = {nullptr, nullptr};
     const float* rwg[2] = {nullptr, nullptr};  // REL 3
@@ -277,12 +278,20 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
                 uint4 u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
                                      pack_bf16x2(f[6], f[7]));
                 if (SPLIT) {
-                    uint4 ul;
-                    split_bf16x2(f[0], f[1], u.x, ul.x);
-                    split_bf16x2(f[2], f[3], u.y, ul.y);
-                    split_bf16x2(f[4], f[5], u.z, ul.z);
-                    split_bf16x2(f[6], f[7], u.w, ul.w);
-                    qrel_lo[qt] = *reinterpret_cast<bf16x8_t*>(&ul);
+                    u32x4_t uh, ul, ul2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t hh, ll;
+                        split_bf16x2(f[2 * e], f[2 * e + 1], hh, ll);
+                        const float r0 = (f[2 * e] - __uint_as_float(hh << 16)) - __uint_as_float(ll << 16);
+                        const float r1 = (f[2 * e + 1] - __uint_as_float(hh & 0xffff0000u)) - __uint_as_float(ll & 0xffff0000u);
+                        uh[e] = hh;
+                        ul[e] = ll;
+                        ul2[e] = pack_bf16x2(r0, r1);
+                    }
+                    u = make_uint4(uh[0], uh[1], uh[2], uh[3]);
+                    qrel_lo[qt] = __builtin_bit_cast(bf16x8_t, ul);
+                    qrel_lo2[qt] = __builtin_bit_cast(bf16x8_t, ul2);
                 }
                 qrel[qt] = *reinterpret_cast<bf16x8_t*>(&u);
             } else if (REL == 3) {
@@ -352,7 +361,10 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel[qt], s[qt][kt], 0, 0, 0);
-                    if (SPLIT) s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo[qt], s[qt][kt], 0, 0, 0);
+                    if (SPLIT) {
+                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo[qt], s[qt][kt], 0, 0, 0);
+                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo2[qt], s[qt][kt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -728,11 +740,14 @@ __global__ __launch_bounds__(256) void relpos_kernel(const bf16_t* __restrict__ 
 typedef __attribute__((ext_vector_type(2))) __bf16 rp_bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int rp_u32x4_t;
 
-template <int NCH>
+// SPLIT ("parity" precision): q = hi + lo planes (q_lo, same strides), fp32 results NOT rounded to bf16 (the fp32 reference
+// keeps them in fp32; only a bf16 model materialises them in bf16).
+template <int NCH, bool SPLIT = false>
 __global__ __launch_bounds__(256) void relpos_rows_kernel(const bf16_t* __restrict__ q, int64_t q_bs, int64_t q_hs,
                                                           int64_t q_rs, const bf16_t* __restrict__ tab_h,
                                                           const bf16_t* __restrict__ tab_w, int H, int SH, int SW,
-                                                          float* __restrict__ rel_h, float* __restrict__ rel_w) {
+                                                          float* __restrict__ rel_h, float* __restrict__ rel_w,
+                                                          const bf16_t* __restrict__ q_lo = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rp_smem[];
     constexpr int D = NCH * 8, kStride = D + 8;  // elements
     rp_u32x4_t* th = reinterpret_cast<rp_u32x4_t*>(rp_smem);                        // [2SH-1][kStride/8] chunks
@@ -752,9 +767,14 @@ __global__ __launch_bounds__(256) void relpos_rows_kernel(const bf16_t* __restri
     const int h = blockIdx.y, b = blockIdx.z;
     const int qh = qi / SW, qw = qi - qh * SW;
     const bf16_t* qv = q + b * q_bs + h * q_hs + (int64_t)qi * q_rs;
-    rp_u32x4_t qr[NCH];
+    rp_u32x4_t qr[NCH], ql[SPLIT ? NCH : 1];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) qr[c] = *reinterpret_cast<const rp_u32x4_t*>(qv + c * 8);
+    if (SPLIT) {
+        const bf16_t* qlv = q_lo + b * q_bs + h * q_hs + (int64_t)qi * q_rs;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) ql[SPLIT ? c : 0] = *reinterpret_cast<const rp_u32x4_t*>(qlv + c * 8);
+    }
     const int64_t bq = ((int64_t)b * H + h) * S + qi;
     auto run = [&](const rp_u32x4_t* tab, int base_row, int n, float* out) {
         // out[j] = q . tab[base_row - j], j = 0..n-1, in groups of 4 (16-byte stores; n % 4 tail scalar)
@@ -773,9 +793,12 @@ __global__ __launch_bounds__(256) void relpos_rows_kernel(const bf16_t* __restri
                         const uint32_t a = qr[c][e], w = t4[e];
                         acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2_t, a),
                                                                __builtin_bit_cast(rp_bf16x2_t, w), acc, false);
+                        if (SPLIT)
+                            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2_t, (uint32_t)ql[SPLIT ? c : 0][e]),
+                                                                   __builtin_bit_cast(rp_bf16x2_t, w), acc, false);
                     }
                 }
-                r[u] = bf16_to_f32(f32_to_bf16(acc));  // the reference materialises rel_h/rel_w in bf16
+                r[u] = SPLIT ? acc : bf16_to_f32(f32_to_bf16(acc));  // the (bf16) reference materialises rel_h/rel_w in bf16
             }
             if ((((uintptr_t)(out + j)) & 15) == 0) {
                 *reinterpret_cast<float4*>(out + j) = make_float4(r[0], r[1], r[2], r[3]);
@@ -795,9 +818,12 @@ __global__ __launch_bounds__(256) void relpos_rows_kernel(const bf16_t* __restri
                     const uint32_t a = qr[c][e], w = t4[e];
                     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2_t, a),
                                                            __builtin_bit_cast(rp_bf16x2_t, w), acc, false);
+                    if (SPLIT)
+                        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2_t, (uint32_t)ql[SPLIT ? c : 0][e]),
+                                                               __builtin_bit_cast(rp_bf16x2_t, w), acc, false);
                 }
             }
-            out[j] = bf16_to_f32(f32_to_bf16(acc));
+            out[j] = SPLIT ? acc : bf16_to_f32(f32_to_bf16(acc));
         }
     };
     run(th, qh + SH - 1, SH, rel_h + bq * SH);
@@ -858,8 +884,17 @@ int attention_bf16(const AttnArgs& a, hipStream_t st) {
 }
 
 int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const bf16_t* tab_h, const bf16_t* tab_w,
-                int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, hipStream_t st) {
+                int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, hipStream_t st, const bf16_t* q_lo) {
     if (!q || !tab_h || !tab_w || !rel_h || !rel_w || (D & 7)) return IVLM_ERR_INVALID_ARG;
+    if (q_lo) {  // "parity" precision: q as hi + lo planes, unrounded fp32 results (SAM head dim only)
+        if (D != 80 || SH > 128 || SW > 128 || H > 65535 || B > 65535 || ((q_bs | q_hs | q_rs) & 7) ||
+            ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(q_lo)) & 15))
+            return IVLM_ERR_UNSUPPORTED;
+        const size_t lds = (size_t)(2 * SH - 1 + 2 * SW - 1) * (D + 8) * 2;
+        relpos_rows_kernel<10, true><<<dim3((SH * SW + 255) / 256, H, B), 256, lds, st>>>(q, q_bs, q_hs, q_rs, tab_h, tab_w, H, SH,
+                                                                                         SW, rel_h, rel_w, q_lo);
+        return ivlm_launch_status();
+    }
     if ((D == 80 || D == 64) && SH <= 128 && SW <= 128 && H <= 65535 && B <= 65535 &&
         ((q_bs | q_hs | q_rs) & 7) == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0) {
         const size_t lds = (size_t)(2 * SH - 1 + 2 * SW - 1) * (D + 8) * 2;
@@ -955,7 +990,17 @@ int ivlm_relpos_bias(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, co
                      int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, ivlm_stream_t stream) {
     ivlm_enter();
     return ivlm::relpos_bias(static_cast<const bf16_t*>(q), q_bs, q_hs, q_rs, static_cast<const bf16_t*>(tab_h),
-                             static_cast<const bf16_t*>(tab_w), B, H, SH, SW, D, rel_h, rel_w, ivlm_stream(stream));
+                             static_cast<const bf16_t*>(tab_w), B, H, SH, SW, D, rel_h, rel_w, ivlm_stream(stream), nullptr);
+}
+
+int ivlm_relpos_bias_split(const void* q, const void* q_lo, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* tab_h,
+                           const void* tab_w, int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w,
+                           ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!q_lo) return IVLM_ERR_INVALID_ARG;
+    return ivlm::relpos_bias(static_cast<const bf16_t*>(q), q_bs, q_hs, q_rs, static_cast<const bf16_t*>(tab_h),
+                             static_cast<const bf16_t*>(tab_w), B, H, SH, SW, D, rel_h, rel_w, ivlm_stream(stream),
+                             static_cast<const bf16_t*>(q_lo));
 }
 
 }  // extern "C"

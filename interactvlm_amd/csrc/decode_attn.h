@@ -15,14 +15,18 @@ constexpr int kDecThreads = 1024, kDecGroups = kDecThreads / 16;  // 64 key rows
 // F32IO: qkv and the output row are fp32 (the decode path keeps fp32 activations between its weight-streaming kernels: q and
 // the softmax weights are then NOT rounded to bf16 - only the K/V rows appended to the bf16 cache are); otherwise bf16 in/out
 // with the roundings of the MFMA prefill path (q, k after RoPE and P rounded to bf16).
-template <bool COHERENT_OUT, bool F32IO = false, int THREADS = 1024>
+// LO ("parity" precision, with F32IO): the cache holds K / V as hi + lo bf16 planes (kcache_lo / vcache_lo, same layout): the
+// appended rows are not rounded to bf16 and the cached ones are read back as hi + lo.
+template <bool COHERENT_OUT, bool F32IO = false, int THREADS = 1024, bool LO = false>
 __device__ __forceinline__ void llama_decode_attn_body(const int h, const void* __restrict__ qkv_v /*[3,H,D]*/,
                                                                 bf16_t* __restrict__ kcache /*[Tmax,H,D]*/,
                                                                 bf16_t* __restrict__ vcache, void* __restrict__ o_v,
                                                                 int H, int D, int pos_arg, float theta, float scale,
                                                                 const float* __restrict__ ct,
                                                                 const float* __restrict__ stab,
-                                                                const int32_t* __restrict__ pos_dev, int tmax = 0) {
+                                                                const int32_t* __restrict__ pos_dev, int tmax = 0,
+                                                                bf16_t* __restrict__ kcache_lo = nullptr,
+                                                                bf16_t* __restrict__ vcache_lo = nullptr) {
     constexpr int kDecThreads = THREADS, kDecGroups = THREADS / 16;  // (shadow the namespace defaults)
     // position from device memory when given: lets one captured HIP graph serve every decode step
     const int pos = pos_dev ? __builtin_amdgcn_readfirstlane(*pos_dev) : pos_arg;
@@ -48,6 +52,8 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const void* 
     const int64_t rstride = (int64_t)H * D;
     const bf16_t* kb = kcache + (int64_t)h * D + csub * 8;
     const bf16_t* vb = vcache + (int64_t)h * D + csub * 8;
+    const bf16_t* kbl = LO ? kcache_lo + (int64_t)h * D + csub * 8 : nullptr;
+    const bf16_t* vbl = LO ? vcache_lo + (int64_t)h * D + csub * 8 : nullptr;
     u32x4_t kr[kU], vr[kU];
 #pragma unroll
     for (int i = 0; i < kU; ++i) {
@@ -84,11 +90,18 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const void* 
         bf16_t* kc = kcache + ((int64_t)pos * H + h) * D;
         kc[t] = ka;
         kc[t + half] = kb;
+        if (LO) {
+            bf16_t* kcl = kcache_lo + ((int64_t)pos * H + h) * D;
+            kcl[t] = f32_to_bf16(kaf - bf16_to_f32(ka));
+            kcl[t + half] = f32_to_bf16(kbf - bf16_to_f32(kb));
+        }
     } else if (t >= 128 && t < 128 + D) {
         const int d = t - 128;
         const float v = ld(2 * (int64_t)H * D + h * D + d);
         vnew_s[d] = v;
-        vcache[((int64_t)pos * H + h) * D + d] = f32_to_bf16(v);
+        const bf16_t vh = f32_to_bf16(v);
+        vcache[((int64_t)pos * H + h) * D + d] = vh;
+        if (LO) vcache_lo[((int64_t)pos * H + h) * D + d] = f32_to_bf16(v - bf16_to_f32(vh));
     }
     __syncthreads();
     // ---- scores ------------------------------------------------------------------------------------------------
@@ -104,6 +117,14 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const void* 
                 for (int e = 0; e < 4; ++e) {
                     d += __uint_as_float(kv[e] << 16) * qr[2 * e];
                     d += __uint_as_float(kv[e] & 0xffff0000u) * qr[2 * e + 1];
+                }
+                if (LO) {
+                    const u32x4_t kl = *reinterpret_cast<const u32x4_t*>(kbl + j * rstride);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        d += __uint_as_float(kl[e] << 16) * qr[2 * e];
+                        d += __uint_as_float(kl[e] & 0xffff0000u) * qr[2 * e + 1];
+                    }
                 }
             } else if (j == pos) {
 #pragma unroll
@@ -165,6 +186,14 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const void* 
                 for (int e = 0; e < 4; ++e) {
                     acc[2 * e] += p * __uint_as_float(vv[e] << 16);
                     acc[2 * e + 1] += p * __uint_as_float(vv[e] & 0xffff0000u);
+                }
+                if (LO) {
+                    const u32x4_t vl = *reinterpret_cast<const u32x4_t*>(vbl + j * rstride);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 * e] += p * __uint_as_float(vl[e] << 16);
+                        acc[2 * e + 1] += p * __uint_as_float(vl[e] & 0xffff0000u);
+                    }
                 }
             } else {
 #pragma unroll

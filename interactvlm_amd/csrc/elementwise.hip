@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kT) void im2col_nchw_kernel(const bf16_t* __restric
 
 // x [B,H,W,C] -> out [(b,y,x), (ky,kx,c)] with zero padding 1; C % 8 == 0
 __global__ __launch_bounds__(kT) void im2col3x3_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
-                                                            int B, int H, int W, int C) {
+                                                            int B, int H, int W, int C, int64_t ldx, int64_t ldo) {
     const int c8n = C >> 3;
     const int64_t total = (int64_t)B * H * W * 9 * c8n;
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(kT) void im2col3x3_nhwc_kernel(const bf16_t* __rest
         const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (sy >= 0 && sy < H && sx >= 0 && sx < W)
-            v = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + sy) * W + sx) * C + c8 * 8);
-        *reinterpret_cast<uint4*>(out + row * (9 * (int64_t)C) + tap * C + c8 * 8) = v;
+            v = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + sy) * W + sx) * ldx + c8 * 8);
+        *reinterpret_cast<uint4*>(out + row * ldo + tap * C + c8 * 8) = v;
     }
 }
 
@@ -268,6 +268,51 @@ __global__ __launch_bounds__(kT) void rope_kv_kernel(bf16_t* __restrict__ qkv, i
     }
 }
 
+// "parity" precision of rope_kv: qkv rows are [hi(3HD) | lo(3HD)] bf16 (the split output of the q|k|v GEMM); q and k are rotated
+// in fp32 on hi + lo and written back as hi + lo; K / V are appended to hi + lo cache planes (no rounding of the cached rows).
+__global__ __launch_bounds__(kT) void rope_kv_split_kernel(bf16_t* __restrict__ qkv, int64_t ld, int T, int H, int D, int pos0,
+                                                           bf16_t* __restrict__ kcache, bf16_t* __restrict__ kcache_lo,
+                                                           bf16_t* __restrict__ vcache, bf16_t* __restrict__ vcache_lo,
+                                                           const float* __restrict__ ct, const float* __restrict__ stab) {
+    const int half = D >> 1;
+    const int64_t total = (int64_t)T * H * half;
+    const int64_t lo = 3 * (int64_t)H * D;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+        const int j = (int)(i % half);
+        const int h = (int)((i / half) % H);
+        const int t = (int)(i / ((int64_t)half * H));
+        const int pos = pos0 + t;
+        const float c = ct[pos * half + j], s = stab[pos * half + j];
+        bf16_t* row = qkv + (int64_t)t * ld;
+        bf16_t* q = row + h * D;
+        bf16_t* k = row + (int64_t)H * D + h * D;
+        const bf16_t* v = row + 2 * (int64_t)H * D + h * D;
+        auto val = [&](const bf16_t* p, int e) { return bf16_to_f32(p[e]) + bf16_to_f32(p[lo + e]); };
+        const float q0 = val(q, j), q1 = val(q, j + half), k0 = val(k, j), k1 = val(k, j + half);
+        const float qa = q0 * c - q1 * s, qb = q1 * c + q0 * s, ka = k0 * c - k1 * s, kb = k1 * c + k0 * s;
+        auto put = [&](bf16_t* p, int e, float x, bf16_t* ch, bf16_t* cl) {
+            const bf16_t hi = f32_to_bf16(x), l = f32_to_bf16(x - bf16_to_f32(hi));
+            p[e] = hi;
+            p[lo + e] = l;
+            if (ch) {
+                ch[e] = hi;
+                cl[e] = l;
+            }
+        };
+        const int64_t crow = ((int64_t)pos * H + h) * D;
+        put(q, j, qa, nullptr, nullptr);
+        put(q, j + half, qb, nullptr, nullptr);
+        put(k, j, ka, kcache ? kcache + crow : nullptr, kcache ? kcache_lo + crow : nullptr);
+        put(k, j + half, kb, kcache ? kcache + crow : nullptr, kcache ? kcache_lo + crow : nullptr);
+        if (kcache) {
+            vcache[crow + j] = v[j];
+            vcache[crow + j + half] = v[j + half];
+            vcache_lo[crow + j] = v[lo + j];
+            vcache_lo[crow + j + half] = v[lo + j + half];
+        }
+    }
+}
+
 // up [B, gh, gw, 2,2, 2,2, C] (two k2s2 transposed convs, channels last)  x  hyper [B, C]
 //   -> low [B, 4gh, 4gw] fp32 at (4y + 2dy + dy2, 4x + 2dx + dx2)
 __global__ __launch_bounds__(kT) void mask_dot_kernel(const void* __restrict__ up, const void* __restrict__ hyper, int kind,
@@ -341,9 +386,12 @@ int im2col_nchw(const bf16_t* x, bf16_t* out, int B, int C, int H, int W, int ks
     im2col_nchw_kernel<<<grid_for((int64_t)B * gh * gw * (Kpad >> 3)), kT, 0, st>>>(x, out, B, C, H, W, ks, stride, Kpad);
     return ivlm_launch_status();
 }
-int im2col3x3_nhwc(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st) {
+int im2col3x3_nhwc(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st, int64_t ldx, int64_t ldo) {
     if (!x || !out || (C & 7)) return IVLM_ERR_INVALID_ARG;
-    im2col3x3_nhwc_kernel<<<grid_for((int64_t)B * H * W * 9 * (C >> 3)), kT, 0, st>>>(x, out, B, H, W, C);
+    if (ldx == 0) ldx = C;
+    if (ldo == 0) ldo = 9 * (int64_t)C;
+    if (ldx < C || ldo < 9 * (int64_t)C || ((ldx | ldo) & 7)) return IVLM_ERR_INVALID_ARG;
+    im2col3x3_nhwc_kernel<<<grid_for((int64_t)B * H * W * 9 * (C >> 3)), kT, 0, st>>>(x, out, B, H, W, C, ldx, ldo);
     return ivlm_launch_status();
 }
 int gather_rows(void* dst, int dst_kind, int64_t ldd, const void* src, int src_kind, int64_t lds_, const int32_t* idx,
@@ -369,8 +417,8 @@ int add_rows(void* out, int out_kind, const void* a, int a_kind, const void* b, 
     return ivlm_launch_status();
 }
 int fill_rows(bf16_t* dst, int64_t ldd, const int32_t* idx, int64_t n_idx, const bf16_t* row, int cols, hipStream_t st) {
+    if (n_idx == 0) return IVLM_OK;  // (an empty index tensor has a null data pointer: nothing to fill, not an error)
     if (!dst || !idx || !row || n_idx < 0 || (cols & 7) || (ldd & 7)) return IVLM_ERR_INVALID_ARG;
-    if (n_idx == 0) return IVLM_OK;
     fill_rows_kernel<<<grid_for(n_idx * (cols >> 3)), kT, 0, st>>>(dst, ldd, idx, n_idx, row, cols);
     return ivlm_launch_status();
 }
@@ -384,6 +432,14 @@ int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta,
     if (!qkv || T <= 0 || (D & 1) || (kcache && !vcache) || (cos_tab && !sin_tab)) return IVLM_ERR_INVALID_ARG;
     rope_kv_kernel<<<grid_for((int64_t)T * H * (D >> 1)), kT, 0, st>>>(qkv, ld, T, H, D, pos0, theta, kcache, vcache,
                                                                        cos_tab, sin_tab);
+    return ivlm_launch_status();
+}
+int rope_kv_split(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, bf16_t* kcache, bf16_t* kcache_lo, bf16_t* vcache,
+                  bf16_t* vcache_lo, const float* cos_tab, const float* sin_tab, hipStream_t st) {
+    if (!qkv || T <= 0 || (D & 1) || !cos_tab || !sin_tab || ld < 6LL * H * D) return IVLM_ERR_INVALID_ARG;
+    if (kcache && (!kcache_lo || !vcache || !vcache_lo)) return IVLM_ERR_INVALID_ARG;
+    rope_kv_split_kernel<<<grid_for((int64_t)T * H * (D >> 1)), kT, 0, st>>>(qkv, ld, T, H, D, pos0, kcache, kcache_lo, vcache,
+                                                                             vcache_lo, cos_tab, sin_tab);
     return ivlm_launch_status();
 }
 int rope_table(float* cos_tab, float* sin_tab, int T, int D, float theta, hipStream_t st) {
@@ -410,6 +466,10 @@ int ivlm_im2col_nchw(const void* x, void* out, int B, int C, int H, int W, int k
 int ivlm_im2col3x3_nhwc(const void* x, void* out, int B, int H, int W, int C, ivlm_stream_t s) {
     ivlm_enter();
     return ivlm::im2col3x3_nhwc(CBF(x), BF(out), B, H, W, C, ivlm_stream(s));
+}
+int ivlm_im2col3x3_nhwc_strided(const void* x, int64_t ldx, void* out, int64_t ldo, int B, int H, int W, int C, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::im2col3x3_nhwc(CBF(x), BF(out), B, H, W, C, ivlm_stream(s), ldx, ldo);
 }
 int ivlm_gather_rows(void* dst, int dst_kind, int64_t ldd, const void* src, int src_dtype, int64_t lds_, const int32_t* idx,
                      const void* add, int add_dtype, int64_t lda, int64_t rows, int cols, const float* fp8_scale,
@@ -441,6 +501,12 @@ int ivlm_rope_kv(void* qkv, int64_t ld, int T, int H, int D, int pos0, float the
                  const float* cos_tab, const float* sin_tab, ivlm_stream_t s) {
     ivlm_enter();
     return ivlm::rope_kv(BF(qkv), ld, T, H, D, pos0, theta, BF(kcache), BF(vcache), ivlm_stream(s), cos_tab, sin_tab);
+}
+int ivlm_rope_kv_split(void* qkv, int64_t ld, int T, int H, int D, int pos0, void* kcache, void* kcache_lo, void* vcache,
+                       void* vcache_lo, const float* cos_tab, const float* sin_tab, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::rope_kv_split(BF(qkv), ld, T, H, D, pos0, BF(kcache), BF(kcache_lo), BF(vcache), BF(vcache_lo), cos_tab, sin_tab,
+                               ivlm_stream(s));
 }
 int ivlm_rope_table(float* cos_tab, float* sin_tab, int T, int D, float theta, ivlm_stream_t s) {
     ivlm_enter();

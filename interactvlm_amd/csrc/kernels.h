@@ -105,11 +105,13 @@ int attention_f32(const float* q, const float* k, const float* v, float* o, cons
                   int D, float scale, int kv_div, hipStream_t st);
 // decomposed relative-position bias terms of SAM's ViT (image_encoder.py:354-392) as fp32 tables
 int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const bf16_t* tab_h, const bf16_t* tab_w,
-                int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, hipStream_t st);
+                int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, hipStream_t st, const bf16_t* q_lo = nullptr);
 
 // ---- data movement / elementwise (elementwise.hip) -----------------------------------------------
 int im2col_nchw(const bf16_t* x, bf16_t* out, int B, int C, int H, int W, int ks, int stride, int Kpad, hipStream_t st);
-int im2col3x3_nhwc(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st);
+int im2col3x3_nhwc(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st, int64_t ldx = 0, int64_t ldo = 0);
+int rope_kv_split(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, bf16_t* kcache, bf16_t* kcache_lo, bf16_t* vcache,
+                  bf16_t* vcache_lo, const float* cos_tab, const float* sin_tab, hipStream_t st);
 // kinds: 0 bf16, 1 fp32, 2 (outputs only) split [hi | lo] bf16 rows of width 2*cols
 // (kind 3, outputs only: e4m3 bytes of x / *scale)
 int gather_rows(void* dst, int dst_kind, int64_t ldd, const void* src, int src_kind, int64_t lds_, const int32_t* idx,
@@ -148,10 +150,11 @@ int phong_shade(const int32_t* p2v, const float* bary, const float* verts, const
 // qkv / o bf16 or fp32 (io_f32); tmax = rows of the cache slab (a position >= tmax is skipped, never appended)
 int llama_decode_attn(const void* qkv, int io_f32, bf16_t* kcache, bf16_t* vcache, int tmax, void* o, int H, int D, int pos,
                       float theta, float scale, hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr,
-                      const int32_t* pos_dev = nullptr);
+                      const int32_t* pos_dev = nullptr, bf16_t* kcache_lo = nullptr, bf16_t* vcache_lo = nullptr);
 int llama_decode_attn_batch(const void* qkv, int io_f32, int64_t ldq, bf16_t* kcache, bf16_t* vcache, int64_t cache_stride,
                             int tmax, void* o, int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta, float scale,
-                            const float* cos_tab, const float* sin_tab, hipStream_t st);
+                            const float* cos_tab, const float* sin_tab, hipStream_t st, bf16_t* kcache_lo = nullptr,
+                            bf16_t* vcache_lo = nullptr);
 
 // fused decode attention + o_proj (decode_fused.hip)
 int llama_attn_oproj(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* attn_scratch, const bf16_t* wo,

@@ -57,7 +57,8 @@ class ClipTower:
         if not (self.use_graph and images.is_cuda) or torch.cuda.is_current_stream_capturing() or ops.TIMER.enabled:
             return self._forward(images)
         B = images.shape[0]
-        ent = self._graphs.get(B)
+        gkey = (B, self.precision)
+        ent = self._graphs.get(gkey)
         if ent is None:
             static_in = images.to(BF16).contiguous().clone()
             side = torch.cuda.Stream(device=images.device)
@@ -68,15 +69,19 @@ class ClipTower:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (an RCCL watchdog thread may be polling events)
                 static_out = self._forward(static_in)
-            ent = self._graphs[B] = (g, static_in, static_out)
+            ent = self._graphs[gkey] = (g, static_in, static_out)
         g, static_in, static_out = ent
         static_in.copy_(images)
         g.replay()
         return static_out.clone()
 
+    precision = "default"  # "parity": fp32-activation arithmetic (hi + lo bf16 operands), see SamImageEncoder.precision
+
     def _forward(self, images):
-        """-> penultimate-layer patch features, bf16 [B, T-1, hidden] (the mm_projector's MFMA operand).  The residual
-        stream is fp32 between the GEMMs (residual epilogues write fp32, the LayerNorms read it)."""
+        """-> penultimate-layer patch features, bf16 [B, T-1, hidden] (the mm_projector's MFMA operand; "parity" precision:
+        [B, T-1, 2*hidden] = [hi | lo] rows).  The residual stream is fp32 between the GEMMs (residual epilogues write fp32,
+        the LayerNorms read it)."""
+        par = self.precision == "parity"
         c = self.cfg
         B = images.shape[0]
         T, Hh, hd = c.tokens, c.heads, c.hidden // c.heads
@@ -87,6 +92,16 @@ class ClipTower:
             ops.gather_rows(self.cls_row, out=x[b, 0:1])  # class_embedding + position_embedding[0] (precomputed constant)
         x = self.pre_ln(x.view(B * T, c.hidden), out_f32=True)
         for L in self.layers:
+            if par:  # every MFMA operand as hi + lo halves; q * scale, softmax in fp32
+                qkv = ops.linear(L["ln1"](x, out_split=True), L["qkv_w"], L["qkv_b"], a_split=True, out_split=True)
+                q6 = qkv.view(B, T, 2, 3, Hh, hd)
+                hi = [q6[:, :, 0, i].permute(0, 2, 1, 3) for i in range(3)]
+                lo = [q6[:, :, 1, i].permute(0, 2, 1, 3) for i in range(3)]
+                a = ops.attention_split(hi[0], lo[0], hi[1], lo[1], hi[2], lo[2], hd ** -0.5, prescale_q=True)
+                x = L["out"](a, residual=x, out_f32=True, a_split=True)
+                h = L["fc1"](L["ln2"](x, out_split=True), act="quick_gelu", a_split=True, out_split=True)
+                x = L["fc2"](h, residual=x, out_f32=True, a_split=True)
+                continue
             y = L["ln1"](x)
             qkv = ops.linear(y, L["qkv_w"], L["qkv_b"]).view(B, T, 3, Hh, hd)
             q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
@@ -96,6 +111,8 @@ class ClipTower:
         if B not in self._patch_rows:  # drop the CLS row of every image
             r = torch.arange(B * T, dtype=torch.int32).view(B, T)[:, 1:].reshape(-1)
             self._patch_rows[B] = r.to(images.device)
+        if par:
+            return ops.gather_rows(x, self._patch_rows[B], out_kind="split").view(B, T - 1, 2 * c.hidden)
         return ops.gather_rows(x, self._patch_rows[B], out_kind="bf16").view(B, T - 1, c.hidden)
 
 
@@ -121,12 +138,53 @@ class Llama:
         self.kcache = torch.zeros(cfg.layers, max_len, H, hd, dtype=BF16, device=device)
         self.vcache = torch.zeros(cfg.layers, max_len, H, hd, dtype=BF16, device=device)
         self.rope = ops.rope_table(max_len, hd, cfg.theta, device)  # fp32 cos/sin, computed once
+        self.precision = "default"
+        self.kcache_lo = self.vcache_lo = None  # "parity" precision: lo planes of the cache (allocated on first use)
+        self._dgraphs = {}
         self._dgraph = None
         self._fused = None
         # attention + o_proj in ONE launch (o_proj blocks wait on device counters): saved a launch per layer when the o_proj
         # GEMV was the persistent kernel; with gemv1_kernel the separate launches are as fast (2.67 vs 2.68 ms/token, same
         # end to end), so the simpler graph is the default and the fused launch stays opt-in (tests cover both)
         self.fuse_attn_oproj = bool(os.environ.get("IVLM_FUSE_ATTN_OPROJ"))
+
+    # ---- "parity" precision (opt-in): the prefill GEMMs take hi + lo bf16 activation operands, the attention three MFMAs per
+    # fragment, and K / V are cached as hi + lo planes (also read by the decode kernels) - no activation is rounded to bf16.
+    def set_precision(self, mode):
+        assert mode in ("default", "parity")
+        if mode == self.precision:
+            return
+        self._dgraphs[self.precision] = self._dgraph
+        self.precision = mode
+        self._dgraph = self._dgraphs.get(mode)
+        if hasattr(self, "_bgraphs"):
+            self._bgraphs = {}
+        if mode == "parity" and self.kcache_lo is None:
+            self.kcache_lo, self.vcache_lo = torch.zeros_like(self.kcache), torch.zeros_like(self.vcache)
+
+    def _lo(self, li):
+        return (self.kcache_lo[li], self.vcache_lo[li]) if self.precision == "parity" else None
+
+    def batch_cache_lo(self, B):
+        bc = getattr(self, "_bcache_lo", None)
+        if bc is None or bc[0].shape[1] < B:
+            kc, vc = self.batch_cache(B)
+            bc = self._bcache_lo = (torch.zeros_like(self._bcache[0]), torch.zeros_like(self._bcache[1]))
+        return bc[0][:, :B], bc[1][:, :B]
+
+    def _layer_parity(self, L, x, T, pos0, kc, vc, kcl, vcl):
+        """one prefill layer on fp32-activation arithmetic: x fp32 [T, hidden] -> fp32 [T, hidden]; kc.. = this layer's cache planes"""
+        c = self.cfg
+        H, hd = c.heads, c.hidden // c.heads
+        qkv = ops.linear(ops.rmsnorm(x, L["ln1"], c.eps, out_split=True), L["qkv"], a_split=True, out_split=True)  # [T, 6*hidden]
+        ops.rope_kv_split(qkv, H, hd, pos0, (kc, kcl, vc, vcl), self.rope)
+        q6 = qkv.view(T, 2, 3, H, hd)
+        qh, ql = (q6[:, i, 0].permute(1, 0, 2).unsqueeze(0) for i in range(2))
+        kv = [t[: pos0 + T].permute(1, 0, 2).unsqueeze(0) for t in (kc, kcl, vc, vcl)]
+        a = ops.attention_split(qh, ql, kv[0], kv[1], kv[2], kv[3], hd ** -0.5, causal=True, q_pos0=pos0)  # [T, 2*hidden]
+        x = ops.linear(a, L["o"], residual=x, out_f32=True, a_split=True)
+        h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps, out_split=True), L["gu"], act="swiglu", a_split=True, out_split=True)
+        return ops.linear(h, L["down"], residual=x, out_f32=True, a_split=True)
 
     def embed_ids(self, ids_i32, out=None):
         """embed_tokens gather: ids int32 [n] -> fp32 [n, hidden] (the start of the fp32 residual stream)."""
@@ -144,7 +202,12 @@ class Llama:
         assert pos0 + T <= self.max_len and x.dtype == F32
         if T == 1 and cache is None:
             return self._decode_step(x, pos0)
-        kc, vc = cache if cache is not None else (self.kcache, self.vcache)
+        kc, vc = cache[:2] if cache is not None else (self.kcache, self.vcache)
+        if self.precision == "parity":
+            kcl, vcl = cache[2:] if cache is not None else (self.kcache_lo, self.vcache_lo)
+            for li, L in enumerate(self.layers):
+                x = self._layer_parity(L, x, T, pos0, kc[li], vc[li], kcl[li], vcl[li])
+            return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
         for li, L in enumerate(self.layers):
             y = ops.rmsnorm(x, L["ln1"], c.eps)
             qkv = ops.linear(y, L["qkv"])  # [T, 3*hidden] == [T, 3, H, hd]
@@ -158,7 +221,7 @@ class Llama:
             x = ops.linear(h, L["down"], residual=x, out_f32=True)
         return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
 
-    def forward_packed(self, xs, kc, vc):
+    def forward_packed(self, xs, kc, vc, lo=None):
         """Prefill of B sequences in ONE pass over the weights: xs = [x_b fp32 [T_b, hidden]] (lengths may differ), kc / vc
         [layers, B, Tmax, H, hd] cache slabs -> [final-norm hidden fp32 [T_b, hidden]].  The four projections of a layer run
         on the packed rows (M = sum T_b: one efficient GEMM instead of B skinny ones, weights streamed once); RoPE + cache
@@ -171,6 +234,24 @@ class Llama:
         for n in lens:
             offs.append(offs[-1] + n)
         x = torch.cat(xs, 0)
+        if self.precision == "parity":  # fp32-activation arithmetic (see _layer_parity), lo = (kc_lo, vc_lo) slabs
+            kcl, vcl = lo
+            for li, L in enumerate(self.layers):
+                qkv = ops.linear(ops.rmsnorm(x, L["ln1"], c.eps, out_split=True), L["qkv"], a_split=True, out_split=True)
+                a = torch.empty(offs[-1], 2 * c.hidden, dtype=BF16, device=x.device)
+                for b, T in enumerate(lens):
+                    qb = qkv[offs[b]: offs[b + 1]]
+                    ops.rope_kv_split(qb, H, hd, 0, (kc[li, b], kcl[li, b], vc[li, b], vcl[li, b]), self.rope)
+                    q6 = qb.view(T, 2, 3, H, hd)
+                    qh, ql = (q6[:, i, 0].permute(1, 0, 2).unsqueeze(0) for i in range(2))
+                    kv = [t[li, b, :T].permute(1, 0, 2).unsqueeze(0) for t in (kc, kcl, vc, vcl)]
+                    ops.attention_split(qh, ql, kv[0], kv[1], kv[2], kv[3], hd ** -0.5, causal=True, q_pos0=0,
+                                        out=a[offs[b]: offs[b + 1]].view(1, T, 2, H, hd))
+                x = ops.linear(a, L["o"], residual=x, out_f32=True, a_split=True)
+                h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps, out_split=True), L["gu"], act="swiglu", a_split=True, out_split=True)
+                x = ops.linear(h, L["down"], residual=x, out_f32=True, a_split=True)
+            x = ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
+            return [x[offs[b]: offs[b + 1]] for b in range(len(lens))]
         for li, L in enumerate(self.layers):
             qkv = ops.linear(ops.rmsnorm(x, L["ln1"], c.eps), L["qkv"])
             a = torch.empty(offs[-1], c.hidden, dtype=BF16, device=x.device)
@@ -217,7 +298,8 @@ class Llama:
                 if self._fused is not None:
                     self._fused["step"].add_(1)
 
-            saved = (self.kcache[:, :1].clone(), self.vcache[:, :1].clone())  # the warm-up / capture runs write row 0
+            caches = [self.kcache, self.vcache] + ([self.kcache_lo, self.vcache_lo] if self.precision == "parity" else [])
+            saved = [t[:, :1].clone() for t in caches]  # the warm-up / capture runs write row 0
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -231,8 +313,8 @@ class Llama:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 body()
-            self.kcache[:, :1].copy_(saved[0])
-            self.vcache[:, :1].copy_(saved[1])
+            for t, sv in zip(caches, saved):
+                t[:, :1].copy_(sv)
             st["graph"] = g
             self._dgraph = st
         return self._dgraph
@@ -250,7 +332,7 @@ class Llama:
             self._bgraphs = {}
         return bc[0][:, :B], bc[1][:, :B]
 
-    def decode_step_batch(self, x, pos_dev, kc, vc):
+    def decode_step_batch(self, x, pos_dev, kc, vc, lo=None):
         """x fp32 [B, hidden] (one new token per sequence), pos_dev int32 [B], kc/vc [layers, B, Tmax, H, hd] ->
         final-norm hidden fp32 [B, hidden]; same arithmetic per row as ``_decode_step`` (fp32 activations: the skinny MFMA
         kernel splits them into hi + lo bf16 operands, the batch-1 GEMV multiplies them exactly - equal to ~1e-5)."""
@@ -260,7 +342,8 @@ class Llama:
             raise ops.IvlmError("decode_step_batch: at most 16 sequences per step (weight-streaming kernels)")
         for li, L in enumerate(self.layers):
             qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps), out_f32=True)
-            a = ops.llama_decode_attn_batch(qkv, kc[li], vc[li], H, hd, pos_dev, c.theta, hd ** -0.5, table=self.rope)
+            a = ops.llama_decode_attn_batch(qkv, kc[li], vc[li], H, hd, pos_dev, c.theta, hd ** -0.5, table=self.rope,
+                                            lo=(lo[0][li], lo[1][li]) if lo is not None else None)
             x = ops.linear(a, L["o"], residual=x, out_f32=True)
             h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps), out_f32=True)
             x = ops.linear(h, L["down"], residual=x, out_f32=True)
@@ -269,18 +352,20 @@ class Llama:
     def decode_graph_batch(self, B):
         """One batched decode step (embed -> layers -> norm -> lm_head -> argmax, positions += 1) as a HIP graph."""
         kc, vc = self.batch_cache(B)
+        lo = self.batch_cache_lo(B) if self.precision == "parity" else None
         st = self._bgraphs.get(B)
         if st is None:
             dev = self.device
             st = dict(tok=torch.zeros(B, dtype=torch.int32, device=dev), pos=torch.zeros(B, dtype=torch.int32, device=dev))
 
             def body():
-                h = self.decode_step_batch(self.embed_ids(st["tok"]), st["pos"], kc, vc)
+                h = self.decode_step_batch(self.embed_ids(st["tok"]), st["pos"], kc, vc, lo)
                 st["hidden"] = h
                 st["nxt"] = ops.argmax(self.logits(h))
                 st["pos"].add_(1)
 
-            saved = (kc[:, :, :1].clone(), vc[:, :, :1].clone())  # the warm-up / capture runs write row 0 of every slab
+            caches = [kc, vc] + (list(lo) if lo is not None else [])
+            saved = [t[:, :, :1].clone() for t in caches]  # the warm-up / capture runs write row 0 of every slab
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -290,8 +375,8 @@ class Llama:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 body()
-            kc[:, :, :1].copy_(saved[0])
-            vc[:, :, :1].copy_(saved[1])
+            for t, sv in zip(caches, saved):
+                t[:, :, :1].copy_(sv)
             st["pos"].zero_()
             st["graph"] = g
             self._bgraphs[B] = st
@@ -307,12 +392,12 @@ class Llama:
         fz = self._fused if isinstance(pos, torch.Tensor) else None
         for li, L in enumerate(self.layers):
             qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps), out_f32=True)
-            if fz is not None:  # attention + o_proj + residual in one launch (W_o streams while the attention runs)
+            if fz is not None and self.precision != "parity":  # attention + o_proj + residual in one launch (W_o streams while the attention runs)
                 x = ops.llama_attn_oproj(qkv, self.kcache[li], self.vcache[li], L["o"], x, H, hd, pos, fz["step"],
                                          fz["counters"][li], fz["status"], c.theta, hd ** -0.5, self.rope, fz["scratch"][li])
             else:
                 a = ops.llama_decode_attn(qkv, self.kcache[li], self.vcache[li], H, hd, pos, c.theta, hd ** -0.5,
-                                          table=self.rope)
+                                          table=self.rope, lo=self._lo(li))
                 x = ops.linear(a, L["o"], residual=x, out_f32=True)
             h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps), out_f32=True)
             x = ops.linear(h, L["down"], residual=x, out_f32=True)

@@ -294,32 +294,41 @@ def _splitk_choice(M, N, K, act, rms):
     return best
 
 
-GEMM_A_F32, GEMM_RES_F32 = 1, 2
+GEMM_A_F32, GEMM_RES_F32, GEMM_A_SPLIT, GEMM_OUT_SPLIT = 1, 2, 4, 8
 F32 = torch.float32
 
 
 def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False, rms=None, out_rows=None,
-           a_rows=None):
+           a_rows=None, a_split=False, out_split=False):
     """act(x @ weight.T + bias) + residual.  out_rows (int32 [M], tile GEMM path): scatter epilogue, see ivlm_hip.h.  x [..., K] bf16 - or fp32 for M <= 16 rows (weight-streaming kernels: exact
-    products) - last dim contiguous, uniform row stride; weight [N, K] bf16; residual bf16 or fp32 (fp32 residual stream)."""
+    products) - last dim contiguous, uniform row stride; weight [N, K] bf16; residual bf16 or fp32 (fp32 residual stream).
+    "Parity" precision (tile GEMM, M > 16): a_split - x is [..., 2K] = [hi | lo] bf16 rows (fp32 activations, see split_rows)
+    against the plain [N, K] weight; out_split - the fp32 result is written as [hi | lo] bf16 rows [..., 2 n_out]."""
     lib = _lib.load()
-    K = x.shape[-1]
     N = weight.shape[0]
-    assert weight.shape[1] == K and x.dtype in (BF16, F32) and weight.dtype == BF16
-    x2 = x.reshape(-1, K)
+    K = weight.shape[1]
+    assert x.shape[-1] == (2 * K if a_split else K) and x.dtype in (BF16, F32) and weight.dtype == BF16
+    x2 = x.reshape(-1, x.shape[-1])
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     M = x2.shape[0] if a_rows is None else a_rows.numel()  # a_rows (int32 [M]): product row m reads x2[a_rows[m]]
     flags = 0
     if x.dtype == F32:
         if M > 16:
-            raise IvlmError("linear: fp32 activations only on the M <= 16 weight-streaming paths (use split_rows + [W|W])")
+            raise IvlmError("linear: fp32 activations only on the M <= 16 weight-streaming paths (use split_rows + a_split)")
         flags |= GEMM_A_F32
+    if a_split:
+        assert x.dtype == BF16
+        flags |= GEMM_A_SPLIT
     n_out = N // 2 if act == "swiglu" else N
+    if out_split:
+        flags |= GEMM_OUT_SPLIT
+    n_cols = 2 * n_out if out_split else n_out
     if out is None:
         lead = x.shape[:-1] if a_rows is None else (M,)
-        out = torch.empty(tuple(lead) + (n_out,), dtype=F32 if out_f32 else BF16, device=x.device)
-    o2 = out.reshape(-1, n_out)
+        out = torch.empty(tuple(lead) + (n_cols,), dtype=F32 if (out_f32 and not out_split) else BF16, device=x.device)
+    assert not out_split or out.dtype == BF16
+    o2 = out.reshape(-1, n_cols)
     assert o2.stride(-1) == 1 and weight.stride(-1) == 1
     r2, ldr = None, 0
     if residual is not None:
@@ -342,8 +351,8 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
             _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, splits, ws.data_ptr(),
             ws.numel() * 4, flags, _stream()), "gemm_bf16_splitk")
     if TIMER.enabled:  # work = algorithmic FLOPs (MFMA path) or weight bytes (GEMV path)
-        if M > 16:
-            TIMER.time("gemm_bf16_mfma", 2.0 * M * N * K, call, tag=(M, N, K, act))
+        if M > 16:  # (a split A operand doubles the MFMA work of the same algorithmic product: counted once)
+            TIMER.time("gemm_bf16_mfma", 2.0 * M * N * K, call, tag=(M, N, K, act, "split" if a_split else ""))
         else:
             TIMER.time("gemv_bf16", 2.0 * N * K, call, tag=(M, N, K, act))
     else:
@@ -359,16 +368,20 @@ IVLM_FP8 = 3
 U8 = torch.uint8
 
 
-def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None, out_f32=False, out_rows=None, fp8_scale=None):
+def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None, out_f32=False, out_rows=None, fp8_scale=None, out_split=False):
     """x bf16 or fp32 [..., cols] -> bf16 (the next GEMM's operand), fp32 (out_f32: the row is itself a stream) or, with
-    fp8_scale (device fp32 scalar), e4m3 bytes of y / scale (uint8 tensor: the operand of linear_fp8)."""
+    fp8_scale (device fp32 scalar), e4m3 bytes of y / scale (uint8 tensor: the operand of linear_fp8); out_split: [hi | lo]
+    bf16 rows [..., 2 cols] (the a_split operand of an fp32-activation GEMM)."""
     lib = _lib.load()
     x = _req(x, None, "x")
-    if out is None:
-        out = torch.empty(x.shape, dtype=U8 if fp8_scale is not None else (F32 if out_f32 else BF16), device=x.device)
-    y = out
     cols = x.shape[-1]
-    ydt = IVLM_FP8 if fp8_scale is not None else _dtc(y)
+    if out is None:
+        if out_split:
+            out = torch.empty(x.shape[:-1] + (2 * cols,), dtype=BF16, device=x.device)
+        else:
+            out = torch.empty(x.shape, dtype=U8 if fp8_scale is not None else (F32 if out_f32 else BF16), device=x.device)
+    y = out
+    ydt = IVLM_FP8 if fp8_scale is not None else (2 if out_split else _dtc(y))
     check(lib.ivlm_layernorm(x.data_ptr(), _dtc(x), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), ydt,
                              x.numel() // cols, cols, float(eps), 1 if gelu else 0, _p(out_rows), _p(fp8_scale), _stream()),
           "layernorm")
@@ -430,13 +443,16 @@ def linear_fp8(xq, wq, scale_a, scale_w, bias=None, act="none", residual=None, o
     return out
 
 
-def rmsnorm(x, weight, eps=1e-5, out_f32=False):
+def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False):
     lib = _lib.load()
     x = _req(x, None, "x")
-    y = torch.empty(x.shape, dtype=F32 if out_f32 else BF16, device=x.device)
     cols = x.shape[-1]
-    check(lib.ivlm_rmsnorm(x.data_ptr(), _dtc(x), weight.data_ptr(), y.data_ptr(), _dtc(y), x.numel() // cols, cols,
-                           float(eps), _stream()), "rmsnorm")
+    if out_split:
+        y = torch.empty(x.shape[:-1] + (2 * cols,), dtype=BF16, device=x.device)
+    else:
+        y = torch.empty(x.shape, dtype=F32 if out_f32 else BF16, device=x.device)
+    check(lib.ivlm_rmsnorm(x.data_ptr(), _dtc(x), weight.data_ptr(), y.data_ptr(), 2 if out_split else _dtc(y),
+                           x.numel() // cols, cols, float(eps), _stream()), "rmsnorm")
     return y
 
 
@@ -467,6 +483,50 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, presca
                                   int(q_pos0), _p(rel_h), _p(rel_w), kh, kw, B // Bk,
                                   1 if (prescale_q or rel is not None) else 0, _stream()), "attention")
     return out
+
+
+def attention_split(q, q_lo, k, k_lo, v, v_lo, scale, causal=False, q_pos0=0, rel=None, out=None, prescale_q=False):
+    """"Parity" precision of ``attention``: every operand as hi + lo bf16 planes (the *_lo tensors have the shapes and strides of
+    the hi ones), fp32-operand arithmetic on the bf16 matrix cores.  out: bf16 [B, Sq, 2, H, D] buffer (default: allocated), the
+    rows [hi(H*D) | lo(H*D)] of the next GEMM's a_split operand; returned as [B*Sq, 2*H*D]."""
+    import ctypes
+
+    lib = _lib.load()
+    B, H, Sq, D = q.shape
+    Bk, Sk = k.shape[0], k.shape[2]
+    for t, tl in ((q, q_lo), (k, k_lo), (v, v_lo)):
+        assert t.dtype == BF16 and tl.dtype == BF16 and t.stride() == tl.stride() and t.shape == tl.shape and t.stride(3) == 1
+    assert B % Bk == 0
+    if out is None:
+        out = torch.empty(B, Sq, 2, H, D, dtype=BF16, device=q.device)
+    assert out.shape == (B, Sq, 2, H, D) and out.stride(4) == 1
+    oh, ol = out[:, :, 0].permute(0, 2, 1, 3), out[:, :, 1].permute(0, 2, 1, 3)  # [B,H,Sq,D] views
+    st = (ctypes.c_int64 * 12)(q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                               v.stride(0), v.stride(1), v.stride(2), oh.stride(0), oh.stride(1), oh.stride(2))
+    rel_h = rel_w = None
+    kh = kw = 0
+    if rel is not None:
+        rel_h, rel_w = rel
+        assert rel_h.dtype == torch.float32 and rel_h.is_contiguous() and rel_w.is_contiguous()
+        kh, kw = rel_h.shape[-1], rel_w.shape[-1]
+    check(lib.ivlm_attention_bf16_split(q.data_ptr(), q_lo.data_ptr(), k.data_ptr(), k_lo.data_ptr(), v.data_ptr(),
+                                        v_lo.data_ptr(), oh.data_ptr(), ol.data_ptr(), ctypes.cast(st, ctypes.c_void_p), B, H,
+                                        Sq, Sk, D, float(scale), 1 if causal else 0, int(q_pos0), _p(rel_h), _p(rel_w), kh, kw,
+                                        B // Bk, 1 if (prescale_q or rel is not None) else 0, _stream()), "attention_split")
+    return out.view(B * Sq, 2 * H * D)
+
+
+def relpos_bias_split(q, q_lo, tab_h, tab_w, SH, SW):
+    """"Parity" precision of ``relpos_bias``: q = hi + lo planes, results unrounded fp32 (the VALU dot-product kernel)."""
+    lib = _lib.load()
+    B, H, S, D = q.shape
+    assert S == SH * SW and q.stride(3) == 1 and q.stride() == q_lo.stride() and tab_h.is_contiguous() and tab_w.is_contiguous()
+    rel_h = torch.empty(B * H, S, SH, dtype=torch.float32, device=q.device)
+    rel_w = torch.empty(B * H, S, SW, dtype=torch.float32, device=q.device)
+    check(lib.ivlm_relpos_bias_split(q.data_ptr(), q_lo.data_ptr(), q.stride(0), q.stride(1), q.stride(2), tab_h.data_ptr(),
+                                     tab_w.data_ptr(), B, H, SH, SW, D, rel_h.data_ptr(), rel_w.data_ptr(), _stream()),
+          "relpos_bias_split")
+    return rel_h, rel_w
 
 
 def attention_f32(q, k, v, scale, out=None):
@@ -562,6 +622,18 @@ def im2col3x3_nhwc(x):
     return out
 
 
+def im2col3x3_nhwc_split(x_split, B, H, W, C):
+    """x_split bf16 [B*H*W, 2C] = [hi | lo] rows -> [B*H*W, 2 * 9C]: both halves unfolded (the a_split operand of the 3x3 conv)."""
+    lib = _lib.load()
+    x_split = _req(x_split, BF16, "x_split")
+    assert x_split.shape == (B * H * W, 2 * C)
+    out = torch.empty(B * H * W, 18 * C, dtype=BF16, device=x_split.device)
+    for half in range(2):
+        check(lib.ivlm_im2col3x3_nhwc_strided(x_split.data_ptr() + half * C * 2, 2 * C, out.data_ptr() + half * 9 * C * 2,
+                                              18 * C, B, H, W, C, _stream()), "im2col3x3_strided")
+    return out
+
+
 _KIND = {"bf16": IVLM_BF16, "f32": IVLM_F32, "split": 2, "fp8": 3}
 
 
@@ -648,6 +720,18 @@ def rope_kv(qkv, H, D, pos0, theta, kcache=None, vcache=None, table=None):
     return qkv
 
 
+def rope_kv_split(qkv, H, D, pos0, caches, table):
+    """"Parity" precision of rope_kv: qkv bf16 [T, 2*3*H*D] = [hi | lo] rows (in place); caches = (k, k_lo, v, v_lo) each
+    [Tmax, H, D] or None; table = (cos, sin) from rope_table()."""
+    lib = _lib.load()
+    assert qkv.dtype == BF16 and qkv.stride(-1) == 1 and qkv.shape[-1] == 6 * H * D
+    T = qkv.shape[0]
+    kc = caches if caches is not None else (None,) * 4
+    check(lib.ivlm_rope_kv_split(qkv.data_ptr(), qkv.stride(0), T, H, D, int(pos0), _p(kc[0]), _p(kc[1]), _p(kc[2]), _p(kc[3]),
+                                 table[0].data_ptr(), table[1].data_ptr(), _stream()), "rope_kv_split")
+    return qkv
+
+
 def rope_table(T, D, theta, device):
     lib = _lib.load()
     c = torch.empty(T, D // 2, dtype=torch.float32, device=device)
@@ -666,9 +750,10 @@ def mask_dot(up, hyper, B, gh, gw):
     return low
 
 
-def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, table=None):
+def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, table=None, lo=None):
     """qkv bf16 | fp32 [1, 3*H*D] of the newest token -> o (same dtype) [1, H*D]; RoPE + cache append fused.
-    pos: python int, or an int32 device tensor [1] (read by the kernel: HIP-graph friendly).  kcache [Tmax, H, D]."""
+    pos: python int, or an int32 device tensor [1] (read by the kernel: HIP-graph friendly).  kcache [Tmax, H, D].
+    lo = (kcache_lo, vcache_lo): "parity" precision, K / V cached as hi + lo planes (fp32 qkv only)."""
     lib = _lib.load()
     assert qkv.dtype in (BF16, F32) and qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
     if out is None:
@@ -676,6 +761,14 @@ def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, ta
     dev_pos = isinstance(pos, torch.Tensor)
     if dev_pos:
         assert pos.dtype == torch.int32 and pos.is_cuda
+    if lo is not None:
+        assert qkv.dtype == F32 and lo[0].is_contiguous() and lo[1].is_contiguous() and lo[0].shape == kcache.shape
+        check(lib.ivlm_llama_decode_attn_split(qkv.data_ptr(), kcache.data_ptr(), lo[0].data_ptr(), vcache.data_ptr(),
+                                               lo[1].data_ptr(), kcache.shape[0], out.data_ptr(), H, D,
+                                               0 if dev_pos else int(pos), pos.data_ptr() if dev_pos else 0, float(theta),
+                                               float(scale), _p(table[0]) if table else 0, _p(table[1]) if table else 0,
+                                               _stream()), "llama_decode_attn_split")
+        return out
     check(lib.ivlm_llama_decode_attn(qkv.data_ptr(), _dtc(qkv), kcache.data_ptr(), vcache.data_ptr(), kcache.shape[0],
                                      out.data_ptr(), H, D, 0 if dev_pos else int(pos), pos.data_ptr() if dev_pos else 0,
                                      float(theta), float(scale), _p(table[0]) if table else 0,
@@ -683,7 +776,7 @@ def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, ta
     return out
 
 
-def llama_decode_attn_batch(qkv, kcache, vcache, H, D, pos_dev, theta, scale, table=None, out=None):
+def llama_decode_attn_batch(qkv, kcache, vcache, H, D, pos_dev, theta, scale, table=None, out=None, lo=None):
     """One decode step of B sequences: qkv bf16 | fp32 [B, 3*H*D], kcache/vcache bf16 [B, Tmax, H, D] (one slab per
     sequence), pos_dev int32 [B] on the device -> o [B, H*D].  A sequence whose position has reached Tmax is skipped: its
     output row is zero (written by the kernel)."""
@@ -694,6 +787,14 @@ def llama_decode_attn_batch(qkv, kcache, vcache, H, D, pos_dev, theta, scale, ta
     assert pos_dev.dtype == torch.int32 and pos_dev.is_cuda and pos_dev.numel() == B and pos_dev.is_contiguous()
     if out is None:
         out = torch.empty(B, H * D, dtype=qkv.dtype, device=qkv.device)
+    if lo is not None:  # "parity" precision: hi + lo cache planes
+        assert qkv.dtype == F32 and lo[0].stride() == kcache.stride() and lo[1].stride() == vcache.stride()
+        check(lib.ivlm_llama_decode_attn_batch_split(qkv.data_ptr(), qkv.stride(0), kcache.data_ptr(), lo[0].data_ptr(),
+                                                     vcache.data_ptr(), lo[1].data_ptr(), kcache.stride(0), kcache.shape[1],
+                                                     out.data_ptr(), out.stride(0), B, H, D, pos_dev.data_ptr(), float(theta),
+                                                     float(scale), _p(table[0]) if table else 0, _p(table[1]) if table else 0,
+                                                     _stream()), "llama_decode_attn_batch_split")
+        return out
     check(lib.ivlm_llama_decode_attn_batch(qkv.data_ptr(), _dtc(qkv), qkv.stride(0), kcache.data_ptr(), vcache.data_ptr(),
                                            kcache.stride(0), kcache.shape[1], out.data_ptr(), out.stride(0), B, H, D,
                                            pos_dev.data_ptr(), float(theta), float(scale), _p(table[0]) if table else 0,

@@ -28,9 +28,10 @@ class _Lin:
         self.w = _dev(w[prefix + ".weight"].reshape(w[prefix + ".weight"].shape[0], -1), device)
         self.b = _dev(w[prefix + ".bias"], device) if bias and (prefix + ".bias") in w else None
 
-    def __call__(self, x, act="none", residual=None, res_mod=0, out=None, out_f32=False, out_rows=None, a_rows=None):
+    def __call__(self, x, act="none", residual=None, res_mod=0, out=None, out_f32=False, out_rows=None, a_rows=None,
+                 a_split=False, out_split=False):
         return ops.linear(x, self.w, self.b, act=act, residual=residual, res_mod=res_mod, out=out, out_f32=out_f32,
-                          out_rows=out_rows, a_rows=a_rows)
+                          out_rows=out_rows, a_rows=a_rows, a_split=a_split, out_split=out_split)
 
 
 class _LinF32(_Lin):
@@ -50,9 +51,9 @@ class _LN:
     def __init__(self, w, prefix, device, eps):
         self.w, self.b, self.eps = _dev(w[prefix + ".weight"], device), _dev(w[prefix + ".bias"], device), eps
 
-    def __call__(self, x, gelu=False, out_f32=False, out=None, out_rows=None, fp8_scale=None):
+    def __call__(self, x, gelu=False, out_f32=False, out=None, out_rows=None, fp8_scale=None, out_split=False):
         return ops.layernorm(x, self.w, self.b, self.eps, gelu=gelu, out_f32=out_f32, out=out, out_rows=out_rows,
-                             fp8_scale=fp8_scale)
+                             fp8_scale=fp8_scale, out_split=out_split)
 
 
 # ================================================================================================
@@ -199,7 +200,7 @@ class SamImageEncoder:
             return self._forward(images)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
-        key = tuple(images.shape) + (self.fp8,)
+        key = tuple(images.shape) + (self.fp8, self.precision)
         ent = self._graphs.get(key)
         dev = images.device
         if ent is None:
@@ -218,11 +219,67 @@ class SamImageEncoder:
         g.replay()
         return static_out.clone()
 
+    # ---- "parity" precision (opt-in): fp32-activation arithmetic on the bf16 matrix cores --------------------------------------
+    # Every activation that the default mode rounds to a bf16 MFMA operand (normed rows, q / k / v, softmax weights, attention
+    # output, MLP hidden) is carried as hi + lo bf16 halves (x = hi + lo to 2^-17): the four GEMMs of a block take [hi | lo]
+    # rows against the plain weight (each W tile used twice: 2 x the MFMA work), the attention runs three MFMAs per fragment,
+    # rel-pos terms / q scaling / softmax stay fp32.  The bf16 weights are exact in both modes.  Measured on the headline
+    # configuration (ViT-H depth 32, 7B): default mode max |dp| 5.8e-3 against the fp32 oracle, this mode < 1e-3 (bench.py).
+    precision = "default"
+
+    def _attention_parity(self, blk, xn, V, side, nwin, win=None):
+        """_attention with split operands: xn [rows, 2D] -> attention output [nwin*S, 2D] ([hi | lo] rows)."""
+        c = self.cfg
+        D = c.embed_dim
+        H, hd = c.num_heads, D // c.num_heads
+        S = side * side
+        if win is None:
+            qkv = blk["qkv"](xn, a_split=True, out_split=True)  # [nwin*S, 2 * 3D]
+        else:
+            unpart, pad, qkv = win
+            blk["qkv"](xn, out=qkv, out_rows=unpart, a_split=True, out_split=True)
+            if "qkv_b_split" not in blk:
+                blk["qkv_b_split"] = torch.cat([blk["qkv"].b, torch.zeros_like(blk["qkv"].b)]).contiguous()
+            ops.fill_rows(qkv, pad, blk["qkv_b_split"])
+        q6 = qkv.view(nwin, S, 2, 3, H, hd)
+        hi = [q6[:, :, 0, i].permute(0, 2, 1, 3) for i in range(3)]
+        lo = [q6[:, :, 1, i].permute(0, 2, 1, 3) for i in range(3)]
+        rel = ops.relpos_bias_split(hi[0], lo[0], blk["rel_h"], blk["rel_w"], side, side)
+        return ops.attention_split(hi[0], lo[0], hi[1], lo[1], hi[2], lo[2], hd ** -0.5, rel=rel)  # [nwin*S, 2D]
+
+    def _forward_parity(self, images):
+        c = self.cfg
+        V = images.shape[0]
+        g, D = c.grid, c.embed_dim
+        cols = ops.im2col_nchw(images.to(BF16).contiguous(), c.patch, c.patch)  # (bf16 pixels x bf16 weights: exact products)
+        x = self.patch(cols, residual=self.pos_embed, res_mod=g * g, out_f32=True)
+        part, unpart, nw, gp, pad = self._window_maps(V)
+        nwin = V * nw * nw
+        key = ("split", V)
+        if key not in self._xw:
+            self._xw[key] = torch.empty(nwin * c.window * c.window, 6 * D, dtype=BF16, device=x.device)
+        for blk in self.blocks:
+            xn = blk["norm1"](x, out_split=True)
+            if blk["glob"]:
+                a = self._attention_parity(blk, xn, V, g, V)
+                x = blk["proj"](a, residual=x, out_f32=True, a_split=True)
+            else:
+                a = self._attention_parity(blk, xn, V, c.window, nwin, win=(unpart, pad, self._xw[key]))
+                x = blk["proj"](a, residual=x, out=x, a_rows=unpart, a_split=True)
+            h = blk["lin1"](blk["norm2"](x, out_split=True), act="gelu", a_split=True, out_split=True)
+            x = blk["lin2"](h, residual=x, out_f32=True, a_split=True)
+        y = self.neck0(ops.gather_rows(x, out_kind="split"), out_f32=True, a_split=True)
+        y = self.neck1(y, out_split=True)  # [V*g*g, 2 * 256]
+        y = ops.linear(ops.im2col3x3_nhwc_split(y, V, g, g, c.out_chans), self.neck2_w, out_f32=True, a_split=True)
+        return self.neck3(y, out_f32=True).view(V, g * g, c.out_chans)
+
     def _forward(self, images):
         """The residual stream x is fp32 (GEMM residual epilogues write it, the LayerNorms read it); MFMA operands are bf16.
         window_partition is folded into the q|k|v GEMM's scatter epilogue and window_unpartition + shortcut into the proj GEMM's
         gather prologue: both GEMMs of a windowed block run on the g*g real rows of every view only - no gather passes over the
         activations, no work on the padded window positions (whose q|k|v rows are just the bias)."""
+        if self.precision == "parity":
+            return self._forward_parity(images)
         c = self.cfg
         V = images.shape[0]
         g, D = c.grid, c.embed_dim

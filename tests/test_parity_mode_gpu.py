@@ -1,0 +1,333 @@
+"""GPU tests of the "parity" precision mode: fp32-activation arithmetic on the bf16 matrix cores.
+Every activation the default mode rounds to a bf16 MFMA operand travels as hi + lo bf16 halves (x = hi + lo to 2^-17):
+GEMMs with a split A operand / split output, split-operand attention (three MFMAs per fragment), split norm outputs, split
+RoPE + KV-cache planes.  References are torch fp64 on the SAME fp32 values (the kernels must be ~2^-17-accurate, where bf16
+operand rounding gives 4e-3), then the three towers and the facade against the fp32 CPU oracle on identical weights."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_weights(spec, seed=0):
+    """fp32 weights whose values are exactly bf16-representable (shared by oracle and HIP path)."""
+    import torch
+
+    from interactvlm_amd import weights as Wt
+
+    return {k: v.to(torch.bfloat16).float() for k, v in Wt.synth_weights(spec, seed).items()}
+
+
+def _join(t_split, n):
+    """[.., 2n] bf16 [hi | lo] -> fp32 [.., n]"""
+    return t_split[..., :n].float() + t_split[..., n:].float()
+
+
+def _rel(got, ref):
+    return float((got.double() - ref.double()).abs().max() / ref.double().abs().max())
+
+
+# (M, N, K): 128x64 tiles + split-K, 128x128 tiles, the 8-phase 256x256 kernel, a ragged edge
+@pytest.mark.parametrize("M,N,K", [(330, 4096, 4096), (257, 1024, 1024), (2000, 1536, 1280), (16384, 3840, 1280),
+                                   (4100, 1280, 5120), (300, 520, 192)])
+@pytest.mark.parametrize("act", ["none", "gelu"])
+def test_gemm_split_operand_and_output(hip_lib, cuda, M, N, K, act):
+    import torch
+    import torch.nn.functional as F
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    x = torch.randn(M, K, generator=g)  # fp32 activations (NOT bf16-representable)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
+    r = torch.randn(M, N, generator=g)
+    ref = x.double() @ w.double().T + b.double()
+    if act == "gelu":
+        ref = F.gelu(ref)
+    ref = ref + r.double()
+    xs = ops.split_rows(x.to(cuda))
+    assert float((_join(xs, K).cpu() - x).abs().max()) < 2.0 ** -16 * float(x.abs().max())
+    got = ops.linear(xs, w.to(cuda), b.to(cuda), act=act, residual=r.to(cuda), out_f32=True, a_split=True)
+    assert got.dtype == torch.float32 and got.shape == (M, N)
+    e = _rel(got.cpu(), ref)
+    assert e < 2e-5, f"a_split GEMM rel err {e}"
+    # the same product with the bf16-rounded operand is ~100x further out: the test can tell the two apart
+    e_bf = _rel(ops.linear(x.to(torch.bfloat16).to(cuda), w.to(cuda), b.to(cuda), act=act, residual=r.to(cuda), out_f32=True).cpu(), ref)
+    assert e_bf > 20 * e
+    # split output == the fp32 output, split
+    gs = ops.linear(xs, w.to(cuda), b.to(cuda), act=act, residual=r.to(cuda), a_split=True, out_split=True)
+    assert gs.dtype == torch.bfloat16 and gs.shape == (M, 2 * N)
+    assert float((_join(gs, N) - got).abs().max()) <= 2.0 ** -16 * float(got.abs().max())
+    assert torch.equal(gs[:, :N], got.to(torch.bfloat16))
+
+
+def test_gemm_split_swiglu_rows_and_strides(hip_lib, cuda):
+    """SwiGLU epilogue with split output (LLaMA gate|up), scatter / gather row maps (SAM window partition folded into the GEMMs)
+    and strided output rows, all with a split A operand."""
+    import torch
+    import torch.nn.functional as F
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    M, K, I = 330, 1024, 1408
+    x = torch.randn(M, K, generator=g)
+    gu = (torch.randn(2 * I, K, generator=g) / K ** 0.5).to(torch.bfloat16)  # rows (gate_j, up_j) interleaved
+    ref = F.silu(x.double() @ gu[0::2].double().T) * (x.double() @ gu[1::2].double().T)
+    xs = ops.split_rows(x.to(cuda))
+    got = ops.linear(xs, gu.to(cuda), act="swiglu", a_split=True, out_split=True)
+    assert got.shape == (M, 2 * I)
+    assert _rel(_join(got, I).cpu(), ref) < 3e-5
+    # scatter epilogue + gather prologue
+    M2, N2 = 2048, 768
+    x2 = torch.randn(M2, K, generator=g)
+    w2 = (torch.randn(N2, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    perm = torch.randperm(M2, generator=g).to(torch.int32)
+    ref2 = x2.double() @ w2.double().T
+    xs2 = ops.split_rows(x2.to(cuda))
+    out = torch.zeros(M2, 2 * N2, dtype=torch.bfloat16, device=cuda)
+    ops.linear(xs2, w2.to(cuda), out=out, out_rows=perm.to(cuda), a_split=True, out_split=True)
+    assert _rel(_join(out, N2).cpu()[perm.long()], ref2) < 2e-5
+    res = torch.randn(M2, N2, generator=g).to(cuda)
+    got3 = ops.linear(xs2, w2.to(cuda), residual=res, out=res.clone(), a_rows=perm.to(cuda), a_split=True)
+    assert _rel(got3.cpu(), ref2[perm.long()] + res.cpu().double()) < 2e-5
+
+
+@pytest.mark.parametrize("cols", [256, 1280, 4096])
+def test_norm_split_outputs(hip_lib, cuda, cols):
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(cols)
+    x = (torch.randn(300, cols, generator=g) * 3).to(cuda)
+    w = (1 + 0.1 * torch.randn(cols, generator=g)).to(torch.bfloat16).to(cuda)
+    b = (0.1 * torch.randn(cols, generator=g)).to(torch.bfloat16).to(cuda)
+    y32 = ops.layernorm(x, w, b, 1e-6, out_f32=True)
+    ys = ops.layernorm(x, w, b, 1e-6, out_split=True)
+    assert ys.shape == (300, 2 * cols) and float((_join(ys, cols) - y32).abs().max()) <= 2.0 ** -16 * float(y32.abs().max())
+    r32 = ops.rmsnorm(x, w, 1e-5, out_f32=True)
+    rs = ops.rmsnorm(x, w, 1e-5, out_split=True)
+    assert float((_join(rs, cols) - r32).abs().max()) <= 2.0 ** -16 * float(r32.abs().max())
+
+
+def _attn_ref(q, k, v, scale, causal=False, q_pos0=0, bias=None):
+    import torch
+
+    s = torch.einsum("bhqd,bhkd->bhqk", q.double() * scale, k.double())
+    if bias is not None:
+        s = s + bias.double()
+    if causal:
+        Sq, Sk = q.shape[2], k.shape[2]
+        s = s.masked_fill(torch.arange(Sk)[None, :] > torch.arange(Sq)[:, None] + q_pos0, float("-inf"))
+    return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, dim=-1), v.double())
+
+
+def _split_planes(t, cuda):
+    """fp32 [B,H,S,D] -> (hi, lo) bf16 device tensors laid out like the GEMM's split output ([B,S,2,H,D] buffer)."""
+    import torch
+
+    B, H, S, D = t.shape
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    buf = torch.stack([hi.permute(0, 2, 1, 3), lo.permute(0, 2, 1, 3)], 2).contiguous().to(cuda)  # [B,S,2,H,D]
+    return buf[:, :, 0].permute(0, 2, 1, 3), buf[:, :, 1].permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,D,causal,q_pos0", [(2, 16, 257, 257, 64, False, 0), (1, 8, 330, 330, 128, True, 0),
+                                                       (1, 4, 100, 333, 128, True, 233), (2, 4, 70, 70, 128, True, 0)])
+def test_attention_split_vs_fp64(hip_lib, cuda, B, H, Sq, Sk, D, causal, q_pos0):
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(Sq + Sk + D)
+    q, k, v = (torch.randn(B, H, s, D, generator=g) for s in (Sq, Sk, Sk))
+    scale = 1.0 / math.sqrt(D)
+    ref = _attn_ref(q, k, v, scale, causal, q_pos0)
+    (qh, ql), (kh, kl), (vh, vl) = (_split_planes(t, cuda) for t in (q, k, v))
+    for pre in ((True, False) if not causal else (False,)):
+        out = ops.attention_split(qh, ql, kh, kl, vh, vl, scale, causal=causal, q_pos0=q_pos0, prescale_q=pre)
+        got = _join(out, H * D).view(B, Sq, H, D).permute(0, 2, 1, 3).cpu()
+        e = float((got.double() - ref).abs().max())
+        assert e < 3e-5, f"split attention max err {e}"
+    # the bf16 kernel on the rounded operands is two orders of magnitude further out
+    o16 = ops.attention(qh.contiguous(), kh.contiguous(), vh.contiguous(), scale, causal=causal, q_pos0=q_pos0)
+    assert float((o16.float().cpu().double() - ref).abs().max()) > 20 * e
+
+
+@pytest.mark.parametrize("B,side", [(6, 14), (1, 64)])
+def test_sam_attention_split_with_relpos(hip_lib, cuda, B, side):
+    """SAM ViT-H attention (head dim 80) with the decomposed rel-pos bias: 14x14 windows (bias folded into the QK^T MFMA as a
+    one-hot product, hi + lo) and the 64x64 global grid (bias from registers / LDS), q scaled before the product."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    H, D, S = 4, 80, side * side
+    g = torch.Generator().manual_seed(side)
+    q, k, v = (torch.randn(B, H, S, D, generator=g) for _ in range(3))
+    th = (0.5 * torch.randn(2 * side - 1, D, generator=g)).to(torch.bfloat16)
+    tw = (0.5 * torch.randn(2 * side - 1, D, generator=g)).to(torch.bfloat16)
+    idx = torch.arange(side)[:, None] - torch.arange(side)[None, :] + side - 1
+    rq = q.double().view(B, H, side, side, D)
+    rel_h = torch.einsum("bhyxd,ykd->bhyxk", rq, th.double()[idx])  # [B,H,qy,qx,ky]
+    rel_w = torch.einsum("bhyxd,xkd->bhyxk", rq, tw.double()[idx])
+    bias = (rel_h[..., :, None] + rel_w[..., None, :]).reshape(B, H, S, S)
+    scale = D ** -0.5
+    ref = _attn_ref(q, k, v, scale, bias=bias)
+    (qh, ql), (kh, kl), (vh, vl) = (_split_planes(t, cuda) for t in (q, k, v))
+    rh, rw = ops.relpos_bias_split(qh, ql, th.to(cuda), tw.to(cuda), side, side)
+    assert float((rh.cpu().double() - rel_h.reshape(B * H, S, side)).abs().max()) < 1e-4 * float(rel_h.abs().max())
+    assert float((rw.cpu().double() - rel_w.reshape(B * H, S, side)).abs().max()) < 1e-4 * float(rel_w.abs().max())
+    out = ops.attention_split(qh, ql, kh, kl, vh, vl, scale, rel=(rh, rw))
+    got = _join(out, H * D).view(B, S, H, D).permute(0, 2, 1, 3).cpu()
+    e = float((got.double() - ref).abs().max())
+    # the floor is the 2^-17 relative split of v (|v| up to 4.5) under a peaked softmax (biases of +-20): ~7e-5; bf16 operands: 1e-2
+    assert e < 1.5e-4, f"SAM split attention ({side}x{side}) max err {e}"
+    o16 = ops.attention(qh.contiguous(), kh.contiguous(), vh.contiguous(), scale, rel=(rh, rw))
+    assert float((o16.float().cpu().double() - ref).abs().max()) > 20 * e
+
+
+def test_rope_split_cache_and_decode_attention(hip_lib, cuda):
+    """RoPE on split q|k|v rows + append to hi + lo cache planes, then the single-token and the batched decode attention
+    reading those planes, against fp64."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    H, D, T, Tmax = 4, 128, 37, 64
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(T + 1, 3 * H * D, generator=g)
+    cos, sin = ops.rope_table(Tmax, D, 10000.0, cuda)
+    caches = [torch.zeros(Tmax, H, D, dtype=torch.bfloat16, device=cuda) for _ in range(4)]  # k, k_lo, v, v_lo
+    qs = ops.split_rows(qkv[:T].to(cuda))
+    ops.rope_kv_split(qs, H, D, 0, tuple(caches), (cos, sin))
+
+    def rope(x, pos):  # x [T,H,D] fp64
+        half = D // 2
+        c, s = cos.cpu().double()[pos][:, None, :], sin.cpu().double()[pos][:, None, :]
+        return torch.cat([x[..., :half] * c - x[..., half:] * s, x[..., half:] * c + x[..., :half] * s], -1)
+
+    q3 = qkv.double().view(T + 1, 3, H, D)
+    pos = torch.arange(T + 1)
+    qr, kr = rope(q3[:, 0], pos), rope(q3[:, 1], pos)
+    got_q = _join(qs, 3 * H * D).cpu().view(T, 3, H, D)[:, 0]
+    assert float((got_q.double() - qr[:T]).abs().max()) < 1e-4
+    kc = caches[0].float() + caches[1].float()
+    vc = caches[2].float() + caches[3].float()
+    assert float((kc[:T].cpu().double() - kr[:T]).abs().max()) < 1e-4
+    assert float((vc[:T].cpu().double() - q3[:T, 2]).abs().max()) < 1e-4
+    # one decode step at position T on the split cache
+    o = ops.llama_decode_attn(qkv[T: T + 1].to(cuda).contiguous(), caches[0], caches[2], H, D, T, 10000.0, D ** -0.5,
+                              table=(cos, sin), lo=(caches[1], caches[3]))
+    s = torch.einsum("hd,thd->ht", qr[T], kr) * D ** -0.5
+    ref = torch.einsum("ht,thd->hd", torch.softmax(s, -1), q3[:, 2]).reshape(1, H * D)
+    assert float((o.cpu().double() - ref).abs().max()) < 2e-5
+    kc2 = caches[0].float() + caches[1].float()
+    assert float((kc2[T].cpu().double() - kr[T]).abs().max()) < 1e-4  # the new row was appended unrounded
+    # batched: two sequences sharing the layout [B, Tmax, H, D]
+    bc = [torch.stack([c, c]).contiguous() for c in caches]
+    for c in bc:
+        c[:, T] = 0
+    pos_dev = torch.tensor([T, T], dtype=torch.int32, device=cuda)
+    ob = ops.llama_decode_attn_batch(qkv[T: T + 1].repeat(2, 1).to(cuda).contiguous(), bc[0], bc[2], H, D, pos_dev, 10000.0,
+                                     D ** -0.5, table=(cos, sin), lo=(bc[1], bc[3]))
+    assert float((ob.cpu().double() - ref).abs().max()) < 2e-5
+
+
+def test_towers_parity_mode_vs_oracle(hip_lib, cuda):
+    """SAM ViT (real width, 4 blocks incl. a global one), CLIP (4 layers) and LLaMA (3 layers, prefill + decode) in parity
+    mode against the fp32 CPU oracle on identical bf16-valued weights: relative errors at the fp32 level (the default mode sits
+    at 1e-2)."""
+    import torch
+
+    from interactvlm_amd import llava, sam
+    from interactvlm_amd import weights as Wt
+    from oracle import nn as O
+
+    torch.set_grad_enabled(False)
+    rel = lambda a, b: float((a.float().cpu() - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    c = Wt.SamEncCfg(depth=4, global_attn_indexes=(2,))
+    w = _bf16_weights(Wt.sam_encoder_spec(c))
+    enc = sam.SamImageEncoder(w, c, cuda)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 1024, 1024, generator=g).to(torch.bfloat16)
+    ref = O.sam_image_encoder(w, Wt.SAM_PREFIX + ".image_encoder", x.float(), c.depth, c.num_heads, c.global_attn_indexes)
+    ref = ref.permute(0, 2, 3, 1).reshape(2, 4096, 256)
+    e_def = rel(enc(x.to(cuda)), ref)
+    enc.precision = "parity"
+    e_par = rel(enc(x.to(cuda)), ref)
+    e_par2 = rel(enc(x.to(cuda)), ref)  # graph replay
+    print(f"\n[SAM ViT-H width, 4 blocks] rel rms err: default {e_def:.2e}, parity {e_par:.2e}")
+    assert e_par < 1e-4 and e_par2 < 1e-4 and e_def > 10 * e_par
+    del enc
+
+    cc = Wt.ClipCfg(hidden=256, layers=4, heads=4, inter=512)
+    w = _bf16_weights(Wt.clip_spec(cc))
+    xc = torch.randn(2, 3, 224, 224, generator=g).to(torch.bfloat16)
+    tower = llava.ClipTower(w, cc, cuda)
+    refc = O.clip_vision(w, Wt.CLIP_PREFIX, xc.float(), 4, 4)
+    e_def = rel(tower(xc.to(cuda)), refc)
+    tower.precision = "parity"
+    fs = tower(xc.to(cuda))
+    assert fs.shape == (2, 256, 512)
+    e_par = rel(_join(fs, 256), refc)
+    print(f"[CLIP, 3 layers run] rel rms err: default {e_def:.2e}, parity {e_par:.2e}")
+    assert e_par < 5e-5 and e_def > 10 * e_par
+
+    lc = Wt.LlamaCfg(hidden=512, layers=3, heads=4, inter=1024, vocab=1000)
+    w = _bf16_weights(Wt.llama_spec(lc))
+    llm = llava.Llama(w, lc, cuda, max_len=256)
+    emb = (torch.randn(90, 512, generator=g) * 0.5).to(torch.bfloat16).float()
+    refl = O.llama(w, "model", emb[None], lc.layers, lc.heads)[0]
+    errs = {}
+    for mode in ("default", "parity"):
+        llm.set_precision(mode)
+        h = [llm.forward(emb[:70].to(cuda), 0)]
+        for t in range(70, 90):
+            h.append(llm.forward(emb[t: t + 1].to(cuda), t))
+        got = torch.cat(h, 0)
+        errs[mode] = (rel(got[:70], refl[:70]), rel(got[70:], refl[70:]))
+    print(f"[LLaMA, 3 layers] rel rms err (prefill rows, decode rows): default {errs['default']}, parity {errs['parity']}")
+    assert max(errs["parity"]) < 5e-5 and errs["default"][0] > 10 * errs["parity"][0]
+
+
+def test_evaluate_parity_mode_vs_oracle(hip_lib, cuda):
+    """The facade in parity mode on the structurally complete tiny configuration: evaluate() and evaluate_batch() against the
+    fp32 oracle on identical weights - per-vertex contacts far inside the 1e-3 target, threshold sets equal."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth, synthetic
+    from interactvlm_amd import weights as Wt
+    from oracle import pipeline as P
+
+    torch.set_grad_enabled(False)
+    cfg = synthetic.config_tiny()
+    w = {k: v.to(torch.bfloat16).float() for k, v in Wt.synth_weights(Wt.ivlm_spec(cfg)).items()}
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    ids, forced = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=8)
+    cams = synthetic.human_cam_params()
+    ic, im = synthetic.images(cfg, cuda)
+    full_ids = torch.cat([ids[0], torch.tensor(forced)])
+    ref = P.model_forward(w, cfg, im[0].float().cpu(), ic.float().cpu(), full_ids, cams[0], tables)["pred_contact"]
+    errs = {}
+    for mode in ("default", "parity", "default"):
+        m.set_precision(mode)
+        out = m.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced)
+        errs[mode] = float((out["pred_contact_3d"].float().cpu() - ref).abs().max())
+    print(f"\n[evaluate, tiny] max |dp| vs fp32 oracle: default {errs['default']:.2e}, parity {errs['parity']:.2e}")
+    assert errs["parity"] < 1e-4 and errs["default"] < 1e-3
+    m.set_precision("parity")
+    single = m.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced)["pred_contact_3d"]
+    ic2, im2 = torch.cat([ic, ic]), torch.cat([im, im])
+    outs = m.evaluate_batch(ic2, im2, [ids[0], ids[0]], [cams[0], cams[0]], [(1024, 1024)] * 2, [(1024, 1024)] * 2,
+                            forced_new_tokens=forced)
+    for o in outs:
+        assert float((o["pred_contact_3d"] - single).abs().max()) < 1e-4
+        assert float((o["pred_contact_3d"].float().cpu() - ref).abs().max()) < 1e-4
