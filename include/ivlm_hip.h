@@ -245,7 +245,8 @@ int ivlm_attention_pingpong(int mode);
  *   like the reference's model-dtype einsum, stored f32).  tab_h bf16 [2*SH-1,D], tab_w bf16 [2*SW-1,D]. */
 int ivlm_relpos_bias(const void *q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void *tab_h, const void *tab_w,
                      int B, int H, int SH, int SW, int D, float *rel_h, float *rel_w, ivlm_stream_t stream);
-/* "Parity" precision of the same operands: q as hi + lo bf16 planes (q_lo: same strides), results unrounded fp32 (D = 80). */
+/* "Parity" precision of the same operands: q as hi + lo bf16 planes (q_lo: same strides), results unrounded fp32 (D = 80).
+ * q_lo == q: there is no lo plane (bf16 q), only the rounding of the results to bf16 is dropped. */
 int ivlm_relpos_bias_split(const void *q, const void *q_lo, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void *tab_h,
                            const void *tab_w, int B, int H, int SH, int SW, int D, float *rel_h, float *rel_w,
                            ivlm_stream_t stream);

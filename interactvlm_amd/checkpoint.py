@@ -146,9 +146,11 @@ def config_from_hf(folder: str, tokenizer_ids: Optional[dict] = None,
 
 
 # Tensors a checkpoint written by merge_lora_weights_and_save_hf_model.py:152-161 may carry besides the inference path's own
-# (tests/golden/state_dict_keys.json is the reference's inventory): the '-DifDe' token types register the SAME mask decoder
-# under two more names (InteractVLM.py:30-32), older transformers saved the rotary inv_freq buffers, and the optional fusion /
-# uncertainty heads are off in every released configuration.
+# (tests/golden/state_dict_keys.json is the reference's inventory): older transformers saved the rotary inv_freq buffers, and the
+# optional fusion / uncertainty heads are off in every released configuration.  The '-DifDe' token types carry two more mask
+# decoders: separately TRAINED deep copies (initialize_separate_decoders, InteractVLM.py:114-121, called from train.py:274 and
+# evaluate.py:557/563) that ModifiedSAM.forward selects by dataset name (:46-52) - with a '-DifDe' configuration they are part of
+# the spec (weights.ivlm_spec) and are loaded as decoders of their own; a non-DifDe configuration ignores them if present.
 TOLERATED_PREFIXES = ("model.visual_model.uncertainty", "model.fusion", "model.visual_model.human_mask_decoder.",
                       "model.visual_model.object_mask_decoder.")
 TOLERATED_SUFFIXES = ("rotary_emb.inv_freq",)
@@ -157,8 +159,9 @@ TOLERATED_SUFFIXES = ("rotary_emb.inv_freq",)
 def check_against_spec(state: Dict[str, torch.Tensor], cfg: Wt.IvlmCfg, ignore: Iterable[str] = TOLERATED_PREFIXES,
                        strict_extras: bool = False) -> None:
     """Every tensor of the inference path present with the right shape; raises CheckpointError listing what is wrong.
-    Known extras (``ignore`` prefixes, TOLERATED_SUFFIXES) are skipped silently; the '-DifDe' duplicate decoders must equal
-    ``mask_decoder.*``; any other unknown tensor is a warning (an error with strict_extras)."""
+    Known extras (``ignore`` prefixes, TOLERATED_SUFFIXES) are skipped silently; any other unknown tensor is a warning (an error
+    with strict_extras).  The '-DifDe' decoders are spec entries of a '-DifDe' configuration (they may differ from
+    ``mask_decoder.*``: they are trained separately)."""
     import warnings
 
     spec = Wt.ivlm_spec(cfg)
@@ -166,11 +169,6 @@ def check_against_spec(state: Dict[str, torch.Tensor], cfg: Wt.IvlmCfg, ignore: 
     bad = [(k, tuple(state[k].shape), tuple(spec[k])) for k in spec if k in state and tuple(state[k].shape) != tuple(spec[k])]
     extra = [k for k in state if k not in spec and not any(k.startswith(p) for p in ignore)
              and not k.endswith(TOLERATED_SUFFIXES)]
-    for dup in ("human_mask_decoder", "object_mask_decoder"):  # registered aliases of one module: same values
-        for k in [k for k in state if k.startswith(f"model.visual_model.{dup}.")]:
-            base = k.replace(f".{dup}.", ".mask_decoder.")
-            if base in state and not torch.equal(state[k], state[base]):
-                bad.append((k, "differs from", base))
     if extra and not strict_extras:
         warnings.warn(f"checkpoint carries {len(extra)} tensors outside the inference path (ignored): {extra[:6]}"
                       f"{' ...' if len(extra) > 6 else ''}")

@@ -742,7 +742,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int rp_u32x4_t;
 
 // SPLIT ("parity" precision): q = hi + lo planes (q_lo, same strides), fp32 results NOT rounded to bf16 (the fp32 reference
 // keeps them in fp32; only a bf16 model materialises them in bf16).
-template <int NCH, bool SPLIT = false>
+template <int NCH, bool SPLIT = false, bool ROUND = !SPLIT>
 __global__ __launch_bounds__(256) void relpos_rows_kernel(const bf16_t* __restrict__ q, int64_t q_bs, int64_t q_hs,
                                                           int64_t q_rs, const bf16_t* __restrict__ tab_h,
                                                           const bf16_t* __restrict__ tab_w, int H, int SH, int SW,
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void relpos_rows_kernel(const bf16_t* __restri
                                                                    __builtin_bit_cast(rp_bf16x2_t, w), acc, false);
                     }
                 }
-                r[u] = SPLIT ? acc : bf16_to_f32(f32_to_bf16(acc));  // the (bf16) reference materialises rel_h/rel_w in bf16
+                r[u] = ROUND ? bf16_to_f32(f32_to_bf16(acc)) : acc;  // the (bf16) reference materialises rel_h/rel_w in bf16
             }
             if ((((uintptr_t)(out + j)) & 15) == 0) {
                 *reinterpret_cast<float4*>(out + j) = make_float4(r[0], r[1], r[2], r[3]);
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256) void relpos_rows_kernel(const bf16_t* __restri
                                                                __builtin_bit_cast(rp_bf16x2_t, w), acc, false);
                 }
             }
-            out[j] = SPLIT ? acc : bf16_to_f32(f32_to_bf16(acc));
+            out[j] = ROUND ? bf16_to_f32(f32_to_bf16(acc)) : acc;
         }
     };
     run(th, qh + SH - 1, SH, rel_h + bq * SH);
@@ -886,6 +886,15 @@ int attention_bf16(const AttnArgs& a, hipStream_t st) {
 int relpos_bias(const bf16_t* q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const bf16_t* tab_h, const bf16_t* tab_w,
                 int B, int H, int SH, int SW, int D, float* rel_h, float* rel_w, hipStream_t st, const bf16_t* q_lo) {
     if (!q || !tab_h || !tab_w || !rel_h || !rel_w || (D & 7)) return IVLM_ERR_INVALID_ARG;
+    if (q_lo == q) {  // (q_lo == q: no lo plane - the bf16 q of the default path, but results kept in fp32, not rounded to bf16)
+        if (D != 80 || SH > 128 || SW > 128 || H > 65535 || B > 65535 || ((q_bs | q_hs | q_rs) & 7) ||
+            (reinterpret_cast<uintptr_t>(q) & 15))
+            return IVLM_ERR_UNSUPPORTED;
+        const size_t lds = (size_t)(2 * SH - 1 + 2 * SW - 1) * (D + 8) * 2;
+        relpos_rows_kernel<10, false, false><<<dim3((SH * SW + 255) / 256, H, B), 256, lds, st>>>(q, q_bs, q_hs, q_rs, tab_h, tab_w,
+                                                                                                H, SH, SW, rel_h, rel_w, nullptr);
+        return ivlm_launch_status();
+    }
     if (q_lo) {  // "parity" precision: q as hi + lo planes, unrounded fp32 results (SAM head dim only)
         if (D != 80 || SH > 128 || SW > 128 || H > 65535 || B > 65535 || ((q_bs | q_hs | q_rs) & 7) ||
             ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(q_lo)) & 15))

@@ -403,7 +403,22 @@ int linear_bf16(const GemmArgs& g, hipStream_t st) {
         if (!g.out_rows && !g.a_rows && (skinny || (g.a_f32 && g.M >= 2))) return gemv_mfma_bf16(g, st);
     }
     if (g.M <= 8 && g.batch == 1 && !g.out_rows && !g.a_rows) return gemv_bf16(g, st);
-    if (g.a_f32) return IVLM_ERR_UNSUPPORTED;  // the tile kernels DMA bf16 operands (use ivlm_gather_rows split + K' = 2K)
+    if (g.a_f32 && g.M <= 16 && g.batch == 1 && !g.out_rows && !g.a_rows) {
+        // 9..16 fp32 rows against a matrix the skinny MFMA kernel does not take (K or N < 1024: cam-pose encoders, AttentionSplitter,
+        // text_hidden_fcs[1], small-width decode batches): two passes of the weight-streaming GEMV over row chunks of <= 8
+        for (int m0 = 0; m0 < g.M; m0 += 8) {
+            GemmArgs c = g;
+            c.M = g.M - m0 < 8 ? g.M - m0 : 8;
+            c.A = reinterpret_cast<const bf16_t*>(reinterpret_cast<const float*>(g.A) + (int64_t)m0 * g.lda);
+            c.C = static_cast<char*>(g.C) + (size_t)m0 * g.ldc * (g.out_f32 ? 4 : 2);
+            if (g.residual && g.res_mod <= 0) c.residual = g.residual + (int64_t)m0 * g.ldr * (g.res_f32 ? 2 : 1);
+            if (g.residual && g.res_mod > 0) return IVLM_ERR_UNSUPPORTED;
+            const int rc = gemv_bf16(c, st);
+            if (rc != IVLM_OK) return rc;
+        }
+        return IVLM_OK;
+    }
+    if (g.a_f32) return IVLM_ERR_UNSUPPORTED;  // the tile kernels DMA bf16 operands (use ivlm_gather_rows split + IVLM_GEMM_A_SPLIT)
     if (g.rms_w) return IVLM_ERR_UNSUPPORTED;  // the RMSNorm fusion exists on the decode (GEMV) path only
     return gemm_bf16(g, st);
 }

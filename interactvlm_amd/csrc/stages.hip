@@ -89,8 +89,9 @@ extern "C" int ivlm_gemm_splitk_choice(int M, int N, int K, int act, int has_rms
 }
 
 static bool cfg_ok(const ivlm_llama_cfg* c) {
+    // (max_len: the decode attention keeps one score per cached position in LDS - decattn::kMaxT = 4096 positions)
     return c && c->layers > 0 && c->hidden > 0 && c->heads > 0 && c->inter > 0 && c->hidden % c->heads == 0 && c->max_len > 0 &&
-           (c->hidden & 7) == 0 && (c->inter & 7) == 0;
+           c->max_len <= 4096 && (c->hidden & 7) == 0 && (c->inter & 7) == 0;
 }
 
 extern "C" size_t ivlm_llama_prefill_workspace_bytes(const ivlm_llama_cfg* c, int T) {

@@ -119,7 +119,11 @@ class ClipTower:
 class Llama:
     """HF LlamaModel + lm_head with a KV cache, one sequence (batch 1) per instance call."""
 
+    MAX_LEN_LIMIT = 4096  # the decode attention kernel keeps one score per cached position in LDS (decattn::kMaxT)
+
     def __init__(self, w, cfg: LlamaCfg, device, prefix="model", max_len=640):
+        if max_len > self.MAX_LEN_LIMIT:
+            raise ops.IvlmError(f"max_len={max_len}: the KV-cached decode kernels support at most {self.MAX_LEN_LIMIT} positions")
         self.cfg, self.device, self.max_len = cfg, device, max_len
         self.embed = _dev(w[prefix + ".embed_tokens.weight"], device)
         self.layers = []

@@ -105,6 +105,12 @@ class InteractVLMForCausalLM:
             vm.mask_decoder.use_graph = False
             vm.image_encoder.use_graph = False
         vm.prompt_encoder = vm.mask_decoder  # text path of the prompt encoder is folded into the decoder object
+        self.use_diff_decoder = "DifDe" in c.token_type
+        if self.use_diff_decoder:  # separately trained decoder copies, picked per sample by dataset name (InteractVLM.py:46-52)
+            vm.human_mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid, decoder="human_mask_decoder")
+            vm.object_mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid, decoder="object_mask_decoder")
+            if os.environ.get("IVLM_NO_GRAPHS"):
+                vm.human_mask_decoder.use_graph = vm.object_mask_decoder.use_graph = False
         vm.postprocess_masks = lambda m, input_size, original_size: postprocess_masks(
             m, input_size, original_size, c.sam.img_size)
         self.model = SimpleNamespace(visual_model=vm, text_hidden_fcs=self.text_hidden_fcs,
@@ -133,15 +139,19 @@ class InteractVLMForCausalLM:
     # as hi + lo bf16 halves (fp32-activation GEMMs / attention on the bf16 matrix cores at 2-3 x the MFMA work), K / V are cached
     # as hi + lo planes; the decode step, text_hidden_fcs and the mask decoder have fp32 activations in both modes.  This is the
     # mode that holds the north star's 1e-3 on per-vertex probabilities at the real depth (bench.py parity_vs_oracle_full_depth).
-    precision_modes = ("default", "parity")
+    # "parity-encoder": only the SAM ViT-H encoder in parity precision.  It owns the default mode's error at the real depth
+    # (tools/diag_precision_modes.py on the headline configuration: 5.8e-3 in default mode, 2.9e-4 with the encoder alone in
+    # parity precision, 8e-6 with everything) - the cheapest mode that holds 1e-3, with a 3x margin.
+    precision_modes = ("default", "parity-encoder", "parity")
     precision = "default"
 
     def set_precision(self, mode):
         assert mode in self.precision_modes, mode
         self.precision = mode
-        self.vision_tower.precision = mode
-        self.model.visual_model.image_encoder.precision = mode
-        self.llm.set_precision(mode)
+        lang = "parity" if mode == "parity" else "default"
+        self.vision_tower.precision = lang
+        self.llm.set_precision(lang)
+        self.model.visual_model.image_encoder.precision = "default" if mode == "default" else "parity"
 
     def get_visual_embs(self, pixel_values):
         """[B,V,3,S,S] -> image embeddings; returned in the reference's [B,V,256,g,g] shape (a strided view of the
@@ -209,7 +219,7 @@ class InteractVLMForCausalLM:
         f = self.vision_tower(images_clip.to(self.device))
         B, T, C = f.shape  # ("parity" precision: C = 2 * hidden, [hi | lo] rows)
         return self.mm_projector(f.reshape(B * T, C), out_f32=True,
-                                 a_split=self.precision == "parity").view(B, T, -1)  # fp32: rows of the LLM's input stream
+                                 a_split=self.vision_tower.precision == "parity").view(B, T, -1)  # fp32: rows of the LLM's input stream
 
     def _seg_token_ids(self):
         ids = [self.seg_token_idx]
@@ -227,7 +237,18 @@ class InteractVLMForCausalLM:
             m = torch.cat([m, torch.zeros(1, dtype=torch.bool, device=m.device)])
         return torch.cat([torch.zeros(self.img_emb_len, dtype=torch.bool, device=m.device), m])
 
-    def _decode_sample(self, hidden, rows_mask, ids, cam_params, image_embeddings, input_size, original_size):
+    def _mask_decoder_for(self, ds_name):
+        """ModifiedSAM.forward's decoder choice (InteractVLM.py:46-54): with '-DifDe' the human decoder serves 'hcontact' samples,
+        the object decoder 'oafford' / 'ocontact', the shared one anything else."""
+        vm = self.model.visual_model
+        if self.use_diff_decoder and ds_name is not None:
+            if "hcontact" in ds_name:
+                return vm.human_mask_decoder
+            if "oafford" in ds_name or "ocontact" in ds_name:
+                return vm.object_mask_decoder
+        return vm.mask_decoder
+
+    def _decode_sample(self, hidden, rows_mask, ids, cam_params, image_embeddings, input_size, original_size, ds_name=None):
         """[SEG] rows -> pred_mask [V,H,W] fp32 for one sample (InteractVLM.py:416-442 / 585-612)."""
         rows = rows_mask.nonzero().flatten()
         V = self.multiview_channels
@@ -246,7 +267,7 @@ class InteractVLMForCausalLM:
         if V > 1:
             emb = emb.repeat(1, V, 1)
         emb = self.process_embeddings(emb, cam_params, token)
-        low, iou = self.model.visual_model.mask_decoder(image_embeddings, emb)
+        low, iou = self._mask_decoder_for(ds_name)(image_embeddings, emb)
         if self.debug_taps is not None:
             self.debug_taps.update(prompt_emb=emb, low_res=low, iou=iou)
         self._last_low = (low, tuple(input_size), tuple(original_size))
@@ -277,7 +298,8 @@ class InteractVLMForCausalLM:
             hidden = self.llm.forward(x, 0)
             rows = self._seg_rows(ids, extra_false_col=True)
             osz = tuple(label_list[i].shape[-2:]) if label_list is not None else tuple(resize_list[i])
-            pm, _ = self._decode_sample(hidden, rows, ids, cam_params[i], emb_sam[i], resize_list[i], osz)
+            pm, _ = self._decode_sample(hidden, rows, ids, cam_params[i], emb_sam[i], resize_list[i], osz,
+                                        ds_name=ds_name_list[i] if ds_name_list else "hcontact")
             pred_masks.append(pm)
             gt_masks.append(masks_list[i][:, 0] if masks_list is not None else None)
         ds_name_list = ds_name_list or ["hcontact"] * B
@@ -388,10 +410,12 @@ class InteractVLMForCausalLM:
         outputs equal B separate calls.  forced_new_tokens: one list per sequence (or one shared list).
         -> [(output_ids [1, L+n], hidden [L+n-1+255, H])] * B."""
         B = len(input_ids_list)
+        if B > 16:  # (checked before any work: the weight-streaming decode kernels take at most 16 rows per step)
+            raise ops.IvlmError(f"generate_batch: {B} sequences per call, at most 16 (evaluate_batch chunks larger batches itself)")
         dev = self.device
         feats = self.encode_images(images_clip)
         kc, vc = self.llm.batch_cache(B)
-        lo = self.llm.batch_cache_lo(B) if self.precision == "parity" else None
+        lo = self.llm.batch_cache_lo(B) if self.llm.precision == "parity" else None
         # one image for all prompts (configs[4]: a human-contact and an object prompt about the same picture): ONE CLIP pass
         shared = feats.shape[0] == 1 and B > 1
         xs = [self._input_embeds(input_ids_list[b].reshape(-1), feats[0 if shared else b]) for b in range(B)]
@@ -476,6 +500,24 @@ class InteractVLMForCausalLM:
         image_embeddings: pre-computed SAM embeddings, one [V, g*g, 256] tensor for all samples (the four
         canonical body renders of hcontact are the same for every image) or a list of B; ``images`` is then not encoded."""
         B = len(input_ids_list)
+        if B > 16:  # larger batches run as consecutive calls of <= 16 sequences (the decode kernels' row limit)
+            if images_clip.shape[0] == 1:
+                raise ops.IvlmError("evaluate_batch: more than 16 prompts about ONE picture are not supported")
+            outs = []
+            for lo in range(0, B, 16):
+                hi = min(lo + 16, B)
+                fn = forced_new_tokens
+                if fn is not None and isinstance(fn[0], (list, tuple)):
+                    fn = fn[lo:hi]
+                emb = image_embeddings[lo:hi] if isinstance(image_embeddings, (list, tuple)) else image_embeddings
+                outs += self.evaluate_batch(images_clip[lo:hi], None if images is None else images[lo:hi], input_ids_list[lo:hi],
+                                            cam_params[lo:hi],
+                                            resize_list[lo:hi], original_size_list[lo:hi],
+                                            contact_type if isinstance(contact_type, str) else contact_type[lo:hi], max_new_tokens,
+                                            fn, eos_token_id,
+                                            lift2d_dict_path[lo:hi] if isinstance(lift2d_dict_path, (list, tuple)) else lift2d_dict_path,
+                                            emb)
+            return outs
         main = torch.cuda.current_stream(self.device)
         if image_embeddings is not None:
             embs = list(image_embeddings) if isinstance(image_embeddings, (list, tuple)) else [image_embeddings] * B
@@ -500,13 +542,13 @@ class InteractVLMForCausalLM:
                 main.wait_event(ev)
                 allv.record_stream(main)
         outs, lows = [], []
+        ctypes = [contact_type] * B if isinstance(contact_type, str) else list(contact_type)
         for b, (output_ids, hidden) in enumerate(gens):
             rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)
             pm, _ = self._decode_sample(hidden, rows, output_ids[0], cam_params[b], embs[b], resize_list[b],
-                                        original_size_list[b])
+                                        original_size_list[b], ds_name=ctypes[b])
             outs.append({"output_ids": output_ids, "pred_masks": [pm], "pred_contact_3d": None})
             lows.append(pm)
-        ctypes = [contact_type] * B if isinstance(contact_type, str) else list(contact_type)
         paths = lift2d_dict_path if isinstance(lift2d_dict_path, (list, tuple)) else [lift2d_dict_path] * B
         have = [b for b in range(B) if lows[b].shape[0] > 0]
         hum = [b for b in have if self.hC_loss_weight > 0 and "hcontact" in ctypes[b]]
@@ -584,7 +626,7 @@ class InteractVLMForCausalLM:
         if image_embeddings is None:
             image_embeddings = self.model.visual_model.image_encoder(images[0].to(self.device))
         pm, _ = self._decode_sample(hidden, rows, output_ids[0], cam_params[0], image_embeddings, resize_list[0],
-                                    original_size_list[0])
+                                    original_size_list[0], ds_name=contact_type)
         pred_masks = [pm]
         pred_contact_3d = None
         if pred_masks[0].shape[0] > 0:

@@ -520,6 +520,8 @@ def relpos_bias_split(q, q_lo, tab_h, tab_w, SH, SW):
     """"Parity" precision of ``relpos_bias``: q = hi + lo planes, results unrounded fp32 (the VALU dot-product kernel)."""
     lib = _lib.load()
     B, H, S, D = q.shape
+    if q_lo is None:
+        q_lo = q  # bf16 q without a lo plane: only the rounding of the results to bf16 is dropped
     assert S == SH * SW and q.stride(3) == 1 and q.stride() == q_lo.stride() and tab_h.is_contiguous() and tab_w.is_contiguous()
     rel_h = torch.empty(B * H, S, SH, dtype=torch.float32, device=q.device)
     rel_w = torch.empty(B * H, S, SW, dtype=torch.float32, device=q.device)

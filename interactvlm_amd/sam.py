@@ -200,7 +200,7 @@ class SamImageEncoder:
             return self._forward(images)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
-        key = tuple(images.shape) + (self.fp8, self.precision)
+        key = tuple(images.shape) + (self.fp8, self.precision, self.parity_sites)
         ent = self._graphs.get(key)
         dev = images.device
         if ent is None:
@@ -227,20 +227,40 @@ class SamImageEncoder:
     # configuration (ViT-H depth 32, 7B): default mode max |dp| 5.8e-3 against the fp32 oracle, this mode < 1e-3 (bench.py).
     precision = "default"
 
+    # which operands travel as hi + lo halves in "parity" precision (diagnostics may switch sites off: tools/diag_precision_modes.py):
+    #   n1 / n2: the normed rows (q|k|v and mlp1 GEMM inputs), attn: q, k, v, softmax weights (split attention, fp32 rel-pos terms),
+    #   proj: the attention output (proj GEMM input), h: the GELU output (mlp2 GEMM input); rel32 (only without attn): fp32
+    #   rel-pos terms in the bf16 attention
+    PARITY_SITES = frozenset(("n1", "attn", "proj", "n2", "h"))
+    parity_sites = PARITY_SITES
+
     def _attention_parity(self, blk, xn, V, side, nwin, win=None):
-        """_attention with split operands: xn [rows, 2D] -> attention output [nwin*S, 2D] ([hi | lo] rows)."""
+        """_attention with split operands: xn [rows, D or 2D] -> attention output [nwin*S, 2D] ([hi | lo] rows), or
+        [nwin*S, D] bf16 when the 'attn' site is off."""
         c = self.cfg
         D = c.embed_dim
         H, hd = c.num_heads, D // c.num_heads
         S = side * side
+        sites = self.parity_sites
+        sa, sn = "attn" in sites, "n1" in sites
         if win is None:
-            qkv = blk["qkv"](xn, a_split=True, out_split=True)  # [nwin*S, 2 * 3D]
+            qkv = blk["qkv"](xn, a_split=sn, out_split=sa)  # [nwin*S, (2 *) 3D]
         else:
             unpart, pad, qkv = win
-            blk["qkv"](xn, out=qkv, out_rows=unpart, a_split=True, out_split=True)
-            if "qkv_b_split" not in blk:
+            blk["qkv"](xn, out=qkv, out_rows=unpart, a_split=sn, out_split=sa)
+            if sa and "qkv_b_split" not in blk:
                 blk["qkv_b_split"] = torch.cat([blk["qkv"].b, torch.zeros_like(blk["qkv"].b)]).contiguous()
-            ops.fill_rows(qkv, pad, blk["qkv_b_split"])
+            ops.fill_rows(qkv, pad, blk["qkv_b_split"] if sa else blk["qkv"].b)
+        if not sa:
+            qkv5 = qkv.view(nwin, S, 3, H, hd)
+            q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+            if "rel32" in sites:
+                rel = ops.relpos_bias_split(q, None, blk["rel_h"], blk["rel_w"], side, side)
+            else:
+                if "rel_cat" not in blk:
+                    blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
+                rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat"])
+            return ops.attention(q, k, v, hd ** -0.5, rel=rel).permute(0, 2, 1, 3).reshape(nwin * S, H * hd)
         q6 = qkv.view(nwin, S, 2, 3, H, hd)
         hi = [q6[:, :, 0, i].permute(0, 2, 1, 3) for i in range(3)]
         lo = [q6[:, :, 1, i].permute(0, 2, 1, 3) for i in range(3)]
@@ -251,23 +271,26 @@ class SamImageEncoder:
         c = self.cfg
         V = images.shape[0]
         g, D = c.grid, c.embed_dim
+        sites = self.parity_sites
+        sa = "attn" in sites
+        sp = sa and "proj" in sites
         cols = ops.im2col_nchw(images.to(BF16).contiguous(), c.patch, c.patch)  # (bf16 pixels x bf16 weights: exact products)
         x = self.patch(cols, residual=self.pos_embed, res_mod=g * g, out_f32=True)
         part, unpart, nw, gp, pad = self._window_maps(V)
         nwin = V * nw * nw
-        key = ("split", V)
+        key = ("split" if sa else "bf16", V)
         if key not in self._xw:
-            self._xw[key] = torch.empty(nwin * c.window * c.window, 6 * D, dtype=BF16, device=x.device)
+            self._xw[key] = torch.empty(nwin * c.window * c.window, (6 if sa else 3) * D, dtype=BF16, device=x.device)
         for blk in self.blocks:
-            xn = blk["norm1"](x, out_split=True)
+            xn = blk["norm1"](x, out_split="n1" in sites)
             if blk["glob"]:
                 a = self._attention_parity(blk, xn, V, g, V)
-                x = blk["proj"](a, residual=x, out_f32=True, a_split=True)
+                x = blk["proj"](a if (sp or not sa) else a[:, :D], residual=x, out_f32=True, a_split=sp)
             else:
                 a = self._attention_parity(blk, xn, V, c.window, nwin, win=(unpart, pad, self._xw[key]))
-                x = blk["proj"](a, residual=x, out=x, a_rows=unpart, a_split=True)
-            h = blk["lin1"](blk["norm2"](x, out_split=True), act="gelu", a_split=True, out_split=True)
-            x = blk["lin2"](h, residual=x, out_f32=True, a_split=True)
+                x = blk["proj"](a if (sp or not sa) else a[:, :D], residual=x, out=x, a_rows=unpart, a_split=sp)
+            h = blk["lin1"](blk["norm2"](x, out_split="n2" in sites), act="gelu", a_split="n2" in sites, out_split="h" in sites)
+            x = blk["lin2"](h, residual=x, out_f32=True, a_split="h" in sites)
         y = self.neck0(ops.gather_rows(x, out_kind="split"), out_f32=True, a_split=True)
         y = self.neck1(y, out_split=True)  # [V*g*g, 2 * 256]
         y = ops.linear(ops.im2col3x3_nhwc_split(y, V, g, g, c.out_chans), self.neck2_w, out_f32=True, a_split=True)
@@ -332,9 +355,11 @@ class SamMaskDecoder:
     fp32-activation GEMM on the bf16 matrix cores, weights exactly the checkpoint's bf16), the attentions run in fp32
     (``ops.attention_f32``), LayerNorms and the hypernetwork product read and write fp32."""
 
-    def __init__(self, w, device, grid=64, prefix=SAM_PREFIX):
+    def __init__(self, w, device, grid=64, prefix=SAM_PREFIX, decoder="mask_decoder"):
+        """decoder: the attribute name of the decoder module to load ('-DifDe' checkpoints also carry 'human_mask_decoder' and
+        'object_mask_decoder', separately trained copies: InteractVLM.py:114-121); the prompt encoder is shared."""
         self.device, self.grid = device, grid
-        pe, md = prefix + ".prompt_encoder", prefix + ".mask_decoder"
+        pe, md = prefix + ".prompt_encoder", prefix + "." + decoder
         self.C = C = w[md + ".iou_token.weight"].shape[1]
         f32 = lambda t: t.to(device=device, dtype=BF16).to(F32).contiguous()  # the checkpoint's bf16 values, held as fp32
         self.no_mask = f32(w[pe + ".no_mask_embed.weight"].reshape(1, C))

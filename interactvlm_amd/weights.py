@@ -247,6 +247,9 @@ def ivlm_spec(c: IvlmCfg) -> Spec:
     s.update(sam_encoder_spec(c.sam))
     s.update(prompt_encoder_spec())
     s.update(mask_decoder_spec())
+    if "DifDe" in c.token_type:  # separately trained copies of the mask decoder (InteractVLM.py:114-121, selected at :46-52)
+        s.update(mask_decoder_spec(SAM_PREFIX + ".human_mask_decoder"))
+        s.update(mask_decoder_spec(SAM_PREFIX + ".object_mask_decoder"))
     _lin(s, "model.text_hidden_fcs.0.0", c.llama.hidden, c.llama.hidden)
     _lin(s, "model.text_hidden_fcs.0.2", c.out_dim, c.llama.hidden)
     if c.multiview_cam_cond:

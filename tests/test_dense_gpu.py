@@ -594,3 +594,22 @@ def test_skinny_tiles_per_block_do_not_change_the_result(hip_lib, cuda, M, N, K,
     finally:
         lib.ivlm_skinny_tuning(0)
         lib.ivlm_gemv_mfma_min_m(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(12, 256, 256), (9, 256, 4096), (16, 2048, 256), (12, 256, 8), (13, 128, 128)])
+def test_fp32_rows_9_to_16_small_matrices(hip_lib, cuda, M, N, K):
+    """9..16 fp32 activation rows against matrices the skinny MFMA kernel does not take (K or N < 1024: cam-pose
+    encoders, AttentionSplitter with n_seg * V > 8, text_hidden_fcs[1] with 9-16 [SEG] rows, narrow decode batches) run as row
+    chunks on the weight-streaming GEMV - exact bf16-weight x fp32-activation products, all epilogues."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(M * 31 + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = _bf(torch.randn(N, generator=g) * 0.1)
+    r = torch.randn(M, N, generator=g)
+    ref = torch.relu(x.double() @ w.double().T + b.double()) + r.double()
+    got = ops.linear(x.to(cuda), w.to(cuda), b.to(cuda), act="relu", residual=r.to(cuda), out_f32=True)
+    assert got.shape == (M, N) and float((got.cpu().double() - ref).abs().max()) < 3e-5 * float(ref.abs().max())

@@ -693,3 +693,47 @@ def test_model_forward_gen_hu_obj_vs_reference_golden(hip_lib, cuda, golden_dir)
     ev = m.evaluate(images_clip.to(bf).to(cuda), images.to(bf).to(cuda), ids[None, :L0], cams, [(1024, 1024)], [(1024, 1024)],
                     contact_type="hcontact", forced_new_tokens=ids[L0:].tolist())
     assert float((ev["pred_contact_3d"].float().cpu() - o["pred_contact"]).abs().max()) < 1e-3
+
+
+def test_difde_decoders_selected_by_dataset_name(hip_lib, cuda):
+    """'-DifDe' token types: the human / object mask decoders are separately trained modules picked per sample by dataset name
+    (InteractVLM.py:46-52, 114-121).  A '-DifDe' model with three different decoders must produce, for an hcontact
+    sample, exactly what a plain model holding the human decoder's weights as mask_decoder.* produces - and likewise for the
+    object decoder on 'ocontact' / 'oafford' names and the shared one on anything else."""
+    import dataclasses
+
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth, synthetic
+    from interactvlm_amd import weights as Wt
+
+    cfg = dataclasses.replace(synthetic.config_tiny(), token_type="Gen-DifDe")
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    assert any(".human_mask_decoder." in k for k in w) and any(".object_mask_decoder." in k for k in w)
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    vm = m.model.visual_model
+    assert m._mask_decoder_for("hcontact_damon") is vm.human_mask_decoder
+    assert m._mask_decoder_for("oafford_piad") is vm.object_mask_decoder and m._mask_decoder_for("ocontact_x") is vm.object_mask_decoder
+    assert m._mask_decoder_for("other") is vm.mask_decoder and m._mask_decoder_for(None) is vm.mask_decoder
+    ids, forced = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=8)
+    cams = synthetic.human_cam_params()
+    ic, im = synthetic.images(cfg, cuda)
+    out = m.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], contact_type="hcontact", forced_new_tokens=forced)
+    emb = m.precompute_visual_embs(im[0])
+    text = torch.randn(1, 4, 256, device=cuda)
+    for name in ("human_mask_decoder", "object_mask_decoder"):
+        w2 = {k: v for k, v in w.items() if ".human_mask_decoder." not in k and ".object_mask_decoder." not in k}
+        w2.update({k.replace("." + name + ".", ".mask_decoder."): v for k, v in w.items() if "." + name + "." in k})
+        m2 = M.InteractVLMForCausalLM(dataclasses.replace(cfg, token_type="Gen"), w2, cuda, lift_tables=tables)
+        low_a, iou_a = getattr(vm, name)(emb, text)
+        low_b, iou_b = m2.model.visual_model.mask_decoder(emb, text)
+        assert torch.equal(low_a, low_b) and torch.equal(iou_a, iou_b)
+        low_c, _ = vm.mask_decoder(emb, text)
+        assert not torch.equal(low_a, low_c)  # the three decoders really are different modules
+        if name == "human_mask_decoder":
+            out2 = m2.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], contact_type="hcontact", forced_new_tokens=forced)
+            assert torch.equal(out["pred_masks"][0], out2["pred_masks"][0])
+            assert torch.equal(out["pred_contact_3d"], out2["pred_contact_3d"])
+        del m2
