@@ -284,7 +284,19 @@ def parity_vs_oracle(dev):
         same = op(got.cpu(), t) == op(refc, t)
         sets[name] = {"equal_outside_error_band": bool(same[~band].all()), "vertices_in_band": int(band.sum()),
                       "mismatches_in_band": int((~same[band]).sum())}
+    # fp8 variant on this configuration (where the bf16 path meets 1e-3): scales calibrated on ANOTHER image / prompt, then the same
+    # evaluation inputs as above
+    ic_c, im_c = synthetic.images(cfg, dev, seed=777)
+    ids_c, forced_c = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=8, seed=777)
+    m.enable_fp8(ic_c, im_c, torch.cat([ids_c[0], torch.tensor(forced_c)])[None])
+    got8 = m.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced)["pred_contact_3d"].float().cpu()
+    m.disable_fp8()
+    fp8_leg = {"max_abs_dp_vs_oracle": round(float((got8 - refc).abs().max()), 5), "rms_dp_vs_oracle": round(float((got8 - refc).pow(2).mean().sqrt()), 5),
+               "max_abs_dp_vs_bf16_path": round(float((got8 - got.cpu()).abs().max()), 5),
+               "f1_vs_oracle": round(float(OM.h_contact_metrics((refc >= thr).float(), got8, thr)[0][0]), 5),
+               "calibration": "another image and prompt (seed 777) than the evaluated one"}
     return {"config": "tiny (2-layer LLaMA hd128, 3-layer CLIP, 2-block SAM ViT hd80, full SAM decoder, 4x1024^2, 6890 v)",
+            "fp8_variant": fp8_leg,
             "max_abs_dp": round(err, 6), "rms_dp": round(float((got.cpu() - refc).pow(2).mean().sqrt()), 6),
             "within_1e-3": bool(err <= 1e-3),
             "f1_vs_oracle": round(float(f1[0]), 5), "precision": round(float(f1[1]), 5), "recall": round(float(f1[2]), 5),
@@ -489,8 +501,10 @@ def main():
     fp8v = None
     if workload == "b1" and world == 1 and not args.no_roofline and not args.no_variants:
         ref_c = step_b1()
-        enc = model.model.visual_model.image_encoder
-        enc.enable_fp8(images[0])
+        # activation scales calibrated on ANOTHER image and prompt continuation than the ones evaluated and timed below
+        ic_cal, im_cal = synthetic.images(cfg, dev, seed=777)
+        ids_cal, forced_cal = synthetic.prompt_ids(cfg, seed=777)
+        model.enable_fp8(ic_cal, im_cal, torch.cat([ids_cal[0], torch.tensor(forced_cal)])[None])
         got_c = step_b1()
         sync()
         t1 = time.perf_counter()
@@ -531,10 +545,14 @@ def main():
                                  "achieved": round(tf, 1), "peak": 5000.0, "unit": "TFLOP/s", "frac": round(tf / 5000.0, 4),
                                  "avg_us": round(us, 1), "square_8192_tflops": round(tf_sq, 1),
                                  "square_8192_frac": round(tf_sq / 5000.0, 4)},
-                "note": "SAM ViT-H qkv / proj / mlp GEMMs with OCP e4m3 operands (per-tensor scales calibrated on this image, "
-                        "fp32 accumulate, v_mfma_scale_f32_16x16x128_f8f6f4); CLIP / LLaMA / attention stay bf16. NOT the "
-                        "headline metric: fp8 cannot meet the 1e-3 parity target"}
-        enc.fp8 = False
+                "note": "BASELINE configs[4]: OCP e4m3 operands (per-tensor scales, fp32 accumulate, v_mfma_scale_f32_16x16x128_f8f6f4) "
+                        "for the GEMMs of the SAM ViT-H encoder, the CLIP tower and the LLaMA prefill; e4m3 WEIGHTS (fp32 "
+                        "activations) for the batch-1 decode linears; attention, lm_head and the KV cache stay bf16.  Activation "
+                        "scales calibrated on another image / prompt (seed 777) than the one evaluated.  The error against the "
+                        "bf16 path on this random-weight 7B configuration is reported for completeness; the meaningful figure is "
+                        "parity_vs_oracle.fp8_variant (the structured configuration where bf16 meets 1e-3).  NOT the headline "
+                        "metric: fp8 cannot meet the 1e-3 parity target"}
+        model.disable_fp8()
         del xq, wq, o8
 
     roof = roof_lift = roof_serial = None
@@ -687,7 +705,7 @@ def main():
             "roofline": (roof_gemv if (roof_serial and roof_serial["gemv"]["ms_per_image"] >= roof_serial["gemm"]["ms_per_image"])
                          else roof),
             "roofline_mfma": roof, "roofline_gemv": roof_gemv, "roofline_lift": roof_lift, "cpu_baseline": cpu,
-            "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "variant_fp8_sam_encoder": fp8v,
+            "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "variant_fp8": fp8v,
             "dp64_one_gpu": dp64_one,
             "one_gpu_same_workload": one_gpu, "parity_vs_oracle": parity,
             "parity_vs_oracle_full_depth": parity_full,

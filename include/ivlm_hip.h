@@ -172,6 +172,15 @@ int ivlm_gemm_fp8(const void *A, int64_t lda, const void *W, int64_t ldw, void *
                   const float *scale_w, const float *scale_out, int flags, const int32_t *out_rows, const int32_t *a_rows,
                   ivlm_stream_t stream);
 
+/* Batch-1 decode linear with e4m3 WEIGHTS (BASELINE.json configs[4]; opt-in variant): C[1,N] = act((x . Wq^T) * *scale_w + bias) +
+ * residual, x fp32 [K] (optionally RMS-normalised: rms_w / rms_eps as in ivlm_gemm_bf16), Wq e4m3 bytes [N,K] (row stride ldw
+ * bytes; K, ldw multiples of 16; K <= 15360), one per-tensor scale in device memory (the tensor ivlm_gemm_fp8 uses for the
+ * prefill).  The decode step streams half the bytes per token; products are exact, the only error is the weight quantisation.
+ * act: none | SwiGLU (row-interleaved gate / up) | ...; flags: IVLM_GEMM_RES_F32. */
+int ivlm_gemv_fp8w(const float *x, const void *Wq, int64_t ldw, const float *scale_w, void *C, const void *bias,
+                   const void *residual, int N, int K, int act, int out_f32, const void *rms_w, float rms_eps, int flags,
+                   ivlm_stream_t stream);
+
 /* Split-K variant for small-M GEMMs (LLaMA prefill, CLIP: too few output tiles for 256 CUs): same result contract as
  * ivlm_gemm_bf16 (batch 1, act != SwiGLU, no RMS fusion); K % (8*splits) == 0, N % 4 == 0.  fp32 partial sums of the
  * `splits` K-slices go to the caller's workspace (ivlm_gemm_splitk_workspace_bytes) and are summed in slice order. */
@@ -210,6 +219,11 @@ int ivlm_layernorm(const void *x, int x_dtype, const void *w, const void *b, voi
  * does, an fp32 x (fp32 residual stream) is not. */
 int ivlm_rmsnorm(const void *x, int x_dtype, const void *w, void *y, int y_dtype, int64_t rows, int cols, float eps,
                  ivlm_stream_t stream);
+
+/* The same with an e4m3 output: y = e4m3(norm(x) / *fp8_scale) (bytes [rows, cols]): the operand of ivlm_gemm_fp8 (fp8 variant of
+ * the LLaMA prefill, BASELINE.json configs[4]). */
+int ivlm_rmsnorm_fp8(const void *x, int x_dtype, const void *w, void *y, int64_t rows, int cols, float eps, const float *fp8_scale,
+                     ivlm_stream_t stream);
 
 /* Fused multi-head attention: o = softmax(scale * q.k^T + bias + mask) . v, never materialising
  * the score matrix (SAM image_encoder.py:235-260, transformer.py:220-242; HF CLIP / LLaMA attention).

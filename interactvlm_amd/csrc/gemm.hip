@@ -299,9 +299,11 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
     }
     if (g.fp8) {
         if (!g.scale_a || !g.scale_w || (g.out_fp8 && (!g.scale_out || g.out_f32 || (g.ldc & 3)))) return IVLM_ERR_INVALID_ARG;
-        // (only the epilogues the SAM encoder uses are instantiated for fp8 operands)
+        // (only the epilogues the fp8 paths use are instantiated: SAM encoder, CLIP, LLaMA prefill)
         if (g.act == ACT_NONE) return launch<ACT_NONE>(g, st);
         if (g.act == ACT_GELU) return launch<ACT_GELU>(g, st);
+        if (g.act == ACT_QUICK_GELU) return launch<ACT_QUICK_GELU>(g, st);
+        if (g.act == ACT_SWIGLU) return (g.N & 3) || g.residual ? IVLM_ERR_UNSUPPORTED : launch<ACT_SWIGLU>(g, st);
         return IVLM_ERR_UNSUPPORTED;
     }
     if (g.out_fp8) return IVLM_ERR_UNSUPPORTED;

@@ -242,6 +242,13 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
             const float o0 = (v[0] / (1.0f + __expf(-v[0]))) * v[1];
             const float o1 = (v[2] / (1.0f + __expf(-v[2]))) * v[3];
             const int64_t o = (int64_t)m * g.ldc + (n >> 1);
+            if (g.out_fp8) {  // e4m3 pair with the consumer's calibrated per-tensor scale (LLaMA gate|up -> down)
+                const float inv = 1.0f / (*g.scale_out);
+                const uint32_t wq = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o0 * inv, -448.0f), 448.0f),
+                                                                    fminf(fmaxf(o1 * inv, -448.0f), 448.0f), 0u, false);
+                *reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(g.C) + (int64_t)bz * g.strideC + o) = (uint16_t)(wq & 0xffffu);
+                return;
+            }
             if (OUT_F32 && g.out_split) {
                 bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
                 uint32_t hi, lo;
@@ -273,10 +280,14 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
         }
         const int64_t o = g.c_panel ? (int64_t)(n >> 6) * g.c_panel + (int64_t)m * 64 + (n & 63) : (int64_t)m * g.ldc + n;
         if (g.out_fp8) {  // e4m3 output with the consumer's calibrated per-tensor scale (mlp1 -> mlp2)
+            // (values beyond the calibrated range saturate at +-448: e4m3 has no infinity, an unclamped overflow converts to NaN)
             const float inv = 1.0f / (*g.scale_out);
+            float c4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c4[j] = fminf(fmaxf(v[j] * inv, -448.0f), 448.0f);
             uint32_t w = 0;
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, w, false);
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, w, true);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(c4[0], c4[1], w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(c4[2], c4[3], w, true);
             *reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(g.C) + (int64_t)bz * g.strideC + o) = w;
         } else if (OUT_F32 && g.out_split) {
             bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;

@@ -351,6 +351,106 @@ __global__ __launch_bounds__(64 * kG1Waves, 8) void gemv1_kernel(GemmArgs g) {
     else static_cast<bf16_t*>(g.C)[row] = f32_to_bf16(v);
 }
 
+// ---- e4m3 WEIGHTS for the batch-1 decode linears (BASELINE.json configs[4]; opt-in variant) -----------------------------------
+// The decode step is HBM-bound on the weight bytes, so this is where fp8 pays most: half the bytes per token.  W is a byte
+// matrix [N, K] of OCP e4m3 values with ONE per-tensor scale (W ~ q * *scale_w: the tensor the fp8 prefill GEMM also uses); the
+// activation row stays fp32 in LDS and the products q x x are exact in fp32 (the only error is the weight quantisation).  Same
+// shape as gemv1_kernel: 1024-thread blocks, one row per wave, 16-byte non-temporal loads (16 weights each), fused RMSNorm
+// prologue, SwiGLU / residual epilogues.  Rows of K bytes: K % 16 == 0.
+typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
+
+__device__ __forceinline__ float dot16_fp8(const u32x4_t& w, const f32x4v_t& a0, const f32x4v_t& a1, const f32x4v_t& b0,
+                                           const f32x4v_t& b1, float acc) {
+    // 16 e4m3 weights = elements 16c .. 16c+15 of the row against x chunks 2c (a0 | a1) and 2c + 1 (b0 | b1)
+    const f32x4v_t* xs[4] = {&a0, &a1, &b0, &b1};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2v_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[j], false);
+        const f32x2v_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[j], true);
+        const f32x4v_t& x = *xs[j];
+        acc = fmaf(lo[0], x[0], acc);
+        acc = fmaf(lo[1], x[1], acc);
+        acc = fmaf(hi[0], x[2], acc);
+        acc = fmaf(hi[1], x[3], acc);
+    }
+    return acc;
+}
+
+template <bool RMS>
+__global__ __launch_bounds__(64 * kG1Waves, 8) void gemv1_fp8w_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float s_red[kG1Waves];
+    __shared__ float s_val[kG1Waves];
+    constexpr int U = 4;  // 4 x 16 bytes in flight per lane: one pass over a 4096-byte row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = g.K >> 3;   // fp32 x chunks of 8 elements (two 16-byte planes)
+    const int nw16 = g.K >> 4;     // 16-byte weight chunks per row
+    f32x4v_t* xf = reinterpret_cast<f32x4v_t*>(smem);
+    const int row = blockIdx.x * kG1Waves + wave;
+    const bool live = row < g.N;
+    const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint8_t*>(g.W) + (int64_t)(live ? row : g.N - 1) * g.ldw);
+    u32x4_t w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wp + min(lane + 64 * u, nw16 - 1));
+    float ssq = 0.0f;
+    for (int c = threadIdx.x; c < nchunk; c += 64 * kG1Waves) {
+        const f32x4v_t* xp = reinterpret_cast<const f32x4v_t*>(g.A) + 2 * c;
+        f32x4v_t xa = xp[0], xb = xp[1];
+        if (RMS) {
+            const u32x4_t gv = *(reinterpret_cast<const u32x4_t*>(g.rms_w) + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ssq += xa[j] * xa[j] + xb[j] * xb[j];
+            xa[0] *= __uint_as_float(gv[0] << 16); xa[1] *= __uint_as_float(gv[0] & 0xffff0000u);
+            xa[2] *= __uint_as_float(gv[1] << 16); xa[3] *= __uint_as_float(gv[1] & 0xffff0000u);
+            xb[0] *= __uint_as_float(gv[2] << 16); xb[1] *= __uint_as_float(gv[2] & 0xffff0000u);
+            xb[2] *= __uint_as_float(gv[3] << 16); xb[3] *= __uint_as_float(gv[3] & 0xffff0000u);
+        }
+        xf[c] = xa;
+        xf[nchunk + c] = xb;
+    }
+    if (RMS) {
+        ssq = wave_sum(ssq);
+        if (lane == 0) s_red[wave] = ssq;
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    for (int c = lane; c < nw16; c += 64 * U) {
+        if (c != lane) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c + 64 * u < nw16) w[u] = __builtin_nontemporal_load(wp + c + 64 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cc = c + 64 * u;
+            if (cc < nw16) acc = dot16_fp8(w[u], xf[2 * cc], xf[nchunk + 2 * cc], xf[2 * cc + 1], xf[nchunk + 2 * cc + 1], acc);
+        }
+    }
+    acc = wave_sum(acc) * (*g.scale_w);
+    if (RMS) {
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kG1Waves; ++i) q += s_red[i];
+        acc *= rsqrtf(q / (float)g.K + g.rms_eps);
+    }
+    float v = acc + ((g.bias && live) ? bf16_to_f32(g.bias[row]) : 0.0f);
+    if (g.act == ACT_SWIGLU) {
+        if (lane == 0) s_val[wave] = v;
+        __syncthreads();
+        if (lane != 0 || (wave & 1) || !live) return;
+        const float o = (v / (1.0f + __expf(-v))) * s_val[wave + 1];
+        const int64_t idx = row >> 1;
+        if (g.out_f32) static_cast<float*>(g.C)[idx] = o;
+        else static_cast<bf16_t*>(g.C)[idx] = f32_to_bf16(o);
+        return;
+    }
+    if (lane != 0 || !live) return;
+    v = act_apply(v, g.act);
+    if (g.residual) v += gemm_residual_f32_or_bf16(g, row);
+    if (g.out_f32) static_cast<float*>(g.C)[row] = v;
+    else static_cast<bf16_t*>(g.C)[row] = f32_to_bf16(v);
+}
+
 int g_gemv1_ksplit = 0;  // 0 = rule below (A/B hook: ivlm_gemv1_tuning)
 
 template <bool RMS, int KS>
@@ -511,6 +611,30 @@ int gemv_bf16(const GemmArgs& g, hipStream_t st) {
     }
 }
 
+// M = 1, fp32 x, e4m3 weight bytes [N, K] (row stride ldw BYTES), per-tensor scale in device memory
+int gemv1_fp8w(const GemmArgs& g, hipStream_t st) {
+    if (!g.A || !g.W || !g.C || !g.scale_w || g.M != 1 || !g.a_f32 || g.N <= 0 || g.K <= 0) return IVLM_ERR_INVALID_ARG;
+    if ((g.K & 15) || (g.ldw & 15) || (size_t)g.K * 4 > 60 * 1024) return IVLM_ERR_UNSUPPORTED;
+    if (g.act == ACT_SWIGLU && ((g.N & 1) || g.residual)) return IVLM_ERR_UNSUPPORTED;
+    static bool set0 = false, set1 = false;
+    if (g.rms_w) {
+        auto kfn = gemv1_fp8w_kernel<true>;
+        if (!set1) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            set1 = true;
+        }
+        ivlm_launch(kfn, dim3((g.N + kG1Waves - 1) / kG1Waves), dim3(64 * kG1Waves), (size_t)g.K * 4, st, g);
+    } else {
+        auto kfn = gemv1_fp8w_kernel<false>;
+        if (!set0) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            set0 = true;
+        }
+        ivlm_launch(kfn, dim3((g.N + kG1Waves - 1) / kG1Waves), dim3(64 * kG1Waves), (size_t)g.K * 4, st, g);
+    }
+    return ivlm_launch_status();
+}
+
 int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st) {
     if (!x || !out || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
     argmax_kernel<<<rows, 1024, 0, st>>>(x, cols, out);
@@ -527,6 +651,29 @@ extern "C" int ivlm_gemv_tuning(int max_blocks_per_cu, int rows2_min_n) {  // be
 }
 
 extern "C" void ivlm_gemv1_tuning(int ksplit) { ivlm::g_gemv1_ksplit = ksplit; }
+
+extern "C" int ivlm_gemv_fp8w(const float* x, const void* Wq, int64_t ldw, const float* scale_w, void* C, const void* bias,
+                              const void* residual, int N, int K, int act, int out_f32, const void* rms_w, float rms_eps, int flags,
+                              ivlm_stream_t stream) {
+    ivlm_enter();
+    ivlm::GemmArgs g;
+    g.A = reinterpret_cast<const bf16_t*>(x);
+    g.a_f32 = 1;
+    g.W = static_cast<const bf16_t*>(Wq);
+    g.ldw = ldw;
+    g.scale_w = scale_w;
+    g.C = C;
+    g.bias = static_cast<const bf16_t*>(bias);
+    g.residual = static_cast<const bf16_t*>(residual);
+    g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
+    g.M = 1; g.N = N; g.K = K;
+    g.lda = K;
+    g.act = act;
+    g.out_f32 = out_f32;
+    g.rms_w = static_cast<const bf16_t*>(rms_w);
+    g.rms_eps = rms_eps;
+    return ivlm::gemv1_fp8w(g, ivlm_stream(stream));
+}
 
 extern "C" int ivlm_argmax_f32(const float* x, int rows, int cols, int32_t* out, ivlm_stream_t stream) {
     ivlm_enter();

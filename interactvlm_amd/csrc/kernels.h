@@ -74,7 +74,8 @@ int linear_bf16(const GemmArgs& g, hipStream_t st);
 int layernorm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols, float eps,
               hipStream_t st, int gelu = 0, const int32_t* out_rows = nullptr, const float* fp8_scale = nullptr);
 // y = x * rsqrt(mean(x^2)+eps) * w  (LLaMA RMSNorm; fp32 statistics; a bf16 input is cast back before the weight multiply as HF does)
-int rmsnorm(const void* x, int x_f32, const bf16_t* w, void* y, int y_f32, int64_t rows, int cols, float eps, hipStream_t st);
+int rmsnorm(const void* x, int x_f32, const bf16_t* w, void* y, int y_f32, int64_t rows, int cols, float eps, hipStream_t st,
+            const float* fp8_scale = nullptr);
 
 // ---- attention ---------------------------------------------------------------------------------
 struct AttnArgs {
@@ -165,6 +166,8 @@ int gemm_splitk_choice(int M, int N, int K, int act, int has_rms);
 
 // ---- skinny GEMM (gemv.hip): M <= 8 rows of activations against streamed weights -------------------
 int gemv_bf16(const GemmArgs& g, hipStream_t st);
+// batch-1 GEMV with e4m3 weight bytes (per-tensor scale g.scale_w), fp32 x (gemv.hip)
+int gemv1_fp8w(const GemmArgs& g, hipStream_t st);
 // skinny GEMM on MFMA (gemv_mfma.hip): M <= 16 activation rows, split-K inside the block, RMSNorm prologue optional
 int gemv_mfma_bf16(const GemmArgs& g, hipStream_t st);
 int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st);

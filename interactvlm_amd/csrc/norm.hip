@@ -151,11 +151,13 @@ int layernorm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* 
     return ivlm_launch_status();
 }
 
-int rmsnorm(const void* x, int x_f32, const bf16_t* w, void* y, int y_f32, int64_t rows, int cols, float eps, hipStream_t st) {
+int rmsnorm(const void* x, int x_f32, const bf16_t* w, void* y, int y_f32, int64_t rows, int cols, float eps, hipStream_t st,
+            const float* fp8_scale) {
     if (!x || !w || !y || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
     if ((cols & 7) || cols > kMaxChunks * 512) return IVLM_ERR_UNSUPPORTED;
-    if (cols <= 4 * 512) launch_norm<true, 4, false>(x, x_f32, w, nullptr, y, y_f32, rows, cols, eps, st);
-    else launch_norm<true, kMaxChunks, false>(x, x_f32, w, nullptr, y, y_f32, rows, cols, eps, st);
+    if (fp8_scale && y_f32) return IVLM_ERR_INVALID_ARG;  // (fp8_scale: y is e4m3 bytes of the normalised row / *fp8_scale)
+    if (cols <= 4 * 512) launch_norm<true, 4, false>(x, x_f32, w, nullptr, y, y_f32, rows, cols, eps, st, nullptr, fp8_scale);
+    else launch_norm<true, kMaxChunks, false>(x, x_f32, w, nullptr, y, y_f32, rows, cols, eps, st, nullptr, fp8_scale);
     return ivlm_launch_status();
 }
 
@@ -171,6 +173,13 @@ int ivlm_layernorm(const void* x, int x_dtype, const void* w, const void* b, voi
     return ivlm::layernorm(x, x_dtype == IVLM_F32, static_cast<const bf16_t*>(w), static_cast<const bf16_t*>(b), y,
                            y_dtype == IVLM_F32 ? 1 : (y_dtype == IVLM_BF16_SPLIT ? 2 : 0), rows, cols, eps, ivlm_stream(stream), gelu,
                            out_rows, fp8_scale);
+}
+
+int ivlm_rmsnorm_fp8(const void* x, int x_dtype, const void* w, void* y, int64_t rows, int cols, float eps, const float* fp8_scale,
+                     ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!fp8_scale) return IVLM_ERR_INVALID_ARG;
+    return ivlm::rmsnorm(x, x_dtype == IVLM_F32, static_cast<const bf16_t*>(w), y, 0, rows, cols, eps, ivlm_stream(stream), fp8_scale);
 }
 
 int ivlm_rmsnorm(const void* x, int x_dtype, const void* w, void* y, int y_dtype, int64_t rows, int cols, float eps,

@@ -57,7 +57,7 @@ class ClipTower:
         if not (self.use_graph and images.is_cuda) or torch.cuda.is_current_stream_capturing() or ops.TIMER.enabled:
             return self._forward(images)
         B = images.shape[0]
-        gkey = (B, self.precision)
+        gkey = (B, self.precision, self.fp8)
         ent = self._graphs.get(gkey)
         if ent is None:
             static_in = images.to(BF16).contiguous().clone()
@@ -77,6 +77,27 @@ class ClipTower:
 
     precision = "default"  # "parity": fp32-activation arithmetic (hi + lo bf16 operands), see SamImageEncoder.precision
 
+    # ---- fp8 (OCP e4m3) operands for the four GEMMs of every layer (BASELINE.json configs[4]; opt-in): per-tensor scales, the
+    # weights quantised once, the activation ranges calibrated on one bf16 pass over calibration images and then fixed.
+    fp8 = False
+    _calibrating = False
+
+    def enable_fp8(self, calib_images):
+        dev = self.device
+        for L in self.layers:
+            for n, w_ in (("qkv", L["qkv_w"]), ("out", L["out"].w), ("fc1", L["fc1"].w), ("fc2", L["fc2"].w)):
+                L[n + "_q"], L[n + "_s"] = ops.quantize_fp8(w_)
+            L["amax"] = {k: torch.zeros(1, dtype=F32, device=dev) for k in ("y1", "a", "y2", "h")}
+        self._calibrating = True
+        try:
+            self._forward(calib_images.to(dev))
+        finally:
+            self._calibrating = False
+        for L in self.layers:
+            L["s"] = {k: (v / 448.0).clamp_(min=1e-12) for k, v in L["amax"].items()}
+        self.fp8 = True
+        self._graphs.clear()
+
     def _forward(self, images):
         """-> penultimate-layer patch features, bf16 [B, T-1, hidden] (the mm_projector's MFMA operand; "parity" precision:
         [B, T-1, 2*hidden] = [hi | lo] rows).  The residual stream is fp32 between the GEMMs (residual epilogues write fp32,
@@ -92,6 +113,17 @@ class ClipTower:
             ops.gather_rows(self.cls_row, out=x[b, 0:1])  # class_embedding + position_embedding[0] (precomputed constant)
         x = self.pre_ln(x.view(B * T, c.hidden), out_f32=True)
         for L in self.layers:
+            if self.fp8:  # e4m3 operands for qkv / out / fc1 / fc2 (attention stays bf16, the residual stream fp32)
+                sc = L["s"]
+                qkv = ops.linear_fp8(L["ln1"](x, fp8_scale=sc["y1"]), L["qkv_q"], sc["y1"], L["qkv_s"], L["qkv_b"]).view(B, T, 3, Hh, hd)
+                q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+                a = ops.attention(q, k, v, hd ** -0.5, prescale_q=True).permute(0, 2, 1, 3).reshape(B * T, c.hidden)
+                aq = ops.gather_rows(a, out_kind="fp8", scale=sc["a"])
+                x = ops.linear_fp8(aq, L["out_q"], sc["a"], L["out_s"], L["out"].b, residual=x, out_kind="f32")
+                h8 = ops.linear_fp8(L["ln2"](x, fp8_scale=sc["y2"]), L["fc1_q"], sc["y2"], L["fc1_s"], L["fc1"].b, act="quick_gelu",
+                                    out_kind="fp8", scale_out=sc["h"])
+                x = ops.linear_fp8(h8, L["fc2_q"], sc["h"], L["fc2_s"], L["fc2"].b, residual=x, out_kind="f32")
+                continue
             if par:  # every MFMA operand as hi + lo halves; q * scale, softmax in fp32
                 qkv = ops.linear(L["ln1"](x, out_split=True), L["qkv_w"], L["qkv_b"], a_split=True, out_split=True)
                 q6 = qkv.view(B, T, 2, 3, Hh, hd)
@@ -102,12 +134,18 @@ class ClipTower:
                 h = L["fc1"](L["ln2"](x, out_split=True), act="quick_gelu", a_split=True, out_split=True)
                 x = L["fc2"](h, residual=x, out_f32=True, a_split=True)
                 continue
+            cal = L.get("amax") if self._calibrating else None
             y = L["ln1"](x)
             qkv = ops.linear(y, L["qkv_w"], L["qkv_b"]).view(B, T, 3, Hh, hd)
             q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-            a = ops.attention(q, k, v, hd ** -0.5, prescale_q=True)
-            x = L["out"](a.permute(0, 2, 1, 3).reshape(B * T, c.hidden), residual=x, out_f32=True)
-            x = L["fc2"](L["fc1"](L["ln2"](x), act="quick_gelu"), residual=x, out_f32=True)
+            a = ops.attention(q, k, v, hd ** -0.5, prescale_q=True).permute(0, 2, 1, 3).reshape(B * T, c.hidden)
+            x = L["out"](a, residual=x, out_f32=True)
+            y2 = L["ln2"](x)
+            h = L["fc1"](y2, act="quick_gelu")
+            if cal:
+                for k_, t_ in (("y1", y), ("a", a), ("y2", y2), ("h", h)):
+                    ops.amax(t_, cal[k_])
+            x = L["fc2"](h, residual=x, out_f32=True)
         if B not in self._patch_rows:  # drop the CLS row of every image
             r = torch.arange(B * T, dtype=torch.int32).view(B, T)[:, 1:].reshape(-1)
             self._patch_rows[B] = r.to(images.device)
@@ -166,6 +204,38 @@ class Llama:
         if mode == "parity" and self.kcache_lo is None:
             self.kcache_lo, self.vcache_lo = torch.zeros_like(self.kcache), torch.zeros_like(self.vcache)
 
+    # ---- fp8 (OCP e4m3; BASELINE.json configs[4], opt-in) -------------------------------------------------------------------
+    # Prefill: e4m3 operands for the four GEMMs of a layer on the MX matrix instruction (per-tensor scales: weights quantised
+    # once, activation ranges calibrated on one bf16 pass over a calibration prompt, then fixed; RMSNorm / SwiGLU epilogue write
+    # e4m3 directly).  Decode (batch 1): e4m3 WEIGHTS, fp32 activations - the step is HBM-bound on the weight bytes, so this
+    # halves its traffic (the products are exact; the only error is the weight quantisation).  lm_head, attention and the KV
+    # cache stay bf16; the batched decode (evaluate_batch) keeps bf16 weights.
+    fp8 = False
+    _calibrating = False
+
+    def enable_fp8(self, calib_x):
+        """calib_x fp32 [T, hidden]: input embeddings of a calibration prompt (with its image features spliced in)."""
+        dev = self.device
+        for L in self.layers:
+            for n in ("qkv", "o", "gu", "down"):
+                L[n + "_q"], L[n + "_s"] = ops.quantize_fp8(L[n])
+            L["amax"] = {k: torch.zeros(1, dtype=F32, device=dev) for k in ("y1", "a", "y2", "h")}
+        self._calibrating = True
+        try:
+            self.forward(calib_x, 0)
+        finally:
+            self._calibrating = False
+        for L in self.layers:
+            L["s"] = {k: (v / 448.0).clamp_(min=1e-12) for k, v in L["amax"].items()}
+        self.fp8 = True
+        self._dgraph = None
+        self._dgraphs = {}
+
+    def disable_fp8(self):
+        self.fp8 = False
+        self._dgraph = None
+        self._dgraphs = {}
+
     def _lo(self, li):
         return (self.kcache_lo[li], self.vcache_lo[li]) if self.precision == "parity" else None
 
@@ -212,16 +282,33 @@ class Llama:
             for li, L in enumerate(self.layers):
                 x = self._layer_parity(L, x, T, pos0, kc[li], vc[li], kcl[li], vcl[li])
             return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
+        fp8 = self.fp8 and T > 16 and not self._calibrating
         for li, L in enumerate(self.layers):
-            y = ops.rmsnorm(x, L["ln1"], c.eps)
-            qkv = ops.linear(y, L["qkv"])  # [T, 3*hidden] == [T, 3, H, hd]
+            cal = L.get("amax") if self._calibrating else None
+            sc = L["s"] if fp8 else None
+            if fp8:
+                qkv = ops.linear_fp8(ops.rmsnorm(x, L["ln1"], c.eps, fp8_scale=sc["y1"]), L["qkv_q"], sc["y1"], L["qkv_s"])
+            else:
+                y = ops.rmsnorm(x, L["ln1"], c.eps)
+                qkv = ops.linear(y, L["qkv"])  # [T, 3*hidden] == [T, 3, H, hd]
             ops.rope_kv(qkv, H, hd, pos0, c.theta, kc[li], vc[li], table=self.rope)
             q = qkv.view(T, 3, H, hd)[:, 0].permute(1, 0, 2).unsqueeze(0)  # [1,H,T,hd]
             k = kc[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
             v = vc[li, : pos0 + T].permute(1, 0, 2).unsqueeze(0)
-            a = ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=pos0)
-            x = ops.linear(a.permute(0, 2, 1, 3).reshape(T, c.hidden), L["o"], residual=x, out_f32=True)
-            h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps), L["gu"], act="swiglu")
+            a = ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=pos0).permute(0, 2, 1, 3).reshape(T, c.hidden)
+            if fp8:
+                x = ops.linear_fp8(ops.gather_rows(a, out_kind="fp8", scale=sc["a"]), L["o_q"], sc["a"], L["o_s"], residual=x,
+                                   out_kind="f32")
+                h8 = ops.linear_fp8(ops.rmsnorm(x, L["ln2"], c.eps, fp8_scale=sc["y2"]), L["gu_q"], sc["y2"], L["gu_s"],
+                                    act="swiglu", out_kind="fp8", scale_out=sc["h"])
+                x = ops.linear_fp8(h8, L["down_q"], sc["h"], L["down_s"], residual=x, out_kind="f32")
+                continue
+            x = ops.linear(a, L["o"], residual=x, out_f32=True)
+            y2 = ops.rmsnorm(x, L["ln2"], c.eps)
+            h = ops.linear(y2, L["gu"], act="swiglu")
+            if cal:
+                for k_, t_ in (("y1", y), ("a", a), ("y2", y2), ("h", h)):
+                    ops.amax(t_, cal[k_])
             x = ops.linear(h, L["down"], residual=x, out_f32=True)
         return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
 
@@ -394,6 +481,14 @@ class Llama:
         c = self.cfg
         H, hd = c.heads, c.hidden // c.heads
         fz = self._fused if isinstance(pos, torch.Tensor) else None
+        if self.fp8:  # e4m3 weights, fp32 activations: half the bytes per token
+            for li, L in enumerate(self.layers):
+                qkv = ops.linear_fp8w(x, L["qkv_q"], L["qkv_s"], rms=(L["ln1"], c.eps))
+                a = ops.llama_decode_attn(qkv, self.kcache[li], self.vcache[li], H, hd, pos, c.theta, hd ** -0.5, table=self.rope)
+                x = ops.linear_fp8w(a, L["o_q"], L["o_s"], residual=x)
+                h = ops.linear_fp8w(x, L["gu_q"], L["gu_s"], act="swiglu", rms=(L["ln2"], c.eps))
+                x = ops.linear_fp8w(h, L["down_q"], L["down_s"], residual=x)
+            return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
         for li, L in enumerate(self.layers):
             qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps), out_f32=True)
             if fz is not None and self.precision != "parity":  # attention + o_proj + residual in one launch (W_o streams while the attention runs)

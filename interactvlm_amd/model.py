@@ -153,6 +153,27 @@ class InteractVLMForCausalLM:
         self.llm.set_precision(lang)
         self.model.visual_model.image_encoder.precision = "default" if mode == "default" else "parity"
 
+    # fp8 variant (BASELINE.json configs[4], opt-in; never a parity claim): e4m3 operands for the GEMMs of the SAM ViT-H encoder,
+    # the CLIP tower and the LLaMA prefill, e4m3 WEIGHTS for the batch-1 decode linears.  Activation scales are calibrated on the
+    # inputs given HERE and then fixed: evaluate other images afterwards.
+    def enable_fp8(self, images_clip, images, input_ids):
+        """images_clip [1,3,h,w], images [1,V,3,S,S], input_ids [1,L] (prompt, ideally with a typical answer appended)."""
+        self.set_precision("default")
+        dev = self.device
+        self.model.visual_model.image_encoder.enable_fp8(images[0].to(dev))
+        self.vision_tower.enable_fp8(images_clip.to(dev))
+        feats = self.encode_images(images_clip)[0]
+        self.llm.enable_fp8(self._input_embeds(input_ids[0].to(dev), feats))
+        self.fp8 = True
+
+    def disable_fp8(self):
+        self.model.visual_model.image_encoder.fp8 = False
+        self.vision_tower.fp8 = False
+        self.llm.disable_fp8()
+        self.fp8 = False
+
+    fp8 = False
+
     def get_visual_embs(self, pixel_values):
         """[B,V,3,S,S] -> image embeddings; returned in the reference's [B,V,256,g,g] shape (a strided view of the
         channels-last buffer the decoder consumes) — InteractVLM.py:251-261."""

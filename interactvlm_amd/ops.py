@@ -419,12 +419,13 @@ def linear_fp8(xq, wq, scale_a, scale_w, bias=None, act="none", residual=None, o
     assert xq.dtype == U8 and wq.dtype == U8 and wq.shape[1] == K
     x2 = xq.reshape(-1, K)
     M = x2.shape[0] if a_rows is None else a_rows.numel()
+    n_out = N // 2 if act == "swiglu" else N
     if out is None:
         dt = {"bf16": BF16, "f32": F32, "fp8": U8}[out_kind]
-        out = torch.empty((M, N), dtype=dt, device=xq.device)
+        out = torch.empty((M, n_out), dtype=dt, device=xq.device)
     else:
         out_kind = {BF16: "bf16", F32: "f32", U8: "fp8"}[out.dtype]
-    o2 = out.reshape(-1, N)
+    o2 = out.reshape(-1, n_out)
     r2, ldr, flags = None, 0, 0
     if residual is not None:
         r2 = residual.reshape(-1, N)
@@ -443,10 +444,39 @@ def linear_fp8(xq, wq, scale_a, scale_w, bias=None, act="none", residual=None, o
     return out
 
 
-def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False):
+def linear_fp8w(x, wq, scale_w, bias=None, act="none", residual=None, out_f32=True, rms=None):
+    """Batch-1 decode linear with e4m3 weights: act((x . wq^T) * scale_w + bias) + residual; x fp32 [1, K] (exact products),
+    wq uint8 [N, K], scale_w device fp32 [1]; rms = (weight, eps) fuses the preceding RMSNorm."""
+    lib = _lib.load()
+    x = _req(x, F32, "x")
+    N, K = wq.shape
+    assert x.numel() == K and wq.dtype == U8 and wq.stride(1) == 1
+    n_out = N // 2 if act == "swiglu" else N
+    out = torch.empty(1, n_out, dtype=F32 if out_f32 else BF16, device=x.device)
+    flags = 0
+    if residual is not None:
+        assert residual.is_contiguous() and residual.numel() == N
+        if residual.dtype == F32:
+            flags |= GEMM_RES_F32
+    call = lambda: check(lib.ivlm_gemv_fp8w(x.data_ptr(), wq.data_ptr(), wq.stride(0), scale_w.data_ptr(), out.data_ptr(), _p(bias),
+                                            _p(residual), N, K, ACT[act], 1 if out_f32 else 0, _p(rms[0]) if rms else 0,
+                                            float(rms[1]) if rms else 0.0, flags, _stream()), "gemv_fp8w")
+    if TIMER.enabled:
+        TIMER.time("gemv_fp8w", 1.0 * N * K, call, tag=(1, N, K, act))  # work = weight BYTES
+    else:
+        call()
+    return out
+
+
+def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False, fp8_scale=None):
     lib = _lib.load()
     x = _req(x, None, "x")
     cols = x.shape[-1]
+    if fp8_scale is not None:  # e4m3 bytes of the normalised row / scale: the operand of linear_fp8
+        y = torch.empty(x.shape, dtype=U8, device=x.device)
+        check(lib.ivlm_rmsnorm_fp8(x.data_ptr(), _dtc(x), weight.data_ptr(), y.data_ptr(), x.numel() // cols, cols, float(eps),
+                                   fp8_scale.data_ptr(), _stream()), "rmsnorm_fp8")
+        return y
     if out_split:
         y = torch.empty(x.shape[:-1] + (2 * cols,), dtype=BF16, device=x.device)
     else:

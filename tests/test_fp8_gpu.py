@@ -99,3 +99,107 @@ def test_sam_encoder_fp8_vs_bf16_path(hip_lib, cuda):
     print(f"\n[SAM encoder fp8 vs bf16, 4 blocks at ViT-H width] rel rms {rel:.4f}, max abs {float((got - ref).abs().max()):.3f}")
     # e4m3 carries 3 mantissa bits: ~4 % rms per GEMM on these random-weight blocks, accumulating over the depth
     assert rel < 0.3
+
+
+@pytest.mark.parametrize("N,K,act,rms", [(12288, 4096, "none", True), (4096, 4096, "none", False), (22016, 4096, "swiglu", True),
+                                         (4096, 11008, "none", False), (1000, 512, "relu", False)])
+def test_gemv_fp8_weights_vs_torch(hip_lib, cuda, N, K, act, rms):
+    """Batch-1 decode linear with e4m3 weights: exact products q x x in fp32 against the dequantised matrix in fp64 (fused RMSNorm
+    prologue, SwiGLU over interleaved rows, fp32 residual)."""
+    import torch
+    import torch.nn.functional as F
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(N + K)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(cuda)
+    wq, sw = ops.quantize_fp8(w)
+    x = torch.randn(1, K, generator=g).to(cuda)
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).to(cuda)
+    res = torch.randn(1, N, generator=g).to(cuda) if act != "swiglu" else None
+    got = ops.linear_fp8w(x, wq, sw, act=act, residual=res, rms=(gam, 1e-5) if rms else None)
+    wd = _deq(wq).double() * float(sw)
+    xd = x.cpu().double()
+    if rms:
+        xd = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5) * gam.cpu().double()
+    y = xd @ wd.T
+    if act == "swiglu":
+        y = F.silu(y[:, 0::2]) * y[:, 1::2]
+    elif act == "relu":
+        y = torch.relu(y)
+    if res is not None:
+        y = y + res.cpu().double()
+    assert got.shape == y.shape
+    assert float((got.cpu().double() - y).abs().max()) < 2e-5 * max(1.0, float(y.abs().max()))
+
+
+def test_rmsnorm_fp8_output_and_swiglu_fp8_gemm(hip_lib, cuda):
+    """RMSNorm with an e4m3 output == quantising its fp32 output; the fp8 GEMM's SwiGLU epilogue with an e4m3 output == torch on
+    the same quantised operands (the LLaMA prefill's gate|up -> down hand-over)."""
+    import torch
+    import torch.nn.functional as F
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(330, 4096, generator=g) * 2).to(cuda)
+    gam = (1 + 0.1 * torch.randn(4096, generator=g)).to(torch.bfloat16).to(cuda)
+    y = ops.rmsnorm(x, gam, 1e-5, out_f32=True)
+    sc = ops.amax(y) / 448.0
+    yq = ops.rmsnorm(x, gam, 1e-5, fp8_scale=sc)
+    assert yq.dtype == torch.uint8 and torch.equal(yq, ops.quantize_fp8(y, sc)[0])
+    I = 2752
+    w = (torch.randn(2 * I, 4096, generator=g) / 64).to(torch.bfloat16).to(cuda)
+    wq, sw = ops.quantize_fp8(w)
+    ref = (_deq(yq).double() * float(sc)) @ (_deq(wq).double() * float(sw)).T
+    ref = F.silu(ref[:, 0::2]) * ref[:, 1::2]
+    got = ops.linear_fp8(yq, wq, sc, sw, act="swiglu", out_kind="f32")
+    assert got.shape == (330, I) and float((got.cpu().double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+    so = ops.amax(got) / 448.0
+    g8 = ops.linear_fp8(yq, wq, sc, sw, act="swiglu", out_kind="fp8", scale_out=so)
+    assert g8.dtype == torch.uint8 and g8.shape == (330, I)
+    # e4m3 rounding of the fp32 result (a value on a rounding boundary may fall either way with the fp32 summation order)
+    d = (_deq(g8) * float(so) - got.cpu()).abs() / (got.cpu().abs() + float(so))
+    assert float(d.max()) < 0.13 and float(d.mean()) < 0.03
+
+
+def test_language_path_fp8_vs_bf16(hip_lib, cuda):
+    """CLIP tower and LLaMA (prefill GEMMs with e4m3 operands, decode GEMVs with e4m3 weights) in the fp8 variant against their
+    bf16 path on a small configuration: calibrated on one input, evaluated on ANOTHER.  Three mantissa bits: a few percent."""
+    import torch
+
+    from interactvlm_amd import llava
+    from interactvlm_amd import weights as Wt
+
+    torch.set_grad_enabled(False)
+    rel = lambda a, b: float((a.float() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt())
+    g = torch.Generator().manual_seed(11)
+    cc = Wt.ClipCfg(hidden=256, layers=4, heads=4, inter=512)
+    w = {k: v.to(torch.bfloat16).float() for k, v in Wt.synth_weights(Wt.clip_spec(cc)).items()}
+    tower = llava.ClipTower(w, cc, cuda)
+    xa, xb = (torch.randn(1, 3, 224, 224, generator=g).to(torch.bfloat16).to(cuda) for _ in range(2))
+    ref = tower(xb).float()
+    tower.enable_fp8(xa)
+    got = tower(xb).float()
+    e = rel(got, ref)
+    print(f"\n[CLIP fp8 vs bf16, calibrated on another image] rel rms {e:.3f}")
+    assert got.shape == ref.shape and 0 < e < 0.15
+
+    lc = Wt.LlamaCfg(hidden=512, layers=3, heads=4, inter=1024, vocab=1000)
+    w = {k: v.to(torch.bfloat16).float() for k, v in Wt.synth_weights(Wt.llama_spec(lc)).items()}
+    llm = llava.Llama(w, lc, cuda, max_len=256)
+    ea, eb = ((torch.randn(90, 512, generator=g) * 0.5).to(cuda) for _ in range(2))
+
+    def run():
+        h = [llm.forward(eb[:70], 0)]
+        for t in range(70, 90):
+            h.append(llm.forward(eb[t: t + 1], t))
+        return torch.cat(h, 0)
+    ref = run()
+    llm.enable_fp8(ea)
+    got = run()
+    e_pre, e_dec = rel(got[:70], ref[:70]), rel(got[70:], ref[70:])
+    print(f"[LLaMA fp8 vs bf16] rel rms: prefill rows {e_pre:.3f}, decode rows {e_dec:.3f}")
+    assert 0 < e_pre < 0.15 and 0 < e_dec < 0.15
+    llm.disable_fp8()
+    assert torch.equal(run(), ref)
