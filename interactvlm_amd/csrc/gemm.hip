@@ -29,19 +29,23 @@ constexpr int BK = 64;
 //   <2,2,4,4>: 128x128 block, 256 threads, 64 KiB LDS, 2 blocks/CU  (small / skinny problems)
 //   <2,4,8,4>: 256x256 block, 512 threads, 128 KiB LDS, 1 block/CU  (per-wave 128x64: 32 MFMAs per 12 fragment
 //              reads instead of 16 per 8, and half the global->LDS bytes per FLOP)
-template <int WM_, int WN_, int MI_, int NI_>
+template <int WM_, int WN_, int MI_, int NI_, int MINB_ = 2>
 struct TileCfg {
     static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_;
+    static constexpr int kMinBlocks = MINB_;  // launch bound: resident blocks per CU the register budget is sized for
     static constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
     static constexpr int kWaves = WM * WN, kThreads = kWaves * 64;
     static constexpr int kTileBytesA = BM * BK * 2, kTileBytesW = BN * BK * 2;
     static constexpr int kStageBytes = kTileBytesA + kTileBytesW;
     static constexpr int kLdsBytes = 2 * kStageBytes;
-    static constexpr int PA = BM / 8 / kWaves, PW = BN / 8 / kWaves;  // 1-KiB DMA pieces per wave per tile
+    // 1-KiB DMA pieces (8 rows) per wave per tile; a tile whose piece count is not a multiple of the wave count (176 rows = 22
+    // pieces over 4 waves) gives its last waves one piece less (guarded where the pieces are addressed and issued)
+    static constexpr int PA = (BM / 8 + kWaves - 1) / kWaves, PW = (BN / 8 + kWaves - 1) / kWaves;
+    static_assert(BM % 8 == 0 && BN % 8 == 0, "whole 8-row pieces");
 };
 
 template <int ACT, bool OUT_F32, typename CFG, bool FP8 = false>
-__global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
+__global__ __launch_bounds__(CFG::kThreads, CFG::kMinBlocks) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NI = CFG::NI, PA = CFG::PA, PW = CFG::PW;
     constexpr int kTileBytesA = CFG::kTileBytesA, kStageBytes = CFG::kStageBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
     const int64_t w_rs = g.w_kstep ? 64 : g.ldw, w_ks = g.w_kstep ? g.w_kstep : BK;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int row = (wave * PA + i) * 8 + (lane >> 3);
+        const int row = (wave * PA + i) * 8 + (lane >> 3);  // (rows past BM belong to no piece: never issued, see stage())
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source chunk that lands in LDS chunk lane&7
         kcolA[i] = chunk * 8;
         int ra = m0 + row;
@@ -92,9 +96,13 @@ __global__ __launch_bounds__(CFG::kThreads, 2) void gemm_bf16_kernel(GemmArgs g)
         const int koff = kw * BK;
         const bf16_t* zero = reinterpret_cast<const bf16_t*>(kGemmZeroChunk);
 #pragma unroll
-        for (int i = 0; i < PA; ++i) glds16(kcolA[i] + koff < g.K ? srcA[i] + kw * a_ks + alo : zero, baseA + i * 1024);
+        for (int i = 0; i < PA; ++i)
+            if ((BM / 8) % CFG::kWaves == 0 || (wave * PA + i) * 8 < BM)
+                glds16(kcolA[i] + koff < g.K ? srcA[i] + kw * a_ks + alo : zero, baseA + i * 1024);
 #pragma unroll
-        for (int i = 0; i < PW; ++i) glds16(kcolW[i] + koff < g.K ? srcW[i] + kw * w_ks : zero, baseW + i * 1024);
+        for (int i = 0; i < PW; ++i)
+            if ((BN / 8) % CFG::kWaves == 0 || (wave * PW + i) * 8 < BN)
+                glds16(kcolW[i] + koff < g.K ? srcW[i] + kw * w_ks : zero, baseW + i * 1024);
     };
 
     // ---- fragment read offsets (bytes within a tile), constant over the K loop ---------------
@@ -205,6 +213,14 @@ int launch_cfg(const GemmArgs& g, hipStream_t st) {
 }
 
 using Cfg128x64 = TileCfg<2, 2, 4, 2>;  // 128 x 64 block: more tiles for skinny problems (LLM prefill o/down)
+// Row-stationary tile for the LLaMA prefill (M = 330 = two row tiles of 176): a wave owns ALL rows of a 32-column strip, so each A
+// fragment read feeds 2 MFMAs and each W fragment 11 (0.59 LDS reads per MFMA against 0.75 for the 128 x 64 tile), the tile's
+// arithmetic intensity is 74 FLOP per DMA byte against 43, and 2 x 172 tiles of gate|up fit the 512 block slots in ONE round
+// (3 x 172 tiles of 128 x 128 need a second round for 4 tiles).  Cold weights (tools/bench_prefill_gemm.py): gate|up 115 -> 86 us,
+// q|k|v 73 -> 60 us (with 2 K slices); o / down (N = 4096) do not gain.
+using Cfg176x128 = TileCfg<1, 4, 11, 2>;     // 176 x 128, 2 blocks per CU (78 KB of LDS each)
+// (352 x 128 - all 330 rows in one block, one wave per SIMD with its accumulators in AGPRs - was built and measured: 134 us for
+//  q|k|v and 136 us for gate|up against 60 / 86 us for 176 x 128: a single wave per SIMD cannot hide its own LDS latency.)
 using Cfg128x96 = TileCfg<2, 2, 4, 3>;  // 128 x 96 block: M ~ 330 prefill against wide N (3 tile rows: see choose_tile)
 
 // Pick the block tile from the tile counts (measured with tools/bench_gemm.py):
@@ -213,7 +229,8 @@ using Cfg128x96 = TileCfg<2, 2, 4, 3>;  // 128 x 96 block: M ~ 330 prefill again
 //   * 256^2 (+10 % on SAM qkv / mlp1) when it fills whole waves of the 256 CUs (quantisation efficiency >= 0.85);
 //   * 128^2 otherwise.
 inline int choose_tile(const GemmArgs& g) {
-    if (g.tile == 128 || g.tile == 256 || g.tile == 64 || g.tile == 96 || g.tile == 512) return g.tile;
+    if (g.tile == 128 || g.tile == 256 || g.tile == 64 || g.tile == 96 || g.tile == 512 || g.tile == 176) return g.tile;
+    if (g.M > 128 && g.M <= 352 && g.N >= 8192 && g.batch <= 2 && (g.act == ACT_NONE || g.act == ACT_SWIGLU)) return 176;  // LLaMA prefill, wide N
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
     // (128x96 tiles for the LLaMA prefill's wide projections, M ~ 330 = 3 tile rows: faster in the warm micro-benchmark -
     //  qkv 58.6 -> 54.6 us, gate|up 105.5 -> 93.2 us - but SLOWER in the pipeline, where the 100-180 MB of weights come cold
@@ -240,6 +257,11 @@ int launch(const GemmArgs& g, hipStream_t st) {
         case 256: return g.out_f32 ? launch_cfg<ACT, true, Cfg256>(g, st) : launch_cfg<ACT, false, Cfg256>(g, st);
         case 64: return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64>(g, st) : launch_cfg<ACT, false, Cfg128x64>(g, st);
         case 96: return g.out_f32 ? launch_cfg<ACT, true, Cfg128x96>(g, st) : launch_cfg<ACT, false, Cfg128x96>(g, st);
+        case 176:  // (instantiated for the epilogues the prefill uses only: keeps the build small)
+            if constexpr (ACT == ACT_NONE || ACT == ACT_SWIGLU)
+                return g.out_f32 ? launch_cfg<ACT, true, Cfg176x128>(g, st) : launch_cfg<ACT, false, Cfg176x128>(g, st);
+            else
+                return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64>(g, st) : launch_cfg<ACT, false, Cfg128x64>(g, st);
         default: return g.out_f32 ? launch_cfg<ACT, true, Cfg128>(g, st) : launch_cfg<ACT, false, Cfg128>(g, st);
     }
 }
@@ -441,7 +463,7 @@ extern "C" int ivlm_gemm_nsplit(int on) {  // benchmark hook: column split of un
 
 extern "C" int ivlm_gemm_tile_override(int tile) {
     const int prev = g_tile_override;
-    if (tile == 0 || tile == 64 || tile == 96 || tile == 128 || tile == 256 || tile == 512) g_tile_override = tile;
+    if (tile == 0 || tile == 64 || tile == 96 || tile == 128 || tile == 256 || tile == 512 || tile == 176) g_tile_override = tile;
     return prev;
 }
 

@@ -23,6 +23,10 @@ namespace ivlm {
 int gemm_splitk_choice(int M, int N, int K, int act, int has_rms) {
     if (M <= 8 || M > 1024 || act == ACT_SWIGLU || has_rms || (N & 3) || (K & 63)) return 1;
     if (M <= 16 && N >= 1024 && K >= 1024) return 1;  // the skinny MFMA kernel takes these
+    if (M > 128 && M <= 352 && N >= 8192) {  // the row-stationary 176 x 128 tiles (gemm.hip): two K slices when they leave CUs idle
+        const long t176 = (long)((M + 175) / 176) * ((N + 127) / 128);
+        return (t176 < 256 && (K / 64) % 2 == 0 && K / 2 >= 512) ? 2 : 1;
+    }
     const long tiles = (long)((M + 127) / 128) * ((N + 63) / 64);
     if (tiles >= 256) return 1;
     int best = 1;

@@ -284,6 +284,9 @@ def _splitk_choice(M, N, K, act, rms):
         return 1
     if M <= 16 and N >= 1024 and K >= 1024:
         return 1  # the skinny split-K MFMA kernel (csrc/gemv_mfma.hip) takes these
+    if 128 < M <= 352 and N >= 8192:  # the row-stationary 176 x 128 tiles (gemm.hip): two K slices when they leave CUs idle
+        t176 = ((M + 175) // 176) * ((N + 127) // 128)
+        return 2 if (t176 < 256 and (K // 64) % 2 == 0 and K // 2 >= 512) else 1
     tiles = ((M + 127) // 128) * ((N + 63) // 64)
     if tiles >= 256:
         return 1

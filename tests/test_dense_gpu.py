@@ -613,3 +613,34 @@ def test_fp32_rows_9_to_16_small_matrices(hip_lib, cuda, M, N, K):
     ref = torch.relu(x.double() @ w.double().T + b.double()) + r.double()
     got = ops.linear(x.to(cuda), w.to(cuda), b.to(cuda), act="relu", residual=r.to(cuda), out_f32=True)
     assert got.shape == (M, N) and float((got.cpu().double() - ref).abs().max()) < 3e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,act", [(330, 12288, 4096, "none"), (330, 22016, 4096, "swiglu"), (200, 8192, 1024, "none"),
+                                       (352, 8192, 512, "swiglu"), (129, 8320, 4096, "none")])
+def test_row_stationary_prefill_tile(hip_lib, cuda, M, N, K, act):
+    """The 176 x 128 row-stationary tile of the LLaMA prefill (128 < M <= 352, N >= 8192; q|k|v with two K slices): same numbers
+    as the 128 x 64 tiling and within a bf16 ulp of fp32."""
+    import torch
+    import torch.nn.functional as F
+
+    from interactvlm_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(cuda)
+    w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+    ref = x.float() @ w.float().T
+    if act == "swiglu":
+        ref = F.silu(ref[:, 0::2]) * ref[:, 1::2]
+    got = ops.linear(x, w, act=act, out_f32=True)
+    lib = _lib.load()
+    lib.ivlm_gemm_tile_override(64)
+    ops.SPLITK = False
+    try:
+        base = ops.linear(x, w, act=act, out_f32=True)
+    finally:
+        ops.SPLITK = True
+        lib.ivlm_gemm_tile_override(0)
+    assert torch.allclose(got, base, atol=3e-5, rtol=1e-5)
+    assert torch.allclose(got, ref, atol=2e-4, rtol=1e-4)
+    gb = ops.linear(x, w, act=act)
+    assert gb.dtype == torch.bfloat16 and torch.allclose(gb.float(), ref, atol=2e-2, rtol=1e-2)

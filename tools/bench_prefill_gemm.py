@@ -51,7 +51,7 @@ def main():
         line = f"{name:7s} N={N} K={K}:"
         auto = ops._splitk_choice(M, N, K, act, None)
         line += f" auto(tile 0, splits {auto}) {t(lambda: run(0, auto)):6.1f} us |"
-        for tile in (128, 256, 512):
+        for tile in (64, 128, 176, 352):
             for sp in ((1,) if act == "swiglu" else (1, 2, 4, 8)):
                 if K % (sp * 64):
                     continue
