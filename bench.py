@@ -632,9 +632,11 @@ def main():
             except ValueError:
                 pm = {}
         if pm:
-            roof["traffic"] = pm.get("gemm_bf16_kernel")
-            roof_lift["traffic"] = pm.get("lift_plan_kernel")
-            roof_gemv["traffic"] = pm.get("gemv_kernel")
+            src = "committed profile (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                  "per launch, FETCH doubled per the gfx950 note of the guide) - NOT measured in this run"
+            for r_, key in ((roof, "gemm_bf16_kernel"), (roof_lift, "lift_plan_kernel"), (roof_gemv, "gemv_kernel")):
+                r_["traffic"] = pm.get(key)
+                r_["traffic_source"] = src
 
     cpu = parity = parity_full = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -677,6 +679,15 @@ def main():
                 c_["mask_logit_range"] = round(float(ref["masks"].abs().max()), 2)
                 parity_full[mode] = c_
 
+    precision_modes = None
+    if rank == 0 and parity_full is not None:
+        # the same model / image / weights in every precision mode: throughput next to the error against the fp32 CPU oracle
+        precision_modes = {m_: {"images_per_s": parity_full[m_]["images_per_s"], "max_abs_dp_vs_fp32_oracle": parity_full[m_]["max_abs_dp"],
+                                "within_1e-3": parity_full[m_]["within_1e-3"]}
+                           for m_ in ("default", "parity-encoder", "parity") if m_ in parity_full}
+        precision_modes["note"] = ("`value` is the default (bf16-operand) mode; 'parity-encoder' (SAM ViT-H encoder with hi + lo bf16 "
+                                   "operands) is the cheapest mode that holds the north star's 1e-3 at the real depth, 'parity' carries "
+                                   "no bf16 activation rounding anywhere")
     if rank == 0:
         fl = flops_per_image(cfg, T0, len(forced), V)
         shape = ("interactvlm-3d-hcontact-damon shape: LLaVA-1.5-7B + CLIP ViT-L/14 + SAM ViT-H, 75-id prompt (330 positions) + "
@@ -697,7 +708,9 @@ def main():
             "scaling": "weak" if workload == "b1" else "strong",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "config": wl,
             "kernel_timing": "HIP events attached to each kernel launch (hipExtLaunchKernelGGL), on the launch stream",
-            "precision": "bf16 weights and MFMA operands, fp32 residual streams, fp32 activations on the decode and mask-decoder paths",
+            "precision": "default mode: bf16 weights and MFMA operands, fp32 residual streams, fp32 activations on the decode and "
+                         "mask-decoder paths (the precision class of the reference's own bf16 GPU model); see precision_modes",
+            "precision_modes": precision_modes,
             "algorithmic_tflop_per_image": round(fl["total"] / 1e12, 2),
             # `roofline` = the kernel family with the largest share of GPU time (decode GEMV: HBM-bound);
             # the MFMA GEMMs and the mask-to-vertex lift (the two north-star targets) follow under their own keys

@@ -240,7 +240,8 @@ inline int choose_tile(const GemmArgs& g) {
     const double q = (double)t256 / (double)(((t256 + 255) / 256) * 256);
     const double edge = (double)(((g.M + 255) / 256) * 256) * (((g.N + 255) / 256) * 256) / ((double)g.M * g.N);
     if (t256 >= 512 && q >= 0.85 && edge < 1.1) return 512;  // 256^2 tile, 8-phase ping-pong pipeline (gemm256.hip)
-    if (t256 >= 256 && g.K >= 2048 && edge < 1.1) return 512;     // long K amortises its prologue/epilogue even at 1-2 waves of tiles (SAM mlp2: 911 vs 837 TF)
+    const int keff = g.a_split ? 2 * g.K : g.K;  // (a split A operand walks every K tile twice)
+    if (t256 >= 256 && keff >= 2048 && edge < 1.1) return 512;     // long K amortises its prologue/epilogue even at 1-2 waves of tiles (SAM mlp2: 911 vs 837 TF)
     return 128;
 }
 
@@ -280,7 +281,7 @@ static int nsplit_cols(const GemmArgs& g) {
     const long tm = (g.M + 255) / 256, tn = g.N / 256;
     const long tiles = tm * tn;
     const double q = (double)tiles / (double)(((tiles + 255) / 256) * 256);
-    if (q >= 0.8 || tn < 2 || g.K < 2048) return 0;  // (K = 1280: the split loses - 76.6 vs 70.4 us on SAM proj)
+    if (q >= 0.8 || tn < 2 || (g.a_split ? 2 * g.K : g.K) < 2048) return 0;  // (K = 1280: the split loses - 76.6 vs 70.4 us on SAM proj)
     for (long c = tn - 1; c >= tn / 2; --c)
         if ((tm * c) % 256 == 0 || (double)(tm * c) / (double)(((tm * c + 255) / 256) * 256) >= 0.97) return (int)(c * 256);
     return 0;

@@ -1,0 +1,36 @@
+"""SAM ViT-H encoder alone (4 views), default vs parity precision: wall time per call (graph replay)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from interactvlm_amd import sam, synthetic
+    from interactvlm_amd import weights as Wt
+
+    dev = torch.device("cuda:0")
+    c = Wt.SamEncCfg()
+    cfg = synthetic.config_7b()
+    spec = Wt.sam_encoder_spec(c)
+    w = {k: v for k, v in synthetic.device_weights(cfg, dev).items() if k in spec}
+    enc = sam.SamImageEncoder(w, c, dev)
+    _, im = synthetic.images(cfg, dev)
+    n = int(os.environ.get("N", "5"))
+    for mode in (os.environ.get("MODES", "default,parity").split(",")):
+        enc.precision = mode
+        enc(im[0])
+        enc(im[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            enc(im[0])
+        torch.cuda.synchronize()
+        print(f"{mode}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms per 4 views")
+
+
+if __name__ == "__main__":
+    main()
