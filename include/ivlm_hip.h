@@ -124,6 +124,10 @@ int ivlm_lift_points(const float *probs, const int32_t *pid, int pid_batched, in
  *   low  f32|bf16 [n,h,w]  ->  out f32 [n,oh,ow] */
 int ivlm_postprocess_masks(const void *low, int dtype, int n, int h, int w, int img, int in_h, int in_w,
                            int oh, int ow, int apply_sigmoid, float *out, ivlm_stream_t stream);
+/* The same with the sigmoid of InteractVLM.py:452-456 applied only where the ground-truth mask gt f32 [n,oh,ow] differs from
+ * ignore_label ('oafford' samples with 'HM' object views; raw logits elsewhere). */
+int ivlm_postprocess_masks_valid(const void *low, int dtype, int n, int h, int w, int img, int in_h, int in_w, int oh, int ow,
+                                 const float *gt, float ignore_label, float *out, ivlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense building blocks (bf16 storage, fp32 accumulation) used by the stage runners below and

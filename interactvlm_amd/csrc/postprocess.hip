@@ -10,11 +10,13 @@ using namespace ivlm_bilinear;
 
 template <typename T, bool IDENT2, bool SIGMOID>
 __global__ __launch_bounds__(256) void postprocess_kernel(const T* __restrict__ low, int h, int w, int img, int in_h,
-                                                          int in_w, int oh, int ow, float* __restrict__ out) {
+                                                          int in_w, int oh, int ow, float* __restrict__ out,
+                                                          const float* __restrict__ gt, float ignore_label) {
     const int n = blockIdx.z;
     const int y = blockIdx.y;
     const T* lowp = low + (size_t)n * h * w;
     float* orow = out + ((size_t)n * oh + y) * ow;
+    const float* grow = (SIGMOID && gt) ? gt + ((size_t)n * oh + y) * ow : nullptr;  // sigmoid only where gt != ignore_label
     const float s1y = (float)h / (float)img, s1x = (float)w / (float)img;
     const float s2y = (float)in_h / (float)oh, s2x = (float)in_w / (float)ow;
     const Axis by = IDENT2 ? Axis{y, y, 1.0f, 0.0f} : axis_src(y, s2y, in_h);
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const T* __restrict__ 
                     const float d = stage1(lowp, h, w, s1y, s1x, by.i1, bx.i1);
                     val = (a * bx.l0 + b * bx.l1) * by.l0 + (c * bx.l0 + d * bx.l1) * by.l1;
                 }
-                if (SIGMOID) val = sigmoid_f32(val);
+                if (SIGMOID && (!grow || grow[x] != ignore_label)) val = sigmoid_f32(val);
             }
             r[j] = val;
         }
@@ -51,16 +53,16 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const T* __restrict__ 
 
 template <typename T>
 int launch_postprocess(const T* low, int n, int h, int w, int img, int in_h, int in_w, int oh, int ow, int sig,
-                       float* out, hipStream_t st) {
+                       float* out, hipStream_t st, const float* gt = nullptr, float ignore_label = 0.0f) {
     const bool ident2 = (in_h == oh && in_w == ow);
     int gx = (ow + 1023) / 1024;
     dim3 grid(gx, oh, n);
     if (ident2) {
-        if (sig) postprocess_kernel<T, true, true><<<grid, 256, 0, st>>>(low, h, w, img, in_h, in_w, oh, ow, out);
-        else postprocess_kernel<T, true, false><<<grid, 256, 0, st>>>(low, h, w, img, in_h, in_w, oh, ow, out);
+        if (sig) postprocess_kernel<T, true, true><<<grid, 256, 0, st>>>(low, h, w, img, in_h, in_w, oh, ow, out, gt, ignore_label);
+        else postprocess_kernel<T, true, false><<<grid, 256, 0, st>>>(low, h, w, img, in_h, in_w, oh, ow, out, nullptr, 0.0f);
     } else {
-        if (sig) postprocess_kernel<T, false, true><<<grid, 256, 0, st>>>(low, h, w, img, in_h, in_w, oh, ow, out);
-        else postprocess_kernel<T, false, false><<<grid, 256, 0, st>>>(low, h, w, img, in_h, in_w, oh, ow, out);
+        if (sig) postprocess_kernel<T, false, true><<<grid, 256, 0, st>>>(low, h, w, img, in_h, in_w, oh, ow, out, gt, ignore_label);
+        else postprocess_kernel<T, false, false><<<grid, 256, 0, st>>>(low, h, w, img, in_h, in_w, oh, ow, out, nullptr, 0.0f);
     }
     return ivlm_launch_status();
 }
@@ -80,5 +82,21 @@ extern "C" int ivlm_postprocess_masks(const void* low, int dtype, int n, int h, 
     if (dtype == IVLM_BF16)
         return launch_postprocess(static_cast<const bf16_t*>(low), n, h, w, img, in_h, in_w, oh, ow, apply_sigmoid,
                                   out, st);
+    return IVLM_ERR_UNSUPPORTED;
+}
+
+// postprocess + the in-place sigmoid of InteractVLM.py:452-456 ('oafford' samples with 'HM' object views): sigmoid on the pixels
+// whose ground-truth mask is not the ignore label, raw logits elsewhere.  gt f32 [n,oh,ow].
+extern "C" int ivlm_postprocess_masks_valid(const void* low, int dtype, int n, int h, int w, int img, int in_h, int in_w, int oh,
+                                            int ow, const float* gt, float ignore_label, float* out, ivlm_stream_t stream) {
+    IVLM_CHECK_ARG(low && out && gt);
+    IVLM_CHECK_ARG(n > 0 && h > 0 && w > 0 && img > 0 && oh > 0 && ow > 0);
+    IVLM_CHECK_ARG(in_h > 0 && in_w > 0 && in_h <= img && in_w <= img && oh <= 65535 && n <= 65535);
+    hipStream_t st = ivlm_stream(stream);
+    ivlm_enter();
+    if (dtype == IVLM_F32)
+        return launch_postprocess(static_cast<const float*>(low), n, h, w, img, in_h, in_w, oh, ow, 1, out, st, gt, ignore_label);
+    if (dtype == IVLM_BF16)
+        return launch_postprocess(static_cast<const bf16_t*>(low), n, h, w, img, in_h, in_w, oh, ow, 1, out, st, gt, ignore_label);
     return IVLM_ERR_UNSUPPORTED;
 }

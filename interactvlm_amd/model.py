@@ -269,7 +269,8 @@ class InteractVLMForCausalLM:
                 return vm.object_mask_decoder
         return vm.mask_decoder
 
-    def _decode_sample(self, hidden, rows_mask, ids, cam_params, image_embeddings, input_size, original_size, ds_name=None):
+    def _decode_sample(self, hidden, rows_mask, ids, cam_params, image_embeddings, input_size, original_size, ds_name=None,
+                       sigmoid_gt=None):
         """[SEG] rows -> pred_mask [V,H,W] fp32 for one sample (InteractVLM.py:416-442 / 585-612)."""
         rows = rows_mask.nonzero().flatten()
         V = self.multiview_channels
@@ -292,6 +293,10 @@ class InteractVLMForCausalLM:
         if self.debug_taps is not None:
             self.debug_taps.update(prompt_emb=emb, low_res=low, iou=iou)
         self._last_low = (low, tuple(input_size), tuple(original_size))
+        if sigmoid_gt is not None:  # 'oafford' + 'HM' views: sigmoid where the gt mask is labelled, in the postprocess kernel
+            gt = sigmoid_gt.to(self.device, F32).reshape(low.shape[0], 1, *tuple(original_size)).contiguous()
+            return postprocess_masks(low, input_size, original_size, self.config.sam.img_size, sigmoid_gt=gt,
+                                     ignore_label=float(IGNORE_LABEL))[:, 0], iou
         return postprocess_masks(low, input_size, original_size, self.config.sam.img_size)[:, 0], iou
 
     # ------------------------------------------------------------------------------------------
@@ -319,15 +324,15 @@ class InteractVLMForCausalLM:
             hidden = self.llm.forward(x, 0)
             rows = self._seg_rows(ids, extra_false_col=True)
             osz = tuple(label_list[i].shape[-2:]) if label_list is not None else tuple(resize_list[i])
-            pm, _ = self._decode_sample(hidden, rows, ids, cam_params[i], emb_sam[i], resize_list[i], osz,
-                                        ds_name=ds_name_list[i] if ds_name_list else "hcontact")
+            ds_name = ds_name_list[i] if ds_name_list else "hcontact"
+            gt = masks_list[i][:, 0] if masks_list is not None else None
+            # InteractVLM.py:452-456: 'oafford' samples with 'HM' object views get a sigmoid on the labelled pixels
+            hm = gt is not None and "oafford" in ds_name and "HM" in (self.oC_sam_view_type or "")
+            pm, _ = self._decode_sample(hidden, rows, ids, cam_params[i], emb_sam[i], resize_list[i], osz, ds_name=ds_name,
+                                        sigmoid_gt=gt if hm else None)
             pred_masks.append(pm)
-            gt_masks.append(masks_list[i][:, 0] if masks_list is not None else None)
+            gt_masks.append(gt)
         ds_name_list = ds_name_list or ["hcontact"] * B
-        for idx, ds_name in enumerate(ds_name_list):  # InteractVLM.py:452-456
-            if "oafford" in ds_name and "HM" in (self.oC_sam_view_type or ""):
-                valid = gt_masks[idx].to(self.device) != IGNORE_LABEL
-                pred_masks[idx] = torch.where(valid, torch.sigmoid(pred_masks[idx]), pred_masks[idx])
         result = {"gt_masks": gt_masks, "pred_masks": pred_masks}
         if self.hC_loss_weight > 0:
             result["pred_human_3d_contact"] = self.human_3d_contact_predictor(pred_masks, ds_name_list)

@@ -251,8 +251,10 @@ def lift_points(probs, pid, num_points: int, want_nviews=False):
     return (out, nviews) if want_nviews else out
 
 
-def postprocess_masks(low_res, input_size, original_size, img_size: int = 1024, apply_sigmoid: bool = False):
-    """low_res f32|bf16 [...,h,w] -> f32 [...,oh,ow] (Sam.postprocess_masks)."""
+def postprocess_masks(low_res, input_size, original_size, img_size: int = 1024, apply_sigmoid: bool = False, sigmoid_gt=None,
+                      ignore_label: float = -1.0):
+    """low_res f32|bf16 [...,h,w] -> f32 [...,oh,ow] (Sam.postprocess_masks).  sigmoid_gt (f32, the output's shape): sigmoid on the
+    pixels where it differs from ignore_label (InteractVLM.py:452-456), raw logits elsewhere."""
     lib = _lib.load()
     low_res = _req(low_res, None, "low_res")
     lead = tuple(low_res.shape[:-2])
@@ -262,6 +264,13 @@ def postprocess_masks(low_res, input_size, original_size, img_size: int = 1024, 
         n *= s
     oh, ow = int(original_size[0]), int(original_size[1])
     out = torch.empty(lead + (oh, ow), dtype=torch.float32, device=low_res.device)
+    if sigmoid_gt is not None:
+        gt = _req(sigmoid_gt, torch.float32, "sigmoid_gt")
+        assert gt.numel() == out.numel()
+        check(lib.ivlm_postprocess_masks_valid(low_res.data_ptr(), _dt(low_res), n, h, w, int(img_size), int(input_size[0]),
+                                               int(input_size[1]), oh, ow, gt.data_ptr(), float(ignore_label), out.data_ptr(),
+                                               _stream()), "postprocess_masks_valid")
+        return out
     check(lib.ivlm_postprocess_masks(low_res.data_ptr(), _dt(low_res), n, h, w, int(img_size), int(input_size[0]),
                                      int(input_size[1]), oh, ow, 1 if apply_sigmoid else 0, out.data_ptr(),
                                      _stream()), "postprocess_masks")

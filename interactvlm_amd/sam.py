@@ -494,6 +494,6 @@ class SamMaskDecoder:
         return low.unsqueeze(1), iou[:, 0:1]
 
 
-def postprocess_masks(low_res, input_size, original_size, img_size=1024, apply_sigmoid=False):
-    """Sam.postprocess_masks (sam.py:137-172)."""
-    return ops.postprocess_masks(low_res.contiguous(), input_size, original_size, img_size, apply_sigmoid)
+def postprocess_masks(low_res, input_size, original_size, img_size=1024, apply_sigmoid=False, sigmoid_gt=None, ignore_label=-1.0):
+    """Sam.postprocess_masks (sam.py:137-172) (+ the masked sigmoid of InteractVLM.py:452-456 when sigmoid_gt is given)."""
+    return ops.postprocess_masks(low_res.contiguous(), input_size, original_size, img_size, apply_sigmoid, sigmoid_gt, ignore_label)
