@@ -75,8 +75,13 @@ __device__ __forceinline__ void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\
 // i.e. fp32-operand attention on the bf16 matrix cores at 3x the MFMA work; the output is written as hi + lo planes again.
 // The LDS tiles double (dynamic LDS, one block per CU), one register set stages the next tile.
 template <int DQK, int DV, bool CAUSAL, int REL, bool PP, bool SPLIT = false>
-__global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_kernel(AttnArgs a) {
-    constexpr int NT = PP ? 512 : 256;  // threads per block
+__global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_kernel(AttnArgs a) {
+    // SPLIT: 8 waves of ONE 16-query tile each (the same 128 queries per block): two waves per SIMD to cover each other's LDS
+    // and MFMA latencies - with two query tiles per wave the split kernel needs > 256 registers, i.e. one wave per SIMD (measured:
+    // SAM global attention 1618 us, windows 302 us that way)
+    constexpr int QT = SPLIT ? 1 : 2;          // 16-query tiles per wave
+    constexpr int kQPerWave = 16 * QT;         // (shadows the namespace constant)
+    constexpr int NT = (PP || SPLIT) ? 512 : 256;  // threads per block
     constexpr int kQBlk = PP ? 2 * kQPerBlock : kQPerBlock;
     constexpr int KS = DQK / 32;        // MFMA k-steps over the head dim
     constexpr int DT = DV / 16;         // 16-wide output tiles over the head dim
@@ -141,10 +146,10 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
     }
 
     // ---- Q fragments (B operand): lane holds Q[q0 + qt*16 + l15][(s*4+g)*8 .. +8] ---------------
-    bf16x8_t qf[2][KS];
-    bf16x8_t qfl[2][SPLIT ? KS : 1];  // SPLIT: the lo halves
+    bf16x8_t qf[QT][KS];
+    bf16x8_t qfl[QT][SPLIT ? KS : 1];  // SPLIT: the lo halves
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         int qi = q0 + qt * 16 + l15;
         qi = qi < a.Sq ? qi : a.Sq - 1;
 #pragma unroll
@@ -179,12 +184,17 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
         }
     }
 
-    f32x4_t o[2][DT];
+    f32x4_t o[QT][DT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {kNegBig, kNegBig}, l_run[2] = {0.f, 0.f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        m_run[qt] = kNegBig;
+        l_run[qt] = 0.f;
+    }
 
     int ntiles = (a.Sk + kKV - 1) / kKV;
     if (CAUSAL) {
@@ -254,16 +264,16 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
     const int voff = (g * 4 + (l15 >> 2)) * 16 + (l15 & 3) * 4;         // tr-read address: key g*4 + i/4, d-quad i%4
 
     // ---- rel-pos operands of this lane's two queries -------------------------------------------
-    bf16x8_t qrel[2];       // REL 1: [rel_h(KH) | rel_w(KW) | 0] features g*8 .. g*8+7
-    bf16x8_t qrel_lo[2];    //        (SPLIT: the fp32 bias values as hi + lo + lo2 operands - three bf16 terms carry all 24 bits:
-    bf16x8_t qrel_lo2[2];   //         the one-hot MFMAs add them exactly; a bias of +-20 split in two would be off by 1e-4)
-    f32x4_t rwf[2][4];      // REL 2: rel_w[q][kt*16 + g*4 + r]: tile-invariant, SEEDS the score accumulators (no add later)
-    const float* rhp[2] = {nullptr, nullptr};
-    const float* rwg[2] = {nullptr, nullptr};  // REL 3
+    bf16x8_t qrel[QT];       // REL 1: [rel_h(KH) | rel_w(KW) | 0] features g*8 .. g*8+7
+    bf16x8_t qrel_lo[QT];    //        (SPLIT: the fp32 bias values as hi + lo + lo2 operands - three bf16 terms carry all 24 bits:
+    bf16x8_t qrel_lo2[QT];   //         the one-hot MFMAs add them exactly; a bias of +-20 split in two would be off by 1e-4)
+    f32x4_t rwf[QT][4];      // REL 2: rel_w[q][kt*16 + g*4 + r]: tile-invariant, SEEDS the score accumulators (no add later)
+    const float* rhp[QT] = {};
+    const float* rwg[QT] = {};  // REL 3
     if (REL != 0) {
         const int64_t bh = (int64_t)b * a.H + h;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             int qi = q0 + qt * 16 + l15;
             qi = qi < a.Sq ? qi : a.Sq - 1;
             const float* rh = a.rel_h + (bh * a.Sq + qi) * a.rel_kh;
@@ -310,9 +320,9 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
     const float sc2 = a.prescale_q ? kLog2e : a.scale * kLog2e;
 
     // ---- the three phases of a key tile (state: s = scores then probabilities, pf = packed P^T fragments) ------------
-    f32x4_t s[2][4];
-    bf16x8_t pf[2][2];
-    bf16x8_t pfl[2][SPLIT ? 2 : 1];  // SPLIT: lo halves of the probabilities
+    f32x4_t s[QT][4];
+    bf16x8_t pf[QT][2];
+    bf16x8_t pfl[QT][SPLIT ? 2 : 1];  // SPLIT: lo halves of the probabilities
     auto nkt_of = [&](int t) __attribute__((always_inline)) {
         int nkt = (a.Sk - t * kKV + 15) >> 4;  // 16-key sub-tiles that hold real keys (wave-uniform)
         return nkt < 4 ? nkt : 4;
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
         const int nkt = nkt_of(t);
         // ---- S^T = K . Q^T : s[qt][kt] holds keys kt*16 + g*4 + r of query l15 ------------------
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) s[qt][kt] = REL == 2 ? rwf[qt][kt] : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -333,13 +343,13 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
                 const bf16x8_t kf =
                     *reinterpret_cast<const bf16x8_t*>(&Kb[ks * KPL + (kt * 16 + l15) * 32 + kswz]);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
                 if (SPLIT) {
                     const bf16x8_t kfl =
                         *reinterpret_cast<const bf16x8_t*>(&Kb[KBUF + ks * KPL + (kt * 16 + l15) * 32 + kswz]);
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
+                    for (int qt = 0; qt < QT; ++qt) {
                         s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[qt][ks], s[qt][kt], 0, 0, 0);
                         s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qf[qt][ks], s[qt][kt], 0, 0, 0);
                     }
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
                 uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
                 const bf16x8_t hot = *reinterpret_cast<bf16x8_t*>(&u);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel[qt], s[qt][kt], 0, 0, 0);
                     if (SPLIT) {
                         s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo[qt], s[qt][kt], 0, 0, 0);
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
         if (REL == 3 || edge) {
             asm volatile("" ::: "memory");  // keep this a real branch (if-converted it costs 2 VALU per score on EVERY tile)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 const int qi = q0 + qt * 16 + l15;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
             }
         }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             // log2-domain score y = x * sc2 + bias2 (monotonic in x): the maximum is taken on the raw scores, and the
             // subtraction of the running maximum rides in the same fma as the scaling: p = exp2(x * sc2 + (bias2 - m))
             float bias2 = 0.0f;
@@ -450,7 +460,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
 
         // ---- P^T fragments straight from the score registers (key order permuted per 32-step) --
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 uint4 u;  // round-to-nearest-even pairs in one instruction each (probabilities: finite, no NaN handling needed)
@@ -490,7 +500,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
                 const s16x8_t v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, v8);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
                     o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s2], o[qt][dt], 0, 0, 0);
                 if (SPLIT) {
                     const bf16_t* vpl = vp + VBUF;
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
                     const s16x8_t v8l = __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7);
                     const bf16x8_t vfl = __builtin_bit_cast(bf16x8_t, v8l);
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
+                    for (int qt = 0; qt < QT; ++qt) {
                         o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl[qt][s2], o[qt][dt], 0, 0, 0);
                         o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf[qt][s2], o[qt][dt], 0, 0, 0);
                     }
@@ -604,7 +614,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_ke
     // ---- normalise and store: lane holds O[query l15][d = dt*16 + g*4 + r] ---------------------
     bf16_t* __restrict__ O = a.o + b * a.o_bs + h * a.o_hs;
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const int qi = q0 + qt * 16 + l15;
         if (qi >= a.Sq) continue;
         const float inv = l_run[qt] > 0.0f ? 1.0f / l_run[qt] : 0.0f;
@@ -641,7 +651,7 @@ int launch_split_k(const AttnArgs& a, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B);
-    kfn<<<grid, 256, lds, st>>>(a);
+    kfn<<<grid, 512, lds, st>>>(a);
     return ivlm_launch_status();
 }
 
