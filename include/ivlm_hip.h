@@ -235,7 +235,10 @@ int ivlm_rmsnorm_fp8(const void *x, int x_dtype, const void *w, void *y, int64_t
  *   strides[12] = {q_b,q_h,q_row, k_b,k_h,k_row, v_b,v_h,v_row, o_b,o_h,o_row} (multiples of 8; o: of 4)
  *   D in {16,32,64,80,128};  causal: key j visible to query i iff j <= i + q_pos0 (KV cache offset)
  *   prescale_q: 1 = scores are bf16(q*scale).k (SAM image_encoder.py:244, HF CLIP); 0 = (q.k)*scale (HF LLaMA)
- *   rel_h f32 [B*H,Sq,rel_kh], rel_w f32 [B*H,Sq,rel_kw] (or NULL): bias[q,k] = rel_h[q,k/rel_kw] + rel_w[q,k%rel_kw] */
+ *   rel_h f32 [B*H,Sq,rel_kh], rel_w f32 [B*H,Sq,rel_kw] (or NULL): bias[q,k] = rel_h[q,k/rel_kw] + rel_w[q,k%rel_kw]
+ *   TABLE MODE (rel_w == NULL, rel_h != NULL; D = 80, rel_kh == rel_kw == side, 2 * side <= 32, Sq == Sk == side^2: SAM's 14 x 14
+ *   windows): rel_h points to the bf16 table [64, D] = [rel_pos_h (2 side - 1 rows) ; rel_pos_w (2 side - 1 rows) ; zeros] and the
+ *   kernel computes the terms itself (one small MFMA product per query tile) - no ivlm_relpos_bias pass, no [B*H,Sq,2 side] arrays. */
 int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, const int64_t *strides_host, int B,
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float *rel_h,
                         const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q,

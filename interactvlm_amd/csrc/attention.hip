@@ -101,11 +101,15 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
     // REL 2: rel_h[query][key row] of the block's queries, one value per (query, key tile).  Read from global at its point of use it is a dependent load in every tile, and the s_waitcnt the
     // compiler puts in front of it also drains the K/V prefetches of the following tiles.
     __shared__ __attribute__((aligned(16))) float Rh_[(REL == 2 && !SPLIT) ? kQBlk * kKV : 4];
+    // REL 4: per-wave scratch of the rel-pos table product G^T = T . Q^T (64 table rows x 16 queries, row stride 65 floats)
+    constexpr int kGW = 16 * 65;
+    __shared__ float Gs_[(REL == 4 && !SPLIT) ? (NT / 64) * kGW : 4];
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_dyn[];
     constexpr int KB2 = SPLIT ? 2 * KBUF : KBUF, VB2 = SPLIT ? 2 * VBUF : VBUF;  // elements per buffer
     bf16_t* const Ks0 = SPLIT ? reinterpret_cast<bf16_t*>(attn_dyn) : &Ks_[0][0];
     bf16_t* const Vs0 = SPLIT ? Ks0 + 2 * KB2 : &Vs_[0][0];
     float* const Rh = SPLIT ? reinterpret_cast<float*>(Vs0 + 2 * VB2) : &Rh_[0];
+    float* const Gs = SPLIT ? Rh : &Gs_[0];  // (SPLIT: the dynamic region behind the tiles; REL 2 and REL 4 never coincide)
     auto Ks = [&](int buf) __attribute__((always_inline)) { return Ks0 + buf * KB2; };
     auto Vs = [&](int buf) __attribute__((always_inline)) { return Vs0 + buf * VB2; };
 
@@ -158,10 +162,25 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
             uint4 u = make_uint4(0, 0, 0, 0);
             if (d0 < DV) u = *reinterpret_cast<const uint4*>(Q + (int64_t)qi * a.q_rs + d0);
             if (SPLIT) {
-                u32x4_t uh = u32x4_t{u.x, u.y, u.z, u.w}, ul = u32x4_t{0u, 0u, 0u, 0u};
+                u32x4_t ul = u32x4_t{0u, 0u, 0u, 0u};
                 if (d0 < DV) ul = *reinterpret_cast<const u32x4_t*>(Ql + (int64_t)qi * a.q_rs + d0);
-                if (a.prescale_q) {  // (q * scale) in fp32 on the hi + lo value, split again: no rounding to bf16
-                    const float sc = a.scale;
+                qfl[qt][s] = __builtin_bit_cast(bf16x8_t, ul);
+            }
+            qf[qt][s] = *reinterpret_cast<bf16x8_t*>(&u);
+        }
+    }
+    // q * scale before the dot product (SAM, HF-CLIP).  Default precision: rounded to bf16 like the reference's bf16 model does;
+    // SPLIT: in fp32 on the hi + lo value, split again.  (REL 4 first needs the UNSCALED q for the rel-pos terms: applied below.)
+    auto prescale = [&]() __attribute__((always_inline)) {
+        if (!a.prescale_q) return;
+        const float sc = a.scale;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                u32x4_t uh = __builtin_bit_cast(u32x4_t, qf[qt][s_]);
+                if (SPLIT) {
+                    u32x4_t ul = __builtin_bit_cast(u32x4_t, qfl[qt][SPLIT ? s_ : 0]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x0 = (__uint_as_float(uh[e] << 16) + __uint_as_float(ul[e] << 16)) * sc;
@@ -171,18 +190,16 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                         uh[e] = hh;
                         ul[e] = ll;
                     }
+                    qfl[qt][SPLIT ? s_ : 0] = __builtin_bit_cast(bf16x8_t, ul);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        uh[e] = pack_bf16x2(__uint_as_float(uh[e] << 16) * sc, __uint_as_float(uh[e] & 0xffff0000u) * sc);
                 }
-                u = make_uint4(uh[0], uh[1], uh[2], uh[3]);
-                qfl[qt][s] = __builtin_bit_cast(bf16x8_t, ul);
-            } else if (a.prescale_q) {  // (q * scale) rounded to bf16 BEFORE the dot product, like SAM / HF-CLIP do
-                u.x = pack_bf16x2(__uint_as_float(u.x << 16) * a.scale, __uint_as_float(u.x & 0xffff0000u) * a.scale);
-                u.y = pack_bf16x2(__uint_as_float(u.y << 16) * a.scale, __uint_as_float(u.y & 0xffff0000u) * a.scale);
-                u.z = pack_bf16x2(__uint_as_float(u.z << 16) * a.scale, __uint_as_float(u.z & 0xffff0000u) * a.scale);
-                u.w = pack_bf16x2(__uint_as_float(u.w << 16) * a.scale, __uint_as_float(u.w & 0xffff0000u) * a.scale);
+                qf[qt][s_] = __builtin_bit_cast(bf16x8_t, uh);
             }
-            qf[qt][s] = *reinterpret_cast<bf16x8_t*>(&u);
-        }
-    }
+    };
+    if (REL != 4) prescale();
 
     f32x4_t o[QT][DT];
 #pragma unroll
@@ -270,7 +287,78 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
     f32x4_t rwf[QT][4];      // REL 2: rel_w[q][kt*16 + g*4 + r]: tile-invariant, SEEDS the score accumulators (no add later)
     const float* rhp[QT] = {};
     const float* rwg[QT] = {};  // REL 3
-    if (REL != 0) {
+    // packs 8 fp32 bias values (features g*8 .. g*8+7 of this lane's query) into the one-hot MFMA operand(s)
+    auto pack_qrel = [&](const float (&f)[8], int qt) __attribute__((always_inline)) {
+        uint4 u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+        if (SPLIT) {
+            u32x4_t uh, ul, ul2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t hh, ll;
+                split_bf16x2(f[2 * e], f[2 * e + 1], hh, ll);
+                const float r0 = (f[2 * e] - __uint_as_float(hh << 16)) - __uint_as_float(ll << 16);
+                const float r1 = (f[2 * e + 1] - __uint_as_float(hh & 0xffff0000u)) - __uint_as_float(ll & 0xffff0000u);
+                uh[e] = hh;
+                ul[e] = ll;
+                ul2[e] = pack_bf16x2(r0, r1);
+            }
+            u = make_uint4(uh[0], uh[1], uh[2], uh[3]);
+            qrel_lo[qt] = __builtin_bit_cast(bf16x8_t, ul);
+            qrel_lo2[qt] = __builtin_bit_cast(bf16x8_t, ul2);
+        }
+        qrel[qt] = *reinterpret_cast<bf16x8_t*>(&u);
+    };
+    if (REL == 4) {
+        // The decomposed rel-pos terms computed HERE instead of by a kernel of their own (54 us and 120 MB of traffic per
+        // windowed block): G^T = T . Q^T on the matrix cores - T = [rel_pos_h ; rel_pos_w ; 0] (64 rows, a.rel_h), Q the UNSCALED
+        // query fragments already in registers - lands in C layout (lane = query l15, rows g*4+r of each 16-row tile), goes through
+        // a per-wave LDS scratch and comes back as the 2 * side Toeplitz picks of this lane's query:
+        //   rel_h[q][kh] = G[q][qh - kh + side - 1],   rel_w[q][kw] = G[q][(2 side - 1) + qw - kw + side - 1].
+        const bf16_t* tab = reinterpret_cast<const bf16_t*>(a.rel_h);
+        const int side = a.rel_kh;
+        float* Gw = Gs + wave * kGW;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4_t gacc[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) gacc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int d0 = (ks * 4 + g) * 8;
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    u32x4_t t4 = u32x4_t{0u, 0u, 0u, 0u};
+                    if (d0 < DV) t4 = *reinterpret_cast<const u32x4_t*>(tab + (rt * 16 + l15) * DV + d0);
+                    const bf16x8_t tf = __builtin_bit_cast(bf16x8_t, t4);
+                    gacc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, qf[qt][ks], gacc[rt], 0, 0, 0);
+                    if (SPLIT) gacc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, qfl[qt][SPLIT ? ks : 0], gacc[rt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Gw[l15 * 65 + rt * 16 + g * 4 + r] = gacc[rt][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            int qi = q0 + qt * 16 + l15;
+            qi = qi < a.Sq ? qi : a.Sq - 1;
+            const int qh = qi / side, qw = qi - qh * side;
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int fi = g * 8 + e;
+                float v = 0.0f;
+                if (fi < side) v = Gw[l15 * 65 + qh - fi + side - 1];
+                else if (fi < 2 * side) v = Gw[l15 * 65 + (2 * side - 1) + qw - (fi - side) + side - 1];
+                // default precision: the bf16 reference materialises the terms in bf16 (pack_qrel rounds); SPLIT keeps fp32
+                f[e] = v;
+            }
+            pack_qrel(f, qt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();  // the scratch is reused by the next query tile
+        }
+        prescale();
+    } else if (REL != 0) {
         const int64_t bh = (int64_t)b * a.H + h;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -285,25 +373,7 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                     const int fi = g * 8 + e;
                     f[e] = fi < a.rel_kh ? rh[fi] : (fi < a.rel_kh + a.rel_kw ? rw[fi - a.rel_kh] : 0.0f);
                 }
-                uint4 u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
-                                     pack_bf16x2(f[6], f[7]));
-                if (SPLIT) {
-                    u32x4_t uh, ul, ul2;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        uint32_t hh, ll;
-                        split_bf16x2(f[2 * e], f[2 * e + 1], hh, ll);
-                        const float r0 = (f[2 * e] - __uint_as_float(hh << 16)) - __uint_as_float(ll << 16);
-                        const float r1 = (f[2 * e + 1] - __uint_as_float(hh & 0xffff0000u)) - __uint_as_float(ll & 0xffff0000u);
-                        uh[e] = hh;
-                        ul[e] = ll;
-                        ul2[e] = pack_bf16x2(r0, r1);
-                    }
-                    u = make_uint4(uh[0], uh[1], uh[2], uh[3]);
-                    qrel_lo[qt] = __builtin_bit_cast(bf16x8_t, ul);
-                    qrel_lo2[qt] = __builtin_bit_cast(bf16x8_t, ul2);
-                }
-                qrel[qt] = *reinterpret_cast<bf16x8_t*>(&u);
+                pack_qrel(f, qt);
             } else if (REL == 3) {
                 rhp[qt] = rh;
                 rwg[qt] = rw;
@@ -355,7 +425,7 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                     }
                 }
             }
-            if (REL == 1) {
+            if (REL == 1 || REL == 4) {
                 const int key = t * kKV + kt * 16 + l15;
                 const int kh = key / a.rel_kw;
                 const int f1 = kh - g * 8, f2 = a.rel_kh + (key - kh * a.rel_kw) - g * 8;  // hot slots e
@@ -643,7 +713,7 @@ template <int DQK, int DV, bool CAUSAL, int REL>
 int launch_split_k(const AttnArgs& a, hipStream_t st) {
     constexpr int KS = DQK / 32, DT = DV / 16;
     constexpr size_t lds = (size_t)(2 * 2 * KS * (kKV * 32 + 32) + 2 * 2 * DT * (kKV * 16 + 16)) * 2 +
-                           (REL == 2 ? (size_t)kQPerBlock * kKV * 4 : 0);
+                           (REL == 2 ? (size_t)kQPerBlock * kKV * 4 : (REL == 4 ? (size_t)8 * 16 * 65 * 4 : 0));
     auto kfn = attn_kernel<DQK, DV, CAUSAL, REL, false, true>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -665,6 +735,7 @@ int launch_split(const AttnArgs& a, hipStream_t st) {
         if (!a.causal && !rel) return launch_split_k<DQK, DV, false, 0>(a, st);
     } else if constexpr (DV == 80) {
         if (!a.causal && rel && a.prescale_q) {
+            if (!a.rel_w) return launch_split_k<DQK, DV, false, 4>(a, st);  // rel-pos terms from the table, in the kernel
             if (a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw) return launch_split_k<DQK, DV, false, 2>(a, st);
             if (a.rel_kh + a.rel_kw <= 32) return launch_split_k<DQK, DV, false, 1>(a, st);
             return launch_split_k<DQK, DV, false, 3>(a, st);
@@ -684,7 +755,9 @@ int launch_dp(const AttnArgs& a, hipStream_t st) {
     } else if (rel) {
         if (DV != 80) return IVLM_ERR_UNSUPPORTED;  // only SAM's ViT uses rel-pos; keeps the build small
         if (!a.prescale_q) return IVLM_ERR_UNSUPPORTED;
-        if (a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw)
+        if (!a.rel_w)  // rel_h is the bf16 table [64, D]: the rel-pos terms are computed in the kernel (windows: 2 * side <= 32)
+            attn_kernel<DQK, DV, false, DV == 80 ? 4 : 0, false><<<dim3((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B), 256, 0, st>>>(a);
+        else if (a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw)
             attn_kernel<DQK, DV, false, DV == 80 ? 2 : 0, PP><<<grid, NT, 0, st>>>(a);
         else if (a.rel_kh + a.rel_kw <= 32)
             attn_kernel<DQK, DV, false, DV == 80 ? 1 : 0, PP><<<grid, NT, 0, st>>>(a);
@@ -881,7 +954,12 @@ int attention_bf16(const AttnArgs& a, hipStream_t st) {
     if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.q_hs | a.k_hs | a.v_hs | a.q_bs | a.k_bs | a.v_bs) & 7)
         return IVLM_ERR_UNSUPPORTED;  // 16-byte row chunks
     if ((a.o_rs | a.o_hs | a.o_bs) & 3) return IVLM_ERR_UNSUPPORTED;
-    if (a.rel_h && (!a.rel_w || a.rel_kh <= 0 || a.rel_kw <= 0)) return IVLM_ERR_INVALID_ARG;
+    if (a.rel_h && (a.rel_kh <= 0 || a.rel_kw <= 0)) return IVLM_ERR_INVALID_ARG;
+    if (a.rel_h && !a.rel_w) {  // table mode: square windows whose 2 * side terms fit one MFMA k-step, queries = keys = side^2
+        if (a.rel_kh != a.rel_kw || 2 * a.rel_kh > 32 || a.Sq != a.rel_kh * a.rel_kw || a.Sk != a.Sq || a.D != 80 ||
+            (reinterpret_cast<uintptr_t>(a.rel_h) & 15))
+            return IVLM_ERR_UNSUPPORTED;
+    }
     if ((a.q_lo || a.k_lo || a.v_lo || a.o_lo) && !(a.q_lo && a.k_lo && a.v_lo && a.o_lo)) return IVLM_ERR_INVALID_ARG;
     switch (a.D) {
         case 16: return launch_d<32, 16>(a, st);

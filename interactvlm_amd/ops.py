@@ -498,10 +498,21 @@ def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False, fp8_scale=None)
     return y
 
 
-def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, prescale_q=False):
+def relpos_table64(tab_h, tab_w):
+    """[rel_pos_h ; rel_pos_w ; zeros] as a bf16 [64, D] table: the operand of the attention kernels' TABLE MODE (rel_tab=...)."""
+    n = tab_h.shape[0] + tab_w.shape[0]
+    assert n <= 64
+    t = torch.zeros(64, tab_h.shape[1], dtype=BF16, device=tab_h.device)
+    t[: tab_h.shape[0]] = tab_h
+    t[tab_h.shape[0]: n] = tab_w
+    return t
+
+
+def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, prescale_q=False, rel_tab=None):
     """q [B,H,Sq,D], k/v [Bk,H,Sk,D] (arbitrary strides, last dim contiguous; B % Bk == 0: K/V of batch
     b // (B//Bk)) -> o [B,H,Sq,D] as a view of a [B,Sq,H,D] buffer (so o.transpose(1,2) is contiguous).
-    rel = (rel_h f32 [B*H,Sq,KH], rel_w f32 [B*H,Sq,KW]) adds SAM's decomposed rel-pos bias."""
+    rel = (rel_h f32 [B*H,Sq,KH], rel_w f32 [B*H,Sq,KW]) adds SAM's decomposed rel-pos bias; rel_tab = (relpos_table64(...), side)
+    lets the kernel compute those terms itself (14 x 14 windows)."""
     import ctypes
 
     lib = _lib.load()
@@ -520,14 +531,18 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, presca
         rel_h, rel_w = rel
         assert rel_h.dtype == torch.float32 and rel_h.is_contiguous() and rel_w.is_contiguous()
         kh, kw = rel_h.shape[-1], rel_w.shape[-1]
+    if rel_tab is not None:  # table mode: rel_h = the bf16 table, rel_w = NULL
+        rel_h, kh = rel_tab
+        kw = kh
+        assert rel is None and rel_h.dtype == BF16 and rel_h.shape == (64, D) and rel_h.is_contiguous()
     check(lib.ivlm_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                   ctypes.cast(st, ctypes.c_void_p), B, H, Sq, Sk, D, float(scale), 1 if causal else 0,
                                   int(q_pos0), _p(rel_h), _p(rel_w), kh, kw, B // Bk,
-                                  1 if (prescale_q or rel is not None) else 0, _stream()), "attention")
+                                  1 if (prescale_q or rel is not None or rel_tab is not None) else 0, _stream()), "attention")
     return out
 
 
-def attention_split(q, q_lo, k, k_lo, v, v_lo, scale, causal=False, q_pos0=0, rel=None, out=None, prescale_q=False):
+def attention_split(q, q_lo, k, k_lo, v, v_lo, scale, causal=False, q_pos0=0, rel=None, out=None, prescale_q=False, rel_tab=None):
     """"Parity" precision of ``attention``: every operand as hi + lo bf16 planes (the *_lo tensors have the shapes and strides of
     the hi ones), fp32-operand arithmetic on the bf16 matrix cores.  out: bf16 [B, Sq, 2, H, D] buffer (default: allocated), the
     rows [hi(H*D) | lo(H*D)] of the next GEMM's a_split operand; returned as [B*Sq, 2*H*D]."""
@@ -551,10 +566,15 @@ def attention_split(q, q_lo, k, k_lo, v, v_lo, scale, causal=False, q_pos0=0, re
         rel_h, rel_w = rel
         assert rel_h.dtype == torch.float32 and rel_h.is_contiguous() and rel_w.is_contiguous()
         kh, kw = rel_h.shape[-1], rel_w.shape[-1]
+    if rel_tab is not None:  # table mode (see ``attention``)
+        rel_h, kh = rel_tab
+        kw = kh
+        assert rel is None and rel_h.dtype == BF16 and rel_h.shape == (64, D) and rel_h.is_contiguous()
     check(lib.ivlm_attention_bf16_split(q.data_ptr(), q_lo.data_ptr(), k.data_ptr(), k_lo.data_ptr(), v.data_ptr(),
                                         v_lo.data_ptr(), oh.data_ptr(), ol.data_ptr(), ctypes.cast(st, ctypes.c_void_p), B, H,
                                         Sq, Sk, D, float(scale), 1 if causal else 0, int(q_pos0), _p(rel_h), _p(rel_w), kh, kw,
-                                        B // Bk, 1 if (prescale_q or rel is not None) else 0, _stream()), "attention_split")
+                                        B // Bk, 1 if (prescale_q or rel is not None or rel_tab is not None) else 0, _stream()),
+          "attention_split")
     return out.view(B * Sq, 2 * H * D)
 
 

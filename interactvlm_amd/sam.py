@@ -116,6 +116,7 @@ class SamImageEncoder:
     # the attention output (bf16 kernel) takes one conversion pass.  Patch embedding, attention and neck stay bf16; the residual
     # stream stays fp32.
     fp8 = False
+    rel_in_kernel = True  # window attention computes its rel-pos terms itself (ops.attention rel_tab=...); False: relpos kernel
 
     def enable_fp8(self, calib_images):
         """calib_images [V,3,S,S]: one bf16 pass records the activation ranges, then the fp8 path is switched on."""
@@ -154,6 +155,13 @@ class SamImageEncoder:
             ops.fill_rows(qkv, pad, blk["qkv"].b)
         qkv5 = qkv.view(nwin, S, 3, H, hd)
         q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
+            # windows: the decomposed rel-pos terms are computed inside the attention kernel (one small MFMA product per query
+            # tile against the [rel_pos_h ; rel_pos_w] table) - no relpos pass, no [B*H, S, 2 side] fp32 arrays
+            if "rel_tab64" not in blk:
+                blk["rel_tab64"] = ops.relpos_table64(blk["rel_h"], blk["rel_w"])
+            o = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_tab64"], side))
+            return o.permute(0, 2, 1, 3).reshape(nwin * S, H * hd)
         if "rel_cat" not in blk:
             blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
         rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat"])
@@ -178,10 +186,15 @@ class SamImageEncoder:
             ops.fill_rows(qkv, pad, blk["qkv"].b)
         qkv5 = qkv.view(nw_, S, 3, H, hd)
         q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        if "rel_cat" not in blk:
-            blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
-        rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat"])
-        a = ops.attention(q, k, v, hd ** -0.5, rel=rel).permute(0, 2, 1, 3).reshape(nw_ * S, H * hd)
+        if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
+            if "rel_tab64" not in blk:
+                blk["rel_tab64"] = ops.relpos_table64(blk["rel_h"], blk["rel_w"])
+            a = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_tab64"], side)).permute(0, 2, 1, 3).reshape(nw_ * S, H * hd)
+        else:
+            if "rel_cat" not in blk:
+                blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
+            rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat"])
+            a = ops.attention(q, k, v, hd ** -0.5, rel=rel).permute(0, 2, 1, 3).reshape(nw_ * S, H * hd)
         aq = ops.gather_rows(a, out_kind="fp8", scale=sc["att"])
         x = ops.linear_fp8(aq, blk["proj_q"], sc["att"], blk["proj_s"], blk["proj"].b, residual=x, out=x,
                            a_rows=None if glob else unpart)
@@ -264,6 +277,10 @@ class SamImageEncoder:
         q6 = qkv.view(nwin, S, 2, 3, H, hd)
         hi = [q6[:, :, 0, i].permute(0, 2, 1, 3) for i in range(3)]
         lo = [q6[:, :, 1, i].permute(0, 2, 1, 3) for i in range(3)]
+        if self.rel_in_kernel and 2 * side <= 32 and hd == 80:  # windows: fp32 rel-pos terms from the table, inside the kernel
+            if "rel_tab64" not in blk:
+                blk["rel_tab64"] = ops.relpos_table64(blk["rel_h"], blk["rel_w"])
+            return ops.attention_split(hi[0], lo[0], hi[1], lo[1], hi[2], lo[2], hd ** -0.5, rel_tab=(blk["rel_tab64"], side))
         rel = ops.relpos_bias_split(hi[0], lo[0], blk["rel_h"], blk["rel_w"], side, side)
         return ops.attention_split(hi[0], lo[0], hi[1], lo[1], hi[2], lo[2], hd ** -0.5, rel=rel)  # [nwin*S, 2D]
 

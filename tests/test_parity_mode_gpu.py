@@ -190,6 +190,18 @@ def test_sam_attention_split_with_relpos(hip_lib, cuda, B, side):
     assert e < 1.5e-4, f"SAM split attention ({side}x{side}) max err {e}"
     o16 = ops.attention(qh.contiguous(), kh.contiguous(), vh.contiguous(), scale, rel=(rh, rw))
     assert float((o16.float().cpu().double() - ref).abs().max()) > 20 * e
+    if 2 * side <= 32:  # TABLE MODE: the kernel computes the rel-pos terms itself from [rel_pos_h ; rel_pos_w]
+        tab = ops.relpos_table64(th.to(cuda), tw.to(cuda))
+        out_t = ops.attention_split(qh, ql, kh, kl, vh, vl, scale, rel_tab=(tab, side))
+        got_t = _join(out_t, H * D).view(B, S, H, D).permute(0, 2, 1, 3).cpu()
+        e_t = float((got_t.double() - ref).abs().max())
+        assert e_t < 1.5e-4, f"table-mode split attention max err {e_t}"
+        # default precision: same numbers as the relpos kernel + array mode on the bf16 q (terms rounded to bf16 in both)
+        qb, kb, vb = qh.contiguous(), kh.contiguous(), vh.contiguous()
+        a_arr = ops.attention(qb, kb, vb, scale, rel=ops.relpos_bias(qb, th.to(cuda), tw.to(cuda), side, side))
+        a_tab = ops.attention(qb, kb, vb, scale, rel_tab=(tab, side))
+        d = float((a_arr.float() - a_tab.float()).abs().max())
+        assert d < 2e-2, d  # (fp32 summation order of the table product may flip a bf16 rounding of a term)
 
 
 def test_rope_split_cache_and_decode_attention(hip_lib, cuda):

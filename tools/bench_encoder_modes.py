@@ -21,7 +21,11 @@ def main():
     _, im = synthetic.images(cfg, dev)
     n = int(os.environ.get("N", "5"))
     for mode in (os.environ.get("MODES", "default,parity").split(",")):
+      for rik in ((True, False) if os.environ.get("AB_REL") else (True,)):
         enc.precision = mode
+        enc.rel_in_kernel = rik
+        if hasattr(enc, "_graphs"):
+            enc._graphs.clear()
         enc(im[0])
         enc(im[0])
         torch.cuda.synchronize()
@@ -29,7 +33,7 @@ def main():
         for _ in range(n):
             enc(im[0])
         torch.cuda.synchronize()
-        print(f"{mode}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms per 4 views")
+        print(f"{mode} (rel-pos terms in the attention kernel: {rik}): {(time.perf_counter() - t0) / n * 1e3:.2f} ms per 4 views")
 
 
 if __name__ == "__main__":
