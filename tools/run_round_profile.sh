@@ -13,8 +13,8 @@ DB=$(find /tmp/prof_kt -name '*.db' | head -1)
 python $R/tools/rocpd_stats.py $DB 12 > $O/kernel_stats_graphs.txt 2>&1
 python $R/tools/rocpd_rooflines.py $DB >> $O/kernel_stats_graphs.txt 2>&1
 python $R/tools/rocpd_timeline.py $DB > $O/timeline.txt 2>&1
-IVLM_NO_ADVERSARIAL=1 IVLM_NO_GRAPHS=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants > /dev/null 2> $O/pmc_f.err
-IVLM_NO_ADVERSARIAL=1 IVLM_NO_GRAPHS=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants > /dev/null 2> $O/pmc_w.err
+IVLM_NO_ADVERSARIAL=1 IVLM_NO_GRAPHS=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-roofline > /dev/null 2> $O/pmc_f.err
+IVLM_NO_ADVERSARIAL=1 IVLM_NO_GRAPHS=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-roofline > /dev/null 2> $O/pmc_w.err
 python $R/tools/rocpd_pmc.py $(find /tmp/prof_f -name '*.db' | head -1) $(find /tmp/prof_w -name '*.db' | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
 timeout 600 python $R/bench.py --model 13b --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_13b.json 2> $O/bench_13b.err
 tail -2 $O/kernel_stats_graphs.txt; head -c 600 $O/bench.json
