@@ -260,6 +260,9 @@ int ivlm_attention_f32(const float *q, const float *k, const float *v, float *o,
 /* Benchmark/test hook: -1 (default) picks per shape; 0 forces the 4-wave / 128-query block, 1 the 8-wave ping-pong block
  * (256 queries; one wave group on the matrix unit while the other does its softmax on the VALU). */
 int ivlm_attention_pingpong(int mode);
+/* Benchmark/test hook: 1 (default) = SAM's windows in table mode run on the whole-window kernel (one block per (window, head), K / V
+ * of the window resident in LDS, one-pass softmax); 0 = the generic flash kernel for them too. */
+int ivlm_attention_window_kernel(int v2);
 
 /* add_decomposed_rel_pos operands (image_encoder.py:354-392), q_size == k_size == (SH,SW):
  *   rel_h[bh,q,kh] = q . rel_pos_h[qh-kh+SH-1],  rel_w[bh,q,kw] = q . rel_pos_w[qw-kw+SW-1]  (rounded to bf16
@@ -356,7 +359,7 @@ int ivlm_clip_encode(const ivlm_clip_cfg *cfg, const ivlm_clip_head *head, const
 /* ImageEncoderViT.forward (image_encoder.py:110-125; Block :177-193, Attention :235-260, window partition :263-318, decomposed
  * rel-pos :354-392, neck :92-108): images bf16 [V,3,img,img] -> embeddings fp32 [V, grid*grid, out_chans] (channels last).
  * Conv weights in GEMM layout: patch_w [D, 3*p*p], neck0_w [OC, D], neck2_w [OC, (ky,kx,OC)]; rel_cat = [rel_pos_h ; rel_pos_w]
- * zero-padded to a multiple of 8 rows (the rel-pos GEMM of the global blocks). */
+ * zero-padded to a multiple of 64 rows (the rel-pos GEMM of the global blocks; the attention kernel's table mode for the windows). */
 typedef struct {
     int embed_dim, depth, heads, grid, window, patch, img_size, out_chans, mlp_dim;
 } ivlm_sam_cfg;

@@ -705,6 +705,400 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
     }
 }
 
+// ======================================================================================================================
+// Window attention of the SAM ViT (14 x 14 windows: S = 196 keys, head dim 80, decomposed rel-pos bias), second generation.
+// The generic flash kernel above tiles keys by 64 and queries by 128: a 196-token window then runs a fourth key tile holding 4
+// keys, a second query block that is 53 % full, and re-stages K / V for it - with only four tiles per block the load pipeline
+// never fills (129 us per windowed block of 4 views; 28 of the encoder's 32 blocks are windowed).  Here ONE block owns one
+// (window, head): the whole K and V of the window sit in LDS (one barrier in total), 8 waves take the 13 query tiles of 16, and a
+// query tile is a single pass - all 208 (padded) scores in registers, no online-softmax rescaling:
+//     table product G^T = T . Q^T (rel-pos terms, see REL 4 above)  ->  S^T = K . Q^T + one-hot . rel   ->  softmax  ->  O^T = V^T . P^T.
+// SPLIT: hi + lo planes of q / k / v, three MFMAs per fragment, fp32 rel-pos terms, hi + lo output ("parity" precision); the hi + lo
+// K / V planes leave no LDS for the table-product scratch, so SPLIT reads the rel-pos terms from the fp32 arrays of
+// ivlm_relpos_bias_split (array mode) instead of computing them here (table mode).
+template <bool SPLIT>
+__global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
+    constexpr bool TAB = !SPLIT;
+    constexpr int DV = 80, KS = 3, DT = 5, DCH = 10;
+    constexpr int KT = 13;            // 16-key tiles (208 padded keys) of the score pass
+    constexpr int VS = 7;             // 32-key steps (224 padded keys) of the P.V pass
+    constexpr int SPK = KT * 16, SPV = VS * 32;
+    constexpr int KPL = SPK * 32 + 32, VPL = SPV * 16 + 16;   // plane strides (elements), padded like the tiles of attn_kernel
+    constexpr int KBUF = KS * KPL, VBUF = DT * VPL;
+    constexpr int kGW = 16 * 65;
+    extern __shared__ __attribute__((aligned(16))) unsigned char win_dyn[];
+    bf16_t* const Kh = reinterpret_cast<bf16_t*>(win_dyn);
+    bf16_t* const Kl = Kh + KBUF;                              // (SPLIT only)
+    bf16_t* const Vh = Kh + (SPLIT ? 2 : 1) * KBUF;
+    bf16_t* const Vl = Vh + VBUF;                              // (SPLIT only)
+    u32x4_t* const Hot = reinterpret_cast<u32x4_t*>(Vh + (SPLIT ? 2 : 1) * VBUF);  // one-hot rel-pos operands [KT][64 lanes]
+    float* const Gs = reinterpret_cast<float*>(Hot + KT * 64);                    // (table mode only)
+    bf16_t* const Tb = reinterpret_cast<bf16_t*>(Gs + 8 * kGW);                   // (table mode) the rel-pos table, K-plane layout
+    constexpr int TPL = 64 * 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    // XCD-aware block -> (window, head) map: consecutive block ids go to the 8 XCDs round-robin, and the 16 heads of a window read
+    // the SAME q|k|v rows (a head is a 160-byte segment of every 7680-byte row), so all heads of a window are given to ONE XCD,
+    // consecutively: its L2 then fetches the window's rows once instead of every XCD fetching them for its two heads
+    int b, h;
+    {
+        const int nb = a.B, H = a.H;
+        const int i = blockIdx.x, xcd = i & 7, j = i >> 3;
+        const int full = (nb / 8) * 8;             // windows covered by whole rounds of 8
+        const int w = (j / H) * 8 + xcd;
+        if (w < full) {
+            b = w;
+            h = j % H;
+        } else {                                   // tail windows (nb % 8): plain order
+            const int t = i - full * H;
+            b = full + t / H;
+            h = t % H;
+        }
+    }
+    const int S = a.Sq, side = a.rel_kh;
+    const bf16_t* __restrict__ Q = a.q + b * a.q_bs + h * a.q_hs;
+    const bf16_t* __restrict__ K = a.k + b * a.k_bs + h * a.k_hs;
+    const bf16_t* __restrict__ V = a.v + b * a.v_bs + h * a.v_hs;
+    const bf16_t* __restrict__ Ql = SPLIT ? a.q_lo + b * a.q_bs + h * a.q_hs : nullptr;
+    const bf16_t* __restrict__ Kl_g = SPLIT ? a.k_lo + b * a.k_bs + h * a.k_hs : nullptr;
+    const bf16_t* __restrict__ Vl_g = SPLIT ? a.v_lo + b * a.v_bs + h * a.v_hs : nullptr;
+
+    // ---- stage the whole window: K planes [k-step][key][32] (chunk swizzle of attn_kernel), V planes [d tile][key][16];
+    //      padded keys and the two pad chunks of K's third plane are zero -----------------------------------------------
+    // (all global loads of the block are issued before the first LDS store: a load -> store loop serialises ~5 memory round trips)
+    constexpr int NKC = (SPK * 12 + 511) / 512, NVC = (SPV * DCH + 511) / 512;
+    {
+        u32x4_t kr[NKC], vr[NVC], krl[SPLIT ? NKC : 1], vrl[SPLIT ? NVC : 1];
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            const int c = tid + i * 512;
+            const int key = c / 12, dch = c % 12;
+            const bool ok = key < S && dch < DCH;
+            const int64_t off = (int64_t)(ok ? key : 0) * a.k_rs + (ok ? dch : 0) * 8;
+            kr[i] = *reinterpret_cast<const u32x4_t*>(K + off);
+            if (SPLIT) krl[SPLIT ? i : 0] = *reinterpret_cast<const u32x4_t*>(Kl_g + off);
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = tid + i * 512;
+            const int key = c / DCH, dch = c % DCH;
+            const bool ok = key < S;
+            const int64_t off = (int64_t)(ok ? key : 0) * a.v_rs + dch * 8;
+            vr[i] = *reinterpret_cast<const u32x4_t*>(V + off);
+            if (SPLIT) vrl[SPLIT ? i : 0] = *reinterpret_cast<const u32x4_t*>(Vl_g + off);
+        }
+        const u32x4_t zero4 = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            const int c = tid + i * 512;
+            if (c < SPK * 12) {
+                const int key = c / 12, dch = c % 12;
+                const bool ok = key < S && dch < DCH;
+                const int phys = (dch & 3) ^ (((key >> 3) & 1) << 1);
+                const int off = (dch >> 2) * KPL + key * 32 + phys * 8;
+                *reinterpret_cast<u32x4_t*>(&Kh[off]) = ok ? kr[i] : zero4;
+                if (SPLIT) *reinterpret_cast<u32x4_t*>(&Kl[off]) = ok ? krl[SPLIT ? i : 0] : zero4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = tid + i * 512;
+            if (c < SPV * DCH) {
+                const int key = c / DCH, dch = c % DCH;
+                const bool ok = key < S;
+                const int off = (dch >> 1) * VPL + key * 16 + (dch & 1) * 8;
+                *reinterpret_cast<u32x4_t*>(&Vh[off]) = ok ? vr[i] : zero4;
+                if (SPLIT) *reinterpret_cast<u32x4_t*>(&Vl[off]) = ok ? vrl[SPLIT ? i : 0] : zero4;
+            }
+        }
+    }
+    if (TAB) {  // [rel_pos_h ; rel_pos_w ; 0] (64 rows x 80) as three k-step planes [row][32], chunk swizzle as K: 12 KB
+        const bf16_t* tabg = reinterpret_cast<const bf16_t*>(a.rel_h);
+        for (int c = tid; c < 64 * 12; c += 512) {
+            const int row = c / 12, dch = c % 12;
+            u32x4_t v4 = u32x4_t{0u, 0u, 0u, 0u};
+            if (dch < DCH) v4 = *reinterpret_cast<const u32x4_t*>(tabg + row * DV + dch * 8);
+            const int phys = (dch & 3) ^ (((row >> 3) & 1) << 1);
+            *reinterpret_cast<u32x4_t*>(&Tb[(dch >> 2) * TPL + row * 32 + phys * 8]) = v4;
+        }
+    }
+    // the one-hot (kh, side + kw) operand of every 16-key tile depends on the key alone: built once per block (13 KB), read back
+    // as one 16-byte fragment per tile by every query tile
+    for (int c = tid; c < (TAB ? KT * 64 : 0); c += 512) {  // (SPLIT: no LDS left - built per tile in registers)
+        const int kt = c >> 6, ln = c & 63;
+        const int key = kt * 16 + (ln & 15), gg = ln >> 4;
+        const int kh = key / a.rel_kh;
+        const int f1 = kh - gg * 8, f2 = a.rel_kh + (key - kh * a.rel_kh) - gg * 8;
+        u32x4_t w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = (f1 == 2 * j || f2 == 2 * j) ? 0x3F80u : 0u;
+            const uint32_t hi = (f1 == 2 * j + 1 || f2 == 2 * j + 1) ? 0x3F800000u : 0u;
+            w[j] = lo | hi;
+        }
+        Hot[c] = w;
+    }
+    __syncthreads();
+
+    const int kswz = (g ^ ((l15 >> 3) << 1)) * 8;
+    const int voff = (g * 4 + (l15 >> 2)) * 16 + (l15 & 3) * 4;
+    float* Gw = Gs + wave * kGW;
+    const float sc = a.scale;
+    const int nqt = (S + 15) >> 4;
+
+    // the (unscaled) query fragments of a wave's NEXT tile are fetched while it works on the current one
+    bf16x8_t qn[KS], qnl[SPLIT ? KS : 1];
+    auto fetch_q = [&](int qtile) __attribute__((always_inline)) {
+        int qi = qtile * 16 + l15;
+        qi = qi < S ? qi : S - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = (ks * 4 + g) * 8;
+            u32x4_t u = u32x4_t{0u, 0u, 0u, 0u}, ul = u;
+            if (d0 < DV) {
+                u = *reinterpret_cast<const u32x4_t*>(Q + (int64_t)qi * a.q_rs + d0);
+                if (SPLIT) ul = *reinterpret_cast<const u32x4_t*>(Ql + (int64_t)qi * a.q_rs + d0);
+            }
+            qn[ks] = __builtin_bit_cast(bf16x8_t, u);
+            if (SPLIT) qnl[SPLIT ? ks : 0] = __builtin_bit_cast(bf16x8_t, ul);
+        }
+    };
+    if (wave < nqt) fetch_q(wave);
+    for (int qtile = wave; qtile < nqt; qtile += 8) {
+        int qi = qtile * 16 + l15;
+        const bool q_ok = qi < S;
+        qi = q_ok ? qi : S - 1;
+        // ---- query fragments (unscaled) and the rel-pos table product --------------------------------------------------
+        bf16x8_t qf[KS], qfl[SPLIT ? KS : 1];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = qn[ks];
+            if (SPLIT) qfl[SPLIT ? ks : 0] = qnl[SPLIT ? ks : 0];
+        }
+        if (qtile + 8 < nqt) fetch_q(qtile + 8);
+        float f[8];
+        if (TAB) {
+            f32x4_t gacc[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) gacc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(&Tb[ks * TPL + (rt * 16 + l15) * 32 + kswz]);
+                    gacc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, qf[ks], gacc[rt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Gw[l15 * 65 + rt * 16 + g * 4 + r] = gacc[rt][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int qh = qi / side, qw = qi - qh * side;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int fi = g * 8 + e;
+                float v = 0.0f;
+                if (fi < side) v = Gw[l15 * 65 + qh - fi + side - 1];
+                else if (fi < 2 * side) v = Gw[l15 * 65 + (2 * side - 1) + qw - (fi - side) + side - 1];
+                f[e] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        } else {  // array mode: rel_h / rel_w f32 [B*H, S, side]
+            const int64_t bq = ((int64_t)b * a.H + h) * S + qi;
+            const float* rh = a.rel_h + bq * side;
+            const float* rw = a.rel_w + bq * side;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int fi = g * 8 + e;
+                f[e] = fi < side ? rh[fi] : (fi < 2 * side ? rw[fi - side] : 0.0f);
+            }
+        }
+        bf16x8_t qrel, qrel_lo, qrel_lo2;
+        {
+            u32x4_t uh, ul, ul2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t hh, ll;
+                split_bf16x2(f[2 * e], f[2 * e + 1], hh, ll);
+                uh[e] = hh;
+                if (SPLIT) {
+                    const float r0 = (f[2 * e] - __uint_as_float(hh << 16)) - __uint_as_float(ll << 16);
+                    const float r1 = (f[2 * e + 1] - __uint_as_float(hh & 0xffff0000u)) - __uint_as_float(ll & 0xffff0000u);
+                    ul[e] = ll;
+                    ul2[e] = pack_bf16x2(r0, r1);
+                }
+            }
+            qrel = __builtin_bit_cast(bf16x8_t, uh);  // default precision: the terms rounded to bf16, as the bf16 reference holds them
+            if (SPLIT) {
+                qrel_lo = __builtin_bit_cast(bf16x8_t, ul);
+                qrel_lo2 = __builtin_bit_cast(bf16x8_t, ul2);
+            }
+        }
+        // ---- q * scale (bf16-rounded in default precision like SAM's bf16 model; fp32 on hi + lo in SPLIT) --------------
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4_t uh = __builtin_bit_cast(u32x4_t, qf[ks]);
+            if (SPLIT) {
+                u32x4_t ul = __builtin_bit_cast(u32x4_t, qfl[SPLIT ? ks : 0]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = (__uint_as_float(uh[e] << 16) + __uint_as_float(ul[e] << 16)) * sc;
+                    const float x1 = (__uint_as_float(uh[e] & 0xffff0000u) + __uint_as_float(ul[e] & 0xffff0000u)) * sc;
+                    uint32_t hh, ll;
+                    split_bf16x2(x0, x1, hh, ll);
+                    uh[e] = hh;
+                    ul[e] = ll;
+                }
+                qfl[SPLIT ? ks : 0] = __builtin_bit_cast(bf16x8_t, ul);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    uh[e] = pack_bf16x2(__uint_as_float(uh[e] << 16) * sc, __uint_as_float(uh[e] & 0xffff0000u) * sc);
+            }
+            qf[ks] = __builtin_bit_cast(bf16x8_t, uh);
+        }
+        // ---- S^T = K . Q^T + bias: s[kt] holds keys kt*16 + g*4 + r of query l15 -----------------------------------------
+        f32x4_t s[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            s[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&Kh[ks * KPL + (kt * 16 + l15) * 32 + kswz]);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                if (SPLIT) {
+                    const bf16x8_t kfl = *reinterpret_cast<const bf16x8_t*>(&Kl[ks * KPL + (kt * 16 + l15) * 32 + kswz]);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[SPLIT ? ks : 0], s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qf[ks], s[kt], 0, 0, 0);
+                }
+            }
+            bf16x8_t hot;
+            if (TAB) {
+                hot = __builtin_bit_cast(bf16x8_t, Hot[kt * 64 + lane]);
+            } else {
+                const int key = kt * 16 + l15;
+                const int kh = key / side;
+                const int f1 = kh - g * 8, f2 = side + (key - kh * side) - g * 8;
+                u32x4_t w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t lo = (f1 == 2 * j || f2 == 2 * j) ? 0x3F80u : 0u;
+                    const uint32_t hi = (f1 == 2 * j + 1 || f2 == 2 * j + 1) ? 0x3F800000u : 0u;
+                    w[j] = lo | hi;
+                }
+                hot = __builtin_bit_cast(bf16x8_t, w);
+            }
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel, s[kt], 0, 0, 0);
+            if (SPLIT) {
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo, s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo2, s[kt], 0, 0, 0);
+            }
+        }
+        // ---- one-pass softmax over the S valid keys (log2 domain; padded keys -> probability exactly 0) -------------------
+        constexpr int ktl = KT - 1;  // the only tile that can hold padded keys
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (ktl * 16 + g * 4 + r >= S) s[ktl][r] = kNegBig;
+        float mx = kNegBig;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = groups_max(mx) * kLog2e;
+        float rs = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], kLog2e, -mx));
+                s[kt][r] = p;
+                rs += p;
+            }
+        const float inv = 1.0f / groups_sum(rs);
+        // ---- O^T = V^T . P^T over 7 steps of 32 keys (the 14th 16-key tile does not exist: zeros) -------------------------
+        f32x4_t o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < VS; ++s2) {
+            const f32x4_t sa = s[2 * s2];
+            const f32x4_t sb = (2 * s2 + 1 < KT) ? s[(2 * s2 + 1 < KT) ? 2 * s2 + 1 : 0] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            u32x4_t u, ul;
+            u[0] = pack_bf16x2(sa[0], sa[1]);
+            u[1] = pack_bf16x2(sa[2], sa[3]);
+            u[2] = pack_bf16x2(sb[0], sb[1]);
+            u[3] = pack_bf16x2(sb[2], sb[3]);
+            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, u);
+            bf16x8_t pfl;
+            if (SPLIT) {
+                ul[0] = pack_bf16x2(sa[0] - __uint_as_float(u[0] << 16), sa[1] - __uint_as_float(u[0] & 0xffff0000u));
+                ul[1] = pack_bf16x2(sa[2] - __uint_as_float(u[1] << 16), sa[3] - __uint_as_float(u[1] & 0xffff0000u));
+                ul[2] = pack_bf16x2(sb[0] - __uint_as_float(u[2] << 16), sb[1] - __uint_as_float(u[2] & 0xffff0000u));
+                ul[3] = pack_bf16x2(sb[2] - __uint_as_float(u[3] << 16), sb[3] - __uint_as_float(u[3] & 0xffff0000u));
+                pfl = __builtin_bit_cast(bf16x8_t, ul);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+                typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                const bf16_t* vp = Vh + dt * VPL + (2 * s2) * 16 * 16 + voff;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vp));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vp + 16 * 16));
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+                if (SPLIT) {
+                    const bf16_t* vpl = Vl + dt * VPL + (2 * s2) * 16 * 16 + voff;
+                    const s16x4_t lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vpl));
+                    const s16x4_t hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vpl + 16 * 16));
+                    const bf16x8_t vfl = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7));
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- normalise and store: lane holds O[query l15][d = dt*16 + g*4 + r] ---------------------------------------------
+        if (q_ok) {
+            bf16_t* __restrict__ O = a.o + b * a.o_bs + h * a.o_hs + (int64_t)qi * a.o_rs;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                if (SPLIT) {
+                    uint2 wh, wl;
+                    split_bf16x2(o[dt][0] * inv, o[dt][1] * inv, wh.x, wl.x);
+                    split_bf16x2(o[dt][2] * inv, o[dt][3] * inv, wh.y, wl.y);
+                    *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) = wh;
+                    *reinterpret_cast<uint2*>(a.o_lo + b * a.o_bs + h * a.o_hs + (int64_t)qi * a.o_rs + dt * 16 + g * 4) = wl;
+                } else {
+                    *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) =
+                        make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+                }
+            }
+        }
+    }
+}
+
+static int g_win_v2 = 1;  // 0: the generic flash kernel for windows too (A/B hook: ivlm_attention_window_kernel)
+
+template <bool SPLIT>
+static int launch_win(const AttnArgs& a, hipStream_t st) {
+    constexpr int KS = 3, DT = 5, KPL = 13 * 16 * 32 + 32, VPL = 7 * 32 * 16 + 16;
+    constexpr size_t lds = (size_t)(SPLIT ? 2 : 1) * (KS * KPL + DT * VPL) * 2 +
+                           (SPLIT ? 0 : (size_t)13 * 64 * 16 + 8 * 16 * 65 * 4 + 3 * 64 * 32 * 2);
+    static_assert(lds <= 160 * 1024, "window tiles must fit the LDS");
+    auto kfn = win_attn_kernel<SPLIT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    kfn<<<dim3(a.H * a.B), 512, lds, st>>>(a);
+    return ivlm_launch_status();
+}
+
 static int g_attn_pp = -1;  // -1 automatic; 0 / 1 force the 4-wave / 8-wave ping-pong kernel (benchmark hook)
 void attn_set_pingpong(int mode) { g_attn_pp = mode; }
 
@@ -774,6 +1168,12 @@ int launch_d(const AttnArgs& a, hipStream_t st) {
     // the 8-wave ping-pong block (256 queries) is opt-in: measured 5-15 % SLOWER than two independent 4-wave blocks per CU on
     // every shape of the path (SAM global 634 vs 604 us, windows 151 vs 132 us) - the loop is bound by the issue latency of
     // the dependent softmax chain, not by the two waves of a SIMD contending for the same unit
+    if constexpr (DV == 80) {  // SAM's windows: the whole-window kernel (default precision: table mode; SPLIT: array mode)
+        const bool win = g_win_v2 && a.rel_h && a.Sq <= 208 && a.Sq == a.Sk && !a.causal && a.prescale_q && a.H <= 65535 &&
+                         a.B <= 65535 && a.rel_kh == a.rel_kw && 2 * a.rel_kh <= 32 && a.Sq == a.rel_kh * a.rel_kw;
+        if (win && !a.q_lo && !a.rel_w) return launch_win<false>(a, st);
+        if (g_win_v2 > 1 && win && a.q_lo && a.rel_w) return launch_win<true>(a, st);  // (opt-in: the SPLIT instantiation spills)
+    }
     if (a.q_lo) return launch_split<DQK, DV>(a, st);
     const bool pp = g_attn_pp > 0;
     return pp ? launch_dp<DQK, DV, true>(a, st) : launch_dp<DQK, DV, false>(a, st);
@@ -1015,6 +1415,11 @@ int ivlm_relpos_gather(const void* G, int64_t g_head_stride, int npad, int B, in
     ivlm_enter();
     return ivlm::relpos_gather(static_cast<const bf16_t*>(G), g_head_stride, npad, B, H, SH, SW, rel_h, rel_w,
                                ivlm_stream(stream));
+}
+
+int ivlm_attention_window_kernel(int v2) {  // benchmark/test hook: 1 (default) whole-window kernel, 0 generic flash kernel
+    ivlm::g_win_v2 = v2;
+    return 0;
 }
 
 int ivlm_attention_pingpong(int mode) {  // benchmark/test hook: -1 automatic, 0 four-wave kernel, 1 eight-wave ping-pong

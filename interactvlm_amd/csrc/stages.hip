@@ -420,6 +420,11 @@ extern "C" int ivlm_sam_encode(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, c
             gg.M = M; gg.N = npad; gg.K = hdim; gg.batch = H; gg.strideA = hdim; gg.strideW = 0; gg.strideC = (int64_t)M * npad;
             if ((rc = linear_bf16(gg, st))) return rc;
             if ((rc = ivlm_relpos_gather(G, (int64_t)M * npad, npad, nb, H, side, side, rh, rw, stream))) return rc;
+        } else if (2 * side <= 32 && hdim == 80 && 2 * (2 * side - 1) <= 64) {
+            // windows: TABLE MODE of the attention kernel - it computes the decomposed rel-pos terms itself from rel_cat
+            // ([rel_pos_h ; rel_pos_w] zero-padded to 64 rows): no relpos pass, no [nb*H, S, 2 side] arrays
+            rh = reinterpret_cast<float*>(const_cast<void*>(Bk.rel_cat));
+            rw = nullptr;
         } else {
             rh = relh_w; rw = relw_w;
             if ((rc = relpos_bias(qkv, (int64_t)S * 3 * D, hdim, 3 * D, static_cast<const bf16_t*>(Bk.rel_h), static_cast<const bf16_t*>(Bk.rel_w),

@@ -613,9 +613,10 @@ def attention_f32(q, k, v, scale, out=None):
 
 
 def relpos_tables_cat(tab_h, tab_w):
-    """[rel_pos_h ; rel_pos_w] padded with zero rows to a multiple of 8: the weight matrix of the GEMM formulation."""
+    """[rel_pos_h ; rel_pos_w] padded with zero rows to a multiple of 64: the weight matrix of the GEMM formulation (global
+    blocks: 254 -> 256 rows) and the table of the attention kernels' table mode (windows: 54 -> 64 rows)."""
     n = tab_h.shape[0] + tab_w.shape[0]
-    cat = torch.zeros((n + 7) // 8 * 8, tab_h.shape[1], dtype=BF16, device=tab_h.device)
+    cat = torch.zeros((n + 63) // 64 * 64, tab_h.shape[1], dtype=BF16, device=tab_h.device)
     cat[: tab_h.shape[0]] = tab_h
     cat[tab_h.shape[0]: n] = tab_w
     return cat

@@ -158,9 +158,9 @@ class SamImageEncoder:
         if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
             # windows: the decomposed rel-pos terms are computed inside the attention kernel (one small MFMA product per query
             # tile against the [rel_pos_h ; rel_pos_w] table) - no relpos pass, no [B*H, S, 2 side] fp32 arrays
-            if "rel_tab64" not in blk:
-                blk["rel_tab64"] = ops.relpos_table64(blk["rel_h"], blk["rel_w"])
-            o = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_tab64"], side))
+            if "rel_cat" not in blk:
+                blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
+            o = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_cat"], side))
             return o.permute(0, 2, 1, 3).reshape(nwin * S, H * hd)
         if "rel_cat" not in blk:
             blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
@@ -187,9 +187,9 @@ class SamImageEncoder:
         qkv5 = qkv.view(nw_, S, 3, H, hd)
         q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
-            if "rel_tab64" not in blk:
-                blk["rel_tab64"] = ops.relpos_table64(blk["rel_h"], blk["rel_w"])
-            a = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_tab64"], side)).permute(0, 2, 1, 3).reshape(nw_ * S, H * hd)
+            if "rel_cat" not in blk:
+                blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
+            a = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_cat"], side)).permute(0, 2, 1, 3).reshape(nw_ * S, H * hd)
         else:
             if "rel_cat" not in blk:
                 blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
@@ -278,9 +278,9 @@ class SamImageEncoder:
         hi = [q6[:, :, 0, i].permute(0, 2, 1, 3) for i in range(3)]
         lo = [q6[:, :, 1, i].permute(0, 2, 1, 3) for i in range(3)]
         if self.rel_in_kernel and 2 * side <= 32 and hd == 80:  # windows: fp32 rel-pos terms from the table, inside the kernel
-            if "rel_tab64" not in blk:
-                blk["rel_tab64"] = ops.relpos_table64(blk["rel_h"], blk["rel_w"])
-            return ops.attention_split(hi[0], lo[0], hi[1], lo[1], hi[2], lo[2], hd ** -0.5, rel_tab=(blk["rel_tab64"], side))
+            if "rel_cat" not in blk:
+                blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
+            return ops.attention_split(hi[0], lo[0], hi[1], lo[1], hi[2], lo[2], hd ** -0.5, rel_tab=(blk["rel_cat"], side))
         rel = ops.relpos_bias_split(hi[0], lo[0], blk["rel_h"], blk["rel_w"], side, side)
         return ops.attention_split(hi[0], lo[0], hi[1], lo[1], hi[2], lo[2], hd ** -0.5, rel=rel)  # [nwin*S, 2D]
 
