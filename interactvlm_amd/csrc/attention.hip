@@ -719,6 +719,8 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
 template <bool SPLIT>
 __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
     constexpr bool TAB = !SPLIT;
+    // 8 waves (two per SIMD); SPLIT holds its register use under 256 with scheduling barriers in the fragment loops
+    constexpr int NT = 512, NWV = NT / 64;
     constexpr int DV = 80, KS = 3, DT = 5, DCH = 10;
     constexpr int KT = 13;            // 16-key tiles (208 padded keys) of the score pass
     constexpr int VS = 7;             // 32-key steps (224 padded keys) of the P.V pass
@@ -733,7 +735,7 @@ __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
     bf16_t* const Vl = Vh + VBUF;                              // (SPLIT only)
     u32x4_t* const Hot = reinterpret_cast<u32x4_t*>(Vh + (SPLIT ? 2 : 1) * VBUF);  // one-hot rel-pos operands [KT][64 lanes]
     float* const Gs = reinterpret_cast<float*>(Hot + KT * 64);                    // (table mode only)
-    bf16_t* const Tb = reinterpret_cast<bf16_t*>(Gs + 8 * kGW);                   // (table mode) the rel-pos table, K-plane layout
+    bf16_t* const Tb = reinterpret_cast<bf16_t*>(Gs + NWV * kGW);                   // (table mode) the rel-pos table, K-plane layout
     constexpr int TPL = 64 * 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -767,31 +769,31 @@ __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
     // ---- stage the whole window: K planes [k-step][key][32] (chunk swizzle of attn_kernel), V planes [d tile][key][16];
     //      padded keys and the two pad chunks of K's third plane are zero -----------------------------------------------
     // (all global loads of the block are issued before the first LDS store: a load -> store loop serialises ~5 memory round trips)
-    constexpr int NKC = (SPK * 12 + 511) / 512, NVC = (SPV * DCH + 511) / 512;
+    constexpr int NKC = (SPK * 12 + NT - 1) / NT, NVC = (SPV * DCH + NT - 1) / NT;
+    const u32x4_t zero4 = u32x4_t{0u, 0u, 0u, 0u};
     {
-        u32x4_t kr[NKC], vr[NVC], krl[SPLIT ? NKC : 1], vrl[SPLIT ? NVC : 1];
+        u32x4_t kr[NKC], krl[SPLIT ? NKC : 1];
+        u32x4_t vr[SPLIT ? 1 : NVC];  // (default precision: K and V in flight together; SPLIT: K, then V - register budget)
 #pragma unroll
         for (int i = 0; i < NKC; ++i) {
-            const int c = tid + i * 512;
+            const int c = tid + i * NT;
             const int key = c / 12, dch = c % 12;
             const bool ok = key < S && dch < DCH;
             const int64_t off = (int64_t)(ok ? key : 0) * a.k_rs + (ok ? dch : 0) * 8;
             kr[i] = *reinterpret_cast<const u32x4_t*>(K + off);
             if (SPLIT) krl[SPLIT ? i : 0] = *reinterpret_cast<const u32x4_t*>(Kl_g + off);
         }
+        if (!SPLIT) {
 #pragma unroll
-        for (int i = 0; i < NVC; ++i) {
-            const int c = tid + i * 512;
-            const int key = c / DCH, dch = c % DCH;
-            const bool ok = key < S;
-            const int64_t off = (int64_t)(ok ? key : 0) * a.v_rs + dch * 8;
-            vr[i] = *reinterpret_cast<const u32x4_t*>(V + off);
-            if (SPLIT) vrl[SPLIT ? i : 0] = *reinterpret_cast<const u32x4_t*>(Vl_g + off);
+            for (int i = 0; i < NVC; ++i) {
+                const int c = tid + i * NT;
+                const int key = c / DCH, dch = c % DCH;
+                vr[SPLIT ? 0 : i] = *reinterpret_cast<const u32x4_t*>(V + (int64_t)(key < S ? key : 0) * a.v_rs + dch * 8);
+            }
         }
-        const u32x4_t zero4 = u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < NKC; ++i) {
-            const int c = tid + i * 512;
+            const int c = tid + i * NT;
             if (c < SPK * 12) {
                 const int key = c / 12, dch = c % 12;
                 const bool ok = key < S && dch < DCH;
@@ -801,21 +803,41 @@ __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
                 if (SPLIT) *reinterpret_cast<u32x4_t*>(&Kl[off]) = ok ? krl[SPLIT ? i : 0] : zero4;
             }
         }
+        if (!SPLIT) {
+#pragma unroll
+            for (int i = 0; i < NVC; ++i) {
+                const int c = tid + i * NT;
+                if (c < SPV * DCH) {
+                    const int key = c / DCH, dch = c % DCH;
+                    *reinterpret_cast<u32x4_t*>(&Vh[(dch >> 1) * VPL + key * 16 + (dch & 1) * 8]) = key < S ? vr[SPLIT ? 0 : i] : zero4;
+                }
+            }
+        }
+    }
+    if (SPLIT) {
+        u32x4_t vr[NVC], vrl[NVC];
 #pragma unroll
         for (int i = 0; i < NVC; ++i) {
-            const int c = tid + i * 512;
+            const int c = tid + i * NT;
+            const int key = c / DCH, dch = c % DCH;
+            const int64_t off = (int64_t)(key < S ? key : 0) * a.v_rs + dch * 8;
+            vr[i] = *reinterpret_cast<const u32x4_t*>(V + off);
+            vrl[i] = *reinterpret_cast<const u32x4_t*>(Vl_g + off);
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = tid + i * NT;
             if (c < SPV * DCH) {
                 const int key = c / DCH, dch = c % DCH;
-                const bool ok = key < S;
                 const int off = (dch >> 1) * VPL + key * 16 + (dch & 1) * 8;
-                *reinterpret_cast<u32x4_t*>(&Vh[off]) = ok ? vr[i] : zero4;
-                if (SPLIT) *reinterpret_cast<u32x4_t*>(&Vl[off]) = ok ? vrl[SPLIT ? i : 0] : zero4;
+                *reinterpret_cast<u32x4_t*>(&Vh[off]) = key < S ? vr[i] : zero4;
+                *reinterpret_cast<u32x4_t*>(&Vl[off]) = key < S ? vrl[i] : zero4;
             }
         }
     }
     if (TAB) {  // [rel_pos_h ; rel_pos_w ; 0] (64 rows x 80) as three k-step planes [row][32], chunk swizzle as K: 12 KB
         const bf16_t* tabg = reinterpret_cast<const bf16_t*>(a.rel_h);
-        for (int c = tid; c < 64 * 12; c += 512) {
+        for (int c = tid; c < 64 * 12; c += NT) {
             const int row = c / 12, dch = c % 12;
             u32x4_t v4 = u32x4_t{0u, 0u, 0u, 0u};
             if (dch < DCH) v4 = *reinterpret_cast<const u32x4_t*>(tabg + row * DV + dch * 8);
@@ -825,7 +847,7 @@ __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
     }
     // the one-hot (kh, side + kw) operand of every 16-key tile depends on the key alone: built once per block (13 KB), read back
     // as one 16-byte fragment per tile by every query tile
-    for (int c = tid; c < (TAB ? KT * 64 : 0); c += 512) {  // (SPLIT: no LDS left - built per tile in registers)
+    for (int c = tid; c < (TAB ? KT * 64 : 0); c += NT) {  // (SPLIT: no LDS left - built per tile in registers)
         const int kt = c >> 6, ln = c & 63;
         const int key = kt * 16 + (ln & 15), gg = ln >> 4;
         const int kh = key / a.rel_kh;
@@ -865,7 +887,7 @@ __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
         }
     };
     if (wave < nqt) fetch_q(wave);
-    for (int qtile = wave; qtile < nqt; qtile += 8) {
+    for (int qtile = wave; qtile < nqt; qtile += NWV) {
         int qi = qtile * 16 + l15;
         const bool q_ok = qi < S;
         qi = q_ok ? qi : S - 1;
@@ -876,7 +898,7 @@ __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
             qf[ks] = qn[ks];
             if (SPLIT) qfl[SPLIT ? ks : 0] = qnl[SPLIT ? ks : 0];
         }
-        if (qtile + 8 < nqt) fetch_q(qtile + 8);
+        if (qtile + NWV < nqt) fetch_q(qtile + NWV);
         float f[8];
         if (TAB) {
             f32x4_t gacc[4];
@@ -996,6 +1018,7 @@ __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
             if (SPLIT) {
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo, s[kt], 0, 0, 0);
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo2, s[kt], 0, 0, 0);
+                if (kt & 1) __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting all 78 fragment reads: spills)
             }
         }
         // ---- one-pass softmax over the S valid keys (log2 domain; padded keys -> probability exactly 0) -------------------
@@ -1060,6 +1083,7 @@ __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf, o[dt], 0, 0, 0);
                 }
             }
+            if (SPLIT) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- normalise and store: lane holds O[query l15][d = dt*16 + g*4 + r] ---------------------------------------------
         if (q_ok) {
@@ -1172,7 +1196,7 @@ int launch_d(const AttnArgs& a, hipStream_t st) {
         const bool win = g_win_v2 && a.rel_h && a.Sq <= 208 && a.Sq == a.Sk && !a.causal && a.prescale_q && a.H <= 65535 &&
                          a.B <= 65535 && a.rel_kh == a.rel_kw && 2 * a.rel_kh <= 32 && a.Sq == a.rel_kh * a.rel_kw;
         if (win && !a.q_lo && !a.rel_w) return launch_win<false>(a, st);
-        if (g_win_v2 > 1 && win && a.q_lo && a.rel_w) return launch_win<true>(a, st);  // (opt-in: the SPLIT instantiation spills)
+        if (win && a.q_lo && a.rel_w) return launch_win<true>(a, st);
     }
     if (a.q_lo) return launch_split<DQK, DV>(a, st);
     const bool pp = g_attn_pp > 0;

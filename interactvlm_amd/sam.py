@@ -117,6 +117,7 @@ class SamImageEncoder:
     # stream stays fp32.
     fp8 = False
     rel_in_kernel = True  # window attention computes its rel-pos terms itself (ops.attention rel_tab=...); False: relpos kernel
+    parity_window_arrays = True
 
     def enable_fp8(self, calib_images):
         """calib_images [V,3,S,S]: one bf16 pass records the activation ranges, then the fp8 path is switched on."""
@@ -277,7 +278,9 @@ class SamImageEncoder:
         q6 = qkv.view(nwin, S, 2, 3, H, hd)
         hi = [q6[:, :, 0, i].permute(0, 2, 1, 3) for i in range(3)]
         lo = [q6[:, :, 1, i].permute(0, 2, 1, 3) for i in range(3)]
-        if self.rel_in_kernel and 2 * side <= 32 and hd == 80:  # windows: fp32 rel-pos terms from the table, inside the kernel
+        # windows: the whole-window split kernel has no LDS left for the table product, it takes the fp32 terms as arrays
+        # (parity_window_arrays; measured faster than the generic split kernel in table mode)
+        if self.rel_in_kernel and not self.parity_window_arrays and 2 * side <= 32 and hd == 80:
             if "rel_cat" not in blk:
                 blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
             return ops.attention_split(hi[0], lo[0], hi[1], lo[1], hi[2], lo[2], hd ** -0.5, rel_tab=(blk["rel_cat"], side))

@@ -27,6 +27,7 @@ def main():
       for rik in ((True, False) if os.environ.get("AB_REL") else (True,)):
         enc.precision = mode
         enc.rel_in_kernel = rik
+        enc.parity_window_arrays = os.environ.get("PWA", "1") == "1"
         if hasattr(enc, "_graphs"):
             enc._graphs.clear()
         enc(im[0])
