@@ -187,9 +187,36 @@ class InteractVLMForCausalLM:
         return self.model.visual_model.image_encoder(images_views.to(self.device))
 
     def forward(self, **kwargs):
-        if "past_key_values" in kwargs:
-            raise NotImplementedError("the HF generate() protocol is replaced by the KV-cached loop in evaluate()")
+        if "past_key_values" in kwargs:  # InteractVLM.py:263-266: the HF causal-LM forward (what HF generate() calls per step)
+            return self._causal_lm_forward(**kwargs)
         return self.model_forward(**kwargs)
+
+    @torch.no_grad()
+    def _causal_lm_forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
+                           use_cache=None, output_attentions=None, output_hidden_states=None, images=None, return_dict=None):
+        """LlavaLlamaForCausalLM.forward (llava_llama.py:55-135) for ONE sequence, inference only: logits, the last hidden state
+        (eval-mode `hidden_states`, :121-124) and a cache handle.  past_key_values None (or use_cache False, the reference's own
+        setting: InteractVLM.py:128): the whole sequence from position 0, `images` [1,3,h,w] spliced in at the image placeholder
+        (llava_arch.py:98-123).  past_key_values = the handle a previous call returned: only the LAST id is new and is decoded
+        against this model's KV cache.  The cache lives in the model (one sequence at a time), the handle is its length."""
+        if labels is not None or inputs_embeds is not None or output_attentions:
+            raise NotImplementedError("inference-only route: no labels / inputs_embeds / attention maps")
+        ids = input_ids.reshape(-1).to(self.device)
+        if past_key_values is None:
+            if images is not None and bool((ids == IMAGE_TOKEN_INDEX).any()):
+                x = self._input_embeds(ids, self.encode_images(images)[0])
+            else:
+                x = self.llm.embed_ids(ids.to(torch.int32).contiguous())
+            pos0 = 0
+        else:
+            pos0 = int(past_key_values.length)
+            x = self.llm.embed_ids(ids[-1:].to(torch.int32).contiguous())
+        if pos0 + x.shape[0] > self.llm.max_len:
+            raise ops.IvlmError(f"sequence of {pos0 + x.shape[0]} positions exceeds the KV cache (max_len={self.llm.max_len})")
+        h = self.llm.forward(x, pos0)
+        logits = torch.cat([self.llm.logits(h[i: i + 16]) for i in range(0, h.shape[0], 16)], 0)  # fp32 rows, exact products
+        cache = SimpleNamespace(length=pos0 + x.shape[0]) if (use_cache or past_key_values is not None) else None
+        return SimpleNamespace(loss=None, logits=logits[None], past_key_values=cache, hidden_states=h[None], attentions=None)
 
     def process_embeddings(self, embedding, cam_params, token):
         """[n_seg,V,256] view conditioning (InteractVLM.py:268-294)."""

@@ -737,3 +737,37 @@ def test_difde_decoders_selected_by_dataset_name(hip_lib, cuda):
             assert torch.equal(out["pred_masks"][0], out2["pred_masks"][0])
             assert torch.equal(out["pred_contact_3d"], out2["pred_contact_3d"])
         del m2
+
+
+def test_forward_with_past_key_values_is_the_causal_lm_forward(hip_lib, cuda):
+    """forward(past_key_values=...) (InteractVLM.py:263-266 -> llava_llama.py:55-135): a greedy loop driven through it - full
+    sequence first, then one id at a time against the cache handle - yields the ids and hidden states of generate(); with
+    past_key_values=None every call re-runs the whole sequence (the reference's use_cache=False behaviour)."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth, synthetic
+    from interactvlm_amd import weights as Wt
+
+    cfg = synthetic.config_tiny()
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=synth.synth_mesh_tables(4, 64, 64, 6890, fg=0.4, seed=0))
+    m.graph_decode = False
+    ids, _ = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=8)
+    ic, _ = synthetic.images(cfg, cuda)
+    out_ids, hidden = m.generate(ic, ids, max_new_tokens=6, eos_token_id=-1)
+    new = out_ids[0, ids.shape[1]:].tolist()
+    o = m.forward(input_ids=ids, images=ic, past_key_values=None, use_cache=True)
+    assert o.logits.shape == (1, ids.shape[1] + cfg.img_emb_len, cfg.llama.vocab) and o.past_key_values.length == hidden.shape[0] - 5
+    got = [int(o.logits[0, -1].argmax())]
+    cur = ids
+    for _ in range(5):
+        cur = torch.cat([cur, torch.tensor([[got[-1]]])], 1)
+        o = m.forward(input_ids=cur, past_key_values=o.past_key_values, use_cache=True)
+        assert o.logits.shape[1] == 1
+        got.append(int(o.logits[0, -1].argmax()))
+    assert got == new
+    # stateless form: the whole sequence again, same last-row logits as the cached step
+    o2 = m.forward(input_ids=cur, images=ic, past_key_values=None)
+    assert o2.past_key_values is None and int(o2.logits[0, -1].argmax()) == got[-1]
+    assert torch.allclose(o2.hidden_states[0, -1], o.hidden_states[0, -1], atol=2e-2, rtol=2e-2)
