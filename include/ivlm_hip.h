@@ -374,6 +374,12 @@ typedef struct {
 size_t ivlm_sam_encode_workspace_bytes(const ivlm_sam_cfg *cfg, int V);
 int ivlm_sam_encode(const ivlm_sam_cfg *cfg, const ivlm_sam_head *head, const ivlm_sam_block *blocks_host, const void *images, int V,
                     float *embeddings_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* The same stage in "parity" precision (the mode that holds 1e-3 against the reference's fp32 path at the real depth): no
+ * activation is rounded to bf16 - split LayerNorm outputs, split-operand / split-output GEMMs, split-operand attention with fp32
+ * rel-pos terms.  Same structs, its own workspace size (head dim 80). */
+size_t ivlm_sam_encode_parity_workspace_bytes(const ivlm_sam_cfg *cfg, int V);
+int ivlm_sam_encode_parity(const ivlm_sam_cfg *cfg, const ivlm_sam_head *head, const ivlm_sam_block *blocks_host, const void *images,
+                           int V, float *embeddings_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
 
 /* PromptEncoder.forward(text_embeds) + MaskDecoder.forward(multimask_output=False) (prompt_encoder.py:140-186,
  * mask_decoder.py:75-164, transformer.py:62-242) with fp32 activations end to end: image_embeddings fp32 [V, grid*grid, C]

@@ -261,8 +261,17 @@ __global__ void fill_pad_rows_kernel(bf16_t* __restrict__ dst, int64_t ldd, cons
 // generic tile-GEMM call of the sequencers (bias, activation, bf16 / fp32 residual with row modulo, row maps, split-K rule)
 int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int out_f32, int64_t ldc, const void* bias,
          const void* res, int res_f32, int64_t ldr, int res_mod, int M, int N, int K, int act, const int32_t* out_rows,
-         const int32_t* a_rows, float* sk, size_t skb, hipStream_t st) {
+         const int32_t* a_rows, float* sk, size_t skb, hipStream_t st, int a_split = 0, int out_split = 0) {
     GemmArgs g;
+    if (a_split) {  // "parity" precision: A rows are [hi(K) | lo(K)] bf16
+        g.a_split = 1;
+        g.a_lo = K;
+    }
+    if (out_split) {  // the fp32 result written as [hi(N) | lo(N)] bf16 rows
+        g.out_split = 1;
+        g.c_lo = N;
+        out_f32 = 1;
+    }
     g.A = static_cast<const bf16_t*>(A);
     g.W = static_cast<const bf16_t*>(W);
     g.C = C;
@@ -448,6 +457,109 @@ extern "C" int ivlm_sam_encode(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, c
     if ((rc = im2col3x3_nhwc(n1, c3, V, g, g, OC, st))) return rc;
     if ((rc = gemm(c3, 9 * OC, hd->neck2_w, 9 * OC, n0, 0, OC, nullptr, nullptr, 0, 0, 0, R, OC, 9 * OC, ACT_NONE, nullptr, nullptr, nullptr, 0, st))) return rc;
     return layernorm(n0, 0, static_cast<const bf16_t*>(hd->neck3_w), static_cast<const bf16_t*>(hd->neck3_b), embeddings_out, 1, R, OC, 1e-6f, st);
+}
+
+// =====================================================================================================================
+// ivlm_sam_encode_parity: the same stage in "parity" precision - every activation that feeds an MFMA travels as [hi | lo] bf16
+// rows (split LayerNorm outputs, split-operand / split-output GEMMs, split-operand attention with fp32 rel-pos terms, split
+// neck) - the launch order of interactvlm_amd/sam.py SamImageEncoder._forward_parity (bit-identical to it).
+// =====================================================================================================================
+extern "C" size_t ivlm_sam_encode_parity_workspace_bytes(const ivlm_sam_cfg* c, int V) {
+    if (!c || V <= 0) return 0;
+    const size_t g2 = (size_t)c->grid * c->grid, rows = (size_t)V * g2, D = c->embed_dim;
+    const int nw = (c->grid + c->window - 1) / c->window;
+    const size_t wrows = (size_t)V * nw * nw * c->window * c->window, qrows = std::max(rows, wrows);
+    size_t b = al(rows * 3 * c->patch * c->patch * 2) + al(rows * D * 4) + al(rows * 2 * D * 2) + al(qrows * 6 * D * 2) +
+               al(qrows * 2 * D * 2) + al(rows * 2 * c->mlp_dim * 2);
+    b += 2 * al((size_t)V * c->heads * g2 * c->grid * 4);          // rel_h / rel_w of a global block
+    b += 2 * al(wrows * c->heads * c->window * 4);                  // ... of a windowed block
+    b += al(wrows * 4) + al(rows * 4) + al(6 * D * 2);             // part / unpart maps, the [bias | 0] row of the padded positions
+    b += al(rows * c->out_chans * 4) + al(rows * 2 * c->out_chans * 2) + al(rows * 18 * c->out_chans * 2);
+    return b + 1024;
+}
+
+extern "C" int ivlm_sam_encode_parity(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, const ivlm_sam_block* blocks_host,
+                                      const void* images, int V, float* embeddings_out, void* workspace, size_t workspace_bytes,
+                                      ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!c || !hd || !blocks_host || !images || !embeddings_out || !workspace || V <= 0) return IVLM_ERR_INVALID_ARG;
+    if (workspace_bytes < ivlm_sam_encode_parity_workspace_bytes(c, V)) return IVLM_ERR_WORKSPACE;
+    hipStream_t st = ivlm_stream(stream);
+    const int g = c->grid, D = c->embed_dim, H = c->heads, hdim = D / H, wsz = c->window, OC = c->out_chans, MD = c->mlp_dim;
+    const int nw = (g + wsz - 1) / wsz, g2 = g * g, R = V * g2, nwin = V * nw * nw, WS = wsz * wsz, WR = nwin * WS;
+    const int Kp = 3 * c->patch * c->patch;
+    if (hdim != 80) return IVLM_ERR_UNSUPPORTED;  // (the split attention / rel-pos kernels are built for SAM's head dim)
+    Carver cv{static_cast<char*>(workspace), workspace_bytes};
+    bf16_t* cols = static_cast<bf16_t*>(cv.take((size_t)R * Kp * 2));
+    float* x = static_cast<float*>(cv.take((size_t)R * D * 4));
+    bf16_t* xn = static_cast<bf16_t*>(cv.take((size_t)R * 2 * D * 2));
+    const size_t qrows = std::max(R, WR);
+    bf16_t* qkv = static_cast<bf16_t*>(cv.take(qrows * 6 * D * 2));
+    bf16_t* att = static_cast<bf16_t*>(cv.take(qrows * 2 * D * 2));
+    bf16_t* hh = static_cast<bf16_t*>(cv.take((size_t)R * 2 * MD * 2));
+    float* relh_g = static_cast<float*>(cv.take((size_t)V * H * g2 * g * 4));
+    float* relw_g = static_cast<float*>(cv.take((size_t)V * H * g2 * g * 4));
+    float* relh_w = static_cast<float*>(cv.take((size_t)WR * H * wsz * 4));
+    float* relw_w = static_cast<float*>(cv.take((size_t)WR * H * wsz * 4));
+    int32_t* part = static_cast<int32_t*>(cv.take((size_t)WR * 4));
+    int32_t* unpart = static_cast<int32_t*>(cv.take((size_t)R * 4));
+    bf16_t* brow = static_cast<bf16_t*>(cv.take((size_t)6 * D * 2));
+    float* n0 = static_cast<float*>(cv.take((size_t)R * OC * 4));
+    bf16_t* n1 = static_cast<bf16_t*>(cv.take((size_t)R * 2 * OC * 2));
+    bf16_t* c3 = static_cast<bf16_t*>(cv.take((size_t)R * 18 * OC * 2));
+    if (!cv.ok) return IVLM_ERR_WORKSPACE;
+    int rc;
+    sam_window_maps_kernel<<<256, 256, 0, st>>>(V, g, wsz, nw, part, unpart);
+    if ((rc = ivlm_launch_status())) return rc;
+    if ((rc = im2col_nchw(static_cast<const bf16_t*>(images), cols, V, 3, c->img_size, c->img_size, c->patch, c->patch, Kp, st))) return rc;
+    if ((rc = gemm(cols, Kp, hd->patch_w, Kp, x, 1, D, hd->patch_b, hd->pos_embed, 0, D, g2, R, D, Kp, ACT_NONE, nullptr, nullptr, nullptr, 0, st))) return rc;
+    const float scale = 1.0f / sqrtf((float)hdim);
+    for (int l = 0; l < c->depth; ++l) {
+        const ivlm_sam_block& Bk = blocks_host[l];
+        if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(Bk.norm1_w), static_cast<const bf16_t*>(Bk.norm1_b), xn, 2, R, D, 1e-6f, st))) return rc;
+        const int side = Bk.global_attn ? g : wsz, S = side * side, nb = Bk.global_attn ? V : nwin;
+        if (Bk.global_attn) {
+            if ((rc = gemm(xn, 2 * D, Bk.qkv_w, D, qkv, 0, 6 * D, Bk.qkv_b, nullptr, 0, 0, 0, R, 3 * D, D, ACT_NONE, nullptr, nullptr, nullptr, 0, st, 1, 1))) return rc;
+        } else {  // real rows scattered to their window positions; the padded positions get [bias | 0]
+            if ((rc = gemm(xn, 2 * D, Bk.qkv_w, D, qkv, 0, 6 * D, Bk.qkv_b, nullptr, 0, 0, 0, R, 3 * D, D, ACT_NONE, unpart, nullptr, nullptr, 0, st, 1, 1))) return rc;
+            IVLM_HIP_TRY(hipMemsetAsync(brow, 0, (size_t)6 * D * 2, st));
+            IVLM_HIP_TRY(hipMemcpyAsync(brow, Bk.qkv_b, (size_t)3 * D * 2, hipMemcpyDeviceToDevice, st));
+            fill_pad_rows_kernel<<<2048, 256, 0, st>>>(qkv, 6 * D, part, WR, brow, 6 * D);
+            if ((rc = ivlm_launch_status())) return rc;
+        }
+        float* rh = Bk.global_attn ? relh_g : relh_w;
+        float* rw = Bk.global_attn ? relw_g : relw_w;
+        // fp32 rel-pos terms from q = hi + lo (rows: [q k v hi | q k v lo], row stride 6 D)
+        if ((rc = relpos_bias(qkv, (int64_t)S * 6 * D, hdim, 6 * D, static_cast<const bf16_t*>(Bk.rel_h), static_cast<const bf16_t*>(Bk.rel_w),
+                              nb, H, side, side, hdim, rh, rw, st, qkv + 3 * D)))
+            return rc;
+        AttnArgs a{};
+        a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D;
+        a.q_lo = qkv + 3 * D; a.k_lo = qkv + 4 * D; a.v_lo = qkv + 5 * D;
+        a.o = att; a.o_lo = att + D;
+        a.q_bs = a.k_bs = a.v_bs = (int64_t)S * 6 * D;
+        a.q_hs = a.k_hs = a.v_hs = hdim;
+        a.q_rs = a.k_rs = a.v_rs = 6 * D;
+        a.o_bs = (int64_t)S * 2 * D; a.o_hs = hdim; a.o_rs = 2 * D;
+        a.B = nb; a.H = H; a.Sq = S; a.Sk = S; a.D = hdim;
+        a.scale = scale; a.causal = 0; a.q_pos0 = 0;
+        a.rel_h = rh; a.rel_w = rw; a.rel_kh = side; a.rel_kw = side;
+        a.kv_batch_div = 1; a.prescale_q = 1;
+        if ((rc = attention_bf16(a, st))) return rc;
+        if ((rc = gemm(att, 2 * D, Bk.proj_w, D, x, 1, D, Bk.proj_b, x, 1, D, 0, R, D, D, ACT_NONE, nullptr, Bk.global_attn ? nullptr : unpart, nullptr, 0, st, 1, 0)))
+            return rc;
+        if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(Bk.norm2_w), static_cast<const bf16_t*>(Bk.norm2_b), xn, 2, R, D, 1e-6f, st))) return rc;
+        if ((rc = gemm(xn, 2 * D, Bk.lin1_w, D, hh, 0, 2 * MD, Bk.lin1_b, nullptr, 0, 0, 0, R, MD, D, ACT_GELU, nullptr, nullptr, nullptr, 0, st, 1, 1))) return rc;
+        if ((rc = gemm(hh, 2 * MD, Bk.lin2_w, MD, x, 1, D, Bk.lin2_b, x, 1, D, 0, R, D, MD, ACT_NONE, nullptr, nullptr, nullptr, 0, st, 1, 0))) return rc;
+    }
+    // neck: 1x1 conv, LayerNorm2d, 3x3 conv, LayerNorm2d on split operands
+    if ((rc = gather_rows(xn, 2, 2 * D, x, 1, D, nullptr, nullptr, 0, 0, R, D, st))) return rc;
+    if ((rc = gemm(xn, 2 * D, hd->neck0_w, D, n0, 1, OC, nullptr, nullptr, 0, 0, 0, R, OC, D, ACT_NONE, nullptr, nullptr, nullptr, 0, st, 1, 0))) return rc;
+    if ((rc = layernorm(n0, 1, static_cast<const bf16_t*>(hd->neck1_w), static_cast<const bf16_t*>(hd->neck1_b), n1, 2, R, OC, 1e-6f, st))) return rc;
+    if ((rc = im2col3x3_nhwc(n1, c3, V, g, g, OC, st, 2 * OC, 18 * OC))) return rc;
+    if ((rc = im2col3x3_nhwc(n1 + OC, c3 + 9 * OC, V, g, g, OC, st, 2 * OC, 18 * OC))) return rc;
+    if ((rc = gemm(c3, 18 * OC, hd->neck2_w, 9 * OC, n0, 1, OC, nullptr, nullptr, 0, 0, 0, R, OC, 9 * OC, ACT_NONE, nullptr, nullptr, nullptr, 0, st, 1, 0))) return rc;
+    return layernorm(n0, 1, static_cast<const bf16_t*>(hd->neck3_w), static_cast<const bf16_t*>(hd->neck3_b), embeddings_out, 1, R, OC, 1e-6f, st);
 }
 
 // =====================================================================================================================

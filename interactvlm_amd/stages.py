@@ -139,16 +139,19 @@ class SamEncodeStages:
                       p(b["proj"].w), p(b["proj"].b), p(b["norm2"].w), p(b["norm2"].b), p(b["lin1"].w), p(b["lin1"].b),
                       p(b["lin2"].w), p(b["lin2"].b), 1 if b["glob"] else 0) for b in enc.blocks])
 
-    def __call__(self, images):
+    def __call__(self, images, precision="default"):
+        """precision 'parity': ``ivlm_sam_encode_parity`` (fp32-activation arithmetic, see SamImageEncoder.precision)."""
         lib = _lib.load()
         images = images.to(torch.bfloat16).contiguous()
         V = images.shape[0]
         c = self.e.cfg
         out = torch.empty(V, c.grid * c.grid, c.out_chans, dtype=torch.float32, device=images.device)
-        nbytes = lib.ivlm_sam_encode_workspace_bytes(C.byref(self.cfg), V)
+        size_fn, fn = ((lib.ivlm_sam_encode_parity_workspace_bytes, lib.ivlm_sam_encode_parity) if precision == "parity"
+                       else (lib.ivlm_sam_encode_workspace_bytes, lib.ivlm_sam_encode))
+        nbytes = size_fn(C.byref(self.cfg), V)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device)
-        check(lib.ivlm_sam_encode(C.byref(self.cfg), C.byref(self.head), self.blocks, images.data_ptr(), V, out.data_ptr(),
-                                  ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "sam_encode")
+        check(fn(C.byref(self.cfg), C.byref(self.head), self.blocks, images.data_ptr(), V, out.data_ptr(), ws.data_ptr(), nbytes,
+                 torch.cuda.current_stream().cuda_stream), "sam_encode")
         return out
 
 

@@ -95,6 +95,12 @@ def test_sam_encode_stage_equals_python_path(hip_lib, cuda, V):
     got = stages.SamEncodeStages(enc)(x)
     assert got.shape == ref.shape and got.dtype == torch.float32
     assert torch.equal(got, ref), float((got - ref).abs().max())
+    # "parity" precision: ivlm_sam_encode_parity == SamImageEncoder._forward_parity bit for bit (and both differ from the default)
+    enc.precision = "parity"
+    ref_p = enc._forward(x)
+    got_p = stages.SamEncodeStages(enc)(x, precision="parity")
+    assert torch.equal(got_p, ref_p), float((got_p - ref_p).abs().max())
+    assert not torch.equal(ref_p, ref)
 
 
 @pytest.mark.parametrize("V", [4, 1])
