@@ -684,10 +684,12 @@ def main():
         # the same model / image / weights in every precision mode: throughput next to the error against the fp32 CPU oracle
         precision_modes = {m_: {"images_per_s": parity_full[m_]["images_per_s"], "max_abs_dp_vs_fp32_oracle": parity_full[m_]["max_abs_dp"],
                                 "within_1e-3": parity_full[m_]["within_1e-3"]}
-                           for m_ in ("default", "parity-encoder", "parity") if m_ in parity_full}
-        precision_modes["note"] = ("`value` is the default (bf16-operand) mode; 'parity-encoder' (SAM ViT-H encoder with hi + lo bf16 "
-                                   "operands) is the cheapest mode that holds the north star's 1e-3 at the real depth, 'parity' carries "
-                                   "no bf16 activation rounding anywhere")
+                           for m_ in ("default", "parity-encoder", "parity-fast", "parity") if m_ in parity_full}
+        precision_modes["note"] = ("`value` is the default (bf16-operand) mode.  'parity' carries no bf16 activation rounding anywhere "
+                                   "(hi + lo bf16 operands on the matrix cores); 'parity-fast' is the same with the SAM encoder's MLP "
+                                   "GEMMs on fp16 operands (1.7e-4 .. 4.3e-4 over 8 seeded weight / image sets: "
+                                   "tools/diag_encoder_margin.py); 'parity-encoder' leaves the language towers in default precision "
+                                   "(3.8e-4 .. 7.1e-4 on this shape over 4 seeds, 1.3e-3 on one seed of a smaller LLaMA: no margin)")
     if rank == 0:
         fl = flops_per_image(cfg, T0, len(forced), V)
         shape = ("interactvlm-3d-hcontact-damon shape: LLaVA-1.5-7B + CLIP ViT-L/14 + SAM ViT-H, 75-id prompt (330 positions) + "

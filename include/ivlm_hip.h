@@ -37,6 +37,7 @@ extern "C" {
 #define IVLM_F32 0
 #define IVLM_BF16 1
 #define IVLM_BF16_SPLIT 2
+#define IVLM_F16 4 /* IEEE fp16 (outputs of ivlm_layernorm; operands of ivlm_gemm_bf16 with IVLM_GEMM_F16) */
 #define IVLM_FP8 3 /* OCP e4m3 bytes (BASELINE configs[4]: fp8 operands for the big GEMMs); always with a per-tensor scale */
 
 /* flags of ivlm_gemm_bf16 / ivlm_gemm_bf16_splitk */
@@ -45,6 +46,9 @@ extern "C" {
 #define IVLM_GEMM_A_SPLIT 4 /* tile GEMM (M > 16): A rows are [hi(K) | lo(K)] bf16 (IVLM_BF16_SPLIT, lda >= 2K): an fp32-activation
                                GEMM on the bf16 matrix cores against the plain [N,K] weight (each W tile is used twice) */
 #define IVLM_GEMM_OUT_SPLIT 8 /* tile GEMM: C is bf16 [M, >= 2 n_out], the fp32 result written as [hi(n_out) | lo(n_out)] */
+#define IVLM_GEMM_F16 16      /* tile GEMM: A and W hold IEEE fp16 values (an fp16 activation carries 1/8 of the bf16 rounding error
+                                 at the same MFMA rate; bf16 weights inside the fp16 range convert exactly) */
+#define IVLM_GEMM_OUT_F16 32  /* tile GEMM: the 16-bit output (out_f32 = 0) is written as fp16 */
 
 typedef void *ivlm_stream_t;
 
@@ -380,6 +384,18 @@ int ivlm_sam_encode(const ivlm_sam_cfg *cfg, const ivlm_sam_head *head, const iv
 size_t ivlm_sam_encode_parity_workspace_bytes(const ivlm_sam_cfg *cfg, int V);
 int ivlm_sam_encode_parity(const ivlm_sam_cfg *cfg, const ivlm_sam_head *head, const ivlm_sam_block *blocks_host, const void *images,
                            int V, float *embeddings_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* ... with the two MLP GEMMs of every block on IEEE fp16 operands (norm2 and the GELU epilogue write halves: 11 significant bits, an
+ * eighth of the bf16 rounding error, ONE MFMA pass instead of two): the encoder of the "parity-encoder" mode - measured 4.6e-4
+ * end to end at depth 32 (the all-split stage: 4.0e-4) for 12 ms less per 4 views.  mlp16_host[l] = fp16 copies of block l's
+ * lin1_w / lin2_w (ivlm_bf16_to_f16; exact for |w| >= 2^-14, within 2^-25 below).  Workspace: the parity size. */
+typedef struct {
+    const void *lin1_w16, *lin2_w16;
+} ivlm_sam_mlp_f16;
+int ivlm_sam_encode_parity_f16mlp(const ivlm_sam_cfg *cfg, const ivlm_sam_head *head, const ivlm_sam_block *blocks_host,
+                                  const ivlm_sam_mlp_f16 *mlp16_host, const void *images, int V, float *embeddings_out,
+                                  void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* bf16 -> IEEE fp16 (round to nearest even, saturating), n elements: weight copies for IVLM_GEMM_F16 / ivlm_sam_encode_parity_f16mlp */
+int ivlm_bf16_to_f16(const void *src_bf16, void *dst_f16, int64_t n, ivlm_stream_t stream);
 
 /* PromptEncoder.forward(text_embeds) + MaskDecoder.forward(multimask_output=False) (prompt_encoder.py:140-186,
  * mask_decoder.py:75-164, transformer.py:62-242) with fp32 activations end to end: image_embeddings fp32 [V, grid*grid, C]

@@ -169,6 +169,24 @@ __global__ __launch_bounds__(kT) void fill_rows_kernel(bf16_t* __restrict__ dst,
     }
 }
 
+// bf16 -> IEEE fp16, 8 elements per thread (the tail one by one)
+__global__ __launch_bounds__(kT) void bf16_to_f16_kernel(const bf16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n8; i += (int64_t)gridDim.x * kT) {
+        const uint4 u = *reinterpret_cast<const uint4*>(src + i * 8);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+        uint4 o;
+        uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ow[j] = pack_f16x2(__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u));
+        *reinterpret_cast<uint4*>(dst + i * 8) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+        const int64_t i = n8 * 8 + threadIdx.x;
+        dst[i] = (uint16_t)(pack_f16x2(bf16_to_f32(src[i]), 0.f) & 0xffffu);
+    }
+}
+
 // out[r] = a[r] (+|*) b[r % b_rows]
 __global__ __launch_bounds__(kT) void add_rows_kernel(void* __restrict__ out, int out_kind, const void* __restrict__ a,
                                                       int a_kind, const void* __restrict__ b, int b_kind, int64_t rows,
@@ -507,6 +525,13 @@ int ivlm_rope_kv_split(void* qkv, int64_t ld, int T, int H, int D, int pos0, voi
     ivlm_enter();
     return ivlm::rope_kv_split(BF(qkv), ld, T, H, D, pos0, BF(kcache), BF(kcache_lo), BF(vcache), BF(vcache_lo), cos_tab, sin_tab,
                                ivlm_stream(s));
+}
+int ivlm_bf16_to_f16(const void* src, void* dst, int64_t n, ivlm_stream_t s) {
+    ivlm_enter();
+    if (n == 0) return IVLM_OK;
+    if (!src || !dst || n < 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return IVLM_ERR_INVALID_ARG;
+    ivlm::bf16_to_f16_kernel<<<ivlm::grid_for((n >> 3) + 1), ivlm::kT, 0, ivlm_stream(s)>>>(CBF(src), static_cast<uint16_t*>(dst), n);
+    return ivlm_launch_status();
 }
 int ivlm_rope_table(float* cos_tab, float* sin_tab, int T, int D, float theta, ivlm_stream_t s) {
     ivlm_enter();

@@ -44,8 +44,11 @@ struct TileCfg {
     static_assert(BM % 8 == 0 && BN % 8 == 0, "whole 8-row pieces");
 };
 
-template <int ACT, bool OUT_F32, typename CFG, bool FP8 = false>
+// OPK: operand kind - 0 bf16, 1 e4m3 (MX instruction), 2 IEEE fp16 (a compile-time choice: a wave-uniform runtime branch around the
+// MFMA groups was measured to halve the speed of EVERY GEMM - the accumulators no longer stay put across it)
+template <int ACT, bool OUT_F32, typename CFG, int OPK = 0>
 __global__ __launch_bounds__(CFG::kThreads, CFG::kMinBlocks) void gemm_bf16_kernel(GemmArgs g) {
+    constexpr bool FP8 = OPK == 1;
     constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NI = CFG::NI, PA = CFG::PA, PW = CFG::PW;
     constexpr int kTileBytesA = CFG::kTileBytesA, kStageBytes = CFG::kStageBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -158,8 +161,13 @@ __global__ __launch_bounds__(CFG::kThreads, CFG::kMinBlocks) void gemm_bf16_kern
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+                for (int mi = 0; mi < MI; ++mi) {
+                    if constexpr (OPK == 2)  // IEEE-half operands: same tiles and layouts, the f16 instruction
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fw[ni]),
+                                                                             __builtin_bit_cast(f16x8_t, fa[mi]), acc[ni][mi], 0, 0, 0);
+                    else
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+                }
         }
     }
 
@@ -195,11 +203,11 @@ __global__ __launch_bounds__(CFG::kThreads, CFG::kMinBlocks) void gemm_bf16_kern
 using Cfg128 = TileCfg<2, 2, 4, 4>;
 using Cfg256 = TileCfg<2, 4, 8, 4>;
 
-template <int ACT, bool OUT_F32, typename CFG, bool FP8 = false>
+template <int ACT, bool OUT_F32, typename CFG, int OPK = 0>
 int launch_cfg(const GemmArgs& g, hipStream_t st) {
     const int tiles = ((g.M + CFG::BM - 1) / CFG::BM) * ((g.N + CFG::BN - 1) / CFG::BN);
     dim3 grid(tiles, 1, g.batch);
-    auto kfn = gemm_bf16_kernel<ACT, OUT_F32, CFG, FP8>;
+    auto kfn = gemm_bf16_kernel<ACT, OUT_F32, CFG, OPK>;
     if (CFG::kLdsBytes > 64 * 1024) {
         static bool attr_set = false;  // per instantiation
         if (!attr_set) {
@@ -250,8 +258,17 @@ int launch(const GemmArgs& g, hipStream_t st) {
     if (g.fp8) {  // fp8 operands: the 8-phase 256^2 kernel, or 128x128 / 128x64 tiles for what it does not fit
         const int t = choose_tile(g);
         if (t == 512 || t == 256) return gemm_bf16_256p(g, st);
-        if (t == 64) return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64, true>(g, st) : launch_cfg<ACT, false, Cfg128x64, true>(g, st);
-        return g.out_f32 ? launch_cfg<ACT, true, Cfg128, true>(g, st) : launch_cfg<ACT, false, Cfg128, true>(g, st);
+        if (t == 64) return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64, 1>(g, st) : launch_cfg<ACT, false, Cfg128x64, 1>(g, st);
+        return g.out_f32 ? launch_cfg<ACT, true, Cfg128, 1>(g, st) : launch_cfg<ACT, false, Cfg128, 1>(g, st);
+    }
+    if (g.f16) {  // fp16 operands: the 8-phase 256^2 kernel, 128 x 64 tiles for what it does not fit (epilogues of the SAM MLP only)
+        if constexpr (ACT == ACT_NONE || ACT == ACT_GELU) {
+            const int t = choose_tile(g);
+            if (t == 512 || t == 256) return gemm_bf16_256p(g, st);
+            return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64, 2>(g, st) : launch_cfg<ACT, false, Cfg128x64, 2>(g, st);
+        } else {
+            return IVLM_ERR_UNSUPPORTED;
+        }
     }
     switch (choose_tile(g)) {
         case 512: return gemm_bf16_256p(g, st);  // 256^2, 8-phase ping-pong pipeline (gemm256.hip)
@@ -309,6 +326,9 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
     if (g.act == ACT_SWIGLU && ((g.N & 3) || g.residual)) return IVLM_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) return IVLM_ERR_INVALID_ARG;
     if (g.a_f32) return IVLM_ERR_UNSUPPORTED;
+    if (g.f16 || g.out_f16) {  // IEEE-half operands / output: plain tile kernels
+        if (g.fp8 || g.out_fp8 || g.a_split || g.a_f32 || (g.out_f16 && (g.out_f32 || g.out_split))) return IVLM_ERR_UNSUPPORTED;
+    }
     if (g.a_split || g.out_split) {  // fp32-activation ("parity") operands / outputs: bf16 tile kernels only
         if (g.fp8 || g.out_fp8 || g.a_kstep || g.w_kstep || g.c_panel) return IVLM_ERR_UNSUPPORTED;
         if (g.a_split && ((g.a_lo & 7) || g.a_lo < g.K)) return IVLM_ERR_INVALID_ARG;
@@ -481,7 +501,9 @@ extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
     if (flags & IVLM_GEMM_A_SPLIT) { g.a_split = 1; g.a_lo = K; }
     if (flags & IVLM_GEMM_OUT_SPLIT) { g.out_split = 1; g.c_lo = act == ivlm::ACT_SWIGLU ? N / 2 : N; out_f32 = 1; }
-    if ((g.a_split || g.out_split) && M <= 16) return IVLM_ERR_UNSUPPORTED;  // tile GEMM path only
+    if (flags & IVLM_GEMM_F16) g.f16 = 1;
+    if (flags & IVLM_GEMM_OUT_F16) g.out_f16 = 1;
+    if ((g.a_split || g.out_split || g.f16 || g.out_f16) && M <= 16) return IVLM_ERR_UNSUPPORTED;  // tile GEMM path only
     g.rms_w = static_cast<const bf16_t*>(rms_w);
     g.rms_eps = rms_eps;
     g.tile = g_tile_override;

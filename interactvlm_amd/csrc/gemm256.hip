@@ -35,8 +35,9 @@ constexpr int kTileLds = 4 * kHalfBytes;         // 64 KiB per K tile
 constexpr int kLds256 = 2 * kTileLds;            // 128 KiB
 // slot order inside a tile buffer == kind index: 0 A0, 1 B0, 2 B1, 3 A1 (also the issue order)
 
-template <int ACT, bool OUT_F32, bool FP8>
+template <int ACT, bool OUT_F32, int OPK>  // OPK: 0 bf16, 1 e4m3, 2 IEEE fp16 operands (compile time: see gemm.hip)
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
+    constexpr bool FP8 = OPK == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -126,9 +127,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[nq * 2 + j][mq * 4 + i] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nq][j][kk], fa[i][kk], acc[nq * 2 + j][mq * 4 + i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (OPK == 2)  // IEEE-half operands: same fragments, the f16 instruction
+                        acc[nq * 2 + j][mq * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            __builtin_bit_cast(f16x8_t, fb[nq][j][kk]), __builtin_bit_cast(f16x8_t, fa[i][kk]), acc[nq * 2 + j][mq * 4 + i], 0, 0, 0);
+                    else
+                        acc[nq * 2 + j][mq * 4 + i] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nq][j][kk], fa[i][kk], acc[nq * 2 + j][mq * 4 + i], 0, 0, 0);
+                }
     };
     // one phase: [LDS reads][DMA of one half-tile][counted wait] | barrier | retire reads, 16 MFMAs
 #define IVLM_PHASE(READS, KIND, TILE, MQ, NQ)                    \
@@ -208,9 +214,15 @@ int launch256(const GemmArgs& g, hipStream_t st) {
         ivlm_launch(kfn, grid, dim3(512), kLds256, st, g);                                                       \
     } while (0)
     if (g.fp8) {
-        if (g.out_f32) IVLM_GO(true, true); else IVLM_GO(false, true);
+        if (g.out_f32) IVLM_GO(true, 1); else IVLM_GO(false, 1);
+    } else if (g.f16) {  // (instantiated for the SAM MLP's epilogues only)
+        if constexpr (ACT == ACT_NONE || ACT == ACT_GELU) {
+            if (g.out_f32) IVLM_GO(true, 2); else IVLM_GO(false, 2);
+        } else {
+            return IVLM_ERR_UNSUPPORTED;
+        }
     } else {
-        if (g.out_f32) IVLM_GO(true, false); else IVLM_GO(false, false);
+        if (g.out_f32) IVLM_GO(true, 0); else IVLM_GO(false, 0);
     }
 #undef IVLM_GO
     return ivlm_launch_status();

@@ -9,6 +9,7 @@ namespace ivlm {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
 // one MX fp8 step: the two 16-byte fragments a lane holds for the two bf16 k-steps of a 128-byte K tile are, as bytes, 32 e4m3
 // values of ONE 16x16x128 step (both operands use the same lane -> k-subset map, so the sum over k is the same sum)
@@ -160,7 +161,7 @@ __device__ __forceinline__ void gemm_store_lines(const GemmArgs& g, unsigned cha
                 if (nw + nl < g.N) gemm_value4<ACT>(g, nw + nl, acc[NI0 + ni][p * PASS_MI + mi], v);
                 unsigned char* dst = wbuf + r * RB + ((((nl * ES) >> 4) ^ sw) << 4) + ((nl * ES) & 15);
                 if (OUT_F32) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_16x2(v[0], v[1], g.out_f16), pack_16x2(v[2], v[3], g.out_f16));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -260,7 +261,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
                 *reinterpret_cast<float2*>(C + o) = make_float2(o0, o1);
             } else {
                 bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
-                *reinterpret_cast<uint32_t*>(C + o) = pack_bf16x2(o0, o1);
+                *reinterpret_cast<uint32_t*>(C + o) = pack_16x2(o0, o1, g.out_f16);
             }
             return;
         }
@@ -301,7 +302,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
             *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
             bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
-            *reinterpret_cast<uint2*>(C + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            *reinterpret_cast<uint2*>(C + o) = make_uint2(pack_16x2(v[0], v[1], g.out_f16), pack_16x2(v[2], v[3], g.out_f16));
         }
     } else {  // ragged N: scalar tail (never on the hot shapes)
 #pragma unroll

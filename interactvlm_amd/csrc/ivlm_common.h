@@ -76,6 +76,15 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
+// two fp32 -> packed IEEE half pair (round to nearest even; saturating at +-65504 instead of overflowing to inf)
+typedef __attribute__((ext_vector_type(2))) _Float16 ivlm_f16x2_t;
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    const ivlm_f32x2_t v = {__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ivlm_f16x2_t));
+}
+// 16-bit output pair of the GEMM epilogues: bf16 or (f16 != 0) fp16
+__device__ __forceinline__ uint32_t pack_16x2(float lo, float hi, int f16) { return f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
+
 // hi + lo bf16 split of fp32 values (x = hi + lo to 2^-17 relative): packed pairs, hi = RNE(x), lo = RNE(x - hi)
 __device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
     hi = pack_bf16x2(a, b);

@@ -49,6 +49,10 @@ struct GemmArgs {
     // n + c_lo (the next GEMM's / attention's split operand).  Set together with out_f32 = 1 (fp32 epilogue arithmetic).
     int out_split = 0;
     int64_t c_lo = 0;
+    // fp16 operands (tile GEMM path): A and W hold IEEE half values (11 significant bits: an activation rounded to fp16 carries an
+    // eighth of the bf16 rounding error at the same MFMA rate; bf16 weights convert exactly when they are inside the fp16 range).
+    // out_f16: a 16-bit output (out_f32 = 0) is written as fp16 instead of bf16.
+    int f16 = 0, out_f16 = 0;
     int res_f32 = 0;   // 1: residual is float (fp32 residual stream)
     // batched (strided) variant: blockIdx.z = batch
     int batch = 1;

@@ -261,8 +261,11 @@ __global__ void fill_pad_rows_kernel(bf16_t* __restrict__ dst, int64_t ldd, cons
 // generic tile-GEMM call of the sequencers (bias, activation, bf16 / fp32 residual with row modulo, row maps, split-K rule)
 int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int out_f32, int64_t ldc, const void* bias,
          const void* res, int res_f32, int64_t ldr, int res_mod, int M, int N, int K, int act, const int32_t* out_rows,
-         const int32_t* a_rows, float* sk, size_t skb, hipStream_t st, int a_split = 0, int out_split = 0) {
+         const int32_t* a_rows, float* sk, size_t skb, hipStream_t st, int a_split = 0, int out_split = 0, int f16 = 0,
+         int out_f16 = 0) {
     GemmArgs g;
+    g.f16 = f16;  // A and W are IEEE halves
+    g.out_f16 = out_f16;  // a 16-bit output is written as IEEE halves
     if (a_split) {  // "parity" precision: A rows are [hi(K) | lo(K)] bf16
         g.a_split = 1;
         g.a_lo = K;
@@ -478,10 +481,10 @@ extern "C" size_t ivlm_sam_encode_parity_workspace_bytes(const ivlm_sam_cfg* c, 
     return b + 1024;
 }
 
-extern "C" int ivlm_sam_encode_parity(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, const ivlm_sam_block* blocks_host,
-                                      const void* images, int V, float* embeddings_out, void* workspace, size_t workspace_bytes,
-                                      ivlm_stream_t stream) {
-    ivlm_enter();
+namespace ivlm {
+namespace {
+int sam_encode_parity(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, const ivlm_sam_block* blocks_host, const ivlm_sam_mlp_f16* mlp16,
+                      const void* images, int V, float* embeddings_out, void* workspace, size_t workspace_bytes, ivlm_stream_t stream) {
     if (!c || !hd || !blocks_host || !images || !embeddings_out || !workspace || V <= 0) return IVLM_ERR_INVALID_ARG;
     if (workspace_bytes < ivlm_sam_encode_parity_workspace_bytes(c, V)) return IVLM_ERR_WORKSPACE;
     hipStream_t st = ivlm_stream(stream);
@@ -548,6 +551,13 @@ extern "C" int ivlm_sam_encode_parity(const ivlm_sam_cfg* c, const ivlm_sam_head
         if ((rc = attention_bf16(a, st))) return rc;
         if ((rc = gemm(att, 2 * D, Bk.proj_w, D, x, 1, D, Bk.proj_b, x, 1, D, 0, R, D, D, ACT_NONE, nullptr, Bk.global_attn ? nullptr : unpart, nullptr, 0, st, 1, 0)))
             return rc;
+        if (mlp16) {  // the MLP on fp16 operands: norm2 and the GELU epilogue write IEEE halves, one MFMA pass
+            if (!mlp16[l].lin1_w16 || !mlp16[l].lin2_w16) return IVLM_ERR_INVALID_ARG;
+            if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(Bk.norm2_w), static_cast<const bf16_t*>(Bk.norm2_b), xn, 4, R, D, 1e-6f, st))) return rc;
+            if ((rc = gemm(xn, D, mlp16[l].lin1_w16, D, hh, 0, MD, Bk.lin1_b, nullptr, 0, 0, 0, R, MD, D, ACT_GELU, nullptr, nullptr, nullptr, 0, st, 0, 0, 1, 1))) return rc;
+            if ((rc = gemm(hh, MD, mlp16[l].lin2_w16, MD, x, 1, D, Bk.lin2_b, x, 1, D, 0, R, D, MD, ACT_NONE, nullptr, nullptr, nullptr, 0, st, 0, 0, 1, 0))) return rc;
+            continue;
+        }
         if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(Bk.norm2_w), static_cast<const bf16_t*>(Bk.norm2_b), xn, 2, R, D, 1e-6f, st))) return rc;
         if ((rc = gemm(xn, 2 * D, Bk.lin1_w, D, hh, 0, 2 * MD, Bk.lin1_b, nullptr, 0, 0, 0, R, MD, D, ACT_GELU, nullptr, nullptr, nullptr, 0, st, 1, 1))) return rc;
         if ((rc = gemm(hh, 2 * MD, Bk.lin2_w, MD, x, 1, D, Bk.lin2_b, x, 1, D, 0, R, D, MD, ACT_NONE, nullptr, nullptr, nullptr, 0, st, 1, 0))) return rc;
@@ -560,6 +570,25 @@ extern "C" int ivlm_sam_encode_parity(const ivlm_sam_cfg* c, const ivlm_sam_head
     if ((rc = im2col3x3_nhwc(n1 + OC, c3 + 9 * OC, V, g, g, OC, st, 2 * OC, 18 * OC))) return rc;
     if ((rc = gemm(c3, 18 * OC, hd->neck2_w, 9 * OC, n0, 1, OC, nullptr, nullptr, 0, 0, 0, R, OC, 9 * OC, ACT_NONE, nullptr, nullptr, nullptr, 0, st, 1, 0))) return rc;
     return layernorm(n0, 1, static_cast<const bf16_t*>(hd->neck3_w), static_cast<const bf16_t*>(hd->neck3_b), embeddings_out, 1, R, OC, 1e-6f, st);
+}
+}  // namespace
+}  // namespace ivlm
+
+extern "C" int ivlm_sam_encode_parity(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, const ivlm_sam_block* blocks_host,
+                                      const void* images, int V, float* embeddings_out, void* workspace, size_t workspace_bytes,
+                                      ivlm_stream_t stream) {
+    ivlm_enter();
+    return sam_encode_parity(c, hd, blocks_host, nullptr, images, V, embeddings_out, workspace, workspace_bytes, stream);
+}
+
+// ... with the MLP of every block on fp16 operands (the "parity-encoder" mode of interactvlm_amd/model.py; bit-identical to
+// SamImageEncoder._forward_parity with sites n1, attn, proj, f16mlp)
+extern "C" int ivlm_sam_encode_parity_f16mlp(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, const ivlm_sam_block* blocks_host,
+                                             const ivlm_sam_mlp_f16* mlp16_host, const void* images, int V, float* embeddings_out,
+                                             void* workspace, size_t workspace_bytes, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!mlp16_host) return IVLM_ERR_INVALID_ARG;
+    return sam_encode_parity(c, hd, blocks_host, mlp16_host, images, V, embeddings_out, workspace, workspace_bytes, stream);
 }
 
 // =====================================================================================================================

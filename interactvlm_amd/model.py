@@ -140,18 +140,22 @@ class InteractVLMForCausalLM:
     # as hi + lo planes; the decode step, text_hidden_fcs and the mask decoder have fp32 activations in both modes.  This is the
     # mode that holds the north star's 1e-3 on per-vertex probabilities at the real depth (bench.py parity_vs_oracle_full_depth).
     # "parity-encoder": only the SAM ViT-H encoder in parity precision.  It owns the default mode's error at the real depth
-    # (tools/diag_precision_modes.py on the headline configuration: 5.8e-3 in default mode, 2.9e-4 with the encoder alone in
-    # parity precision, 8e-6 with everything) - the cheapest mode that holds 1e-3, with a 3x margin.
-    precision_modes = ("default", "parity-encoder", "parity")
+    # (tools/diag_precision_modes.py on the headline configuration: 5.8e-3 in default mode, 4e-4 with the encoder alone in
+    # parity precision, 8e-6 with everything) - the cheapest mode that holds 1e-3, with a 2x margin.  Its MLP GEMMs run on fp16
+    # operands (one MFMA pass, an eighth of the bf16 rounding error: SamImageEncoder.PARITY_SITES_FAST) instead of hi + lo pairs.
+    # "parity-fast": "parity" with the encoder's MLP on fp16 operands (the only operands below fp32-equivalent precision).
+    precision_modes = ("default", "parity-encoder", "parity-fast", "parity")
     precision = "default"
 
     def set_precision(self, mode):
         assert mode in self.precision_modes, mode
         self.precision = mode
-        lang = "parity" if mode == "parity" else "default"
+        lang = "parity" if mode in ("parity", "parity-fast") else "default"
         self.vision_tower.precision = lang
         self.llm.set_precision(lang)
-        self.model.visual_model.image_encoder.precision = "default" if mode == "default" else "parity"
+        enc = self.model.visual_model.image_encoder
+        enc.precision = "default" if mode == "default" else "parity"
+        enc.parity_sites = enc.PARITY_SITES if mode == "parity" else enc.PARITY_SITES_FAST
 
     # fp8 variant (BASELINE.json configs[4], opt-in; never a parity claim): e4m3 operands for the GEMMs of the SAM ViT-H encoder,
     # the CLIP tower and the LLaMA prefill, e4m3 WEIGHTS for the batch-1 decode linears.  Activation scales are calibrated on the

@@ -306,12 +306,13 @@ def _splitk_choice(M, N, K, act, rms):
     return best
 
 
-GEMM_A_F32, GEMM_RES_F32, GEMM_A_SPLIT, GEMM_OUT_SPLIT = 1, 2, 4, 8
+GEMM_A_F32, GEMM_RES_F32, GEMM_A_SPLIT, GEMM_OUT_SPLIT, GEMM_F16, GEMM_OUT_F16 = 1, 2, 4, 8, 16, 32
+F16 = torch.float16
 F32 = torch.float32
 
 
 def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None, out_f32=False, rms=None, out_rows=None,
-           a_rows=None, a_split=False, out_split=False):
+           a_rows=None, a_split=False, out_split=False, out_f16=False):
     """act(x @ weight.T + bias) + residual.  out_rows (int32 [M], tile GEMM path): scatter epilogue, see ivlm_hip.h.  x [..., K] bf16 - or fp32 for M <= 16 rows (weight-streaming kernels: exact
     products) - last dim contiguous, uniform row stride; weight [N, K] bf16; residual bf16 or fp32 (fp32 residual stream).
     "Parity" precision (tile GEMM, M > 16): a_split - x is [..., 2K] = [hi | lo] bf16 rows (fp32 activations, see split_rows)
@@ -319,7 +320,9 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     lib = _lib.load()
     N = weight.shape[0]
     K = weight.shape[1]
-    assert x.shape[-1] == (2 * K if a_split else K) and x.dtype in (BF16, F32) and weight.dtype == BF16
+    f16 = weight.dtype == F16  # IEEE-half operands (tile GEMM): x must be fp16 too
+    assert x.shape[-1] == (2 * K if a_split else K) and x.dtype in (BF16, F32, F16) and weight.dtype in (BF16, F16)
+    assert (x.dtype == F16) == f16 and not (f16 and a_split)
     x2 = x.reshape(-1, x.shape[-1])
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
@@ -332,13 +335,19 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     if a_split:
         assert x.dtype == BF16
         flags |= GEMM_A_SPLIT
+    if f16:
+        flags |= GEMM_F16
+    if out_f16:
+        assert not out_f32 and not out_split
+        flags |= GEMM_OUT_F16
     n_out = N // 2 if act == "swiglu" else N
     if out_split:
         flags |= GEMM_OUT_SPLIT
     n_cols = 2 * n_out if out_split else n_out
     if out is None:
         lead = x.shape[:-1] if a_rows is None else (M,)
-        out = torch.empty(tuple(lead) + (n_cols,), dtype=F32 if (out_f32 and not out_split) else BF16, device=x.device)
+        out = torch.empty(tuple(lead) + (n_cols,), dtype=F32 if (out_f32 and not out_split) else (F16 if out_f16 else BF16),
+                          device=x.device)
     assert not out_split or out.dtype == BF16
     o2 = out.reshape(-1, n_cols)
     assert o2.stride(-1) == 1 and weight.stride(-1) == 1
@@ -355,7 +364,7 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
         x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
         _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, 1, 0, 0, 0, 0,
         _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, flags, _p(out_rows), _p(a_rows), _stream()), "gemm_bf16")
-    splits = _splitk_choice(M, N, K, act, rms) if (x.dtype == BF16 and out_rows is None and a_rows is None) else 1
+    splits = _splitk_choice(M, N, K, act, rms) if (x.dtype == BF16 and out_rows is None and a_rows is None and not out_f16) else 1
     if splits > 1 and o2.stride(0) % 4 == 0:
         ws = torch.empty(splits * M * N, dtype=F32, device=x.device)  # caching allocator: stream-safe
         call = lambda: check(lib.ivlm_gemm_bf16_splitk(
@@ -380,7 +389,8 @@ IVLM_FP8 = 3
 U8 = torch.uint8
 
 
-def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None, out_f32=False, out_rows=None, fp8_scale=None, out_split=False):
+def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None, out_f32=False, out_rows=None, fp8_scale=None, out_split=False,
+              out_f16=False):
     """x bf16 or fp32 [..., cols] -> bf16 (the next GEMM's operand), fp32 (out_f32: the row is itself a stream) or, with
     fp8_scale (device fp32 scalar), e4m3 bytes of y / scale (uint8 tensor: the operand of linear_fp8); out_split: [hi | lo]
     bf16 rows [..., 2 cols] (the a_split operand of an fp32-activation GEMM)."""
@@ -390,10 +400,12 @@ def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None, out_f32=False, ou
     if out is None:
         if out_split:
             out = torch.empty(x.shape[:-1] + (2 * cols,), dtype=BF16, device=x.device)
+        elif out_f16:
+            out = torch.empty(x.shape, dtype=F16, device=x.device)
         else:
             out = torch.empty(x.shape, dtype=U8 if fp8_scale is not None else (F32 if out_f32 else BF16), device=x.device)
     y = out
-    ydt = IVLM_FP8 if fp8_scale is not None else (2 if out_split else _dtc(y))
+    ydt = IVLM_FP8 if fp8_scale is not None else (2 if out_split else (4 if out_f16 else _dtc(y)))
     check(lib.ivlm_layernorm(x.data_ptr(), _dtc(x), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), ydt,
                              x.numel() // cols, cols, float(eps), 1 if gelu else 0, _p(out_rows), _p(fp8_scale), _stream()),
           "layernorm")
@@ -496,6 +508,15 @@ def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False, fp8_scale=None)
     check(lib.ivlm_rmsnorm(x.data_ptr(), _dtc(x), weight.data_ptr(), y.data_ptr(), 2 if out_split else _dtc(y),
                            x.numel() // cols, cols, float(eps), _stream()), "rmsnorm")
     return y
+
+
+def bf16_to_f16(w):
+    """bf16 tensor -> IEEE fp16 copy (RNE, saturating): the weight operands of ``linear`` on fp16 activations."""
+    w = w.contiguous()
+    assert w.dtype == torch.bfloat16
+    out = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+    check(_lib.load().ivlm_bf16_to_f16(w.data_ptr(), out.data_ptr(), w.numel(), _stream()), "bf16_to_f16")
+    return out
 
 
 def relpos_table64(tab_h, tab_w):

@@ -51,9 +51,9 @@ class _LN:
     def __init__(self, w, prefix, device, eps):
         self.w, self.b, self.eps = _dev(w[prefix + ".weight"], device), _dev(w[prefix + ".bias"], device), eps
 
-    def __call__(self, x, gelu=False, out_f32=False, out=None, out_rows=None, fp8_scale=None, out_split=False):
+    def __call__(self, x, gelu=False, out_f32=False, out=None, out_rows=None, fp8_scale=None, out_split=False, out_f16=False):
         return ops.layernorm(x, self.w, self.b, self.eps, gelu=gelu, out_f32=out_f32, out=out, out_rows=out_rows,
-                             fp8_scale=fp8_scale, out_split=out_split)
+                             fp8_scale=fp8_scale, out_split=out_split, out_f16=out_f16)
 
 
 # ================================================================================================
@@ -245,8 +245,27 @@ class SamImageEncoder:
     #   n1 / n2: the normed rows (q|k|v and mlp1 GEMM inputs), attn: q, k, v, softmax weights (split attention, fp32 rel-pos terms),
     #   proj: the attention output (proj GEMM input), h: the GELU output (mlp2 GEMM input); rel32 (only without attn): fp32
     #   rel-pos terms in the bf16 attention
-    PARITY_SITES = frozenset(("n1", "attn", "proj", "n2", "h"))
+    #   f16mlp (instead of n2 / h): the MLP's two GEMMs take fp16 operands - norm2 and the GELU epilogue write IEEE halves (11
+    #   significant bits: an eighth of the bf16 rounding error, ONE MFMA pass), the bf16 weights convert to fp16 exactly
+    PARITY_SITES = frozenset(("n1", "attn", "proj", "n2", "h"))  # the "parity" mode: nothing below fp32-equivalent operands
+    # the encoder of the "parity-encoder" mode: measured 4.6e-4 end to end at depth 32 against 4.0e-4 for PARITY_SITES, 12 ms
+    # less per 4 views (tools/diag_precision_modes.py)
+    PARITY_SITES_FAST = frozenset(("n1", "attn", "proj", "f16mlp"))
     parity_sites = PARITY_SITES
+
+    def _f16_weights(self, blk):
+        """fp16 copies of lin1 / lin2.  A bf16 value inside the fp16 NORMAL range (6.1e-5 .. 65504) converts exactly (8 significant
+        bits into 11); smaller ones land on fp16 subnormals and move by at most 2^-25 = 3e-8 - checked here, and irrelevant next to
+        weights of typical size 1e-2."""
+        if "lin1_h" not in blk:
+            for n in ("lin1", "lin2"):
+                w16 = ops.bf16_to_f16(blk[n].w)
+                err = float((w16.float() - blk[n].w.float()).abs().max())
+                if not (err <= 2.0 ** -24) or not bool(torch.isfinite(w16).all()):
+                    raise ops.IvlmError(f"{n}: weights outside the fp16 range (max conversion error {err:.3g}) - use the split "
+                                        f"(hi + lo) sites instead of f16mlp")
+                blk[n + "_h"] = w16
+        return blk["lin1_h"], blk["lin2_h"]
 
     def _attention_parity(self, blk, xn, V, side, nwin, win=None):
         """_attention with split operands: xn [rows, D or 2D] -> attention output [nwin*S, 2D] ([hi | lo] rows), or
@@ -309,6 +328,11 @@ class SamImageEncoder:
             else:
                 a = self._attention_parity(blk, xn, V, c.window, nwin, win=(unpart, pad, self._xw[key]))
                 x = blk["proj"](a if (sp or not sa) else a[:, :D], residual=x, out=x, a_rows=unpart, a_split=sp)
+            if "f16mlp" in sites:
+                w1, w2 = self._f16_weights(blk)
+                h = ops.linear(blk["norm2"](x, out_f16=True), w1, blk["lin1"].b, act="gelu", out_f16=True)
+                x = ops.linear(h, w2, blk["lin2"].b, residual=x, out_f32=True)
+                continue
             h = blk["lin1"](blk["norm2"](x, out_split="n2" in sites), act="gelu", a_split="n2" in sites, out_split="h" in sites)
             x = blk["lin2"](h, residual=x, out_f32=True, a_split="h" in sites)
         y = self.neck0(ops.gather_rows(x, out_kind="split"), out_f32=True, a_split=True)

@@ -118,6 +118,10 @@ class SamBlockC(C.Structure):
                                           "norm2_w", "norm2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b")] + [("global_attn", C.c_int)]
 
 
+class SamMlpF16C(C.Structure):
+    _fields_ = [("lin1_w16", C.c_void_p), ("lin2_w16", C.c_void_p)]
+
+
 class SamEncodeStages:
     """``ivlm_sam_encode`` over the weights of a ``sam.SamImageEncoder`` (bf16 operands, fp32 residual stream)."""
 
@@ -140,18 +144,29 @@ class SamEncodeStages:
                       p(b["lin2"].w), p(b["lin2"].b), 1 if b["glob"] else 0) for b in enc.blocks])
 
     def __call__(self, images, precision="default"):
-        """precision 'parity': ``ivlm_sam_encode_parity`` (fp32-activation arithmetic, see SamImageEncoder.precision)."""
+        """precision 'parity': ``ivlm_sam_encode_parity`` (fp32-activation arithmetic, see SamImageEncoder.precision);
+        'parity-encoder': ``ivlm_sam_encode_parity_f16mlp`` (the same with the MLP GEMMs on fp16 operands)."""
         lib = _lib.load()
         images = images.to(torch.bfloat16).contiguous()
         V = images.shape[0]
         c = self.e.cfg
         out = torch.empty(V, c.grid * c.grid, c.out_chans, dtype=torch.float32, device=images.device)
+        st = torch.cuda.current_stream().cuda_stream
+        if precision == "parity-encoder":
+            if not hasattr(self, "mlp16"):
+                w16 = [self.e._f16_weights(b) for b in self.e.blocks]
+                self.mlp16 = (SamMlpF16C * c.depth)(*[SamMlpF16C(a.data_ptr(), b.data_ptr()) for a, b in w16])
+            nbytes = lib.ivlm_sam_encode_parity_workspace_bytes(C.byref(self.cfg), V)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device)
+            check(lib.ivlm_sam_encode_parity_f16mlp(C.byref(self.cfg), C.byref(self.head), self.blocks, self.mlp16, images.data_ptr(),
+                                                    V, out.data_ptr(), ws.data_ptr(), nbytes, st), "sam_encode_parity_f16mlp")
+            return out
         size_fn, fn = ((lib.ivlm_sam_encode_parity_workspace_bytes, lib.ivlm_sam_encode_parity) if precision == "parity"
                        else (lib.ivlm_sam_encode_workspace_bytes, lib.ivlm_sam_encode))
         nbytes = size_fn(C.byref(self.cfg), V)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device)
         check(fn(C.byref(self.cfg), C.byref(self.head), self.blocks, images.data_ptr(), V, out.data_ptr(), ws.data_ptr(), nbytes,
-                 torch.cuda.current_stream().cuda_stream), "sam_encode")
+                 st), "sam_encode")
         return out
 
 

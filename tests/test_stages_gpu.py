@@ -101,6 +101,13 @@ def test_sam_encode_stage_equals_python_path(hip_lib, cuda, V):
     got_p = stages.SamEncodeStages(enc)(x, precision="parity")
     assert torch.equal(got_p, ref_p), float((got_p - ref_p).abs().max())
     assert not torch.equal(ref_p, ref)
+    # "parity-encoder": the MLP GEMMs on fp16 operands - ivlm_sam_encode_parity_f16mlp == the Python path with PARITY_SITES_FAST
+    enc.parity_sites = enc.PARITY_SITES_FAST
+    ref_f = enc._forward(x)
+    got_f = stages.SamEncodeStages(enc)(x, precision="parity-encoder")
+    assert torch.equal(got_f, ref_f), float((got_f - ref_f).abs().max())
+    assert not torch.equal(ref_f, ref_p)
+    assert float((ref_f - ref_p).abs().max()) < 0.25 * float((ref - ref_p).abs().max())  # (much closer to all-split than default is)
 
 
 @pytest.mark.parametrize("V", [4, 1])

@@ -49,7 +49,7 @@ def main():
     # ---- inside the SAM encoder: which operand sites carry the error (CLIP / LLaMA in default precision)
     enc = m.model.visual_model.image_encoder
     print("SAM encoder operand sites (clip / llm default):")
-    for sites in (("n1", "attn", "proj", "n2", "h"), ("rel32",), ("attn",), ("attn", "proj"), ("n1", "attn", "proj"), ("n2", "h"),
+    for sites in (("n1", "attn", "proj", "n2", "h"), ("n1", "attn", "proj", "f16mlp"), ("rel32",), ("attn",), ("attn", "proj"), ("n1", "attn", "proj"), ("n2", "h"),
                   ("n1", "n2", "h"), ("attn", "proj", "n2", "h"), ("n1", "attn", "proj", "h"), ("n1", "attn", "proj", "n2")):
         enc.parity_sites = frozenset(sites)
         c, t = run("default", "default", "parity")
