@@ -238,6 +238,24 @@ def attention_splitter_spec(prefix: str = "attention_splitter") -> Spec:
     return s
 
 
+def uncertainty_spec(prefix: str = SAM_PREFIX + ".uncertainty") -> Spec:  # components.py:40-53
+    s: Spec = {}
+    _lin(s, prefix + ".linear1", 64, 256)
+    _lin(s, prefix + ".linear2", 16, 64)
+    _lin(s, prefix + ".linear3", 1, 16)
+    return s
+
+
+def fusion_spec(prefix: str = SAM_PREFIX + ".fusion", sam_dim=256, llava_dim=5120, fusion_dim=128) -> Spec:  # components.py:79-119
+    s: Spec = {}
+    _lin(s, prefix + ".sam_proj", fusion_dim, sam_dim)
+    _lin(s, prefix + ".llava_proj", fusion_dim, llava_dim)
+    for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+        _lin(s, f"{prefix}.fusion.{n}", fusion_dim, fusion_dim)
+    _lin(s, prefix + ".output_proj", sam_dim, fusion_dim)
+    return s
+
+
 def ivlm_spec(c: IvlmCfg) -> Spec:
     """Every tensor InteractVLMForCausalLM's state dict holds on the inference path."""
     s: Spec = {}

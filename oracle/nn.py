@@ -7,6 +7,7 @@ keyed by the reference's state-dict names.  Citations are into /root/reference.
   prompt_encoder_*    model/segment_anything/modeling/prompt_encoder.py:67-76,140-238
   mask_decoder        model/segment_anything/modeling/mask_decoder.py:75-191, transformer.py:16-242
   cam encoders        model/components.py:491-572,  process_embeddings  model/InteractVLM.py:268-294
+  optional heads      model/components.py:40-153 (UncertaintyModule, LLaVASAMFusion), model/InteractVLM.py:20-44
   clip_vision         HF CLIPVisionModel as used by llava/model/multimodal_encoder/clip_encoder.py:31-60
   llama               HF LlamaModel as used by llava/model/language_model/llava_llama.py:55-135
   splice              llava/model/llava_arch.py:185-208 (mm_use_im_start_end branch)
@@ -252,6 +253,79 @@ def attention_splitter(w, p, x):  # components.py:155-193
         a = F.softmax(torch.matmul(q, k.transpose(-2, -1)) / (k.size(-1) ** 0.5), dim=-1)
         outs.append(linear(w, p + ".output_proj", torch.matmul(a, v)))
     return outs[0], outs[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# optional heads of ModifiedSAM (InteractVLM.py:20-38,41-44; off in every released configuration).  Both modules cast their
+# inputs to bf16 and therefore only run inside the bf16 model: the restatement keeps fp32 tensors holding bf16 VALUES and rounds
+# where the bf16 modules round (after every linear / matmul / softmax / activation / add).
+# ------------------------------------------------------------------------------------------------
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _linear_bf16(w, prefix, x, fused=True):
+    """nn.Linear on bf16 tensors: fp32 accumulation, bias added before the one rounding (ATen's addmm route).  fused=False: the
+    matmul result is rounded, then the bias is added and the sum rounded again - the route at::linear takes for a 3-D input
+    that is not contiguous (matmul + add)."""
+    if not fused:
+        return _bf(_bf(F.linear(x, _bf(w[prefix + ".weight"]))) + _bf(w[prefix + ".bias"]))
+    return _bf(F.linear(x, _bf(w[prefix + ".weight"]), _bf(w[prefix + ".bias"])))
+
+
+def uncertainty_head(w, p, emb):  # components.py:40-78; emb [B,256,H,W] -> [B,1,H,W] (bf16 values)
+    B, C, H, Wd = emb.shape
+    x = _bf(emb).permute(0, 2, 3, 1).reshape(B * H * Wd, C)
+    x = F.relu(_linear_bf16(w, p + ".linear1", x))
+    x = F.relu(_linear_bf16(w, p + ".linear2", x))
+    x = _bf(F.softplus(_linear_bf16(w, p + ".linear3", x)))
+    return x.reshape(B, H, Wd, 1).permute(0, 3, 1, 2)
+
+
+def uncertainty_resize(m, size, lambda_bf16=False):
+    """InteractVLM.py:446-447 / 615-616: F.interpolate(bilinear, align_corners=False) on the bf16 map.  The four-tap sum runs in
+    fp32 and is rounded to bf16 once; ATen's CPU kernel additionally rounds the interpolation weights to the tensor's dtype
+    (lambda_bf16=True reproduces tests/golden/optional_heads.npz, made on the CPU, bit for bit), its GPU kernel keeps them in
+    fp32 (the default here - the reference's deployed bf16 model runs on the GPU)."""
+    h, wd = m.shape[-2:]
+
+    def taps(o, i):
+        x = ((torch.arange(o, dtype=torch.float32) + 0.5) * (i / o) - 0.5).clamp(min=0)
+        i0 = x.floor().long().clamp(max=i - 1)
+        i1 = (i0 + 1).clamp(max=i - 1)
+        l1 = x - i0.float()
+        if lambda_bf16:
+            l1 = _bf(l1)
+            return i0, i1, _bf(1 - l1), l1
+        return i0, i1, 1 - l1, l1
+
+    y0, y1, wy0, wy1 = taps(size[0], h)
+    x0, x1, wx0, wx1 = taps(size[1], wd)
+    mf = m.float()
+    top = mf[..., y0, :][..., :, x0] * wx0 + mf[..., y0, :][..., :, x1] * wx1
+    bot = mf[..., y1, :][..., :, x0] * wx0 + mf[..., y1, :][..., :, x1] * wx1
+    return _bf(top * wy0[:, None] + bot * wy1[:, None])
+
+
+def sam_fusion(w, p, sam, llava, num_heads=8):  # components.py:79-153; sam [B,256,H,W], llava [1,L,hidden] -> [B,256,H,W]
+    B, C, H, Wd = sam.shape
+    sam = _bf(sam)
+    x = sam.permute(0, 2, 3, 1).reshape(B, H * Wd, C)
+    # (components.py:134-137: permute + reshape of [B,C,H,W] is a strided VIEW [B, H*W, C], not a copy -> the unfused route)
+    sp = _linear_bf16(w, p + ".sam_proj", x, fused=False)
+    lp = _linear_bf16(w, p + ".llava_proj", _bf(llava))
+    E = sp.shape[-1]
+    hd = E // num_heads
+    # components.py:93-96: view(batch_size = the QUERY's batch, -1, heads, hd) - with one LLaVA sequence and B views the key /
+    # value positions are dealt to the views in consecutive runs of L / B (an error in the reference when B does not divide L)
+    q = _linear_bf16(w, p + ".fusion.q_proj", sp).view(B, -1, num_heads, hd).transpose(1, 2)
+    k = _linear_bf16(w, p + ".fusion.k_proj", lp).view(B, -1, num_heads, hd).transpose(1, 2)
+    v = _linear_bf16(w, p + ".fusion.v_proj", lp).view(B, -1, num_heads, hd).transpose(1, 2)
+    a = _bf(_bf(torch.matmul(q, k.transpose(-2, -1))) / (hd ** 0.5))
+    a = _bf(F.softmax(a, dim=-1))
+    o = _bf(torch.matmul(a, v)).transpose(1, 2).contiguous().view(B, -1, E)
+    o = _linear_bf16(w, p + ".output_proj", _linear_bf16(w, p + ".fusion.out_proj", o))
+    return _bf(sam + o.reshape(B, H, Wd, C).permute(0, 3, 1, 2))
 
 
 def process_embeddings(w, embedding, cam_params, token, cfg):

@@ -538,7 +538,55 @@ def gen_metrics():
           prf_o_per_sample=np.asarray(prf_o, np.float64))
 
 
-GENERATORS = {"lift": gen_lift, "lift_points": gen_lift_points, "sam_decoder": gen_sam_decoder, "cam": gen_cam,
+# ------------------------------------------------------------------------------------------
+# optional heads of ModifiedSAM (model/components.py:40-153; off in every released configuration): the reference's own modules
+# in bf16 (both cast their inputs to bf16, so they only run inside the bf16 model), inputs re-derivable from their synth keys
+# ------------------------------------------------------------------------------------------
+HEADS_UNC_SIZE = (187, 250)     # evaluate()'s original_size for the uncertainty map (InteractVLM.py:614-617)
+HEADS_FUSION_HW = 16            # spatial side of the fusion fixture (the module takes H, W from its input)
+HEADS_FUSION_L = 20             # LLaVA positions (the module's view(batch, -1, ...) splits them over the 4 views)
+
+
+def _bf16_bits(t):
+    import torch
+    return t.detach().to(torch.bfloat16).contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def gen_optional_heads():
+    import torch
+    import torch.nn.functional as F
+    _ref_shims.install()
+    import model.components as RC
+
+    out = {}
+    unc = RC.UncertaintyModule()
+    synth.fill_state_dict(unc, 0, "model.visual_model.uncertainty.")
+    unc.bfloat16()
+    emb = torch.from_numpy(synth.synth_normal("heads/sam_embeddings", (4, 256, 64, 64), 1.0, 0))
+    with torch.no_grad():
+        m = unc(emb)  # [4,1,64,64] bf16
+        r = F.interpolate(m, size=HEADS_UNC_SIZE, mode="bilinear", align_corners=False)
+        m1 = unc(emb[:1])
+    assert m.dtype == torch.bfloat16 and r.dtype == torch.bfloat16
+    out["uncertainty_map"] = _bf16_bits(m)
+    out["uncertainty_resized"] = _bf16_bits(r)
+    out["uncertainty_map_V1"] = _bf16_bits(m1)
+
+    fus = RC.LLaVASAMFusion()
+    synth.fill_state_dict(fus, 0, "model.visual_model.fusion.")
+    fus.bfloat16()
+    hw = HEADS_FUSION_HW
+    sam = torch.from_numpy(synth.synth_normal("heads/fusion_sam", (4, 256, hw, hw), 1.0, 0))
+    llava = torch.from_numpy(synth.synth_normal("heads/fusion_llava", (1, HEADS_FUSION_L, 5120), 1.0, 0))
+    with torch.no_grad():
+        f4 = fus(sam, llava)                       # the 4 views attend to consecutive quarters of the LLaVA positions
+        f1 = fus(sam[:1], llava[:, :7])            # one view: all positions
+    out["fusion_V4"] = _bf16_bits(f4)
+    out["fusion_V1"] = _bf16_bits(f1)
+    _save("optional_heads.npz", **out)
+
+
+GENERATORS = {"optional_heads": gen_optional_heads, "lift": gen_lift, "lift_points": gen_lift_points, "sam_decoder": gen_sam_decoder, "cam": gen_cam,
               "sam_encoder": gen_sam_encoder, "sam_encoder_full": gen_sam_encoder_full, "model_forward": gen_model_forward,
               "model_forward_oafford": lambda: gen_model_forward(batch2=True),
               "model_forward_huobj": lambda: gen_model_forward(huobj=True), "metrics": gen_metrics,

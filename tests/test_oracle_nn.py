@@ -173,3 +173,43 @@ def test_model_forward_gen_hu_obj_end_to_end(golden_dir):
     o = P.model_forward(w, cfg, images, images_clip, ids, cams, tables)
     np.testing.assert_allclose(o["low_res"].numpy(), d["low_res"], atol=5e-5)
     np.testing.assert_allclose(o["pred_contact"].numpy(), d["pred_contact"], atol=1e-5)
+
+
+def _bf16_from_bits(a):
+    return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).float()
+
+
+def test_optional_heads_vs_reference_golden(golden_dir):
+    """UncertaintyModule / LLaVASAMFusion (components.py:40-153), the reference's own bf16 modules.  bf16 arithmetic is not
+    reproducible to the bit across GEMM back ends (accumulation order decides the rounding of each intermediate), so the bound is
+    a few bf16 ulps of the value range, not exactness; most elements do agree exactly."""
+    d = _g(golden_dir, "optional_heads.npz")
+    w = Wt.synth_weights({**Wt.uncertainty_spec(), **Wt.fusion_spec()})
+    emb = torch.from_numpy(synth.synth_normal("heads/sam_embeddings", (4, 256, 64, 64), 1.0, 0))
+    m = O.uncertainty_head(w, SAM_PREFIX + ".uncertainty", emb)
+    ref = _bf16_from_bits(d["uncertainty_map"])
+    assert m.shape == ref.shape == (4, 1, 64, 64) and float(ref.min()) > 0
+    assert float((m - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    assert float((m == ref).float().mean()) > 0.9
+    m1 = O.uncertainty_head(w, SAM_PREFIX + ".uncertainty", emb[:1])
+    assert float((m1 - _bf16_from_bits(d["uncertainty_map_V1"])).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    # the resize alone, on the reference's own map: exact with ATen's CPU convention (interpolation weights rounded to bf16),
+    # within one ulp of the top binade with fp32 weights (the GPU kernel's convention, the oracle's default); fp32 weights ==
+    # F.interpolate in fp32, rounded
+    rr = _bf16_from_bits(d["uncertainty_resized"])
+    assert torch.equal(O.uncertainty_resize(ref, rr.shape[-2:], lambda_bf16=True), rr)
+    r = O.uncertainty_resize(ref, rr.shape[-2:])
+    assert float((r - rr).abs().max()) <= 2.0 ** -7 * float(rr.abs().max()) and float((r == rr).float().mean()) > 0.8
+    f32 = torch.nn.functional.interpolate(ref, size=tuple(rr.shape[-2:]), mode="bilinear", align_corners=False)
+    assert float((r == f32.to(torch.bfloat16).float()).float().mean()) > 0.999
+
+    hw = 16
+    sam = torch.from_numpy(synth.synth_normal("heads/fusion_sam", (4, 256, hw, hw), 1.0, 0))
+    llava = torch.from_numpy(synth.synth_normal("heads/fusion_llava", (1, 20, 5120), 1.0, 0))
+    for key, s_, l_ in (("fusion_V4", sam, llava), ("fusion_V1", sam[:1], llava[:, :7])):
+        f = O.sam_fusion(w, SAM_PREFIX + ".fusion", s_, l_)
+        fr = _bf16_from_bits(d[key]).reshape(f.shape)
+        delta = (fr - s_.to(torch.bfloat16).float())  # what the head adds to the embeddings
+        assert float(delta.abs().max()) > 0.05  # (not a no-op)
+        assert float((f - fr).abs().max()) <= 2.0 ** -6 * float(fr.abs().max()), key
+        assert float((f == fr).float().mean()) > 0.99
