@@ -128,6 +128,16 @@ int ivlm_lift_points(const float *probs, const int32_t *pid, int pid_batched, in
  *   low  f32|bf16 [n,h,w]  ->  out f32 [n,oh,ow] */
 int ivlm_postprocess_masks(const void *low, int dtype, int n, int h, int w, int img, int in_h, int in_w,
                            int oh, int ow, int apply_sigmoid, float *out, ivlm_stream_t stream);
+/* Optional heads of ModifiedSAM (InteractVLM.py:20-44; off in every released configuration).
+ * UncertaintyModule.forward (components.py:55-78): embeddings fp32 [rows, 256] (channels last: rows = views * 64 * 64), bf16
+ * weights linear1 [64,256] / linear2 [16,64] / linear3 [1,16] + biases -> out fp32 [rows] holding the bf16 values of the bf16
+ * module (input, every linear output and the softplus rounded to bf16 as the module running inside the bf16 model rounds them). */
+int ivlm_uncertainty_mlp(const float *embeddings, int64_t rows, const void *w1, const void *b1, const void *w2, const void *b2,
+                         const void *w3, const void *b3, float *out, ivlm_stream_t stream);
+/* F.interpolate(src, size=(oh, ow), mode="bilinear", align_corners=False) (InteractVLM.py:446-447, 615-616): src fp32 [n,h,w] ->
+ * dst [n,oh,ow] fp32 or bf16 (fp32 taps and weights, one rounding). */
+int ivlm_resize_bilinear(const float *src, int n, int h, int w, void *dst, int dst_dtype, int oh, int ow, ivlm_stream_t stream);
+
 /* The same with the sigmoid of InteractVLM.py:452-456 applied only where the ground-truth mask gt f32 [n,oh,ow] differs from
  * ignore_label ('oafford' samples with 'HM' object views; raw logits elsewhere). */
 int ivlm_postprocess_masks_valid(const void *low, int dtype, int n, int h, int w, int img, int in_h, int in_w, int oh, int ow,

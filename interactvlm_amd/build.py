@@ -24,6 +24,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-a
 EXTRA = {
     "lift.hip": ["-ffp-contract=off"],
     "postprocess.hip": ["-ffp-contract=off"],
+    "heads.hip": ["-ffp-contract=off"],
 }
 
 

@@ -141,17 +141,19 @@ def config_from_hf(folder: str, tokenizer_ids: Optional[dict] = None,
         token_type=str(get("token_type", "Gen")), multiview_channels=int(get("multiview_channels", 4)),
         multiview_cam_cond=bool(get("multiview_cam_cond", True)), cam_encoder_type=str(get("cam_encoder_type", "vi_v1")),
         hC_sam_view_type=str(get("hC_sam_view_type", "4MV-Z_Vitru")), oC_sam_view_type=str(get("oC_sam_view_type", "4MV-Z_HM")),
-        hC_loss_weight=float(get("hC_loss_weight", 1.0)), oC_loss_weight=float(get("oC_loss_weight", 0.0)))
+        hC_loss_weight=float(get("hC_loss_weight", 1.0)), oC_loss_weight=float(get("oC_loss_weight", 0.0)),
+        use_fusion=bool(get("use_fusion", get("use_feat_fusion", False))), use_uncertainty=bool(get("use_uncertainty", False)))
     return cfg
 
 
 # Tensors a checkpoint written by merge_lora_weights_and_save_hf_model.py:152-161 may carry besides the inference path's own
 # (tests/golden/state_dict_keys.json is the reference's inventory): older transformers saved the rotary inv_freq buffers, and the
-# optional fusion / uncertainty heads are off in every released configuration.  The '-DifDe' token types carry two more mask
+# optional fusion / uncertainty heads (ModifiedSAM.fusion / .uncertainty, InteractVLM.py:33-38) are off in every released configuration
+# and part of the spec only when config.json switches them on (use_fusion / use_uncertainty, InteractVLM.py:149-150).  The '-DifDe' token types carry two more mask
 # decoders: separately TRAINED deep copies (initialize_separate_decoders, InteractVLM.py:114-121, called from train.py:274 and
 # evaluate.py:557/563) that ModifiedSAM.forward selects by dataset name (:46-52) - with a '-DifDe' configuration they are part of
 # the spec (weights.ivlm_spec) and are loaded as decoders of their own; a non-DifDe configuration ignores them if present.
-TOLERATED_PREFIXES = ("model.visual_model.uncertainty", "model.fusion", "model.visual_model.human_mask_decoder.",
+TOLERATED_PREFIXES = ("model.visual_model.uncertainty.", "model.visual_model.fusion.", "model.visual_model.human_mask_decoder.",
                       "model.visual_model.object_mask_decoder.")
 TOLERATED_SUFFIXES = ("rotary_emb.inv_freq",)
 

@@ -22,6 +22,7 @@ import torch
 from . import ops
 from .components import HumanContact3DPredictor, ObjectMeshContact3DPredictor, ObjectPCAfford3DPredictor
 from .constants import IGNORE_LABEL, IMAGE_TOKEN_INDEX
+from .heads import SamFusionHead, UncertaintyHead
 from .llava import ClipTower, Llama
 from .sam import SamImageEncoder, SamMaskDecoder, _Lin, _dev, postprocess_masks
 from .weights import IvlmCfg
@@ -79,7 +80,8 @@ class InteractVLMForCausalLM:
         self.multiview_channels, self.multiview_cam_cond = c.multiview_channels, c.multiview_cam_cond
         self.cam_encoder_type = c.cam_encoder_type
         self.base_token_type = c.token_type.replace("-DifDe", "")
-        self.use_fusion = self.use_uncertainty = False  # off in every released config (scripts/run_train.sh:61-62)
+        # optional heads of ModifiedSAM (InteractVLM.py:33-38); off in every released config (scripts/run_train.sh:61-62)
+        self.use_fusion, self.use_uncertainty = bool(c.use_fusion), bool(c.use_uncertainty)
         self.debug_taps = None  # set to a dict to record intermediate tensors (tests / diagnostics only)
         self.overlap_sam_encoder = True
         # HIP-graph replay of the decode step / CLIP tower (launch-bound on the host otherwise); IVLM_NO_GRAPHS=1 turns both
@@ -111,6 +113,10 @@ class InteractVLMForCausalLM:
             vm.object_mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid, decoder="object_mask_decoder")
             if os.environ.get("IVLM_NO_GRAPHS"):
                 vm.human_mask_decoder.use_graph = vm.object_mask_decoder.use_graph = False
+        if self.use_fusion:
+            vm.fusion = SamFusionHead(w, dev)
+        if self.use_uncertainty:
+            vm.uncertainty = UncertaintyHead(w, dev, grid=c.sam.grid)
         vm.postprocess_masks = lambda m, input_size, original_size: postprocess_masks(
             m, input_size, original_size, c.sam.img_size)
         self.model = SimpleNamespace(visual_model=vm, text_hidden_fcs=self.text_hidden_fcs,
@@ -301,12 +307,15 @@ class InteractVLMForCausalLM:
         return vm.mask_decoder
 
     def _decode_sample(self, hidden, rows_mask, ids, cam_params, image_embeddings, input_size, original_size, ds_name=None,
-                       sigmoid_gt=None):
-        """[SEG] rows -> pred_mask [V,H,W] fp32 for one sample (InteractVLM.py:416-442 / 585-612)."""
+                       sigmoid_gt=None, llava_features=None):
+        """[SEG] rows -> pred_mask [V,H,W] fp32 for one sample (InteractVLM.py:416-442 / 585-612).  llava_features: the hidden
+        rows the fusion head attends to when ``use_fusion`` (ModifiedSAM.forward, InteractVLM.py:41-44)."""
         rows = rows_mask.nonzero().flatten()
         V = self.multiview_channels
         if rows.numel() == 0:
             return torch.zeros((0,) + tuple(original_size), dtype=torch.float32, device=self.device), None
+        if self.use_fusion:
+            image_embeddings = self.model.visual_model.fusion(image_embeddings, llava_features)
         sel = hidden[rows.to(hidden.device)].contiguous()
         if sel.shape[0] > 16:
             raise ops.IvlmError("more than 16 [SEG] rows in one sample")
@@ -348,7 +357,7 @@ class InteractVLMForCausalLM:
             images.to(self.device).reshape((B * images.shape[1],) + tuple(images.shape[2:])))
         V = images.shape[1]
         emb_sam = emb_sam.view(B, V, emb_sam.shape[1], emb_sam.shape[2])
-        pred_masks, gt_masks = [], []
+        pred_masks, gt_masks, uncertainty_maps = [], [], []
         for i in range(B):
             ids = input_ids[i].to(self.device)
             x = self._input_embeds(ids, feats[i if feats.shape[0] > 1 else 0])
@@ -359,12 +368,17 @@ class InteractVLMForCausalLM:
             gt = masks_list[i][:, 0] if masks_list is not None else None
             # InteractVLM.py:452-456: 'oafford' samples with 'HM' object views get a sigmoid on the labelled pixels
             hm = gt is not None and "oafford" in ds_name and "HM" in (self.oC_sam_view_type or "")
+            # use_fusion: the sample's whole last-layer sequence (llava_features[i].unsqueeze(0), InteractVLM.py:414,431)
             pm, _ = self._decode_sample(hidden, rows, ids, cam_params[i], emb_sam[i], resize_list[i], osz, ds_name=ds_name,
-                                        sigmoid_gt=gt if hm else None)
+                                        sigmoid_gt=gt if hm else None, llava_features=hidden if self.use_fusion else None)
             pred_masks.append(pm)
             gt_masks.append(gt)
+            if self.use_uncertainty:  # on the un-fused embeddings, resized to the label size (InteractVLM.py:445-448)
+                uncertainty_maps.append(self.model.visual_model.uncertainty.resized(emb_sam[i], osz).squeeze(0))
         ds_name_list = ds_name_list or ["hcontact"] * B
         result = {"gt_masks": gt_masks, "pred_masks": pred_masks}
+        if self.use_uncertainty:
+            result["uncertainty_maps"] = uncertainty_maps
         if self.hC_loss_weight > 0:
             result["pred_human_3d_contact"] = self.human_3d_contact_predictor(pred_masks, ds_name_list)
         if self.oC_loss_weight > 0:
@@ -603,8 +617,10 @@ class InteractVLMForCausalLM:
         for b, (output_ids, hidden) in enumerate(gens):
             rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)
             pm, _ = self._decode_sample(hidden, rows, output_ids[0], cam_params[b], embs[b], resize_list[b],
-                                        original_size_list[b], ds_name=ctypes[b])
+                                        original_size_list[b], ds_name=ctypes[b], llava_features=self._eval_llava_features(hidden, 0))
             outs.append({"output_ids": output_ids, "pred_masks": [pm], "pred_contact_3d": None})
+            if self.use_uncertainty:
+                outs[-1]["uncertainty_maps"] = [self._eval_uncertainty(embs[b], original_size_list[b])]
             lows.append(pm)
         paths = lift2d_dict_path if isinstance(lift2d_dict_path, (list, tuple)) else [lift2d_dict_path] * B
         have = [b for b in range(B) if lows[b].shape[0] > 0]
@@ -683,7 +699,7 @@ class InteractVLMForCausalLM:
         if image_embeddings is None:
             image_embeddings = self.model.visual_model.image_encoder(images[0].to(self.device))
         pm, _ = self._decode_sample(hidden, rows, output_ids[0], cam_params[0], image_embeddings, resize_list[0],
-                                    original_size_list[0], ds_name=contact_type)
+                                    original_size_list[0], ds_name=contact_type, llava_features=self._eval_llava_features(hidden, 0))
         pred_masks = [pm]
         pred_contact_3d = None
         if pred_masks[0].shape[0] > 0:
@@ -699,4 +715,19 @@ class InteractVLMForCausalLM:
                 # same operator precedence as the reference (InteractVLM.py:626): 'oafford' always takes the mesh lift
                 pred_contact_3d = self.object_3d_contact_predictor(pred_masks, ds_names=["ocontact"],
                                                                    lift2d_dict_path=lift2d_dict_path)
-        return {"output_ids": output_ids, "pred_masks": pred_masks, "pred_contact_3d": pred_contact_3d}
+        result = {"output_ids": output_ids, "pred_masks": pred_masks, "pred_contact_3d": pred_contact_3d}
+        if self.use_uncertainty:
+            result["uncertainty_maps"] = [self._eval_uncertainty(image_embeddings, original_size_list[0])]
+        return result
+
+    def _eval_llava_features(self, hidden, i):
+        """evaluate()'s argument to the fusion head: ``output_hidden_states[-1]`` is the LAST sample's [T, hidden] sequence and
+        ``llava_features[i].unsqueeze(0)`` its ROW i as [1, hidden] (InteractVLM.py:583,601) - one key / value position, which the
+        head can only deal to a single view (components.py:94-95 raises for multiview_channels > 1; so does SamFusionHead)."""
+        return hidden[i: i + 1] if self.use_fusion else None
+
+    def _eval_uncertainty(self, image_embeddings, original_size):
+        """evaluate()'s uncertainty map.  The reference hands UncertaintyModule a 5-D tensor there (image_embeddings[i].unsqueeze(0)
+        with multi-view embeddings, InteractVLM.py:615 -> the permute of components.py:62 raises); this returns what its
+        model_forward branch computes for the same sample (InteractVLM.py:445-448) instead of failing."""
+        return self.model.visual_model.uncertainty.resized(image_embeddings, original_size).squeeze(0)

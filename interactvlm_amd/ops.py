@@ -787,6 +787,29 @@ def add_rows(a, b, out=None, op="add", out_kind=None):
     return out
 
 
+def uncertainty_mlp(emb, w1, b1, w2, b2, w3, b3):
+    """UncertaintyModule's per-pixel MLP (components.py:55-78) with the bf16 module's rounding points: emb fp32 [..., 256]
+    (channels last) -> fp32 [...] holding bf16 values."""
+    emb = _req(emb, F32, "emb")
+    assert emb.shape[-1] == 256 and tuple(w1.shape) == (64, 256) and tuple(w2.shape) == (16, 64) and w3.numel() == 16
+    ws = [_req(t, BF16, "w") for t in (w1, b1, w2, b2, w3, b3)]
+    out = torch.empty(emb.shape[:-1], dtype=F32, device=emb.device)
+    check(_lib.load().ivlm_uncertainty_mlp(emb.data_ptr(), out.numel(), *[t.data_ptr() for t in ws], out.data_ptr(), _stream()),
+          "uncertainty_mlp")
+    return out
+
+
+def resize_bilinear(src, size, dtype=torch.float32):
+    """F.interpolate(src, size, mode='bilinear', align_corners=False): src fp32 [..., h, w] -> [..., oh, ow] fp32 or bf16."""
+    src = _req(src, F32, "src")
+    h, w = src.shape[-2:]
+    oh, ow = int(size[0]), int(size[1])
+    out = torch.empty(src.shape[:-2] + (oh, ow), dtype=dtype, device=src.device)
+    n = src.numel() // (h * w)
+    check(_lib.load().ivlm_resize_bilinear(src.data_ptr(), n, h, w, out.data_ptr(), _dtc(out), oh, ow, _stream()), "resize_bilinear")
+    return out
+
+
 def dense_pe(gauss, h, w, dtype=torch.float32):
     lib = _lib.load()
     gauss = _req(gauss, torch.float32, "gauss")

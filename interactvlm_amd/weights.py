@@ -80,6 +80,8 @@ class IvlmCfg:
     oC_sam_view_type: str = "4MV-Z_HM"
     hC_loss_weight: float = 1.0
     oC_loss_weight: float = 0.0
+    use_fusion: bool = False       # LLaVASAMFusion head (InteractVLM.py:149; off in every released configuration)
+    use_uncertainty: bool = False  # UncertaintyModule head (InteractVLM.py:150)
 
 
 def _lin(spec: Spec, name: str, out: int, inp: int, bias: bool = True):
@@ -274,6 +276,10 @@ def ivlm_spec(c: IvlmCfg) -> Spec:
         s.update(cam_encoder_spec(c.cam_encoder_type, c.multiview_channels))
     if c.token_type.replace("-DifDe", "") in ("Gen-Hu-Obj", "Gen-Int"):
         s.update(attention_splitter_spec())
+    if c.use_fusion:  # (constructed with its defaults, InteractVLM.py:35: llava_embed_dim = 5120 whatever the language model is)
+        s.update(fusion_spec())
+    if c.use_uncertainty:
+        s.update(uncertainty_spec())
     return s
 
 

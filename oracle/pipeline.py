@@ -70,11 +70,19 @@ def model_forward(w, cfg, images, images_clip, input_ids, cam_params, tables, in
     k = int(rows.nonzero()[0]) - cfg.img_emb_len + 1
     token = int(input_ids[k]) if k > 0 else None
     emb = sam_embed(w, cfg, images)
-    masks, low, iou = decode_masks(w, cfg, seg_emb, token, cam_params, emb, input_size, original_size)
+    extra = {}
+    dec_emb = emb
+    if getattr(cfg, "use_fusion", False):  # ModifiedSAM.forward, InteractVLM.py:41-44 (llava_features = the whole sequence, :414,431)
+        dec_emb = O.sam_fusion(w, "model.visual_model.fusion", emb, hidden[None])
+        extra["fused_emb"] = dec_emb
+    if getattr(cfg, "use_uncertainty", False):  # on the un-fused embeddings, InteractVLM.py:445-448
+        unc = O.uncertainty_head(w, "model.visual_model.uncertainty", emb)
+        extra["uncertainty_map"] = O.uncertainty_resize(unc, original_size)
+    masks, low, iou = decode_masks(w, cfg, seg_emb, token, cam_params, dec_emb, input_size, original_size)
     vid, bary = tables
     contact, nviews = L.lift_mesh_soft(masks.numpy()[None], vid, bary, 6890)
     return dict(clip_feat=feat, hidden=hidden, seg_emb=seg_emb, sam_emb=emb, low_res=low, pred_masks=masks,
-                pred_contact=torch.from_numpy(contact), nviews=nviews)
+                pred_contact=torch.from_numpy(contact), nviews=nviews, **extra)
 
 
 def model_forward_oafford(w, cfg, images, images_clip, input_ids, cam_params, point_maps, valid_mask,

@@ -472,13 +472,15 @@ def gen_state_keys():
         np.savez(os.path.join(d, "bary_coords_map_1024.npz"), **{n: bary[i] for i, n in enumerate(names)})
         for tag, token_type, cam, oc in (("Gen/vi_v1", "Gen", "vi_v1", 0.0), ("Gen/simple", "Gen", "simple", 0.0),
                                          ("Gen-Hu-Obj/view_index", "Gen-Hu-Obj", "view_index", 1.0),
-                                         ("Gen-Hu-Obj-DifDe/vi_v1", "Gen-Hu-Obj-DifDe", "vi_v1", 1.0)):
+                                         ("Gen-Hu-Obj-DifDe/vi_v1", "Gen-Hu-Obj-DifDe", "vi_v1", 1.0),
+                                         ("Gen/vi_v1/heads", "Gen", "vi_v1", 0.0)):  # .../heads: use_fusion + use_uncertainty
+            heads = tag.endswith("/heads")
             cfg = RI.LlavaLlamaForCausalLM.config_class(
                 hidden_size=t["hidden"], intermediate_size=t["inter"], num_hidden_layers=t["layers"],
                 num_attention_heads=t["heads"], num_key_value_heads=t["heads"], vocab_size=t["vocab"], rms_norm_eps=1e-5,
                 max_position_embeddings=1024, attn_implementation="eager")
             for k, v in dict(vision_tower=clip_dir, mm_vision_tower=clip_dir, mm_hidden_size=t["clip_hidden"],
-                             mm_use_im_start_end=True, mm_vision_select_layer=-2, use_fusion=False, use_uncertainty=False,
+                             mm_use_im_start_end=True, mm_vision_select_layer=-2, use_fusion=heads, use_uncertainty=heads,
                              img_emb_len=255, seg_token_idx=32000, hseg_token_idx=32003, oseg_token_idx=32004,
                              token_type=token_type, hC_sam_view_type="4MV-Z_Vitru", oC_sam_view_type="4MV-Z_HM",
                              hC_loss_weight=1.0, oC_loss_weight=oc, multiview_channels=4, multiview_cam_cond=True,
