@@ -223,8 +223,11 @@ void ivlm_skinny_tuning(int tiles_per_block);
 
 /* Benchmark hook: column split of GEMMs whose 256 x 256 tile count under-fills its last round (default 1 = on). */
 int ivlm_gemm_nsplit(int on);
-/* Benchmark/test hook: force the GEMM block tile (64 = 128x64, 128, 256; 0 = automatic choice). Returns the previous value. */
+/* Benchmark/test hook: force the GEMM block tile (64 = 128x64, 128, 256, 512 = the 8-phase 256x256 kernel, 320 = 256x320, 176;
+ * 0 = automatic choice). Returns the previous value. */
 int ivlm_gemm_tile_override(int tile);
+/* Benchmark/test hook: automatic choice of the 256 x 320 tile for N % 320 == 0 (SAM ViT-H widths; default on). Returns the previous value. */
+int ivlm_gemm_tile320(int on);
 
 /* nn.LayerNorm over the last dim (also SAM LayerNorm2d with NHWC activations, common.py:32-42);
  * x / y bf16 or fp32 (dtype codes), fp32 statistics, cols % 8 == 0, cols <= 8192.  gelu_after != 0 fuses the exact-erf GELU

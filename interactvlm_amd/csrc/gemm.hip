@@ -236,8 +236,25 @@ using Cfg128x96 = TileCfg<2, 2, 4, 3>;  // 128 x 96 block: M ~ 330 prefill again
 //     put more CUs to work (LLM prefill o/down, CLIP: +15-30 %);
 //   * 256^2 (+10 % on SAM qkv / mlp1) when it fills whole waves of the 256 CUs (quantisation efficiency >= 0.85);
 //   * 128^2 otherwise.
+// 256 x 320 tiles (gemm320.hip): N a multiple of 320 (SAM ViT-H: 1280 / 3840 / 5120) and enough row tiles that whole rounds of
+// the 256 CUs are filled - proj / mlp2 of the 4-view call are exactly ONE round instead of 1.25 rounds of 256^2 tiles
+inline bool tile320_fits(const GemmArgs& g) {
+    if (g.fp8 || g.out_fp8 || g.batch != 1 || g.a_kstep || g.w_kstep || g.c_panel || g.rms_w) return false;
+    if ((g.act != ACT_NONE && g.act != ACT_GELU) || g.N % 320 || g.M < 2048) return false;
+    if (!(g.out_f32 ? gemm_whole_lines_ok<true>(g, g.act) : gemm_whole_lines_ok<false>(g, g.act))) return false;  // (its only epilogue)
+    // 16-bit outputs stay on 256^2 tiles: the wave's fifth fragment column is stored directly (32-byte row pieces), which costs
+    // what the saved round gains (tools/bench_sam_gemms.py: qkv 193 vs 190 us, mlp1 260 vs 240 us; fp32 out: mlp2 189 vs 208 us,
+    // proj 80-85 vs 90-93 us)
+    if (!g.out_f32 || g.out_split) return false;
+    const long tm = (g.M + 255) / 256, tiles = tm * (g.N / 320);
+    const double q = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+    return tiles >= 256 && q >= 0.85 && (double)(tm * 256) / (double)g.M < 1.1;
+}
+static int g_tile320 = 1;  // benchmark hook (ivlm_gemm_tile320): 0 = never pick the 256 x 320 tile automatically
+
 inline int choose_tile(const GemmArgs& g) {
-    if (g.tile == 128 || g.tile == 256 || g.tile == 64 || g.tile == 96 || g.tile == 512 || g.tile == 176) return g.tile;
+    if (g.tile == 128 || g.tile == 256 || g.tile == 64 || g.tile == 96 || g.tile == 512 || g.tile == 176 || g.tile == 320) return g.tile;
+    if (g_tile320 && tile320_fits(g)) return 320;
     if (g.M > 128 && g.M <= 352 && g.N >= 8192 && g.batch <= 2 && (g.act == ACT_NONE || g.act == ACT_SWIGLU)) return 176;  // LLaMA prefill, wide N
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
     // (128x96 tiles for the LLaMA prefill's wide projections, M ~ 330 = 3 tile rows: faster in the warm micro-benchmark -
@@ -264,6 +281,7 @@ int launch(const GemmArgs& g, hipStream_t st) {
     if (g.f16) {  // fp16 operands: the 8-phase 256^2 kernel, 128 x 64 tiles for what it does not fit (epilogues of the SAM MLP only)
         if constexpr (ACT == ACT_NONE || ACT == ACT_GELU) {
             const int t = choose_tile(g);
+            if (t == 320) return gemm_bf16_320p(g, st);
             if (t == 512 || t == 256) return gemm_bf16_256p(g, st);
             return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64, 2>(g, st) : launch_cfg<ACT, false, Cfg128x64, 2>(g, st);
         } else {
@@ -271,6 +289,11 @@ int launch(const GemmArgs& g, hipStream_t st) {
         }
     }
     switch (choose_tile(g)) {
+        case 320: {  // 256 x 320 (gemm320.hip); a FORCED 320 on a problem outside its epilogue falls through to 128^2
+            const int rc = gemm_bf16_320p(g, st);
+            if (rc != IVLM_ERR_UNSUPPORTED) return rc;
+            return g.out_f32 ? launch_cfg<ACT, true, Cfg128>(g, st) : launch_cfg<ACT, false, Cfg128>(g, st);
+        }
         case 512: return gemm_bf16_256p(g, st);  // 256^2, 8-phase ping-pong pipeline (gemm256.hip)
         case 256: return g.out_f32 ? launch_cfg<ACT, true, Cfg256>(g, st) : launch_cfg<ACT, false, Cfg256>(g, st);
         case 64: return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64>(g, st) : launch_cfg<ACT, false, Cfg128x64>(g, st);
@@ -295,6 +318,7 @@ void gemm_set_nsplit(int on) { g_nsplit = on; }
 // (512 small blocks, 2-3 per CU).  Two launches of the existing kernels; no partial sums, the epilogues are per column.
 static int nsplit_cols(const GemmArgs& g) {
     if (!g_nsplit || g.tile != 0 || g.batch != 1 || g.act == ACT_SWIGLU || g.M < 4096 || (g.N & 255)) return 0;
+    if (g_tile320 && tile320_fits(g)) return 0;  // (whole rounds of 256 x 320 tiles: nothing to split off)
     const long tm = (g.M + 255) / 256, tn = g.N / 256;
     const long tiles = tm * tn;
     const double q = (double)tiles / (double)(((tiles + 255) / 256) * 256);
@@ -482,9 +506,15 @@ extern "C" int ivlm_gemm_nsplit(int on) {  // benchmark hook: column split of un
     return 0;
 }
 
+extern "C" int ivlm_gemm_tile320(int on) {  // benchmark hook: automatic choice of the 256 x 320 tile (default on); returns the previous value
+    const int prev = ivlm::g_tile320;
+    ivlm::g_tile320 = on ? 1 : 0;
+    return prev;
+}
+
 extern "C" int ivlm_gemm_tile_override(int tile) {
     const int prev = g_tile_override;
-    if (tile == 0 || tile == 64 || tile == 96 || tile == 128 || tile == 256 || tile == 512 || tile == 176) g_tile_override = tile;
+    if (tile == 0 || tile == 64 || tile == 96 || tile == 128 || tile == 256 || tile == 512 || tile == 176 || tile == 320) g_tile_override = tile;
     return prev;
 }
 

@@ -129,7 +129,7 @@ __device__ __forceinline__ void gemm_value4(const GemmArgs& g, int n, const f32x
 // reads the residual as - WHOLE lines: 8 rows x 128 B or 4 rows x 256 B per wave instruction.  Same values, same order of
 // operations per element as gemm_epilogue4 (bit-identical results).
 template <bool OUT_F32>
-__device__ __forceinline__ bool gemm_whole_lines_ok(const GemmArgs& g, int act) {
+__host__ __device__ __forceinline__ bool gemm_whole_lines_ok(const GemmArgs& g, int act) {
     return act != ACT_SWIGLU && !g.out_fp8 && g.batch == 1 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
            (OUT_F32 ? ((g.N & 3) == 0 && (g.ldc & 3) == 0 && (!g.residual || (g.ldr & 3) == 0) && (!g.out_split || (g.c_lo & 3) == 0))
                     : ((g.N & 7) == 0 && !g.residual && (g.c_panel ? (g.c_panel & 7) == 0 : (g.ldc & 7) == 0)));

@@ -67,6 +67,7 @@ struct GemmArgs {
 int gemm_bf16(const GemmArgs& g, hipStream_t st);
 // 256x256 tile with the 8-phase ping-pong K loop (gemm256.hip); same contract as gemm_bf16
 int gemm_bf16_256p(const GemmArgs& g, hipStream_t st);
+int gemm_bf16_320p(const GemmArgs& g, hipStream_t st);  // 256 x 320 tiles (gemm320.hip)
 // split-K variant for small M (fp32 partials in `workspace`, >= splits*M*N*4 bytes); act != SWIGLU
 int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st);
 // nn.Linear dispatch: GEMV (M <= 8) or the MFMA tile kernel

@@ -81,7 +81,7 @@ def test_gemm_splitk_matches_single_pass(hip_lib, cuda, M, N, K):
     assert torch.allclose(out[:, :N].float(), x.float() @ w.float().T, atol=2e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("tile", [64, 96, 128, 256, 512])
+@pytest.mark.parametrize("tile", [64, 96, 128, 256, 512, 320])
 def test_gemm_forced_tiles(hip_lib, cuda, tile):
     """Both block-tile configurations on a shape with ragged M/N edges and a K tail."""
     import torch
@@ -103,11 +103,11 @@ def test_gemm_forced_tiles(hip_lib, cuda, tile):
     assert torch.allclose(got.cpu(), ref, atol=3e-3, rtol=1e-3)
 
 
-@pytest.mark.parametrize("tile", [512])
+@pytest.mark.parametrize("tile", [512, 320])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (4096, 1280, 1280), (1000, 520, 200), (2048, 3840, 1288)])
 def test_gemm_8phase_matches_simple_kernel_bitwise(hip_lib, cuda, M, N, K, tile):
-    """The 8-phase ping-pong 256^2 kernel (tile code 512) accumulates in the same order as the plain double-buffered
-    256^2 kernel, so the two must agree BIT FOR BIT; repeated launches screen for LDS races in the staggered pipeline
+    """The 8-phase ping-pong 256^2 kernel (tile code 512) and the 256 x 320 kernel (320, gemm320.hip) accumulate in the same
+    order as the plain double-buffered 256^2 kernel, so they must agree with it BIT FOR BIT; repeated launches screen for LDS races in the staggered pipeline
     (a late DMA / early read shows up as a few wrong tiles in some runs)."""
     import torch
 
@@ -249,7 +249,8 @@ def test_gemm_fp32_residual_and_scatter_epilogue(hip_lib, cuda):
     out = ops.linear(x, w, residual=stream, out=stream, out_rows=rows.to(cuda))
     assert out.data_ptr() == stream.data_ptr() and torch.allclose(stream, exp, atol=1e-3, rtol=1e-4)
     # gather prologue: product row r reads A row a_rows[r] (proj of a windowed SAM block on the real rows only), every tile
-    for tile, (M2, N2, K2) in ((0, (24, 64, 128)), (128, (300, 256, 192)), (512, (700, 512, 256)), (64, (500, 192, 64))):
+    for tile, (M2, N2, K2) in ((0, (24, 64, 128)), (128, (300, 256, 192)), (512, (700, 512, 256)), (64, (500, 192, 64)),
+                                (320, (700, 640, 256)), (0, (4096, 1280, 192))):
         src = _bf(torch.randn(M2 + 37, K2, generator=g)).to(cuda)
         amap = torch.randperm(M2 + 37, generator=g)[:M2].to(torch.int32)
         w2 = _bf(torch.randn(N2, K2, generator=g) / K2 ** 0.5).to(cuda)

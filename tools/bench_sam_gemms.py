@@ -1,0 +1,55 @@
+"""The four GEMMs of a SAM ViT-H block as the encoder issues them (4 views: 16384 rows; bias, GELU, fp32 residual in place, the
+window gather of proj), alone, with the automatic tile choice and with the 256 x 320 tile switched off (M=... env for other row counts)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from interactvlm_amd import _lib, ops
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    M = int(os.environ.get("M", "16384"))
+    D, MD = 1280, 5120
+    g = torch.Generator().manual_seed(0)
+    bf = lambda *s: (torch.randn(*s, generator=g) / s[-1] ** 0.5).to(torch.bfloat16).to(dev)
+    xn, att, hh = bf(M, D), bf(M + 3216, D), bf(M, MD)
+    x = torch.randn(M, D, generator=g).to(dev)
+    rows = torch.randperm(M + 3216, generator=g)[:M].to(torch.int32).to(dev)
+    w = {"qkv": bf(3 * D, D), "proj": bf(D, D), "lin1": bf(MD, D), "lin2": bf(D, MD)}
+    b = {k: bf(v.shape[0]) for k, v in w.items()}
+    qkv_out = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev)
+    h_out = torch.empty(M, MD, dtype=torch.bfloat16, device=dev)
+    calls = {
+        "qkv   16384x3840x1280 bf16 out": lambda: ops.linear(xn, w["qkv"], b["qkv"], out=qkv_out),
+        "proj  16384x1280x1280 gather + fp32 residual in place": lambda: ops.linear(att, w["proj"], b["proj"], residual=x, out=x, a_rows=rows),
+        "proj  (global block: no gather)": lambda: ops.linear(xn, w["proj"], b["proj"], residual=x, out=x),
+        "lin1  16384x5120x1280 GELU bf16 out": lambda: ops.linear(xn, w["lin1"], b["lin1"], act="gelu", out=h_out),
+        "lin2  16384x1280x5120 fp32 residual in place": lambda: ops.linear(hh, w["lin2"], b["lin2"], residual=x, out=x),
+    }
+    flops = {"qkv": 2 * M * 3 * D * D, "proj": 2 * M * D * D, "lin1": 2 * M * MD * D, "lin2": 2 * M * MD * D}
+    for name, fn in calls.items():
+        line = f"{name:58s}"
+        for on in (1, 0):
+            lib.ivlm_gemm_tile320(on)
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(20):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) / 20 * 1e3
+            line += f"  {'320-tile' if on else 'before  '} {us:7.1f} us {flops[name.split()[0]] / us / 1e6:7.0f} TF"
+        lib.ivlm_gemm_tile320(1)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
