@@ -564,6 +564,34 @@ def test_evaluate_batch_equals_per_image_evaluate(hip_lib, cuda, golden_dir, gra
         assert torch.equal(outs3[b]["pred_contact_3d"], outs[b]["pred_contact_3d"])
 
 
+@pytest.mark.parametrize("B", [16, 17])
+def test_evaluate_batch_of_16_and_chunking(hip_lib, cuda, golden_dir, B):
+    """The decode kernels' row limit: 16 sequences in one batched step (the dp64 job's per-call batch), 17 = one call of 16 + one
+    of 1 - every image equal to evaluate() of that image alone."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth
+    from interactvlm_amd import weights as Wt
+
+    d, cfg, ids, images_clip, images, cams, tables = _toy(golden_dir)
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    bf = torch.bfloat16
+    ic = torch.from_numpy(synth.synth_normal("eb16/images_clip", (B, 3, 224, 224), 1.0, 0)).to(bf).to(cuda)
+    im = torch.from_numpy(synth.synth_normal("eb16/images", (B, 4, 3, 1024, 1024), 1.0, 0)).to(bf).to(cuda)
+    prompts = [ids[:40] if b % 3 else torch.cat([ids[:30], ids[34:40]]) for b in range(B)]
+    forced = [ids[40:].tolist()] * B
+    sizes = [(1024, 1024)] * B
+    outs = m.evaluate_batch(ic, im, prompts, [cams[0]] * B, sizes, sizes, forced_new_tokens=forced)
+    assert len(outs) == B
+    for b in (0, 7, 9, 15, B - 1):
+        one = m.evaluate(ic[b: b + 1], im[b: b + 1], prompts[b][None], cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced[b])
+        assert torch.equal(outs[b]["output_ids"], one["output_ids"])
+        e = float((outs[b]["pred_contact_3d"] - one["pred_contact_3d"]).abs().max())
+        assert e < 1e-3, (b, e)
+
+
 def test_full_depth_towers_vs_oracle(hip_lib, cuda):
     """Parity evidence at the REAL depths (evidence stopped at depth 2-4): the SAM ViT-H encoder with all 32
     blocks at its real width on one view, and a 32-layer LLaMA (narrower: the fp32 CPU oracle of the 7B width would need
