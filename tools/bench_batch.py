@@ -37,11 +37,11 @@ def main():
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t) / args.reps
 
-    for B in (1, 2, 4, 8):
+    for B in (1, 4, 8, 16):
         ic, im = synthetic.images(cfg, dev, seed=5, batch=B)
         t_gen = timeit(lambda: m.generate_batch(ic, [ids[0]] * B, forced_new_tokens=forced))
         t_clip = timeit(lambda: m.encode_images(ic))
-        t_sam = timeit(lambda: [m.model.visual_model.image_encoder(im[b]) for b in range(B)])
+        t_sam = timeit(lambda: m.model.visual_model.image_encoder(im.reshape((B * im.shape[1],) + tuple(im.shape[2:]))))
         t_all = timeit(lambda: m.evaluate_batch(ic, im, [ids[0]] * B, [cams[0]] * B, [(S, S)] * B, [(S, S)] * B,
                                                 forced_new_tokens=forced))
         m.overlap_sam_encoder = False
