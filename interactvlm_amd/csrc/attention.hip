@@ -717,10 +717,13 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
 // K / V planes leave no LDS for the table-product scratch, so SPLIT reads the rel-pos terms from the fp32 arrays of
 // ivlm_relpos_bias_split (array mode) instead of computing them here (table mode).
 template <bool SPLIT>
-__global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArgs a) {
     constexpr bool TAB = !SPLIT;
-    // 8 waves (two per SIMD); SPLIT holds its register use under 256 with scheduling barriers in the fragment loops
-    constexpr int NT = 512, NWV = NT / 64;
+    // SPLIT: 8 waves (two per SIMD, 240 registers: held under 256 with scheduling barriers in the fragment loops), the 13 query tiles
+    // in two rounds.  Default precision: 126 registers allow 16 waves (four per SIMD) - every query tile has a wave of its own (ONE
+    // round; the kernel is latency-bound: ~12 % MFMA utilisation), the other three waves only help staging.
+    constexpr int NT = SPLIT ? 512 : 1024, NWV = NT / 64;
+    constexpr int NGW = SPLIT ? 8 : 13;  // waves that own a table-product scratch slice (a query tile)
     constexpr int DV = 80, KS = 3, DT = 5, DCH = 10;
     constexpr int KT = 13;            // 16-key tiles (208 padded keys) of the score pass
     constexpr int VS = 7;             // 32-key steps (224 padded keys) of the P.V pass
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
     bf16_t* const Vl = Vh + VBUF;                              // (SPLIT only)
     u32x4_t* const Hot = reinterpret_cast<u32x4_t*>(Vh + (SPLIT ? 2 : 1) * VBUF);  // one-hot rel-pos operands [KT][64 lanes]
     float* const Gs = reinterpret_cast<float*>(Hot + KT * 64);                    // (table mode only)
-    bf16_t* const Tb = reinterpret_cast<bf16_t*>(Gs + NWV * kGW);                   // (table mode) the rel-pos table, K-plane layout
+    bf16_t* const Tb = reinterpret_cast<bf16_t*>(Gs + NGW * kGW);                   // (table mode) the rel-pos table, K-plane layout
     constexpr int TPL = 64 * 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(512, 1) void win_attn_kernel(AttnArgs a) {
 
     const int kswz = (g ^ ((l15 >> 3) << 1)) * 8;
     const int voff = (g * 4 + (l15 >> 2)) * 16 + (l15 & 3) * 4;
-    float* Gw = Gs + wave * kGW;
+    float* Gw = Gs + (wave < NGW ? wave : 0) * kGW;  // (waves without a query tile never touch it)
     const float sc = a.scale;
     const int nqt = (S + 15) >> 4;
 
@@ -1111,7 +1114,7 @@ template <bool SPLIT>
 static int launch_win(const AttnArgs& a, hipStream_t st) {
     constexpr int KS = 3, DT = 5, KPL = 13 * 16 * 32 + 32, VPL = 7 * 32 * 16 + 16;
     constexpr size_t lds = (size_t)(SPLIT ? 2 : 1) * (KS * KPL + DT * VPL) * 2 +
-                           (SPLIT ? 0 : (size_t)13 * 64 * 16 + 8 * 16 * 65 * 4 + 3 * 64 * 32 * 2);
+                           (SPLIT ? 0 : (size_t)13 * 64 * 16 + 13 * 16 * 65 * 4 + 3 * 64 * 32 * 2);
     static_assert(lds <= 160 * 1024, "window tiles must fit the LDS");
     auto kfn = win_attn_kernel<SPLIT>;
     static bool attr_set = false;
@@ -1119,7 +1122,7 @@ static int launch_win(const AttnArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    kfn<<<dim3(a.H * a.B), 512, lds, st>>>(a);
+    kfn<<<dim3(a.H * a.B), SPLIT ? 512 : 1024, lds, st>>>(a);
     return ivlm_launch_status();
 }
 
