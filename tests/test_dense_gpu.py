@@ -248,6 +248,24 @@ def test_gemm_fp32_residual_and_scatter_epilogue(hip_lib, cuda):
             exp[rows[m]] += y[m]
     out = ops.linear(x, w, residual=stream, out=stream, out_rows=rows.to(cuda))
     assert out.data_ptr() == stream.data_ptr() and torch.allclose(stream, exp, atol=1e-3, rtol=1e-4)
+    # the same scatter through the 256 x 320 tile (whole-line part and the directly stored fifth fragment column)
+    M3, N3, K3, R3 = 700, 640, 192, 600
+    rows3 = torch.full((M3,), -1, dtype=torch.int32)
+    rows3[torch.randperm(M3, generator=g)[:R3]] = torch.randperm(R3, generator=g).to(torch.int32)
+    x3 = _bf(torch.randn(M3, K3, generator=g)).to(cuda)
+    w3 = _bf(torch.randn(N3, K3, generator=g) / K3 ** 0.5).to(cuda)
+    stream3 = torch.randn(R3, N3, generator=g).to(cuda)
+    exp3 = stream3.clone()
+    y3 = x3.float() @ w3.float().T
+    valid = rows3 >= 0
+    exp3[rows3[valid].long().to(cuda)] += y3[valid.to(cuda)]
+    from interactvlm_amd import _lib as _l
+    prev = _l.load().ivlm_gemm_tile_override(320)
+    try:
+        ops.linear(x3, w3, residual=stream3, out=stream3, out_rows=rows3.to(cuda))
+    finally:
+        _l.load().ivlm_gemm_tile_override(prev)
+    assert torch.allclose(stream3, exp3, atol=1e-3, rtol=1e-4)
     # gather prologue: product row r reads A row a_rows[r] (proj of a windowed SAM block on the real rows only), every tile
     for tile, (M2, N2, K2) in ((0, (24, 64, 128)), (128, (300, 256, 192)), (512, (700, 512, 256)), (64, (500, 192, 64)),
                                 (320, (700, 640, 256)), (0, (4096, 1280, 192))):
