@@ -242,10 +242,6 @@ inline bool tile320_fits(const GemmArgs& g) {
     if (g.fp8 || g.out_fp8 || g.batch != 1 || g.a_kstep || g.w_kstep || g.c_panel || g.rms_w) return false;
     if ((g.act != ACT_NONE && g.act != ACT_GELU) || g.N % 320 || g.M < 2048) return false;
     if (!(g.out_f32 ? gemm_whole_lines_ok<true>(g, g.act) : gemm_whole_lines_ok<false>(g, g.act))) return false;  // (its only epilogue)
-    // 16-bit outputs stay on 256^2 tiles: the wave's fifth fragment column is stored directly (32-byte row pieces), which costs
-    // what the saved round gains (tools/bench_sam_gemms.py: qkv 193 vs 190 us, mlp1 260 vs 240 us; fp32 out: mlp2 189 vs 208 us,
-    // proj 80-85 vs 90-93 us)
-    if (!g.out_f32 || g.out_split) return false;
     const long tm = (g.M + 255) / 256, tiles = tm * (g.N / 320);
     const double q = (double)tiles / (double)(((tiles + 255) / 256) * 256);
     return tiles >= 256 && q >= 0.85 && (double)(tm * 256) / (double)g.M < 1.1;

@@ -4,9 +4,11 @@
 //     qkv (N = 3840):         64 x 12 = 768 = 3 rounds of 1.25 tile units   (256^2: 960 tiles = 3.75 -> 4 rounds)
 //     mlp1 (N = 5120):        64 x 16 = 1024 = 4 rounds                     (256^2: 1280 = 5 rounds of 1.0: the same)
 // Same contract and epilogues as gemm256_kernel; the differences:
-//   * 8 waves as 2 (M) x 4 (N), a wave owns 128 x 80 of the output = 8 x 5 fragments (160 accumulator registers), and reads its
-//     fragments ONE k-step (32) at a time: 4 + 5 fragment registers sets live instead of both k-steps of a quadrant.  13 LDS
-//     fragment reads per 40 MFMAs (256^2: 12 per 32).
+//   * 8 waves as 2 (M) x 4 (N), a wave owns 128 x 80 of the output = 8 x 5 fragments (160 accumulator registers): columns
+//     wc*64 .. +63 of the tile's first 256 and columns 256 + wc*16 .. +15 of its last 64 (so that the epilogue writes whole,
+//     line-aligned rows: the four fifth fragment columns of a wave row are stored together).  Fragments are read ONE k-step (32)
+//     at a time: 4 + 5 fragment register sets live instead of both k-steps of a quadrant.  13 LDS fragment reads per 40 MFMAs
+//     (256^2: 12 per 32).
 //   * a K tile (BK = 64) is a 32-KiB A image + a 40-KiB W image; two K tiles = 144 KiB of LDS (of 160), one block per CU.
 //   * four phases per K tile, 20 MFMAs each: (k-step 0, rows 0-63) | (k-step 0, rows 64-127) | (k-step 1, ...) | (k-step 1, ...);
 //     W fragments of a k-step are read in its first phase and reused by the second.
@@ -86,7 +88,10 @@ __global__ __launch_bounds__(512, 2) void gemm320_kernel(GemmArgs g) {
     // ---- fragment read offsets (bytes inside an image) ------------------------------------------------------------------------
     const int sw = (((lane & 15) >> 1) & 7);
     const int offA = (wr * 128 + (lane & 15)) * 128 + (((lane >> 4) ^ sw) << 4);  // + (mq * 4 + i) * 2048, ^ (kk << 6)
-    const int offW = (wc * 80 + (lane & 15)) * 128 + (((lane >> 4) ^ sw) << 4);   // + j * 2048,            ^ (kk << 6)
+    // a wave's columns: fragments 0-3 = columns wc*64 .. wc*64+63 of the first 256 (whole, line-aligned rows in the epilogue),
+    // fragment 4 = columns 256 + wc*16 .. +15: the fifth fragments of the four waves of a wave row form one 64-column strip
+    const int offW = (wc * 64 + (lane & 15)) * 128 + (((lane >> 4) ^ sw) << 4);   // + j * 2048 (j < 4),  ^ (kk << 6)
+    const int offW4 = (256 + wc * 16 + (lane & 15)) * 128 + (((lane >> 4) ^ sw) << 4);
 
     f32x4_t acc[5][8];  // [n fragment][m fragment]
 #pragma unroll
@@ -102,7 +107,8 @@ __global__ __launch_bounds__(512, 2) void gemm320_kernel(GemmArgs g) {
     };
     auto read_w = [&](const unsigned char* tb, int kk) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(tb + kABytes + ((offW + j * 2048) ^ (kk << 6)));
+        for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(tb + kABytes + ((offW + j * 2048) ^ (kk << 6)));
+        fw[4] = *reinterpret_cast<const bf16x8_t*>(tb + kABytes + (offW4 ^ (kk << 6)));
     };
     auto mfma_rows = [&](int mq) {
 #pragma unroll
@@ -158,16 +164,19 @@ __global__ __launch_bounds__(512, 2) void gemm320_kernel(GemmArgs g) {
 #undef IVLM_PHASE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-chunk DMAs must not outlive the block's LDS
 
-    // ---- epilogue: the first four fragment columns (64 columns) as whole lines through LDS (gemm_common.h), the fifth directly.
-    // (The dispatcher only sends problems for which gemm_whole_lines_ok holds: no per-fragment fallback here - a second, not fully
-    //  unrolled loop over the accumulators would index them dynamically and push all 160 registers through scratch.)
-    const int mw = m0 + wr * 128, nw = n0 + wc * 80;
+    // ---- epilogue (whole lines through LDS, gemm_common.h): a wave's first four fragment columns from its own 16-KB slice; then the
+    // fifth fragment columns of the four waves of a wave row as ONE shared 128 x 64 strip (bf16 16 KB / fp32 32 KB per wave row), of
+    // which every wave stores 32 rows.  (The dispatcher only sends problems for which gemm_whole_lines_ok holds: no per-fragment
+    //  fallback here - a second, not fully unrolled loop over the accumulators would index them dynamically and push all 160
+    //  registers through scratch.)
+    const int mw = m0 + wr * 128;
     __syncthreads();  // every wave is done with the K tiles
-    gemm_store_lines<ACT, OUT_F32, 8, 4, OUT_F32 ? 4 : 8, 5, 0>(g, smem + wave * 16384, mw, nw, lane, acc);
-    const int m4 = mw + (lane & 15), n4 = nw + 64 + (lane >> 4) * 4;
-#define IVLM_F4(MI) gemm_epilogue4<ACT, OUT_F32>(g, bz, m4 + (MI) * 16, n4, acc[4][MI])
-    IVLM_F4(0); IVLM_F4(1); IVLM_F4(2); IVLM_F4(3); IVLM_F4(4); IVLM_F4(5); IVLM_F4(6); IVLM_F4(7);
-#undef IVLM_F4
+    gemm_store_lines<ACT, OUT_F32, 8, 4, OUT_F32 ? 4 : 8, 5, 0>(g, smem + wave * 16384, mw, n0 + wc * 64, lane, acc);
+    __syncthreads();  // the strips overlay the slices
+    unsigned char* strip = smem + wr * (OUT_F32 ? 32768 : 16384);
+    gemm_stage_strip<ACT, OUT_F32, 8, 5>(g, strip, wc * 16, n0 + 256 + wc * 16, lane, acc, 4);
+    __syncthreads();
+    gemm_store_strip_rows<OUT_F32>(g, strip, wc * 32, 32, mw, n0 + 256, lane);
 }
 
 template <int ACT>

@@ -212,6 +212,75 @@ __device__ __forceinline__ void gemm_store_lines(const GemmArgs& g, unsigned cha
     }
 }
 
+// ---- the same through a tile SHARED by several waves (gemm320.hip: the fifth fragment column of the four waves of a wave row forms
+// one 64-column strip).  Stage: a wave writes one 16-column fragment column (MI fragments = MI * 16 rows) at local column `cl` of a
+// [rows x 64] tile; after a block barrier, rows: a wave stores `nrows` rows of the tile as whole lines.  Same swizzle, same values
+// and order of operations per element as gemm_store_lines / gemm_epilogue4.
+template <int ACT, bool OUT_F32, int MI, int NI_ALL>
+__device__ __forceinline__ void gemm_stage_strip(const GemmArgs& g, unsigned char* tile, int cl, int n_global, int lane,
+                                                 const f32x4_t (&acc)[NI_ALL][MI], int ni_src) {
+    constexpr int ES = OUT_F32 ? 4 : 2;
+    constexpr int RB = 64 * ES, CH = RB / 16;
+    const int nl = cl + (lane >> 4) * 4;  // local column of the lane's four values
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int r = mi * 16 + (lane & 15);
+        const int sw = CH == 8 ? ((r >> 1) & 7) : (r & 15);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (n_global + (lane >> 4) * 4 < g.N) gemm_value4<ACT>(g, n_global + (lane >> 4) * 4, acc[ni_src][mi], v);
+        unsigned char* dst = tile + r * RB + ((((nl * ES) >> 4) ^ sw) << 4) + ((nl * ES) & 15);
+        if (OUT_F32) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_16x2(v[0], v[1], g.out_f16), pack_16x2(v[2], v[3], g.out_f16));
+    }
+}
+
+template <bool OUT_F32>
+__device__ __forceinline__ void gemm_store_strip_rows(const GemmArgs& g, const unsigned char* tile, int row0, int nrows, int m_base, int n_base,
+                                                      int lane) {
+    constexpr int ES = OUT_F32 ? 4 : 2;
+    constexpr int RB = 64 * ES, CH = RB / 16, RPI = 64 / CH;
+    const int cc = lane % CH, n = n_base + cc * (16 / ES);
+    for (int it = 0; it < nrows / RPI; ++it) {
+        const int rr = row0 + it * RPI + lane / CH;
+        const int sw = CH == 8 ? ((rr >> 1) & 7) : (rr & 15);
+        const unsigned char* src = tile + rr * RB + ((cc ^ sw) << 4);
+        int m = m_base + rr;
+        if (m >= g.M || n >= g.N) continue;
+        if (g.out_rows) {
+            m = g.out_rows[m];
+            if (m < 0) continue;
+        }
+        if (OUT_F32) {
+            float4 q = *reinterpret_cast<const float4*>(src);
+            if (g.residual) {
+                const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
+                if (g.res_f32) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.residual) + rrow * g.ldr + n);
+                    q.x += r4.x; q.y += r4.y; q.z += r4.z; q.w += r4.w;
+                } else {
+                    const uint2 r2 = *reinterpret_cast<const uint2*>(g.residual + rrow * g.ldr + n);
+                    q.x += bf16_to_f32((bf16_t)(r2.x & 0xffff));
+                    q.y += bf16_to_f32((bf16_t)(r2.x >> 16));
+                    q.z += bf16_to_f32((bf16_t)(r2.y & 0xffff));
+                    q.w += bf16_to_f32((bf16_t)(r2.y >> 16));
+                }
+            }
+            if (g.out_split) {
+                uint32_t h0, l0, h1, l1;
+                split_bf16x2(q.x, q.y, h0, l0);
+                split_bf16x2(q.z, q.w, h1, l1);
+                bf16_t* cb = static_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n;
+                *reinterpret_cast<uint2*>(cb) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(cb + g.c_lo) = make_uint2(l0, l1);
+            } else {
+                *reinterpret_cast<float4*>(static_cast<float*>(g.C) + (int64_t)m * g.ldc + n) = q;
+            }
+        } else {
+            *reinterpret_cast<uint4*>(static_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n) = *reinterpret_cast<const uint4*>(src);
+        }
+    }
+}
+
 // Epilogue for one accumulator fragment: the lane owns C[m][n .. n+3] (operands were swapped so that the four
 // registers are consecutive N).  bias -> activation (or SwiGLU) -> residual -> store.
 template <int ACT, bool OUT_F32>
