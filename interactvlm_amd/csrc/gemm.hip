@@ -242,6 +242,11 @@ inline bool tile320_fits(const GemmArgs& g) {
     if (g.fp8 || g.out_fp8 || g.batch != 1 || g.a_kstep || g.w_kstep || g.c_panel || g.rms_w) return false;
     if ((g.act != ACT_NONE && g.act != ACT_GELU) || g.N % 320 || g.M < 2048) return false;
     if (!(g.out_f32 ? gemm_whole_lines_ok<true>(g, g.act) : gemm_whole_lines_ok<false>(g, g.act))) return false;  // (its only epilogue)
+    // fp32 outputs only (SAM proj / mlp2: 1.25 rounds of 256^2 tiles -> one round).  The 16-bit-output GEMMs (qkv, mlp1) are also
+    // faster on this tile ALONE (qkv 163 -> 155 us, encoder 29.64 -> 29.56 ms) but evaluate() is SLOWER with them on it (101.2 vs
+    // 99.8 ms, alternating runs on one box; tile off everywhere: 100.5): a 256 x 320 tile holds its CU 25 % longer than a 256^2
+    // one, and the decode / prefill kernels of the other stream - the critical path - wait for CUs at tile granularity.
+    if (!g.out_f32 || g.out_split) return false;
     const long tm = (g.M + 255) / 256, tiles = tm * (g.N / 320);
     const double q = (double)tiles / (double)(((tiles + 255) / 256) * 256);
     return tiles >= 256 && q >= 0.85 && (double)(tm * 256) / (double)g.M < 1.1;
