@@ -38,6 +38,8 @@ extern "C" {
 #define IVLM_BF16 1
 #define IVLM_BF16_SPLIT 2
 #define IVLM_F16 4 /* IEEE fp16 (outputs of ivlm_layernorm; operands of ivlm_gemm_bf16 with IVLM_GEMM_F16) */
+#define IVLM_F16_SPLIT 5 /* a row [hi(cols) | lo(cols)] of IEEE halves with x = hi + lo (outputs of ivlm_layernorm / ivlm_rmsnorm; the
+                          * A operand of ivlm_gemm_bf16 with IVLM_GEMM_F16 | IVLM_GEMM_A_SPLIT; its hi half alone is the IVLM_F16 row) */
 #define IVLM_FP8 3 /* OCP e4m3 bytes (BASELINE configs[4]: fp8 operands for the big GEMMs); always with a per-tensor scale */
 
 /* flags of ivlm_gemm_bf16 / ivlm_gemm_bf16_splitk */
@@ -48,7 +50,9 @@ extern "C" {
 #define IVLM_GEMM_OUT_SPLIT 8 /* tile GEMM: C is bf16 [M, >= 2 n_out], the fp32 result written as [hi(n_out) | lo(n_out)] */
 #define IVLM_GEMM_F16 16      /* tile GEMM: A and W hold IEEE fp16 values (an fp16 activation carries 1/8 of the bf16 rounding error
                                  at the same MFMA rate; bf16 weights inside the fp16 range convert exactly) */
-#define IVLM_GEMM_OUT_F16 32  /* tile GEMM: the 16-bit output (out_f32 = 0) is written as fp16 */
+#define IVLM_GEMM_OUT_F16 32  /* tile GEMM: the 16-bit output (out_f32 = 0) is written as fp16; with IVLM_GEMM_OUT_SPLIT: the [hi | lo]
+                                 halves are IEEE halves (IVLM_F16_SPLIT rows).  IVLM_GEMM_F16 | IVLM_GEMM_A_SPLIT: A rows are
+                                 IVLM_F16_SPLIT (the "exact q" projection of the fp16 mode: q = W_q . (hi + lo)) */
 
 typedef void *ivlm_stream_t;
 
@@ -260,6 +264,22 @@ int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, co
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float *rel_h,
                         const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q,
                         ivlm_stream_t stream);
+/* The same operator on IEEE fp16 tensors (q / k / v / o, and in table mode the fp16 [64, D] table): identical tiles and layouts on
+ * v_mfma_f32_16x16x32_f16; q * scale, the softmax weights and the output are rounded to fp16 (11 significant bits: an eighth of
+ * the bf16 rounding error at the same matrix-core rate), saturating at +-65504.  The default precision of the three towers
+ * (image_encoder.py:235-260; HF CLIP / LLaMA attention).  Shapes of the path: D = 64 (plain), D = 80 with rel_h (prescale_q = 1),
+ * D = 128 causal. */
+int ivlm_attention_f16(const void *q, const void *k, const void *v, void *o, const int64_t *strides_host, int B,
+                       int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float *rel_h,
+                       const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q,
+                       ivlm_stream_t stream);
+/* ... with q as hi + lo IEEE halves (q_lo: same strides as q; the IVLM_F16_SPLIT rows of the q projection): the rel-pos table product
+ * and Q.K^T take both halves, the softmax weights are split the same way for P.V (two MFMAs per fragment each) - q, whose rounding
+ * the rel-pos terms amplify, enters the scores exactly; k / v / o stay single fp16.  SAM's shapes: D = 80, prescale_q, no mask;
+ * windows in table mode (rel_w == NULL) or the 64 x 64 grid with the terms as arrays. */
+int ivlm_attention_f16_qsplit(const void *q, const void *q_lo, const void *k, const void *v, void *o, const int64_t *strides_host,
+                              int B, int H, int Sq, int Sk, int D, float scale, const float *rel_h, const float *rel_w, int rel_kh,
+                              int rel_kw, ivlm_stream_t stream);
 /* "Parity" precision of the same operator (fp32-operand attention on the bf16 matrix cores): q / k / v / o are given as hi + lo
  * bf16 planes (x = hi + lo to 2^-17: the [hi | lo] halves of IVLM_BF16_SPLIT rows; the *_lo tensors use the strides of the hi
  * ones), both products run as three MFMAs per fragment (hi.hi + hi.lo + lo.hi), q * scale and the rel-pos bias stay fp32.
@@ -296,6 +316,10 @@ int ivlm_relpos_bias_split(const void *q, const void *q_lo, int64_t q_bs, int64_
  * shifts rel_h[bh,s,kh] = G[qh-kh+SH-1], rel_w[bh,s,kw] = G[(2SH-1) + qw-kw+SW-1] into f32 [B*H,S,SH] / [B*H,S,SW]. */
 int ivlm_relpos_gather(const void *G, int64_t g_head_stride, int npad, int B, int H, int SH, int SW, float *rel_h,
                        float *rel_w, ivlm_stream_t stream);
+/* The same gather from an fp32 G (the product of fp16 q with the fp16 table, ivlm_gemm_bf16 with IVLM_GEMM_F16 and out_f32: the terms
+ * add to the scores, so the fp16-operand path keeps them unrounded); g_head_stride in fp32 elements. */
+int ivlm_relpos_gather_f32(const void *G, int64_t g_head_stride, int npad, int B, int H, int SH, int SW, float *rel_h,
+                           float *rel_w, ivlm_stream_t stream);
 
 /* One decode step of HF LlamaAttention with a KV cache, for the newest token only: rotate-half RoPE of q,k at
  * position pos, append k,v (rounded to bf16) to kcache/vcache [tmax,H,D], o = softmax(q.K[0..pos]^T * scale).V[0..pos].
@@ -306,6 +330,13 @@ int ivlm_relpos_gather(const void *G, int64_t g_head_stride, int npad, int B, in
 int ivlm_llama_decode_attn(const void *qkv, int io_dtype, void *kcache, void *vcache, int tmax, void *o, int H, int D, int pos,
                            const int32_t *pos_dev, float theta, float scale, const float *cos_tab, const float *sin_tab,
                            ivlm_stream_t stream);
+/* The same against an IEEE fp16 KV cache (written by ivlm_rope_kv_f16): fp32 qkv / o, the new K / V rows appended as fp16. */
+int ivlm_llama_decode_attn_f16(const void *qkv, void *kcache, void *vcache, int tmax, void *o, int H, int D, int pos,
+                               const int32_t *pos_dev, float theta, float scale, const float *cos_tab, const float *sin_tab,
+                               ivlm_stream_t stream);
+int ivlm_llama_decode_attn_batch_f16(const void *qkv, int64_t ldq, void *kcache, void *vcache, int64_t cache_stride, int tmax,
+                                     void *o, int64_t ldo, int B, int H, int D, const int32_t *pos_dev, float theta, float scale,
+                                     const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
 
 /* B sequences in one launch (grid H x B): sequence b reads qkv + b*ldq, appends to kcache/vcache + b*cache_stride
  * ([tmax,H,D] each), writes o + b*ldo and sits at position pos_dev[b] (strides in elements, multiples of 8); a sequence with
@@ -486,6 +517,9 @@ int ivlm_dense_pe(const void *gauss, void *pe, int pe_dtype, int h, int w, int F
  * positions pos0+t, and KV-cache append (kcache/vcache [Tmax,H,D], may be NULL). */
 int ivlm_rope_kv(void *qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void *kcache, void *vcache,
                  const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
+/* The same on IEEE fp16 qkv rows and fp16 caches (the fp16-operand prefill: q | k | v from ivlm_gemm_bf16 with IVLM_GEMM_OUT_F16). */
+int ivlm_rope_kv_f16(void *qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void *kcache, void *vcache,
+                     const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);
 /* "Parity" precision of ivlm_rope_kv: qkv rows are IVLM_BF16_SPLIT ([hi(3HD) | lo(3HD)], ld >= 6HD), rotated in fp32 on hi + lo
  * and written back as hi + lo; K / V are appended to hi + lo cache planes ([Tmax,H,D] each; all four or none).  cos / sin tables
  * are required. */

@@ -37,6 +37,34 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // native vector (NOT HIP's uint4 struct): arrays of it are promoted to registers across the K/V loop
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+
+// Operand kind of the 16-bit tiles (F16 template flag): bf16 (default) or IEEE fp16 - same tiles, LDS images and fragment layouts,
+// the f16 matrix instruction; an activation rounded to fp16 (11 significant bits) carries an eighth of the bf16 rounding error.
+template <bool F16>
+__device__ __forceinline__ f32x4_t mma16(const bf16x8_t a, const bf16x8_t b, const f32x4_t c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// two fp32 -> one packed 16-bit pair (RNE; the fp16 form saturates at +-65504), and back
+template <bool F16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    if constexpr (F16) return pack_f16x2(lo, hi);
+    else return pack_bf16x2(lo, hi);
+}
+template <bool F16>
+__device__ __forceinline__ float lo16(uint32_t u) {
+    if constexpr (F16) return (float)__builtin_bit_cast(ivlm_f16x2_t, u)[0];
+    else return __uint_as_float(u << 16);
+}
+template <bool F16>
+__device__ __forceinline__ float hi16(uint32_t u) {
+    if constexpr (F16) return (float)__builtin_bit_cast(ivlm_f16x2_t, u)[1];
+    else return __uint_as_float(u & 0xffff0000u);
+}
+
 constexpr int kQPerWave = 32, kWaves = 4, kQPerBlock = kQPerWave * kWaves, kKV = 64;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kNegBig = -1.0e30f;
@@ -74,8 +102,14 @@ __device__ __forceinline__ void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\
 //     S^T = Kh.Qh^T + Kh.Ql^T + Kl.Qh^T,      O^T = Vh^T.Ph^T + Vh^T.Pl^T + Vl^T.Ph^T      (the lo.lo terms are below 2^-17),
 // i.e. fp32-operand attention on the bf16 matrix cores at 3x the MFMA work; the output is written as hi + lo planes again.
 // The LDS tiles double (dynamic LDS, one block per CU), one register set stages the next tile.
-template <int DQK, int DV, bool CAUSAL, int REL, bool PP, bool SPLIT = false>
+// QLO (with F16; the "exact q" path of the fp16 mode): q arrives as hi + lo IEEE halves (a.q_lo: the [hi | lo] rows of the q projection
+// on split rows) - the rel-pos table product and Q.K^T take both halves (two MFMAs per fragment: q enters the scores exactly), and the
+// softmax weights are split the same way for P.V (two MFMAs per fragment).  k, v and the output stay single fp16.
+template <int DQK, int DV, bool CAUSAL, int REL, bool PP, bool SPLIT = false, bool F16 = false, bool QLO = false>
 __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_kernel(AttnArgs a) {
+    static_assert(!(SPLIT && F16), "fp16 operands are single-pass");
+    static_assert(!QLO || (F16 && !SPLIT && !PP), "QLO: fp16 operands");
+    constexpr uint32_t kOne16 = F16 ? 0x3C00u : 0x3F80u;  // 1.0 as a 16-bit operand
     // SPLIT: 8 waves of ONE 16-query tile each (the same 128 queries per block): two waves per SIMD to cover each other's LDS
     // and MFMA latencies - with two query tiles per wave the split kernel needs > 256 registers, i.e. one wave per SIMD (measured:
     // SAM global attention 1618 us, windows 302 us that way)
@@ -122,7 +156,7 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
     const bf16_t* __restrict__ Q = a.q + b * a.q_bs + h * a.q_hs;
     const bf16_t* __restrict__ K = a.k + bkv * a.k_bs + h * a.k_hs;
     const bf16_t* __restrict__ V = a.v + bkv * a.v_bs + h * a.v_hs;
-    const bf16_t* __restrict__ Ql = SPLIT ? a.q_lo + b * a.q_bs + h * a.q_hs : nullptr;
+    const bf16_t* __restrict__ Ql = (SPLIT || QLO) ? a.q_lo + b * a.q_bs + h * a.q_hs : nullptr;
     const bf16_t* __restrict__ Kl = SPLIT ? a.k_lo + bkv * a.k_bs + h * a.k_hs : nullptr;
     const bf16_t* __restrict__ Vl = SPLIT ? a.v_lo + bkv * a.v_bs + h * a.v_hs : nullptr;
 
@@ -151,7 +185,8 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
 
     // ---- Q fragments (B operand): lane holds Q[q0 + qt*16 + l15][(s*4+g)*8 .. +8] ---------------
     bf16x8_t qf[QT][KS];
-    bf16x8_t qfl[QT][SPLIT ? KS : 1];  // SPLIT: the lo halves
+    constexpr bool QL = SPLIT || QLO;
+    bf16x8_t qfl[QT][QL ? KS : 1];  // SPLIT / QLO: the lo halves
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         int qi = q0 + qt * 16 + l15;
@@ -161,10 +196,10 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
             const int d0 = (s * 4 + g) * 8;
             uint4 u = make_uint4(0, 0, 0, 0);
             if (d0 < DV) u = *reinterpret_cast<const uint4*>(Q + (int64_t)qi * a.q_rs + d0);
-            if (SPLIT) {
+            if (QL) {
                 u32x4_t ul = u32x4_t{0u, 0u, 0u, 0u};
                 if (d0 < DV) ul = *reinterpret_cast<const u32x4_t*>(Ql + (int64_t)qi * a.q_rs + d0);
-                qfl[qt][s] = __builtin_bit_cast(bf16x8_t, ul);
+                qfl[qt][QL ? s : 0] = __builtin_bit_cast(bf16x8_t, ul);
             }
             qf[qt][s] = *reinterpret_cast<bf16x8_t*>(&u);
         }
@@ -191,10 +226,19 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                         ul[e] = ll;
                     }
                     qfl[qt][SPLIT ? s_ : 0] = __builtin_bit_cast(bf16x8_t, ul);
+                } else if (QLO) {
+                    u32x4_t ul = __builtin_bit_cast(u32x4_t, qfl[qt][QLO ? s_ : 0]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t hh, ll;
+                        split_16x2((lo16<true>(uh[e]) + lo16<true>(ul[e])) * sc, (hi16<true>(uh[e]) + hi16<true>(ul[e])) * sc, hh, ll, 1);
+                        uh[e] = hh;
+                        ul[e] = ll;
+                    }
+                    qfl[qt][QLO ? s_ : 0] = __builtin_bit_cast(bf16x8_t, ul);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        uh[e] = pack_bf16x2(__uint_as_float(uh[e] << 16) * sc, __uint_as_float(uh[e] & 0xffff0000u) * sc);
+                    for (int e = 0; e < 4; ++e) uh[e] = pack2<F16>(lo16<F16>(uh[e]) * sc, hi16<F16>(uh[e]) * sc);
                 }
                 qf[qt][s_] = __builtin_bit_cast(bf16x8_t, uh);
             }
@@ -289,7 +333,15 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
     const float* rwg[QT] = {};  // REL 3
     // packs 8 fp32 bias values (features g*8 .. g*8+7 of this lane's query) into the one-hot MFMA operand(s)
     auto pack_qrel = [&](const float (&f)[8], int qt) __attribute__((always_inline)) {
-        uint4 u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+        uint4 u = make_uint4(pack2<F16>(f[0], f[1]), pack2<F16>(f[2], f[3]), pack2<F16>(f[4], f[5]), pack2<F16>(f[6], f[7]));
+        if (F16) {  // the terms ADD to the scores: an fp16 rounding of a bias of +-8 would be an absolute 2e-3 on the score, so
+                    // they travel as hi + lo fp16 operands (22 bits) of two one-hot MFMAs
+            const uint32_t uu[4] = {u.x, u.y, u.z, u.w};
+            u32x4_t ul;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ul[e] = pack2<F16>(f[2 * e] - lo16<F16>(uu[e]), f[2 * e + 1] - hi16<F16>(uu[e]));
+            qrel_lo[qt] = __builtin_bit_cast(bf16x8_t, ul);
+        }
         if (SPLIT) {
             u32x4_t uh, ul, ul2;
 #pragma unroll
@@ -330,8 +382,8 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                     u32x4_t t4 = u32x4_t{0u, 0u, 0u, 0u};
                     if (d0 < DV) t4 = *reinterpret_cast<const u32x4_t*>(tab + (rt * 16 + l15) * DV + d0);
                     const bf16x8_t tf = __builtin_bit_cast(bf16x8_t, t4);
-                    gacc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, qf[qt][ks], gacc[rt], 0, 0, 0);
-                    if (SPLIT) gacc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, qfl[qt][SPLIT ? ks : 0], gacc[rt], 0, 0, 0);
+                    gacc[rt] = mma16<F16>(tf, qf[qt][ks], gacc[rt]);
+                    if (QL) gacc[rt] = mma16<F16>(tf, qfl[qt][QL ? ks : 0], gacc[rt]);
                 }
             }
 #pragma unroll
@@ -392,7 +444,7 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
     // ---- the three phases of a key tile (state: s = scores then probabilities, pf = packed P^T fragments) ------------
     f32x4_t s[QT][4];
     bf16x8_t pf[QT][2];
-    bf16x8_t pfl[QT][SPLIT ? 2 : 1];  // SPLIT: lo halves of the probabilities
+    bf16x8_t pfl[QT][QL ? 2 : 1];  // SPLIT / QLO: lo halves of the probabilities
     auto nkt_of = [&](int t) __attribute__((always_inline)) {
         int nkt = (a.Sk - t * kKV + 15) >> 4;  // 16-key sub-tiles that hold real keys (wave-uniform)
         return nkt < 4 ? nkt : 4;
@@ -413,15 +465,17 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                 const bf16x8_t kf =
                     *reinterpret_cast<const bf16x8_t*>(&Kb[ks * KPL + (kt * 16 + l15) * 32 + kswz]);
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
+                for (int qt = 0; qt < QT; ++qt) {
+                    s[qt][kt] = mma16<F16>(kf, qf[qt][ks], s[qt][kt]);
+                    if (QLO) s[qt][kt] = mma16<F16>(kf, qfl[qt][QLO ? ks : 0], s[qt][kt]);
+                }
                 if (SPLIT) {
                     const bf16x8_t kfl =
                         *reinterpret_cast<const bf16x8_t*>(&Kb[KBUF + ks * KPL + (kt * 16 + l15) * 32 + kswz]);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
-                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[qt][ks], s[qt][kt], 0, 0, 0);
-                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qf[qt][ks], s[qt][kt], 0, 0, 0);
+                        s[qt][kt] = mma16<F16>(kf, qfl[qt][ks], s[qt][kt]);
+                        s[qt][kt] = mma16<F16>(kfl, qf[qt][ks], s[qt][kt]);
                     }
                 }
             }
@@ -432,18 +486,19 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                 uint32_t w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const uint32_t lo = (f1 == 2 * j || f2 == 2 * j) ? 0x3F80u : 0u;
-                    const uint32_t hi = (f1 == 2 * j + 1 || f2 == 2 * j + 1) ? 0x3F800000u : 0u;
+                    const uint32_t lo = (f1 == 2 * j || f2 == 2 * j) ? kOne16 : 0u;
+                    const uint32_t hi = (f1 == 2 * j + 1 || f2 == 2 * j + 1) ? (kOne16 << 16) : 0u;
                     w[j] = lo | hi;
                 }
                 uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
                 const bf16x8_t hot = *reinterpret_cast<bf16x8_t*>(&u);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
-                    s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel[qt], s[qt][kt], 0, 0, 0);
+                    s[qt][kt] = mma16<F16>(hot, qrel[qt], s[qt][kt]);
+                    if (F16) s[qt][kt] = mma16<F16>(hot, qrel_lo[qt], s[qt][kt]);
                     if (SPLIT) {
-                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo[qt], s[qt][kt], 0, 0, 0);
-                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo2[qt], s[qt][kt], 0, 0, 0);
+                        s[qt][kt] = mma16<F16>(hot, qrel_lo[qt], s[qt][kt]);
+                        s[qt][kt] = mma16<F16>(hot, qrel_lo2[qt], s[qt][kt]);
                     }
                 }
             }
@@ -534,11 +589,28 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 uint4 u;  // round-to-nearest-even pairs in one instruction each (probabilities: finite, no NaN handling needed)
-                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.x) : "v"(s[qt][2 * s2][0]), "v"(s[qt][2 * s2][1]));
-                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.y) : "v"(s[qt][2 * s2][2]), "v"(s[qt][2 * s2][3]));
-                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.z) : "v"(s[qt][2 * s2 + 1][0]), "v"(s[qt][2 * s2 + 1][1]));
-                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.w) : "v"(s[qt][2 * s2 + 1][2]), "v"(s[qt][2 * s2 + 1][3]));
+                if constexpr (F16) {  // (probabilities are in [0, 1]: no saturation needed)
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u.x) : "v"(s[qt][2 * s2][0]), "v"(s[qt][2 * s2][1]));
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u.y) : "v"(s[qt][2 * s2][2]), "v"(s[qt][2 * s2][3]));
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u.z) : "v"(s[qt][2 * s2 + 1][0]), "v"(s[qt][2 * s2 + 1][1]));
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u.w) : "v"(s[qt][2 * s2 + 1][2]), "v"(s[qt][2 * s2 + 1][3]));
+                } else {
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.x) : "v"(s[qt][2 * s2][0]), "v"(s[qt][2 * s2][1]));
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.y) : "v"(s[qt][2 * s2][2]), "v"(s[qt][2 * s2][3]));
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.z) : "v"(s[qt][2 * s2 + 1][0]), "v"(s[qt][2 * s2 + 1][1]));
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u.w) : "v"(s[qt][2 * s2 + 1][2]), "v"(s[qt][2 * s2 + 1][3]));
+                }
                 pf[qt][s2] = *reinterpret_cast<bf16x8_t*>(&u);
+                if (QLO) {  // lo halves: p - fp16(p)
+                    uint4 ul;
+                    const f32x4_t& sa = s[qt][2 * s2];
+                    const f32x4_t& sb = s[qt][2 * s2 + 1];
+                    ul.x = pack2<true>(sa[0] - lo16<true>(u.x), sa[1] - hi16<true>(u.x));
+                    ul.y = pack2<true>(sa[2] - lo16<true>(u.y), sa[3] - hi16<true>(u.y));
+                    ul.z = pack2<true>(sb[0] - lo16<true>(u.z), sb[1] - hi16<true>(u.z));
+                    ul.w = pack2<true>(sb[2] - lo16<true>(u.w), sb[3] - hi16<true>(u.w));
+                    pfl[qt][QLO ? s2 : 0] = *reinterpret_cast<bf16x8_t*>(&ul);
+                }
                 if (SPLIT) {  // lo halves: p - bf16(p), exactly representable differences rounded once
                     uint4 ul;
                     const f32x4_t& sa = s[qt][2 * s2];
@@ -570,8 +642,10 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                 const s16x8_t v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, v8);
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s2], o[qt][dt], 0, 0, 0);
+                for (int qt = 0; qt < QT; ++qt) {
+                    o[qt][dt] = mma16<F16>(vf, pf[qt][s2], o[qt][dt]);
+                    if (QLO) o[qt][dt] = mma16<F16>(vf, pfl[qt][QLO ? s2 : 0], o[qt][dt]);
+                }
                 if (SPLIT) {
                     const bf16_t* vpl = vp + VBUF;
                     const s16x4_t lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vpl));
@@ -580,8 +654,8 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                     const bf16x8_t vfl = __builtin_bit_cast(bf16x8_t, v8l);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
-                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl[qt][s2], o[qt][dt], 0, 0, 0);
-                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf[qt][s2], o[qt][dt], 0, 0, 0);
+                        o[qt][dt] = mma16<F16>(vf, pfl[qt][s2], o[qt][dt]);
+                        o[qt][dt] = mma16<F16>(vfl, pf[qt][s2], o[qt][dt]);
                     }
                 }
             }
@@ -698,8 +772,8 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                 *reinterpret_cast<uint2*>(a.o_lo + b * a.o_bs + h * a.o_hs + (int64_t)qi * a.o_rs + dt * 16 + g * 4) = wl;
                 continue;
             }
-            const uint2 w = make_uint2(pack_bf16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv),
-                                       pack_bf16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
+            const uint2 w = make_uint2(pack2<F16>(o[qt][dt][0] * inv, o[qt][dt][1] * inv),
+                                       pack2<F16>(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
             *reinterpret_cast<uint2*>(O + (int64_t)qi * a.o_rs + dt * 16 + g * 4) = w;
         }
     }
@@ -716,8 +790,12 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
 // SPLIT: hi + lo planes of q / k / v, three MFMAs per fragment, fp32 rel-pos terms, hi + lo output ("parity" precision); the hi + lo
 // K / V planes leave no LDS for the table-product scratch, so SPLIT reads the rel-pos terms from the fp32 arrays of
 // ivlm_relpos_bias_split (array mode) instead of computing them here (table mode).
-template <bool SPLIT>
+template <bool SPLIT, bool F16 = false, bool QLO = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArgs a) {
+    static_assert(!(SPLIT && F16), "fp16 operands are single-pass");
+    static_assert(!QLO || F16, "QLO: q (and the softmax weights) as hi + lo IEEE halves, see attn_kernel");
+    constexpr bool QL = SPLIT || QLO;
+    constexpr uint32_t kOne16 = F16 ? 0x3C00u : 0x3F80u;  // 1.0 as a 16-bit operand
     constexpr bool TAB = !SPLIT;
     // SPLIT: 8 waves (two per SIMD, 240 registers: held under 256 with scheduling barriers in the fragment loops), the 13 query tiles
     // in two rounds.  Default precision: 126 registers allow 16 waves (four per SIMD) - every query tile has a wave of its own (ONE
@@ -765,7 +843,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
     const bf16_t* __restrict__ Q = a.q + b * a.q_bs + h * a.q_hs;
     const bf16_t* __restrict__ K = a.k + b * a.k_bs + h * a.k_hs;
     const bf16_t* __restrict__ V = a.v + b * a.v_bs + h * a.v_hs;
-    const bf16_t* __restrict__ Ql = SPLIT ? a.q_lo + b * a.q_bs + h * a.q_hs : nullptr;
+    const bf16_t* __restrict__ Ql = QL ? a.q_lo + b * a.q_bs + h * a.q_hs : nullptr;
     const bf16_t* __restrict__ Kl_g = SPLIT ? a.k_lo + b * a.k_bs + h * a.k_hs : nullptr;
     const bf16_t* __restrict__ Vl_g = SPLIT ? a.v_lo + b * a.v_bs + h * a.v_hs : nullptr;
 
@@ -858,8 +936,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
         u32x4_t w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t lo = (f1 == 2 * j || f2 == 2 * j) ? 0x3F80u : 0u;
-            const uint32_t hi = (f1 == 2 * j + 1 || f2 == 2 * j + 1) ? 0x3F800000u : 0u;
+            const uint32_t lo = (f1 == 2 * j || f2 == 2 * j) ? kOne16 : 0u;
+            const uint32_t hi = (f1 == 2 * j + 1 || f2 == 2 * j + 1) ? (kOne16 << 16) : 0u;
             w[j] = lo | hi;
         }
         Hot[c] = w;
@@ -873,7 +951,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
     const int nqt = (S + 15) >> 4;
 
     // the (unscaled) query fragments of a wave's NEXT tile are fetched while it works on the current one
-    bf16x8_t qn[KS], qnl[SPLIT ? KS : 1];
+    bf16x8_t qn[KS], qnl[QL ? KS : 1];
     auto fetch_q = [&](int qtile) __attribute__((always_inline)) {
         int qi = qtile * 16 + l15;
         qi = qi < S ? qi : S - 1;
@@ -883,10 +961,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
             u32x4_t u = u32x4_t{0u, 0u, 0u, 0u}, ul = u;
             if (d0 < DV) {
                 u = *reinterpret_cast<const u32x4_t*>(Q + (int64_t)qi * a.q_rs + d0);
-                if (SPLIT) ul = *reinterpret_cast<const u32x4_t*>(Ql + (int64_t)qi * a.q_rs + d0);
+                if (QL) ul = *reinterpret_cast<const u32x4_t*>(Ql + (int64_t)qi * a.q_rs + d0);
             }
             qn[ks] = __builtin_bit_cast(bf16x8_t, u);
-            if (SPLIT) qnl[SPLIT ? ks : 0] = __builtin_bit_cast(bf16x8_t, ul);
+            if (QL) qnl[QL ? ks : 0] = __builtin_bit_cast(bf16x8_t, ul);
         }
     };
     if (wave < nqt) fetch_q(wave);
@@ -895,13 +973,15 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
         const bool q_ok = qi < S;
         qi = q_ok ? qi : S - 1;
         // ---- query fragments (unscaled) and the rel-pos table product --------------------------------------------------
-        bf16x8_t qf[KS], qfl[SPLIT ? KS : 1];
+        bf16x8_t qf[KS], qfl[QL ? KS : 1];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[ks] = qn[ks];
-            if (SPLIT) qfl[SPLIT ? ks : 0] = qnl[SPLIT ? ks : 0];
+            if (QL) qfl[QL ? ks : 0] = qnl[QL ? ks : 0];
         }
-        if (qtile + NWV < nqt) fetch_q(qtile + NWV);
+        // (16 waves: S <= 208 is at most 13 query tiles, a wave never has a second one - no prefetch registers held across the tile)
+        constexpr bool ONE = NWV >= 13;
+        if (!ONE && qtile + NWV < nqt) fetch_q(qtile + NWV);
         float f[8];
         if (TAB) {
             f32x4_t gacc[4];
@@ -912,7 +992,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
                     const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(&Tb[ks * TPL + (rt * 16 + l15) * 32 + kswz]);
-                    gacc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, qf[ks], gacc[rt], 0, 0, 0);
+                    gacc[rt] = mma16<F16>(tf, qf[ks], gacc[rt]);
+                    if (QLO) gacc[rt] = mma16<F16>(tf, qfl[QLO ? ks : 0], gacc[rt]);
                 }
             }
 #pragma unroll
@@ -947,8 +1028,13 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
             u32x4_t uh, ul, ul2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                uint32_t hh, ll;
-                split_bf16x2(f[2 * e], f[2 * e + 1], hh, ll);
+                uint32_t hh, ll = 0;
+                if constexpr (F16) {  // hi + lo fp16 operands (22 bits) of two one-hot MFMAs: see attn_kernel
+                    hh = pack_f16x2(f[2 * e], f[2 * e + 1]);
+                    ul[e] = pack_f16x2(f[2 * e] - lo16<true>(hh), f[2 * e + 1] - hi16<true>(hh));
+                } else {
+                    split_bf16x2(f[2 * e], f[2 * e + 1], hh, ll);
+                }
                 uh[e] = hh;
                 if (SPLIT) {
                     const float r0 = (f[2 * e] - __uint_as_float(hh << 16)) - __uint_as_float(ll << 16);
@@ -958,6 +1044,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
                 }
             }
             qrel = __builtin_bit_cast(bf16x8_t, uh);  // default precision: the terms rounded to bf16, as the bf16 reference holds them
+            if (F16) qrel_lo = __builtin_bit_cast(bf16x8_t, ul);
             if (SPLIT) {
                 qrel_lo = __builtin_bit_cast(bf16x8_t, ul);
                 qrel_lo2 = __builtin_bit_cast(bf16x8_t, ul2);
@@ -979,10 +1066,20 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
                     ul[e] = ll;
                 }
                 qfl[SPLIT ? ks : 0] = __builtin_bit_cast(bf16x8_t, ul);
+            } else if (QLO) {
+                u32x4_t ul = __builtin_bit_cast(u32x4_t, qfl[QLO ? ks : 0]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t hh, ll;
+                    split_16x2((lo16<true>(uh[e]) + lo16<true>(ul[e])) * sc, (hi16<true>(uh[e]) + hi16<true>(ul[e])) * sc, hh, ll, 1);
+                    uh[e] = hh;
+                    ul[e] = ll;
+                }
+                qfl[QLO ? ks : 0] = __builtin_bit_cast(bf16x8_t, ul);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    uh[e] = pack_bf16x2(__uint_as_float(uh[e] << 16) * sc, __uint_as_float(uh[e] & 0xffff0000u) * sc);
+                    uh[e] = pack2<F16>(lo16<F16>(uh[e]) * sc, hi16<F16>(uh[e]) * sc);
             }
             qf[ks] = __builtin_bit_cast(bf16x8_t, uh);
         }
@@ -994,11 +1091,12 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&Kh[ks * KPL + (kt * 16 + l15) * 32 + kswz]);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                s[kt] = mma16<F16>(kf, qf[ks], s[kt]);
+                if (QLO) s[kt] = mma16<F16>(kf, qfl[QLO ? ks : 0], s[kt]);
                 if (SPLIT) {
                     const bf16x8_t kfl = *reinterpret_cast<const bf16x8_t*>(&Kl[ks * KPL + (kt * 16 + l15) * 32 + kswz]);
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[SPLIT ? ks : 0], s[kt], 0, 0, 0);
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qf[ks], s[kt], 0, 0, 0);
+                    s[kt] = mma16<F16>(kf, qfl[SPLIT ? ks : 0], s[kt]);
+                    s[kt] = mma16<F16>(kfl, qf[ks], s[kt]);
                 }
             }
             bf16x8_t hot;
@@ -1011,16 +1109,17 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
                 u32x4_t w;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const uint32_t lo = (f1 == 2 * j || f2 == 2 * j) ? 0x3F80u : 0u;
-                    const uint32_t hi = (f1 == 2 * j + 1 || f2 == 2 * j + 1) ? 0x3F800000u : 0u;
+                    const uint32_t lo = (f1 == 2 * j || f2 == 2 * j) ? kOne16 : 0u;
+                    const uint32_t hi = (f1 == 2 * j + 1 || f2 == 2 * j + 1) ? (kOne16 << 16) : 0u;
                     w[j] = lo | hi;
                 }
                 hot = __builtin_bit_cast(bf16x8_t, w);
             }
-            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel, s[kt], 0, 0, 0);
+            s[kt] = mma16<F16>(hot, qrel, s[kt]);
+            if (F16) s[kt] = mma16<F16>(hot, qrel_lo, s[kt]);
             if (SPLIT) {
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo, s[kt], 0, 0, 0);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hot, qrel_lo2, s[kt], 0, 0, 0);
+                s[kt] = mma16<F16>(hot, qrel_lo, s[kt]);
+                s[kt] = mma16<F16>(hot, qrel_lo2, s[kt]);
                 if (kt & 1) __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting all 78 fragment reads: spills)
             }
         }
@@ -1054,12 +1153,19 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
             const f32x4_t sa = s[2 * s2];
             const f32x4_t sb = (2 * s2 + 1 < KT) ? s[(2 * s2 + 1 < KT) ? 2 * s2 + 1 : 0] : f32x4_t{0.f, 0.f, 0.f, 0.f};
             u32x4_t u, ul;
-            u[0] = pack_bf16x2(sa[0], sa[1]);
-            u[1] = pack_bf16x2(sa[2], sa[3]);
-            u[2] = pack_bf16x2(sb[0], sb[1]);
-            u[3] = pack_bf16x2(sb[2], sb[3]);
+            u[0] = pack2<F16>(sa[0], sa[1]);
+            u[1] = pack2<F16>(sa[2], sa[3]);
+            u[2] = pack2<F16>(sb[0], sb[1]);
+            u[3] = pack2<F16>(sb[2], sb[3]);
             const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, u);
             bf16x8_t pfl;
+            if (QLO) {
+                ul[0] = pack2<true>(sa[0] - lo16<true>(u[0]), sa[1] - hi16<true>(u[0]));
+                ul[1] = pack2<true>(sa[2] - lo16<true>(u[1]), sa[3] - hi16<true>(u[1]));
+                ul[2] = pack2<true>(sb[0] - lo16<true>(u[2]), sb[1] - hi16<true>(u[2]));
+                ul[3] = pack2<true>(sb[2] - lo16<true>(u[3]), sb[3] - hi16<true>(u[3]));
+                pfl = __builtin_bit_cast(bf16x8_t, ul);
+            }
             if (SPLIT) {
                 ul[0] = pack_bf16x2(sa[0] - __uint_as_float(u[0] << 16), sa[1] - __uint_as_float(u[0] & 0xffff0000u));
                 ul[1] = pack_bf16x2(sa[2] - __uint_as_float(u[1] << 16), sa[3] - __uint_as_float(u[1] & 0xffff0000u));
@@ -1076,14 +1182,15 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vp));
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vp + 16 * 16));
                 const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+                o[dt] = mma16<F16>(vf, pf, o[dt]);
+                if (QLO) o[dt] = mma16<F16>(vf, pfl, o[dt]);
                 if (SPLIT) {
                     const bf16_t* vpl = Vl + dt * VPL + (2 * s2) * 16 * 16 + voff;
                     const s16x4_t lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vpl));
                     const s16x4_t hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(vpl + 16 * 16));
                     const bf16x8_t vfl = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7));
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl, o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pf, o[dt], 0, 0, 0);
+                    o[dt] = mma16<F16>(vf, pfl, o[dt]);
+                    o[dt] = mma16<F16>(vfl, pf, o[dt]);
                 }
             }
             if (SPLIT) __builtin_amdgcn_sched_barrier(0);
@@ -1101,22 +1208,23 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
                     *reinterpret_cast<uint2*>(a.o_lo + b * a.o_bs + h * a.o_hs + (int64_t)qi * a.o_rs + dt * 16 + g * 4) = wl;
                 } else {
                     *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) =
-                        make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+                        make_uint2(pack2<F16>(o[dt][0] * inv, o[dt][1] * inv), pack2<F16>(o[dt][2] * inv, o[dt][3] * inv));
                 }
             }
         }
+        if (ONE) break;
     }
 }
 
 static int g_win_v2 = 1;  // 0: the generic flash kernel for windows too (A/B hook: ivlm_attention_window_kernel)
 
-template <bool SPLIT>
+template <bool SPLIT, bool F16 = false, bool QLO = false>
 static int launch_win(const AttnArgs& a, hipStream_t st) {
     constexpr int KS = 3, DT = 5, KPL = 13 * 16 * 32 + 32, VPL = 7 * 32 * 16 + 16;
     constexpr size_t lds = (size_t)(SPLIT ? 2 : 1) * (KS * KPL + DT * VPL) * 2 +
                            (SPLIT ? 0 : (size_t)13 * 64 * 16 + 13 * 16 * 65 * 4 + 3 * 64 * 32 * 2);
     static_assert(lds <= 160 * 1024, "window tiles must fit the LDS");
-    auto kfn = win_attn_kernel<SPLIT>;
+    auto kfn = win_attn_kernel<SPLIT, F16, QLO>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1165,6 +1273,42 @@ int launch_split(const AttnArgs& a, hipStream_t st) {
     return IVLM_ERR_UNSUPPORTED;
 }
 
+// fp16 operands (a.f16): the shapes of the path, like the split kernels
+template <int DQK, int DV>
+int launch_f16(const AttnArgs& a, hipStream_t st) {
+    const bool rel = a.rel_h != nullptr;
+    dim3 grid((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B);
+    if (a.q_lo) {  // "exact q" (QLO): SAM's global grid with the rel-pos terms as arrays (windows take the whole-window kernel)
+        if constexpr (DV == 80) {
+            if (!a.causal && rel && a.prescale_q && a.rel_w && a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw) {
+                attn_kernel<DQK, DV, false, 2, false, false, true, true><<<grid, 256, 0, st>>>(a);
+                return ivlm_launch_status();
+            }
+        }
+        return IVLM_ERR_UNSUPPORTED;
+    }
+    if constexpr (DV == 128) {
+        if (a.causal && !rel) {
+            attn_kernel<DQK, DV, true, 0, false, false, true><<<grid, 256, 0, st>>>(a);
+            return ivlm_launch_status();
+        }
+    } else if constexpr (DV == 64) {
+        if (!a.causal && !rel) {
+            attn_kernel<DQK, DV, false, 0, false, false, true><<<grid, 256, 0, st>>>(a);
+            return ivlm_launch_status();
+        }
+    } else if constexpr (DV == 80) {
+        if (!a.causal && rel && a.prescale_q) {
+            if (!a.rel_w) attn_kernel<DQK, DV, false, 4, false, false, true><<<grid, 256, 0, st>>>(a);
+            else if (a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw) attn_kernel<DQK, DV, false, 2, false, false, true><<<grid, 256, 0, st>>>(a);
+            else if (a.rel_kh + a.rel_kw <= 32) attn_kernel<DQK, DV, false, 1, false, false, true><<<grid, 256, 0, st>>>(a);
+            else attn_kernel<DQK, DV, false, 3, false, false, true><<<grid, 256, 0, st>>>(a);
+            return ivlm_launch_status();
+        }
+    }
+    return IVLM_ERR_UNSUPPORTED;
+}
+
 template <int DQK, int DV, bool PP>
 int launch_dp(const AttnArgs& a, hipStream_t st) {
     constexpr int NT = PP ? 512 : 256, QB = PP ? 2 * kQPerBlock : kQPerBlock;
@@ -1198,9 +1342,11 @@ int launch_d(const AttnArgs& a, hipStream_t st) {
     if constexpr (DV == 80) {  // SAM's windows: the whole-window kernel (default precision: table mode; SPLIT: array mode)
         const bool win = g_win_v2 && a.rel_h && a.Sq <= 208 && a.Sq == a.Sk && !a.causal && a.prescale_q && a.H <= 65535 &&
                          a.B <= 65535 && a.rel_kh == a.rel_kw && 2 * a.rel_kh <= 32 && a.Sq == a.rel_kh * a.rel_kw;
-        if (win && !a.q_lo && !a.rel_w) return launch_win<false>(a, st);
-        if (win && a.q_lo && a.rel_w) return launch_win<true>(a, st);
+        if (win && !a.q_lo && !a.rel_w) return a.f16 ? launch_win<false, true>(a, st) : launch_win<false>(a, st);
+        if (win && a.q_lo && !a.rel_w && a.f16) return launch_win<false, true, true>(a, st);
+        if (win && a.q_lo && a.rel_w && !a.f16) return launch_win<true>(a, st);
     }
+    if (a.f16) return launch_f16<DQK, DV>(a, st);
     if (a.q_lo) return launch_split<DQK, DV>(a, st);
     const bool pp = g_attn_pp > 0;
     return pp ? launch_dp<DQK, DV, true>(a, st) : launch_dp<DQK, DV, false>(a, st);
@@ -1345,6 +1491,7 @@ __global__ __launch_bounds__(256) void relpos_rows_kernel(const bf16_t* __restri
 //   rel_h[bh,s,kh] = G[..][qh - kh + SH - 1],   rel_w[bh,s,kw] = G[..][(2 SH - 1) + qw - kw + SW - 1].
 // The dot products (2 x (2S-1) x D MACs per query: 5.6 GFLOP per global block) leave the VALU / LDS for the matrix cores;
 // this kernel only moves data: one thread per 4 consecutive outputs (16-byte stores).
+template <int GK>  // element type of G: 0 bf16, 1 fp16, 2 fp32
 __global__ __launch_bounds__(256) void relpos_gather_kernel(const bf16_t* __restrict__ G, int64_t g_hs /*head stride*/, int npad,
                                                             int H, int SH, int SW, float* __restrict__ rel_h,
                                                             float* __restrict__ rel_w) {
@@ -1358,20 +1505,27 @@ __global__ __launch_bounds__(256) void relpos_gather_kernel(const bf16_t* __rest
     const int qh = s_ / SW, qw = s_ - qh * SW;
     const bf16_t* row = G + h * g_hs + ((int64_t)b * S + s_) * npad;
     const int64_t bq = ((int64_t)b * H + h) * S + s_;
-    if (j < SH) rel_h[bq * SH + j] = bf16_to_f32(row[qh - j + SH - 1]);
-    else rel_w[bq * SW + (j - SH)] = bf16_to_f32(row[(2 * SH - 1) + qw - (j - SH) + SW - 1]);
+    const int col = j < SH ? qh - j + SH - 1 : (2 * SH - 1) + qw - (j - SH) + SW - 1;
+    float g;
+    if constexpr (GK == 2) g = (reinterpret_cast<const float*>(G) + h * g_hs + ((int64_t)b * S + s_) * npad)[col];
+    else g = GK == 1 ? (float)__builtin_bit_cast(_Float16, row[col]) : bf16_to_f32(row[col]);
+    if (j < SH) rel_h[bq * SH + j] = g;
+    else rel_w[bq * SW + (j - SH)] = g;
 }
 
 }  // namespace
 
 int relpos_gather(const bf16_t* G, int64_t g_hs, int npad, int B, int H, int SH, int SW, float* rel_h, float* rel_w,
-                  hipStream_t st) {
+                  hipStream_t st, int f16 = 0 /* G: 0 bf16, 1 fp16, 2 fp32 */) {
     if (!G || !rel_h || !rel_w || B <= 0 || H <= 0 || SH <= 0 || SW <= 0 || npad < 2 * SH - 1 + 2 * SW - 1) return IVLM_ERR_INVALID_ARG;
     if (SH + SW > 256 || H > 65535 || B > 65535) return IVLM_ERR_UNSUPPORTED;
     int bx = 32;
     while (bx < SH + SW) bx <<= 1;
     const int by = 256 / bx;
-    relpos_gather_kernel<<<dim3((SH * SW + by - 1) / by, H, B), dim3(bx, by), 0, st>>>(G, g_hs, npad, H, SH, SW, rel_h, rel_w);
+    const dim3 grid((SH * SW + by - 1) / by, H, B), blk(bx, by);
+    if (f16 == 2) relpos_gather_kernel<2><<<grid, blk, 0, st>>>(G, g_hs, npad, H, SH, SW, rel_h, rel_w);
+    else if (f16) relpos_gather_kernel<1><<<grid, blk, 0, st>>>(G, g_hs, npad, H, SH, SW, rel_h, rel_w);
+    else relpos_gather_kernel<0><<<grid, blk, 0, st>>>(G, g_hs, npad, H, SH, SW, rel_h, rel_w);
     return ivlm_launch_status();
 }
 
@@ -1387,7 +1541,11 @@ int attention_bf16(const AttnArgs& a, hipStream_t st) {
             (reinterpret_cast<uintptr_t>(a.rel_h) & 15))
             return IVLM_ERR_UNSUPPORTED;
     }
-    if ((a.q_lo || a.k_lo || a.v_lo || a.o_lo) && !(a.q_lo && a.k_lo && a.v_lo && a.o_lo)) return IVLM_ERR_INVALID_ARG;
+    if (a.f16) {  // fp16 operands: at most a lo plane of q ("exact q")
+        if (a.k_lo || a.v_lo || a.o_lo) return IVLM_ERR_INVALID_ARG;
+    } else if ((a.q_lo || a.k_lo || a.v_lo || a.o_lo) && !(a.q_lo && a.k_lo && a.v_lo && a.o_lo)) {
+        return IVLM_ERR_INVALID_ARG;
+    }
     switch (a.D) {
         case 16: return launch_d<32, 16>(a, st);
         case 32: return launch_d<32, 32>(a, st);
@@ -1444,6 +1602,13 @@ int ivlm_relpos_gather(const void* G, int64_t g_head_stride, int npad, int B, in
                                ivlm_stream(stream));
 }
 
+int ivlm_relpos_gather_f32(const void* G, int64_t g_head_stride, int npad, int B, int H, int SH, int SW, float* rel_h, float* rel_w,
+                           ivlm_stream_t stream) {
+    ivlm_enter();
+    return ivlm::relpos_gather(static_cast<const bf16_t*>(G), g_head_stride, npad, B, H, SH, SW, rel_h, rel_w,
+                               ivlm_stream(stream), 2);
+}
+
 int ivlm_attention_window_kernel(int v2) {  // benchmark/test hook: 1 (default) whole-window kernel, 0 generic flash kernel
     ivlm::g_win_v2 = v2;
     return 0;
@@ -1454,12 +1619,16 @@ int ivlm_attention_pingpong(int mode) {  // benchmark/test hook: -1 automatic, 0
     return 0;
 }
 
-int ivlm_attention_bf16(const void* q, const void* k, const void* v, void* o, const int64_t* strides /*[12]*/, int B,
+static int attention_16(const void* q, const void* k, const void* v, void* o, const int64_t* strides /*[12]*/, int B,
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float* rel_h,
-                        const float* rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q, ivlm_stream_t stream) {
+                        const float* rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q, int f16, ivlm_stream_t stream,
+                        const void* q_lo = nullptr) {
     ivlm_enter();
     if (!strides) return IVLM_ERR_INVALID_ARG;
     ivlm::AttnArgs a;
+    a.f16 = f16;
+    a.q_lo = static_cast<const bf16_t*>(q_lo);
+    if (reinterpret_cast<uintptr_t>(q_lo) & 15) return IVLM_ERR_INVALID_ARG;
     a.q = static_cast<const bf16_t*>(q);
     a.k = static_cast<const bf16_t*>(k);
     a.v = static_cast<const bf16_t*>(v);
@@ -1479,6 +1648,29 @@ int ivlm_attention_bf16(const void* q, const void* k, const void* v, void* o, co
     a.kv_batch_div = kv_batch_div < 1 ? 1 : kv_batch_div;
     a.prescale_q = prescale_q;
     return ivlm::attention_bf16(a, ivlm_stream(stream));
+}
+
+int ivlm_attention_bf16(const void* q, const void* k, const void* v, void* o, const int64_t* strides /*[12]*/, int B,
+                        int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float* rel_h,
+                        const float* rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q, ivlm_stream_t stream) {
+    return attention_16(q, k, v, o, strides, B, H, Sq, Sk, D, scale, causal, q_pos0, rel_h, rel_w, rel_kh, rel_kw, kv_batch_div,
+                        prescale_q, 0, stream);
+}
+
+// the same operator on IEEE fp16 q / k / v / o (and, in table mode, an fp16 rel-pos table): see ivlm_hip.h
+int ivlm_attention_f16(const void* q, const void* k, const void* v, void* o, const int64_t* strides /*[12]*/, int B,
+                       int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float* rel_h,
+                       const float* rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q, ivlm_stream_t stream) {
+    return attention_16(q, k, v, o, strides, B, H, Sq, Sk, D, scale, causal, q_pos0, rel_h, rel_w, rel_kh, rel_kw, kv_batch_div,
+                        prescale_q, 1, stream);
+}
+
+// ... with q as hi + lo IEEE halves (q_lo: the strides of q): the "exact q" attention of the fp16 mode (SAM shapes), see ivlm_hip.h
+int ivlm_attention_f16_qsplit(const void* q, const void* q_lo, const void* k, const void* v, void* o, const int64_t* strides /*[12]*/,
+                              int B, int H, int Sq, int Sk, int D, float scale, const float* rel_h, const float* rel_w, int rel_kh,
+                              int rel_kw, ivlm_stream_t stream) {
+    if (!q_lo) return IVLM_ERR_INVALID_ARG;
+    return attention_16(q, k, v, o, strides, B, H, Sq, Sk, D, scale, 0, 0, rel_h, rel_w, rel_kh, rel_kw, 1, 1, 1, stream, q_lo);
 }
 
 int ivlm_attention_bf16_split(const void* q, const void* q_lo, const void* k, const void* k_lo, const void* v, const void* v_lo,

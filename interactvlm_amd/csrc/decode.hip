@@ -12,7 +12,7 @@ namespace {
 
 using namespace decattn;
 
-template <bool F32IO, bool LO = false>
+template <bool F32IO, bool LO = false, bool CF16 = false>
 __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_kernel(const void* __restrict__ qkv, bf16_t* __restrict__ kcache,
                                                                         bf16_t* __restrict__ vcache, void* __restrict__ o, int H,
                                                                         int D, int pos_arg, float theta, float scale,
@@ -31,13 +31,13 @@ __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_kernel(const vo
         }
         return;
     }
-    llama_decode_attn_body<false, F32IO, 1024, LO>(blockIdx.x, qkv, kcache, vcache, o, H, D, pos_arg, theta, scale, ct, stab, pos_dev,
+    llama_decode_attn_body<false, F32IO, 1024, LO, CF16>(blockIdx.x, qkv, kcache, vcache, o, H, D, pos_arg, theta, scale, ct, stab, pos_dev,
                                                    tmax, kcache_lo, vcache_lo);
 }
 
 // B sequences of one decode step: blockIdx.y picks the sequence; each has its own cache slab, qkv row, output row and
 // position (the sequences of a batch sit at different lengths: prompts differ, model/InteractVLM.py:524-531 pads them).
-template <bool F32IO, bool LO = false>
+template <bool F32IO, bool LO = false, bool CF16 = false>
 __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_batch_kernel(
     const void* __restrict__ qkv, int64_t ldq, bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache, int64_t cache_stride,
     void* __restrict__ o, int64_t ldo, int H, int D, float theta, float scale, const float* __restrict__ ct,
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_batch_kernel(
         }
         return;
     }
-    llama_decode_attn_body<false, F32IO, 1024, LO>(blockIdx.x, static_cast<const char*>(qkv) + b * ldq * esz,
+    llama_decode_attn_body<false, F32IO, 1024, LO, CF16>(blockIdx.x, static_cast<const char*>(qkv) + b * ldq * esz,
                                                    kcache + b * cache_stride, vcache + b * cache_stride,
                                                    static_cast<char*>(o) + b * ldo * esz, H, D, 0, theta, scale, ct, stab, pos_dev + b,
                                                    tmax, LO ? kcache_lo + b * cache_stride : nullptr,
@@ -67,14 +67,19 @@ __global__ __launch_bounds__(kDecThreads) void llama_decode_attn_batch_kernel(
 
 int llama_decode_attn_batch(const void* qkv, int io_f32, int64_t ldq, bf16_t* kcache, bf16_t* vcache, int64_t cache_stride,
                             int tmax, void* o, int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta, float scale,
-                            const float* cos_tab, const float* sin_tab, hipStream_t st, bf16_t* kcache_lo, bf16_t* vcache_lo) {
+                            const float* cos_tab, const float* sin_tab, hipStream_t st, bf16_t* kcache_lo, bf16_t* vcache_lo,
+                            int cache_f16) {
     if (!qkv || !kcache || !vcache || !o || !pos_dev) return IVLM_ERR_INVALID_ARG;
     if (B <= 0 || B > 65535 || H <= 0 || D <= 0 || D > kMaxD || (D & 15)) return IVLM_ERR_INVALID_ARG;
     if (ldq < 3LL * H * D || ldo < (int64_t)H * D || cache_stride < (int64_t)H * D || ((ldq | ldo | cache_stride) & 7))
         return IVLM_ERR_INVALID_ARG;  // 16-byte rows
     if (tmax <= 0 || (int64_t)tmax * H * D > cache_stride) return IVLM_ERR_INVALID_ARG;
     if ((kcache_lo != nullptr) != (vcache_lo != nullptr) || (kcache_lo && !io_f32)) return IVLM_ERR_INVALID_ARG;
-    if (kcache_lo)
+    if (cache_f16 && (!io_f32 || kcache_lo)) return IVLM_ERR_INVALID_ARG;
+    if (cache_f16)
+        llama_decode_attn_batch_kernel<true, false, true><<<dim3(H, B), kDecThreads, 0, st>>>(
+            qkv, ldq, kcache, vcache, cache_stride, o, ldo, H, D, theta, scale, cos_tab, sin_tab, pos_dev, tmax, nullptr, nullptr);
+    else if (kcache_lo)
         llama_decode_attn_batch_kernel<true, true><<<dim3(H, B), kDecThreads, 0, st>>>(
             qkv, ldq, kcache, vcache, cache_stride, o, ldo, H, D, theta, scale, cos_tab, sin_tab, pos_dev, tmax, kcache_lo, vcache_lo);
     else if (io_f32)
@@ -88,11 +93,15 @@ int llama_decode_attn_batch(const void* qkv, int io_f32, int64_t ldq, bf16_t* kc
 
 int llama_decode_attn(const void* qkv, int io_f32, bf16_t* kcache, bf16_t* vcache, int tmax, void* o, int H, int D, int pos,
                       float theta, float scale, hipStream_t st, const float* cos_tab, const float* sin_tab,
-                      const int32_t* pos_dev, bf16_t* kcache_lo, bf16_t* vcache_lo) {
+                      const int32_t* pos_dev, bf16_t* kcache_lo, bf16_t* vcache_lo, int cache_f16) {
     if (!qkv || !kcache || !vcache || !o || H <= 0 || D <= 0 || D > kMaxD || (D & 15) || tmax <= 0) return IVLM_ERR_INVALID_ARG;
     if (!pos_dev && (pos < 0 || pos >= kMaxT || pos >= tmax)) return IVLM_ERR_INVALID_ARG;
     if ((kcache_lo != nullptr) != (vcache_lo != nullptr) || (kcache_lo && !io_f32)) return IVLM_ERR_INVALID_ARG;
-    if (kcache_lo)
+    if (cache_f16 && (!io_f32 || kcache_lo)) return IVLM_ERR_INVALID_ARG;
+    if (cache_f16)
+        llama_decode_attn_kernel<true, false, true><<<H, kDecThreads, 0, st>>>(qkv, kcache, vcache, o, H, D, pos, theta, scale, cos_tab,
+                                                                               sin_tab, pos_dev, tmax, nullptr, nullptr);
+    else if (kcache_lo)
         llama_decode_attn_kernel<true, true><<<H, kDecThreads, 0, st>>>(qkv, kcache, vcache, o, H, D, pos, theta, scale, cos_tab,
                                                                         sin_tab, pos_dev, tmax, kcache_lo, vcache_lo);
     else if (io_f32)
@@ -144,4 +153,23 @@ extern "C" int ivlm_llama_decode_attn_batch(const void* qkv, int io_dtype, int64
     return ivlm::llama_decode_attn_batch(qkv, io_dtype == IVLM_F32, ldq, static_cast<bf16_t*>(kcache),
                                          static_cast<bf16_t*>(vcache), cache_stride, tmax, o, ldo, B, H, D, pos_dev, theta, scale,
                                          cos_tab, sin_tab, ivlm_stream(stream));
+}
+
+// fp16 KV cache (the fp16-operand prefill appends IEEE halves): fp32 qkv / o, K / V rows appended as fp16 and read back as fp16
+extern "C" int ivlm_llama_decode_attn_f16(const void* qkv, void* kcache, void* vcache, int tmax, void* o, int H, int D, int pos,
+                                          const int32_t* pos_dev, float theta, float scale, const float* cos_tab,
+                                          const float* sin_tab, ivlm_stream_t stream) {
+    ivlm_enter();
+    return ivlm::llama_decode_attn(qkv, 1, static_cast<bf16_t*>(kcache), static_cast<bf16_t*>(vcache), tmax, o, H, D, pos, theta,
+                                   scale, ivlm_stream(stream), cos_tab, sin_tab, pos_dev, nullptr, nullptr, 1);
+}
+
+extern "C" int ivlm_llama_decode_attn_batch_f16(const void* qkv, int64_t ldq, void* kcache, void* vcache, int64_t cache_stride,
+                                                int tmax, void* o, int64_t ldo, int B, int H, int D, const int32_t* pos_dev,
+                                                float theta, float scale, const float* cos_tab, const float* sin_tab,
+                                                ivlm_stream_t stream) {
+    ivlm_enter();
+    return ivlm::llama_decode_attn_batch(qkv, 1, ldq, static_cast<bf16_t*>(kcache), static_cast<bf16_t*>(vcache), cache_stride, tmax,
+                                         o, ldo, B, H, D, pos_dev, theta, scale, cos_tab, sin_tab, ivlm_stream(stream), nullptr,
+                                         nullptr, 1);
 }

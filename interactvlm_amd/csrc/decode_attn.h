@@ -17,7 +17,9 @@ constexpr int kDecThreads = 1024, kDecGroups = kDecThreads / 16;  // 64 key rows
 // with the roundings of the MFMA prefill path (q, k after RoPE and P rounded to bf16).
 // LO ("parity" precision, with F32IO): the cache holds K / V as hi + lo bf16 planes (kcache_lo / vcache_lo, same layout): the
 // appended rows are not rounded to bf16 and the cached ones are read back as hi + lo.
-template <bool COHERENT_OUT, bool F32IO = false, int THREADS = 1024, bool LO = false>
+// CF16 (with F32IO): the cache holds IEEE halves (the fp16-operand prefill appends them): appended rows are rounded to fp16, the
+// cached ones are read as fp16.
+template <bool COHERENT_OUT, bool F32IO = false, int THREADS = 1024, bool LO = false, bool CF16 = false>
 __device__ __forceinline__ void llama_decode_attn_body(const int h, const void* __restrict__ qkv_v /*[3,H,D]*/,
                                                                 bf16_t* __restrict__ kcache /*[Tmax,H,D]*/,
                                                                 bf16_t* __restrict__ vcache, void* __restrict__ o_v,
@@ -82,11 +84,12 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const void* 
         const float qaf = q0 * c - q1 * s, qbf = q1 * c + q0 * s, kaf = k0 * c - k1 * s, kbf = k1 * c + k0 * s;
         // bf16 I/O: round q, k to bf16 exactly like the prefill path (rope_kv_kernel) so both paths see the same values
         const bf16_t qa = f32_to_bf16(qaf), qb = f32_to_bf16(qbf);
-        const bf16_t ka = f32_to_bf16(kaf), kb = f32_to_bf16(kbf);
+        const bf16_t ka = f32_to_h16<CF16>(kaf), kb = f32_to_h16<CF16>(kbf);
         q_s[t] = F32IO ? qaf : bf16_to_f32(qa);
         q_s[t + half] = F32IO ? qbf : bf16_to_f32(qb);
         knew_s[t] = F32IO ? kaf : bf16_to_f32(ka);
         knew_s[t + half] = F32IO ? kbf : bf16_to_f32(kb);
+        static_assert(!CF16 || (F32IO && !LO), "fp16 cache: fp32 qkv / o, no lo planes");
         bf16_t* kc = kcache + ((int64_t)pos * H + h) * D;
         kc[t] = ka;
         kc[t + half] = kb;
@@ -99,7 +102,7 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const void* 
         const int d = t - 128;
         const float v = ld(2 * (int64_t)H * D + h * D + d);
         vnew_s[d] = v;
-        const bf16_t vh = f32_to_bf16(v);
+        const bf16_t vh = f32_to_h16<CF16>(v);
         vcache[((int64_t)pos * H + h) * D + d] = vh;
         if (LO) vcache_lo[((int64_t)pos * H + h) * D + d] = f32_to_bf16(v - bf16_to_f32(vh));
     }
@@ -115,8 +118,8 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const void* 
             if (j < pos) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    d += __uint_as_float(kv[e] << 16) * qr[2 * e];
-                    d += __uint_as_float(kv[e] & 0xffff0000u) * qr[2 * e + 1];
+                    d += pair_lo_f32<CF16>(kv[e]) * qr[2 * e];
+                    d += pair_hi_f32<CF16>(kv[e]) * qr[2 * e + 1];
                 }
                 if (LO) {
                     const u32x4_t kl = *reinterpret_cast<const u32x4_t*>(kbl + j * rstride);
@@ -184,8 +187,8 @@ __device__ __forceinline__ void llama_decode_attn_body(const int h, const void* 
             if (j < pos) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc[2 * e] += p * __uint_as_float(vv[e] << 16);
-                    acc[2 * e + 1] += p * __uint_as_float(vv[e] & 0xffff0000u);
+                    acc[2 * e] += p * pair_lo_f32<CF16>(vv[e]);
+                    acc[2 * e + 1] += p * pair_hi_f32<CF16>(vv[e]);
                 }
                 if (LO) {
                     const u32x4_t vl = *reinterpret_cast<const u32x4_t*>(vbl + j * rstride);

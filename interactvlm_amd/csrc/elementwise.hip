@@ -240,6 +240,8 @@ __global__ __launch_bounds__(kT) void rope_table_kernel(float* __restrict__ ct, 
     st[i] = sinf(ang);
 }
 
+// F16: qkv and the caches hold IEEE halves (the fp16-operand prefill)
+template <bool F16>
 __global__ __launch_bounds__(kT) void rope_kv_kernel(bf16_t* __restrict__ qkv, int64_t ld, int T, int H, int D,
                                                      int pos0, float theta, bf16_t* __restrict__ kcache,
                                                      bf16_t* __restrict__ vcache, const float* __restrict__ ct,
@@ -266,11 +268,11 @@ __global__ __launch_bounds__(kT) void rope_kv_kernel(bf16_t* __restrict__ qkv, i
         bf16_t* q = row + h * D;
         bf16_t* k = row + (int64_t)H * D + h * D;
         const bf16_t* v = row + 2 * (int64_t)H * D + h * D;
-        const float q0 = bf16_to_f32(q[j]), q1 = bf16_to_f32(q[j + half]);
-        const float k0 = bf16_to_f32(k[j]), k1 = bf16_to_f32(k[j + half]);
+        const float q0 = h16_to_f32<F16>(q[j]), q1 = h16_to_f32<F16>(q[j + half]);
+        const float k0 = h16_to_f32<F16>(k[j]), k1 = h16_to_f32<F16>(k[j + half]);
         // q*cos + rotate_half(q)*sin
-        const bf16_t qa = f32_to_bf16(q0 * c - q1 * s), qb = f32_to_bf16(q1 * c + q0 * s);
-        const bf16_t ka = f32_to_bf16(k0 * c - k1 * s), kb = f32_to_bf16(k1 * c + k0 * s);
+        const bf16_t qa = f32_to_h16<F16>(q0 * c - q1 * s), qb = f32_to_h16<F16>(q1 * c + q0 * s);
+        const bf16_t ka = f32_to_h16<F16>(k0 * c - k1 * s), kb = f32_to_h16<F16>(k1 * c + k0 * s);
         q[j] = qa;
         q[j + half] = qb;
         k[j] = ka;
@@ -446,10 +448,14 @@ int dense_pe(const float* gauss, void* pe, int pe_f32, int h, int w, int F, hipS
     return ivlm_launch_status();
 }
 int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, bf16_t* kcache, bf16_t* vcache,
-            hipStream_t st, const float* cos_tab, const float* sin_tab) {
+            hipStream_t st, const float* cos_tab, const float* sin_tab, int f16) {
     if (!qkv || T <= 0 || (D & 1) || (kcache && !vcache) || (cos_tab && !sin_tab)) return IVLM_ERR_INVALID_ARG;
-    rope_kv_kernel<<<grid_for((int64_t)T * H * (D >> 1)), kT, 0, st>>>(qkv, ld, T, H, D, pos0, theta, kcache, vcache,
-                                                                       cos_tab, sin_tab);
+    if (f16)
+        rope_kv_kernel<true><<<grid_for((int64_t)T * H * (D >> 1)), kT, 0, st>>>(qkv, ld, T, H, D, pos0, theta, kcache, vcache,
+                                                                                 cos_tab, sin_tab);
+    else
+        rope_kv_kernel<false><<<grid_for((int64_t)T * H * (D >> 1)), kT, 0, st>>>(qkv, ld, T, H, D, pos0, theta, kcache, vcache,
+                                                                                  cos_tab, sin_tab);
     return ivlm_launch_status();
 }
 int rope_kv_split(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, bf16_t* kcache, bf16_t* kcache_lo, bf16_t* vcache,
@@ -519,6 +525,11 @@ int ivlm_rope_kv(void* qkv, int64_t ld, int T, int H, int D, int pos0, float the
                  const float* cos_tab, const float* sin_tab, ivlm_stream_t s) {
     ivlm_enter();
     return ivlm::rope_kv(BF(qkv), ld, T, H, D, pos0, theta, BF(kcache), BF(vcache), ivlm_stream(s), cos_tab, sin_tab);
+}
+int ivlm_rope_kv_f16(void* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, void* kcache, void* vcache,
+                     const float* cos_tab, const float* sin_tab, ivlm_stream_t s) {
+    ivlm_enter();
+    return ivlm::rope_kv(BF(qkv), ld, T, H, D, pos0, theta, BF(kcache), BF(vcache), ivlm_stream(s), cos_tab, sin_tab, 1);
 }
 int ivlm_rope_kv_split(void* qkv, int64_t ld, int T, int H, int D, int pos0, void* kcache, void* kcache_lo, void* vcache,
                        void* vcache_lo, const float* cos_tab, const float* sin_tab, ivlm_stream_t s) {

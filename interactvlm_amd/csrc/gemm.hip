@@ -279,12 +279,21 @@ int launch(const GemmArgs& g, hipStream_t st) {
         if (t == 64) return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64, 1>(g, st) : launch_cfg<ACT, false, Cfg128x64, 1>(g, st);
         return g.out_f32 ? launch_cfg<ACT, true, Cfg128, 1>(g, st) : launch_cfg<ACT, false, Cfg128, 1>(g, st);
     }
-    if (g.f16) {  // fp16 operands: the 8-phase 256^2 kernel, 128 x 64 tiles for what it does not fit (epilogues of the SAM MLP only)
-        if constexpr (ACT == ACT_NONE || ACT == ACT_GELU) {
+    if (g.f16) {  // fp16 operands: the tilings of the bf16 path (the epilogues the three towers use: keeps the build small)
+        if constexpr (ACT == ACT_NONE || ACT == ACT_GELU || ACT == ACT_QUICK_GELU || ACT == ACT_SWIGLU) {
             const int t = choose_tile(g);
-            if (t == 320) return gemm_bf16_320p(g, st);
+            if (t == 320) {
+                const int rc = gemm_bf16_320p(g, st);
+                if (rc != IVLM_ERR_UNSUPPORTED) return rc;
+            }
             if (t == 512 || t == 256) return gemm_bf16_256p(g, st);
-            return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64, 2>(g, st) : launch_cfg<ACT, false, Cfg128x64, 2>(g, st);
+            if (t == 176) {
+                if constexpr (ACT == ACT_NONE || ACT == ACT_SWIGLU)
+                    return g.out_f32 ? launch_cfg<ACT, true, Cfg176x128, 2>(g, st) : launch_cfg<ACT, false, Cfg176x128, 2>(g, st);
+            }
+            if (t == 64 || t == 176 || t == 96)
+                return g.out_f32 ? launch_cfg<ACT, true, Cfg128x64, 2>(g, st) : launch_cfg<ACT, false, Cfg128x64, 2>(g, st);
+            return g.out_f32 ? launch_cfg<ACT, true, Cfg128, 2>(g, st) : launch_cfg<ACT, false, Cfg128, 2>(g, st);
         } else {
             return IVLM_ERR_UNSUPPORTED;
         }
@@ -352,7 +361,8 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
     if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) return IVLM_ERR_INVALID_ARG;
     if (g.a_f32) return IVLM_ERR_UNSUPPORTED;
     if (g.f16 || g.out_f16) {  // IEEE-half operands / output: plain tile kernels
-        if (g.fp8 || g.out_fp8 || g.a_split || g.a_f32 || (g.out_f16 && (g.out_f32 || g.out_split))) return IVLM_ERR_UNSUPPORTED;
+        // (out_f16 with out_split: the fp32 value leaves as [hi | lo] IEEE halves; a_split with f16: [hi | lo] fp16 rows)
+        if (g.fp8 || g.out_fp8 || g.a_f32 || (g.out_f16 && g.out_f32 && !g.out_split) || (g.a_split && !g.f16)) return IVLM_ERR_UNSUPPORTED;
     }
     if (g.a_split || g.out_split) {  // fp32-activation ("parity") operands / outputs: bf16 tile kernels only
         if (g.fp8 || g.out_fp8 || g.a_kstep || g.w_kstep || g.c_panel) return IVLM_ERR_UNSUPPORTED;
@@ -419,12 +429,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         const int64_t o = (int64_t)m * g.ldc + n;
         if (OUT_F32 && g.out_split) {
             uint32_t h0, l0, h1, l1;
-            split_bf16x2(v[0], v[1], h0, l0);
-            split_bf16x2(v[2], v[3], h1, l1);
+            split_16x2(v[0], v[1], h0, l0, g.out_f16);
+            split_16x2(v[2], v[3], h1, l1, g.out_f16);
             *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(h0, h1);
             *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o + g.c_lo) = make_uint2(l0, l1);
         } else if (OUT_F32) *reinterpret_cast<float4*>(static_cast<float*>(g.C) + o) = make_float4(v[0], v[1], v[2], v[3]);
-        else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(pack_16x2(v[0], v[1], g.out_f16), pack_16x2(v[2], v[3], g.out_f16));
     }
 }
 }  // namespace
@@ -443,6 +453,7 @@ int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_
     p.C = workspace;
     p.ldc = g.N;
     p.out_f32 = 1;
+    p.out_f16 = 0;    // (a 16-bit / split fp16 output is written by the reduce pass)
     p.out_split = 0;  // (the partials are fp32; the reduce pass applies the epilogue, split output included; a_split / a_lo stay)
     p.bias = nullptr;
     p.residual = nullptr;
@@ -618,6 +629,11 @@ extern "C" int ivlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
     if (flags & IVLM_GEMM_A_SPLIT) { g.a_split = 1; g.a_lo = K; }
     if (flags & IVLM_GEMM_OUT_SPLIT) { g.out_split = 1; g.c_lo = N; out_f32 = 1; }
+    if (flags & IVLM_GEMM_F16) g.f16 = 1;
+    if (flags & IVLM_GEMM_OUT_F16) {
+        if (out_f32 && !g.out_split) return IVLM_ERR_INVALID_ARG;
+        g.out_f16 = 1;
+    }
     g.tile = g_tile_override;
     g.A = static_cast<const bf16_t*>(A);
     g.W = static_cast<const bf16_t*>(W);

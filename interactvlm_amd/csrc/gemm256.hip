@@ -215,8 +215,8 @@ int launch256(const GemmArgs& g, hipStream_t st) {
     } while (0)
     if (g.fp8) {
         if (g.out_f32) IVLM_GO(true, 1); else IVLM_GO(false, 1);
-    } else if (g.f16) {  // (instantiated for the SAM MLP's epilogues only)
-        if constexpr (ACT == ACT_NONE || ACT == ACT_GELU) {
+    } else if (g.f16) {  // (instantiated for the epilogues of the three towers only)
+        if constexpr (ACT == ACT_NONE || ACT == ACT_GELU || ACT == ACT_QUICK_GELU || ACT == ACT_SWIGLU) {
             if (g.out_f32) IVLM_GO(true, 2); else IVLM_GO(false, 2);
         } else {
             return IVLM_ERR_UNSUPPORTED;

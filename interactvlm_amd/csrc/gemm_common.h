@@ -194,8 +194,8 @@ __device__ __forceinline__ void gemm_store_lines(const GemmArgs& g, unsigned cha
                 }
                 if (g.out_split) {  // [hi | lo] bf16 halves of the fp32 value (16 lanes x 8 B = one 128-byte line each)
                     uint32_t h0, l0, h1, l1;
-                    split_bf16x2(q.x, q.y, h0, l0);
-                    split_bf16x2(q.z, q.w, h1, l1);
+                    split_16x2(q.x, q.y, h0, l0, g.out_f16);
+                    split_16x2(q.z, q.w, h1, l1, g.out_f16);
                     bf16_t* cb = static_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n;
                     *reinterpret_cast<uint2*>(cb) = make_uint2(h0, h1);
                     *reinterpret_cast<uint2*>(cb + g.c_lo) = make_uint2(l0, l1);
@@ -267,8 +267,8 @@ __device__ __forceinline__ void gemm_store_strip_rows(const GemmArgs& g, const u
             }
             if (g.out_split) {
                 uint32_t h0, l0, h1, l1;
-                split_bf16x2(q.x, q.y, h0, l0);
-                split_bf16x2(q.z, q.w, h1, l1);
+                split_16x2(q.x, q.y, h0, l0, g.out_f16);
+                split_16x2(q.z, q.w, h1, l1, g.out_f16);
                 bf16_t* cb = static_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n;
                 *reinterpret_cast<uint2*>(cb) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2*>(cb + g.c_lo) = make_uint2(l0, l1);
@@ -322,7 +322,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
             if (OUT_F32 && g.out_split) {
                 bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
                 uint32_t hi, lo;
-                split_bf16x2(o0, o1, hi, lo);
+                split_16x2(o0, o1, hi, lo, g.out_f16);
                 *reinterpret_cast<uint32_t*>(C + o) = hi;
                 *reinterpret_cast<uint32_t*>(C + o + g.c_lo) = lo;
             } else if (OUT_F32) {
@@ -362,8 +362,8 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
         } else if (OUT_F32 && g.out_split) {
             bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
             uint32_t h0, l0, h1, l1;
-            split_bf16x2(v[0], v[1], h0, l0);
-            split_bf16x2(v[2], v[3], h1, l1);
+            split_16x2(v[0], v[1], h0, l0, g.out_f16);
+            split_16x2(v[2], v[3], h1, l1, g.out_f16);
             *reinterpret_cast<uint2*>(C + o) = make_uint2(h0, h1);
             *reinterpret_cast<uint2*>(C + o + g.c_lo) = make_uint2(l0, l1);
         } else if (OUT_F32) {
@@ -383,12 +383,14 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, int bz, int m,
             const int64_t o = (int64_t)m * g.ldc + n + j;
             if (OUT_F32 && g.out_split) {
                 bf16_t* C = static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC;
-                C[o] = f32_to_bf16(x);
-                C[o + g.c_lo] = f32_to_bf16(x - bf16_to_f32(C[o]));
+                uint32_t h2, l2;
+                split_16x2(x, 0.0f, h2, l2, g.out_f16);
+                C[o] = (bf16_t)(h2 & 0xffffu);
+                C[o + g.c_lo] = (bf16_t)(l2 & 0xffffu);
             } else if (OUT_F32)
                 (static_cast<float*>(g.C) + (int64_t)bz * g.strideC)[o] = x;
             else
-                (static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC)[o] = f32_to_bf16(x);
+                (static_cast<bf16_t*>(g.C) + (int64_t)bz * g.strideC)[o] = g.out_f16 ? f32_to_h16<true>(x) : f32_to_bf16(x);
         }
     }
 }

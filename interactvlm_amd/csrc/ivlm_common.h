@@ -85,10 +85,43 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
 // 16-bit output pair of the GEMM epilogues: bf16 or (f16 != 0) fp16
 __device__ __forceinline__ uint32_t pack_16x2(float lo, float hi, int f16) { return f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
 
+// one 16-bit storage element <-> fp32, operand kind chosen at compile time: F16 = IEEE half (saturating stores), else bf16
+template <bool F16>
+__device__ __forceinline__ float h16_to_f32(uint16_t v) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v);
+    else return bf16_to_f32(v);
+}
+template <bool F16>
+__device__ __forceinline__ uint16_t f32_to_h16(float f) {
+    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
+    else return f32_to_bf16(f);
+}
+template <bool F16>
+__device__ __forceinline__ float pair_lo_f32(uint32_t u) {
+    if constexpr (F16) return (float)__builtin_bit_cast(ivlm_f16x2_t, u)[0];
+    else return __uint_as_float(u << 16);
+}
+template <bool F16>
+__device__ __forceinline__ float pair_hi_f32(uint32_t u) {
+    if constexpr (F16) return (float)__builtin_bit_cast(ivlm_f16x2_t, u)[1];
+    else return __uint_as_float(u & 0xffff0000u);
+}
+
 // hi + lo bf16 split of fp32 values (x = hi + lo to 2^-17 relative): packed pairs, hi = RNE(x), lo = RNE(x - hi)
 __device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
     hi = pack_bf16x2(a, b);
     lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+
+// the same with the element type chosen at run time: f16 != 0 -> hi + lo IEEE halves (x = hi + lo to 2^-22 while lo stays normal)
+__device__ __forceinline__ void split_16x2(float a, float b, uint32_t& hi, uint32_t& lo, int f16) {
+    if (f16) {
+        hi = pack_f16x2(a, b);
+        const ivlm_f16x2_t h = __builtin_bit_cast(ivlm_f16x2_t, hi);
+        lo = pack_f16x2(a - (float)h[0], b - (float)h[1]);
+    } else {
+        split_bf16x2(a, b, hi, lo);
+    }
 }
 
 // ---- wave64 reductions (fixed butterfly order => deterministic) ------------------------------

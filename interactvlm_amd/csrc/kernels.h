@@ -102,6 +102,7 @@ struct AttnArgs {
     // "parity" precision: lo planes of q / k / v / o (x = hi + lo; same strides as the hi tensors).  All four set or none.
     const bf16_t *q_lo = nullptr, *k_lo = nullptr, *v_lo = nullptr;
     bf16_t* o_lo = nullptr;
+    int f16 = 0;  // 1: q / k / v / o (and the table-mode rel-pos table) are IEEE fp16: same tiles, the f16 matrix instruction
 };
 
 // softmax(scale * Q.K^T (+ rel-pos bias) (+ causal mask)) . V ; bf16 in/out, fp32 softmax. D in {16,32,64,80,128}.
@@ -128,7 +129,7 @@ int add_rows(void* out, int out_kind, const void* a, int a_kind, const void* b, 
 int fill_rows(bf16_t* dst, int64_t ldd, const int32_t* idx, int64_t n_idx, const bf16_t* row, int cols, hipStream_t st);
 int dense_pe(const float* gauss, void* pe, int pe_f32, int h, int w, int F, hipStream_t st);
 int rope_kv(bf16_t* qkv, int64_t ld, int T, int H, int D, int pos0, float theta, bf16_t* kcache, bf16_t* vcache,
-            hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr);
+            hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr, int f16 = 0);
 int rope_table(float* cos_tab, float* sin_tab, int T, int D, float theta, hipStream_t st);
 int normalize_pad_u8(const uint8_t* src, int H, int W, int y0, int x0, int ch, int cw, const float* mean3,
                      const float* std3, void* out, int out_bf16, int OH, int OW, hipStream_t st);
@@ -156,11 +157,11 @@ int phong_shade(const int32_t* p2v, const float* bary, const float* verts, const
 // qkv / o bf16 or fp32 (io_f32); tmax = rows of the cache slab (a position >= tmax is skipped, never appended)
 int llama_decode_attn(const void* qkv, int io_f32, bf16_t* kcache, bf16_t* vcache, int tmax, void* o, int H, int D, int pos,
                       float theta, float scale, hipStream_t st, const float* cos_tab = nullptr, const float* sin_tab = nullptr,
-                      const int32_t* pos_dev = nullptr, bf16_t* kcache_lo = nullptr, bf16_t* vcache_lo = nullptr);
+                      const int32_t* pos_dev = nullptr, bf16_t* kcache_lo = nullptr, bf16_t* vcache_lo = nullptr, int cache_f16 = 0);
 int llama_decode_attn_batch(const void* qkv, int io_f32, int64_t ldq, bf16_t* kcache, bf16_t* vcache, int64_t cache_stride,
                             int tmax, void* o, int64_t ldo, int B, int H, int D, const int32_t* pos_dev, float theta, float scale,
                             const float* cos_tab, const float* sin_tab, hipStream_t st, bf16_t* kcache_lo = nullptr,
-                            bf16_t* vcache_lo = nullptr);
+                            bf16_t* vcache_lo = nullptr, int cache_f16 = 0);
 
 // fused decode attention + o_proj (decode_fused.hip)
 int llama_attn_oproj(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* attn_scratch, const bf16_t* wo,

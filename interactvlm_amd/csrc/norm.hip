@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const void* __restrict__ xv, 
     }
     const int64_t orow = out_rows ? (int64_t)out_rows[row] : row;
     // y_split (bf16 output only): the row is written as [hi(cols) | lo(cols)], the A operand of an fp32-activation GEMM
-    uint4* yr = reinterpret_cast<uint4*>(static_cast<bf16_t*>(yv) + orow * (y_split == 1 ? 2 * cols : cols));
+    uint4* yr = reinterpret_cast<uint4*>(static_cast<bf16_t*>(yv) + orow * ((y_split & 1) ? 2 * cols : cols));
     float4* yr4 = reinterpret_cast<float4*>(static_cast<float*>(yv) + orow * cols);
     const uint4* wr = reinterpret_cast<const uint4*>(w);
     const uint4* br = reinterpret_cast<const uint4*>(b);
@@ -112,10 +112,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const void* __restrict__ xv, 
                 yr4[2 * idx + 1] = make_float4(o[4], o[5], o[6], o[7]);
             } else if (y_split == 2) {  // IEEE fp16 row (operand of an fp16 GEMM)
                 yr[idx] = make_uint4(pack_f16x2(o[0], o[1]), pack_f16x2(o[2], o[3]), pack_f16x2(o[4], o[5]), pack_f16x2(o[6], o[7]));
-            } else if (y_split) {
+            } else if (y_split) {  // 1: [hi | lo] bf16 halves, 3: [hi | lo] IEEE halves
                 uint32_t h[4], l[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) split_bf16x2(o[2 * j], o[2 * j + 1], h[j], l[j]);
+                for (int j = 0; j < 4; ++j) split_16x2(o[2 * j], o[2 * j + 1], h[j], l[j], y_split == 3);
                 yr[idx] = make_uint4(h[0], h[1], h[2], h[3]);
                 yr[nchunk + idx] = make_uint4(l[0], l[1], l[2], l[3]);
             } else {
@@ -131,7 +131,8 @@ template <bool RMS, int MAXC, bool GELU>
 static void launch_norm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols,
                         float eps, hipStream_t st, const int32_t* out_rows = nullptr, const float* fp8_scale = nullptr) {
     const unsigned grid = (unsigned)((rows + 3) / 4);
-    const int y_split = y_f32 == 2 ? 1 : (y_f32 == 4 ? 2 : 0);  // (y kind: 0 bf16, 1 fp32, 2 split bf16 [hi | lo], 4 fp16)
+    // (y kind: 0 bf16, 1 fp32, 2 split bf16 [hi | lo], 4 fp16, 5 split fp16 [hi | lo])
+    const int y_split = y_f32 == 2 ? 1 : (y_f32 == 4 ? 2 : (y_f32 == 5 ? 3 : 0));
     if (x_f32 && y_f32 == 1) norm_kernel<RMS, MAXC, GELU, true, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale, 0);
     else if (x_f32) norm_kernel<RMS, MAXC, GELU, true, false><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale, y_split);
     else if (y_f32 == 1) norm_kernel<RMS, MAXC, GELU, false, true><<<grid, 256, 0, st>>>(x, w, b, y, rows, cols, eps, out_rows, fp8_scale, 0);
@@ -173,8 +174,8 @@ int ivlm_layernorm(const void* x, int x_dtype, const void* w, const void* b, voi
     if ((y_dtype == IVLM_FP8) != (fp8_scale != nullptr)) return IVLM_ERR_INVALID_ARG;
     if (y_dtype == IVLM_FP8 && (gelu || cols > 2048)) return IVLM_ERR_UNSUPPORTED;
     return ivlm::layernorm(x, x_dtype == IVLM_F32, static_cast<const bf16_t*>(w), static_cast<const bf16_t*>(b), y,
-                           y_dtype == IVLM_F32 ? 1 : (y_dtype == IVLM_BF16_SPLIT ? 2 : (y_dtype == IVLM_F16 ? 4 : 0)), rows, cols, eps,
-                           ivlm_stream(stream), gelu, out_rows, fp8_scale);
+                           y_dtype == IVLM_F32 ? 1 : (y_dtype == IVLM_BF16_SPLIT ? 2 : (y_dtype == IVLM_F16 ? 4 : (y_dtype == IVLM_F16_SPLIT ? 5 : 0))),
+                           rows, cols, eps, ivlm_stream(stream), gelu, out_rows, fp8_scale);
 }
 
 int ivlm_rmsnorm_fp8(const void* x, int x_dtype, const void* w, void* y, int64_t rows, int cols, float eps, const float* fp8_scale,
@@ -188,7 +189,8 @@ int ivlm_rmsnorm(const void* x, int x_dtype, const void* w, void* y, int y_dtype
                  ivlm_stream_t stream) {
     ivlm_enter();
     return ivlm::rmsnorm(x, x_dtype == IVLM_F32, static_cast<const bf16_t*>(w), y,
-                         y_dtype == IVLM_F32 ? 1 : (y_dtype == IVLM_BF16_SPLIT ? 2 : 0), rows, cols, eps, ivlm_stream(stream));
+                         y_dtype == IVLM_F32 ? 1 : (y_dtype == IVLM_BF16_SPLIT ? 2 : (y_dtype == IVLM_F16 ? 4 : (y_dtype == IVLM_F16_SPLIT ? 5 : 0))),
+                         rows, cols, eps, ivlm_stream(stream));
 }
 
 }  // extern "C"

@@ -75,7 +75,16 @@ class ClipTower:
         g.replay()
         return static_out.clone()
 
-    precision = "default"  # "parity": fp32-activation arithmetic (hi + lo bf16 operands), see SamImageEncoder.precision
+    # "parity": fp32-activation arithmetic (hi + lo bf16 operands), see SamImageEncoder.precision; "f16": every MFMA operand as
+    # IEEE fp16 (one pass, an eighth of the bf16 operand rounding; fp16 copies of the weights made on first use)
+    precision = "default"
+
+    def _f16(self, L):
+        if "qkv_h" not in L:
+            L["qkv_h"] = ops.f16_weight(L["qkv_w"], "clip qkv")
+            for n in ("out", "fc1", "fc2"):
+                L[n + "_h"] = ops.f16_weight(L[n].w, "clip " + n)
+        return L
 
     # ---- fp8 (OCP e4m3) operands for the four GEMMs of every layer (BASELINE.json configs[4]; opt-in): per-tensor scales, the
     # weights quantised once, the activation ranges calibrated on one bf16 pass over calibration images and then fixed.
@@ -134,6 +143,15 @@ class ClipTower:
                 h = L["fc1"](L["ln2"](x, out_split=True), act="quick_gelu", a_split=True, out_split=True)
                 x = L["fc2"](h, residual=x, out_f32=True, a_split=True)
                 continue
+            if self.precision == "f16":
+                L = self._f16(L)
+                qkv = ops.linear(L["ln1"](x, out_f16=True), L["qkv_h"], L["qkv_b"], out_f16=True).view(B, T, 3, Hh, hd)
+                q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+                a = ops.attention(q, k, v, hd ** -0.5, prescale_q=True).permute(0, 2, 1, 3).reshape(B * T, c.hidden)
+                x = ops.linear(a, L["out_h"], L["out"].b, residual=x, out_f32=True)
+                h = ops.linear(L["ln2"](x, out_f16=True), L["fc1_h"], L["fc1"].b, act="quick_gelu", out_f16=True)
+                x = ops.linear(h, L["fc2_h"], L["fc2"].b, residual=x, out_f32=True)
+                continue
             cal = L.get("amax") if self._calibrating else None
             y = L["ln1"](x)
             qkv = ops.linear(y, L["qkv_w"], L["qkv_b"]).view(B, T, 3, Hh, hd)
@@ -149,7 +167,7 @@ class ClipTower:
         if B not in self._patch_rows:  # drop the CLS row of every image
             r = torch.arange(B * T, dtype=torch.int32).view(B, T)[:, 1:].reshape(-1)
             self._patch_rows[B] = r.to(images.device)
-        if par:
+        if par or self.precision == "f16":  # (the mm_projector takes hi + lo rows in both: 0.03 % of the image's FLOPs)
             return ops.gather_rows(x, self._patch_rows[B], out_kind="split").view(B, T - 1, 2 * c.hidden)
         return ops.gather_rows(x, self._patch_rows[B], out_kind="bf16").view(B, T - 1, c.hidden)
 
@@ -192,8 +210,11 @@ class Llama:
 
     # ---- "parity" precision (opt-in): the prefill GEMMs take hi + lo bf16 activation operands, the attention three MFMAs per
     # fragment, and K / V are cached as hi + lo planes (also read by the decode kernels) - no activation is rounded to bf16.
+    # "f16": the prefill GEMMs and attention take IEEE fp16 operands (one MFMA pass, an eighth of the bf16 operand rounding; fp16
+    # copies of the layer weights, +12.6 GB for 7B, made on first use), K / V are cached as fp16 (the same cache storage, seen
+    # as fp16) and read as fp16 by the decode kernels, whose activations are fp32 in every mode.
     def set_precision(self, mode):
-        assert mode in ("default", "parity")
+        assert mode in ("default", "parity", "f16")
         if mode == self.precision:
             return
         self._dgraphs[self.precision] = self._dgraph
@@ -239,6 +260,33 @@ class Llama:
     def _lo(self, li):
         return (self.kcache_lo[li], self.vcache_lo[li]) if self.precision == "parity" else None
 
+    def _caches(self):
+        """this instance's single-sequence cache in the element type of the precision mode (fp16 mode: the same bytes as fp16)"""
+        if self.precision == "f16":
+            return self.kcache.view(torch.float16), self.vcache.view(torch.float16)
+        return self.kcache, self.vcache
+
+    def _f16(self, L):
+        if "qkv_h" not in L:
+            for n in ("qkv", "o", "gu", "down"):
+                L[n + "_h"] = ops.f16_weight(L[n], "llama " + n)
+        return L
+
+    def _layer_f16(self, L, x, T, pos0, kc, vc, a_out=None):
+        """one prefill layer on fp16 operands: x fp32 [T, hidden] -> fp32 [T, hidden]; kc / vc = this layer's fp16 cache planes"""
+        c = self.cfg
+        H, hd = c.heads, c.hidden // c.heads
+        L = self._f16(L)
+        qkv = ops.linear(ops.rmsnorm(x, L["ln1"], c.eps, out_f16=True), L["qkv_h"], out_f16=True)
+        ops.rope_kv(qkv, H, hd, pos0, c.theta, kc, vc, table=self.rope)
+        q = qkv.view(T, 3, H, hd)[:, 0].permute(1, 0, 2).unsqueeze(0)
+        k = kc[: pos0 + T].permute(1, 0, 2).unsqueeze(0)
+        v = vc[: pos0 + T].permute(1, 0, 2).unsqueeze(0)
+        a = ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=pos0).permute(0, 2, 1, 3).reshape(T, c.hidden)
+        x = ops.linear(a, L["o_h"], residual=x, out_f32=True)
+        h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps, out_f16=True), L["gu_h"], act="swiglu", out_f16=True)
+        return ops.linear(h, L["down_h"], residual=x, out_f32=True)
+
     def batch_cache_lo(self, B):
         bc = getattr(self, "_bcache_lo", None)
         if bc is None or bc[0].shape[1] < B:
@@ -276,7 +324,15 @@ class Llama:
         assert pos0 + T <= self.max_len and x.dtype == F32
         if T == 1 and cache is None:
             return self._decode_step(x, pos0)
-        kc, vc = cache[:2] if cache is not None else (self.kcache, self.vcache)
+        if 1 < T <= 16 and cache is None and self.precision != "default":
+            # (the fp16 / split tile GEMMs need M > 16: a short chunk goes token by token through the fp32-activation decode
+            #  kernels, which are exact on the bf16 weights)
+            return torch.cat([self._decode_step(x[t: t + 1], pos0 + t) for t in range(T)], 0)
+        kc, vc = cache[:2] if cache is not None else self._caches()
+        if self.precision == "f16":
+            for li, L in enumerate(self.layers):
+                x = self._layer_f16(L, x, T, pos0, kc[li], vc[li])
+            return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
         if self.precision == "parity":
             kcl, vcl = cache[2:] if cache is not None else (self.kcache_lo, self.vcache_lo)
             for li, L in enumerate(self.layers):
@@ -325,6 +381,24 @@ class Llama:
         for n in lens:
             offs.append(offs[-1] + n)
         x = torch.cat(xs, 0)
+        if self.precision == "f16":  # fp16 operands (see _layer_f16); kc / vc are fp16 views of the slabs
+            for li, L in enumerate(self.layers):
+                L = self._f16(L)
+                qkv = ops.linear(ops.rmsnorm(x, L["ln1"], c.eps, out_f16=True), L["qkv_h"], out_f16=True)
+                a = torch.empty(offs[-1], c.hidden, dtype=torch.float16, device=x.device)
+                for b, T in enumerate(lens):
+                    qb = qkv[offs[b]: offs[b + 1]]
+                    ops.rope_kv(qb, H, hd, 0, c.theta, kc[li, b], vc[li, b], table=self.rope)
+                    q = qb.view(T, 3, H, hd)[:, 0].permute(1, 0, 2).unsqueeze(0)
+                    k = kc[li, b, :T].permute(1, 0, 2).unsqueeze(0)
+                    v = vc[li, b, :T].permute(1, 0, 2).unsqueeze(0)
+                    ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=0,
+                                  out=a[offs[b]: offs[b + 1]].view(1, T, H, hd).permute(0, 2, 1, 3))
+                x = ops.linear(a, L["o_h"], residual=x, out_f32=True)
+                h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps, out_f16=True), L["gu_h"], act="swiglu", out_f16=True)
+                x = ops.linear(h, L["down_h"], residual=x, out_f32=True)
+            x = ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
+            return [x[offs[b]: offs[b + 1]] for b in range(len(lens))]
         if self.precision == "parity":  # fp32-activation arithmetic (see _layer_parity), lo = (kc_lo, vc_lo) slabs
             kcl, vcl = lo
             for li, L in enumerate(self.layers):
@@ -390,7 +464,7 @@ class Llama:
                     self._fused["step"].add_(1)
 
             caches = [self.kcache, self.vcache] + ([self.kcache_lo, self.vcache_lo] if self.precision == "parity" else [])
-            saved = [t[:, :1].clone() for t in caches]  # the warm-up / capture runs write row 0
+            saved = [t[:, :1].clone() for t in caches]  # the warm-up / capture runs write row 0 (fp16 mode: the same bytes)
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -421,6 +495,8 @@ class Llama:
             bc = self._bcache = tuple(torch.zeros(c.layers, B, self.max_len, H, hd, dtype=BF16, device=self.device)
                                       for _ in range(2))
             self._bgraphs = {}
+        if self.precision == "f16":  # the same slabs, seen as fp16
+            return bc[0].view(torch.float16)[:, :B], bc[1].view(torch.float16)[:, :B]
         return bc[0][:, :B], bc[1][:, :B]
 
     def decode_step_batch(self, x, pos_dev, kc, vc, lo=None):
@@ -489,14 +565,14 @@ class Llama:
                 h = ops.linear_fp8w(x, L["gu_q"], L["gu_s"], act="swiglu", rms=(L["ln2"], c.eps))
                 x = ops.linear_fp8w(h, L["down_q"], L["down_s"], residual=x)
             return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
+        kc_, vc_ = self._caches()
         for li, L in enumerate(self.layers):
             qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps), out_f32=True)
-            if fz is not None and self.precision != "parity":  # attention + o_proj + residual in one launch (W_o streams while the attention runs)
+            if fz is not None and self.precision == "default":  # attention + o_proj + residual in one launch (W_o streams while the attention runs)
                 x = ops.llama_attn_oproj(qkv, self.kcache[li], self.vcache[li], L["o"], x, H, hd, pos, fz["step"],
                                          fz["counters"][li], fz["status"], c.theta, hd ** -0.5, self.rope, fz["scratch"][li])
             else:
-                a = ops.llama_decode_attn(qkv, self.kcache[li], self.vcache[li], H, hd, pos, c.theta, hd ** -0.5,
-                                          table=self.rope, lo=self._lo(li))
+                a = ops.llama_decode_attn(qkv, kc_[li], vc_[li], H, hd, pos, c.theta, hd ** -0.5, table=self.rope, lo=self._lo(li))
                 x = ops.linear(a, L["o"], residual=x, out_f32=True)
             h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps), out_f32=True)
             x = ops.linear(h, L["down"], residual=x, out_f32=True)

@@ -150,18 +150,18 @@ class InteractVLMForCausalLM:
     # parity precision, 8e-6 with everything) - the cheapest mode that holds 1e-3, with a 2x margin.  Its MLP GEMMs run on fp16
     # operands (one MFMA pass, an eighth of the bf16 rounding error: SamImageEncoder.PARITY_SITES_FAST) instead of hi + lo pairs.
     # "parity-fast": "parity" with the encoder's MLP on fp16 operands (the only operands below fp32-equivalent precision).
-    precision_modes = ("default", "parity-encoder", "parity-fast", "parity")
+    precision_modes = ("default", "f16", "f16q", "parity-encoder", "parity-fast", "parity")
     precision = "default"
 
     def set_precision(self, mode):
         assert mode in self.precision_modes, mode
         self.precision = mode
-        lang = "parity" if mode in ("parity", "parity-fast") else "default"
+        lang = "parity" if mode in ("parity", "parity-fast") else ("f16" if mode in ("f16", "f16q") else "default")
         self.vision_tower.precision = lang
         self.llm.set_precision(lang)
         enc = self.model.visual_model.image_encoder
         enc.precision = "default" if mode == "default" else "parity"
-        enc.parity_sites = enc.PARITY_SITES if mode == "parity" else enc.PARITY_SITES_FAST
+        enc.parity_sites = {"parity": enc.PARITY_SITES, "f16": enc.SITES_F16, "f16q": enc.SITES_F16Q}.get(mode, enc.PARITY_SITES_FAST)
 
     # fp8 variant (BASELINE.json configs[4], opt-in; never a parity claim): e4m3 operands for the GEMMs of the SAM ViT-H encoder,
     # the CLIP tower and the LLaMA prefill, e4m3 WEIGHTS for the batch-1 decode linears.  Activation scales are calibrated on the
@@ -277,7 +277,7 @@ class InteractVLMForCausalLM:
         f = self.vision_tower(images_clip.to(self.device))
         B, T, C = f.shape  # ("parity" precision: C = 2 * hidden, [hi | lo] rows)
         return self.mm_projector(f.reshape(B * T, C), out_f32=True,
-                                 a_split=self.vision_tower.precision == "parity").view(B, T, -1)  # fp32: rows of the LLM's input stream
+                                 a_split=self.vision_tower.precision in ("parity", "f16")).view(B, T, -1)  # fp32: rows of the LLM's input stream
 
     def _seg_token_ids(self):
         ids = [self.seg_token_idx]

@@ -322,7 +322,7 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     K = weight.shape[1]
     f16 = weight.dtype == F16  # IEEE-half operands (tile GEMM): x must be fp16 too
     assert x.shape[-1] == (2 * K if a_split else K) and x.dtype in (BF16, F32, F16) and weight.dtype in (BF16, F16)
-    assert (x.dtype == F16) == f16 and not (f16 and a_split)
+    assert (x.dtype == F16) == f16  # (f16 with a_split: [hi | lo] IEEE halves, the IVLM_F16_SPLIT rows of layernorm(out_split, out_f16))
     x2 = x.reshape(-1, x.shape[-1])
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
@@ -333,12 +333,14 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
             raise IvlmError("linear: fp32 activations only on the M <= 16 weight-streaming paths (use split_rows + a_split)")
         flags |= GEMM_A_F32
     if a_split:
-        assert x.dtype == BF16
+        assert x.dtype in (BF16, F16)
         flags |= GEMM_A_SPLIT
     if f16:
         flags |= GEMM_F16
-    if out_f16:
-        assert not out_f32 and not out_split
+    if out is not None and out.dtype == F16:
+        out_f16 = True
+    if out_f16:  # (with out_split: the fp32 result as [hi | lo] IEEE halves)
+        assert not out_f32 or out_split
         flags |= GEMM_OUT_F16
     n_out = N // 2 if act == "swiglu" else N
     if out_split:
@@ -348,7 +350,7 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
         lead = x.shape[:-1] if a_rows is None else (M,)
         out = torch.empty(tuple(lead) + (n_cols,), dtype=F32 if (out_f32 and not out_split) else (F16 if out_f16 else BF16),
                           device=x.device)
-    assert not out_split or out.dtype == BF16
+    assert not out_split or out.dtype == (F16 if out_f16 else BF16)
     o2 = out.reshape(-1, n_cols)
     assert o2.stride(-1) == 1 and weight.stride(-1) == 1
     r2, ldr = None, 0
@@ -364,7 +366,7 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
         x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
         _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, 1, 0, 0, 0, 0,
         _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, flags, _p(out_rows), _p(a_rows), _stream()), "gemm_bf16")
-    splits = _splitk_choice(M, N, K, act, rms) if (x.dtype == BF16 and out_rows is None and a_rows is None and not out_f16) else 1
+    splits = _splitk_choice(M, N, K, act, rms) if (x.dtype in (BF16, F16) and out_rows is None and a_rows is None) else 1
     if splits > 1 and o2.stride(0) % 4 == 0:
         ws = torch.empty(splits * M * N, dtype=F32, device=x.device)  # caching allocator: stream-safe
         call = lambda: check(lib.ivlm_gemm_bf16_splitk(
@@ -399,13 +401,13 @@ def layernorm(x, weight, bias, eps=1e-5, gelu=False, out=None, out_f32=False, ou
     cols = x.shape[-1]
     if out is None:
         if out_split:
-            out = torch.empty(x.shape[:-1] + (2 * cols,), dtype=BF16, device=x.device)
+            out = torch.empty(x.shape[:-1] + (2 * cols,), dtype=F16 if out_f16 else BF16, device=x.device)
         elif out_f16:
             out = torch.empty(x.shape, dtype=F16, device=x.device)
         else:
             out = torch.empty(x.shape, dtype=U8 if fp8_scale is not None else (F32 if out_f32 else BF16), device=x.device)
     y = out
-    ydt = IVLM_FP8 if fp8_scale is not None else (2 if out_split else (4 if out_f16 else _dtc(y)))
+    ydt = IVLM_FP8 if fp8_scale is not None else ((5 if out_f16 else 2) if out_split else (4 if out_f16 else _dtc(y)))
     check(lib.ivlm_layernorm(x.data_ptr(), _dtc(x), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), ydt,
                              x.numel() // cols, cols, float(eps), 1 if gelu else 0, _p(out_rows), _p(fp8_scale), _stream()),
           "layernorm")
@@ -492,7 +494,7 @@ def linear_fp8w(x, wq, scale_w, bias=None, act="none", residual=None, out_f32=Tr
     return out
 
 
-def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False, fp8_scale=None):
+def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False, fp8_scale=None, out_f16=False):
     lib = _lib.load()
     x = _req(x, None, "x")
     cols = x.shape[-1]
@@ -504,8 +506,8 @@ def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False, fp8_scale=None)
     if out_split:
         y = torch.empty(x.shape[:-1] + (2 * cols,), dtype=BF16, device=x.device)
     else:
-        y = torch.empty(x.shape, dtype=F32 if out_f32 else BF16, device=x.device)
-    check(lib.ivlm_rmsnorm(x.data_ptr(), _dtc(x), weight.data_ptr(), y.data_ptr(), 2 if out_split else _dtc(y),
+        y = torch.empty(x.shape, dtype=F16 if out_f16 else (F32 if out_f32 else BF16), device=x.device)
+    check(lib.ivlm_rmsnorm(x.data_ptr(), _dtc(x), weight.data_ptr(), y.data_ptr(), 2 if out_split else (4 if out_f16 else _dtc(y)),
                            x.numel() // cols, cols, float(eps), _stream()), "rmsnorm")
     return y
 
@@ -519,6 +521,17 @@ def bf16_to_f16(w):
     return out
 
 
+def f16_weight(w, name="weight"):
+    """fp16 copy of a bf16 weight matrix for the fp16-operand GEMMs, checked: a bf16 value inside the fp16 normal range converts
+    exactly; one below it moves by at most 2^-25; one above it (> 65504) cannot be represented - raise."""
+    w16 = bf16_to_f16(w)
+    err = float((w16.float() - w.float()).abs().max())
+    if not (err <= 2.0 ** -24) or not bool(torch.isfinite(w16).all()):
+        raise IvlmError(f"{name}: weights outside the fp16 range (max conversion error {err:.3g}) - use a split (hi + lo) "
+                        f"precision mode instead of fp16 operands")
+    return w16
+
+
 def relpos_table64(tab_h, tab_w):
     """[rel_pos_h ; rel_pos_w ; zeros] as a bf16 [64, D] table: the operand of the attention kernels' TABLE MODE (rel_tab=...)."""
     n = tab_h.shape[0] + tab_w.shape[0]
@@ -529,7 +542,7 @@ def relpos_table64(tab_h, tab_w):
     return t
 
 
-def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, prescale_q=False, rel_tab=None):
+def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, prescale_q=False, rel_tab=None, q_lo=None):
     """q [B,H,Sq,D], k/v [Bk,H,Sk,D] (arbitrary strides, last dim contiguous; B % Bk == 0: K/V of batch
     b // (B//Bk)) -> o [B,H,Sq,D] as a view of a [B,Sq,H,D] buffer (so o.transpose(1,2) is contiguous).
     rel = (rel_h f32 [B*H,Sq,KH], rel_w f32 [B*H,Sq,KW]) adds SAM's decomposed rel-pos bias; rel_tab = (relpos_table64(...), side)
@@ -539,11 +552,12 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, presca
     lib = _lib.load()
     B, H, Sq, D = q.shape
     Bk, Sk = k.shape[0], k.shape[2]
-    assert q.dtype == BF16 and k.dtype == BF16 and v.dtype == BF16
+    dt = q.dtype  # bf16, or IEEE fp16 (every tensor, incl. the table of table mode): the f16 matrix instruction
+    assert dt in (BF16, F16) and k.dtype == dt and v.dtype == dt
     assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1 and B % Bk == 0
     if out is None:
-        out = torch.empty(B, Sq, H, D, dtype=BF16, device=q.device).permute(0, 2, 1, 3)
-    assert out.stride(3) == 1
+        out = torch.empty(B, Sq, H, D, dtype=dt, device=q.device).permute(0, 2, 1, 3)
+    assert out.stride(3) == 1 and out.dtype == dt
     st = (ctypes.c_int64 * 12)(q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                                v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2))
     rel_h = rel_w = None
@@ -555,11 +569,18 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, presca
     if rel_tab is not None:  # table mode: rel_h = the bf16 table, rel_w = NULL
         rel_h, kh = rel_tab
         kw = kh
-        assert rel is None and rel_h.dtype == BF16 and rel_h.shape == (64, D) and rel_h.is_contiguous()
-    check(lib.ivlm_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
-                                  ctypes.cast(st, ctypes.c_void_p), B, H, Sq, Sk, D, float(scale), 1 if causal else 0,
-                                  int(q_pos0), _p(rel_h), _p(rel_w), kh, kw, B // Bk,
-                                  1 if (prescale_q or rel is not None or rel_tab is not None) else 0, _stream()), "attention")
+        assert rel is None and rel_h.dtype == dt and rel_h.shape == (64, D) and rel_h.is_contiguous()
+    if q_lo is not None:  # fp16 "exact q": q = q + q_lo as IEEE halves (SAM shapes; the strides of q)
+        assert dt == F16 and q_lo.dtype == F16 and q_lo.stride() == q.stride() and q_lo.shape == q.shape and not causal and B == Bk
+        check(lib.ivlm_attention_f16_qsplit(q.data_ptr(), q_lo.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                            ctypes.cast(st, ctypes.c_void_p), B, H, Sq, Sk, D, float(scale), _p(rel_h), _p(rel_w),
+                                            kh, kw, _stream()), "attention_f16_qsplit")
+        return out
+    fn = lib.ivlm_attention_f16 if dt == F16 else lib.ivlm_attention_bf16
+    check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+             ctypes.cast(st, ctypes.c_void_p), B, H, Sq, Sk, D, float(scale), 1 if causal else 0,
+             int(q_pos0), _p(rel_h), _p(rel_w), kh, kw, B // Bk,
+             1 if (prescale_q or rel is not None or rel_tab is not None) else 0, _stream()), "attention")
     return out
 
 
@@ -646,7 +667,7 @@ def relpos_tables_cat(tab_h, tab_w):
 RELPOS_GEMM = True  # rel-pos operands through one batched MFMA GEMM + gather instead of the VALU dot-product kernel
 
 
-def relpos_bias(q, tab_h, tab_w, SH, SW, cat=None):
+def relpos_bias(q, tab_h, tab_w, SH, SW, cat=None, q_lo=None):
     """q [B,H,S=SH*SW,D] -> (rel_h f32 [B*H,S,SH], rel_w f32 [B*H,S,SW]).  cat = relpos_tables_cat(tab_h, tab_w)
     (pre-built once per block) selects the GEMM formulation when the q rows of all (b, s) are uniformly strided."""
     lib = _lib.load()
@@ -656,20 +677,31 @@ def relpos_bias(q, tab_h, tab_w, SH, SW, cat=None):
     rel_w = torch.empty(B * H, S, SW, dtype=torch.float32, device=q.device)
     # (measured, SAM ViT-H: global 64x64 grid 242 -> 139 us; 14x14 windows 54 -> 62 us - the GEMM's N = 54 wastes half a tile and
     #  the gather moves as many bytes as the dot kernel writes - so only grids of 32x32 and up take this path)
-    if (RELPOS_GEMM and cat is not None and min(SH, SW) >= 32 and q.dtype == BF16 and q.stride(0) == S * q.stride(2) and q.stride(2) % 8 == 0
+    f16 = q.dtype == F16  # fp16 q against the fp16 table (cat), fp32 G and terms
+    if f16 and not (cat is not None and cat.dtype == F16 and min(SH, SW) >= 32):
+        raise IvlmError("relpos_bias: fp16 q needs the fp16 cat table and a grid of 32 x 32 or more (GEMM formulation)")
+    if (RELPOS_GEMM and cat is not None and min(SH, SW) >= 32 and q.dtype == cat.dtype and q.stride(0) == S * q.stride(2) and q.stride(2) % 8 == 0
             and q.stride(1) % 8 == 0 and D % 8 == 0 and q.data_ptr() % 16 == 0):
         npad, M = cat.shape[0], B * S
-        G = torch.empty(H, M, npad, dtype=BF16, device=q.device)
+        # (fp16 q: G stays fp32 - the terms ADD to the scores, an fp16 rounding of a term of +-8 would be an absolute 2e-3)
+        G = torch.empty(H, M, npad, dtype=F32 if f16 else BF16, device=q.device)
         call = lambda: check(lib.ivlm_gemm_bf16(q.data_ptr(), q.stride(2), cat.data_ptr(), D, G.data_ptr(), npad, 0, 0, 0, 0,
-                                                M, npad, D, 0, 0, H, q.stride(1), 0, M * npad, 0, 0, 0.0, 0, 0, 0, _stream()),
-                             "relpos gemm")
+                                                M, npad, D, 0, 1 if f16 else 0, H, q.stride(1), 0, M * npad, 0, 0, 0.0,
+                                                GEMM_F16 if f16 else 0, 0, 0, _stream()), "relpos gemm")
         if TIMER.enabled:
             TIMER.time("gemm_bf16_mfma", 2.0 * H * M * npad * D, call, tag=("relpos", M, npad, D))
         else:
             call()
-        check(lib.ivlm_relpos_gather(G.data_ptr(), M * npad, npad, B, H, SH, SW, rel_h.data_ptr(), rel_w.data_ptr(),
-                                     _stream()), "relpos_gather")
+        if q_lo is not None:  # fp16 "exact q": G += q_lo . T (the second product accumulates through the fp32 residual epilogue)
+            assert f16 and q_lo.dtype == F16 and q_lo.stride() == q.stride() and q_lo.data_ptr() % 16 == 0
+            check(lib.ivlm_gemm_bf16(q_lo.data_ptr(), q.stride(2), cat.data_ptr(), D, G.data_ptr(), npad, 0, G.data_ptr(), npad, 0,
+                                     M, npad, D, 0, 1, H, q.stride(1), 0, M * npad, M * npad, 0, 0.0, GEMM_F16 | GEMM_RES_F32, 0, 0,
+                                     _stream()), "relpos gemm (lo)")
+        check((lib.ivlm_relpos_gather_f32 if f16 else lib.ivlm_relpos_gather)(
+            G.data_ptr(), M * npad, npad, B, H, SH, SW, rel_h.data_ptr(), rel_w.data_ptr(), _stream()), "relpos_gather")
         return rel_h, rel_w
+    if f16:
+        raise IvlmError("relpos_bias: fp16 q with a layout the GEMM formulation cannot take")
     check(lib.ivlm_relpos_bias(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), tab_h.data_ptr(), tab_w.data_ptr(),
                                B, H, SH, SW, D, rel_h.data_ptr(), rel_w.data_ptr(), _stream()), "relpos_bias")
     return rel_h, rel_w
@@ -757,7 +789,7 @@ def gather_rows(src, idx=None, add=None, out=None, out_kind=None, scale=None):
 def fill_rows(dst, idx, row):
     """dst[idx[r]] = row (bf16 [C] broadcast to the listed rows of dst [R, C])."""
     lib = _lib.load()
-    assert dst.dtype == BF16 and row.dtype == BF16 and dst.stride(-1) == 1 and row.is_contiguous()
+    assert dst.dtype in (BF16, F16) and row.dtype == dst.dtype and dst.stride(-1) == 1 and row.is_contiguous()  # (a 16-bit copy)
     assert idx.dtype == torch.int32 and idx.is_contiguous() and row.numel() == dst.shape[-1]
     check(lib.ivlm_fill_rows(dst.data_ptr(), dst.stride(0), idx.data_ptr(), idx.numel(), row.data_ptr(), dst.shape[-1],
                              _stream()), "fill_rows")
@@ -822,10 +854,10 @@ def dense_pe(gauss, h, w, dtype=torch.float32):
 def rope_kv(qkv, H, D, pos0, theta, kcache=None, vcache=None, table=None):
     """qkv [T, 3*H*D] (in place). table = (cos, sin) fp32 [Tmax, D/2] from rope_table()."""
     lib = _lib.load()
-    assert qkv.dtype == BF16 and qkv.stride(-1) == 1
+    assert qkv.dtype in (BF16, F16) and qkv.stride(-1) == 1 and (kcache is None or (kcache.dtype == qkv.dtype == vcache.dtype))
     T = qkv.shape[0]
-    check(lib.ivlm_rope_kv(qkv.data_ptr(), qkv.stride(0), T, H, D, int(pos0), float(theta), _p(kcache), _p(vcache),
-                           _p(table[0]) if table else 0, _p(table[1]) if table else 0, _stream()), "rope_kv")
+    check((lib.ivlm_rope_kv_f16 if qkv.dtype == F16 else lib.ivlm_rope_kv)(qkv.data_ptr(), qkv.stride(0), T, H, D, int(pos0), float(theta), _p(kcache), _p(vcache),
+                                                                           _p(table[0]) if table else 0, _p(table[1]) if table else 0, _stream()), "rope_kv")
     return qkv
 
 
@@ -878,6 +910,13 @@ def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, ta
                                                float(scale), _p(table[0]) if table else 0, _p(table[1]) if table else 0,
                                                _stream()), "llama_decode_attn_split")
         return out
+    if kcache.dtype == F16:  # fp16 cache (the fp16-operand prefill): fp32 qkv / o
+        assert qkv.dtype == F32 and vcache.dtype == F16
+        check(lib.ivlm_llama_decode_attn_f16(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), kcache.shape[0], out.data_ptr(),
+                                             H, D, 0 if dev_pos else int(pos), pos.data_ptr() if dev_pos else 0, float(theta),
+                                             float(scale), _p(table[0]) if table else 0, _p(table[1]) if table else 0, _stream()),
+              "llama_decode_attn_f16")
+        return out
     check(lib.ivlm_llama_decode_attn(qkv.data_ptr(), _dtc(qkv), kcache.data_ptr(), vcache.data_ptr(), kcache.shape[0],
                                      out.data_ptr(), H, D, 0 if dev_pos else int(pos), pos.data_ptr() if dev_pos else 0,
                                      float(theta), float(scale), _p(table[0]) if table else 0,
@@ -903,6 +942,13 @@ def llama_decode_attn_batch(qkv, kcache, vcache, H, D, pos_dev, theta, scale, ta
                                                      out.data_ptr(), out.stride(0), B, H, D, pos_dev.data_ptr(), float(theta),
                                                      float(scale), _p(table[0]) if table else 0, _p(table[1]) if table else 0,
                                                      _stream()), "llama_decode_attn_batch_split")
+        return out
+    if kcache.dtype == F16:
+        assert qkv.dtype == F32 and vcache.dtype == F16
+        check(lib.ivlm_llama_decode_attn_batch_f16(qkv.data_ptr(), qkv.stride(0), kcache.data_ptr(), vcache.data_ptr(),
+                                                   kcache.stride(0), kcache.shape[1], out.data_ptr(), out.stride(0), B, H, D,
+                                                   pos_dev.data_ptr(), float(theta), float(scale), _p(table[0]) if table else 0,
+                                                   _p(table[1]) if table else 0, _stream()), "llama_decode_attn_batch_f16")
         return out
     check(lib.ivlm_llama_decode_attn_batch(qkv.data_ptr(), _dtc(qkv), qkv.stride(0), kcache.data_ptr(), vcache.data_ptr(),
                                            kcache.stride(0), kcache.shape[1], out.data_ptr(), out.stride(0), B, H, D,

@@ -251,21 +251,74 @@ class SamImageEncoder:
     # the encoder of the "parity-encoder" mode: measured 4.6e-4 end to end at depth 32 against 4.0e-4 for PARITY_SITES, 12 ms
     # less per 4 views (tools/diag_precision_modes.py)
     PARITY_SITES_FAST = frozenset(("n1", "attn", "proj", "f16mlp"))
+    # the "f16" mode: EVERY MFMA operand of a block as IEEE fp16 in one pass (f16attn: norm1 output, q | k | v, softmax weights,
+    # attention output, rel-pos table; f16mlp: norm2 output, GELU hidden) - the bf16 path's launches and FLOPs at an eighth of its
+    # operand rounding; the neck (0.1 % of the FLOPs) takes hi + lo operands
+    SITES_F16 = frozenset(("f16attn", "f16mlp"))
+    # ... with the "exact q" path (f16q): norm1 writes [hi | lo] IEEE halves, q = W_q . (hi + lo) leaves its own GEMM as hi + lo
+    # halves (k | v: a single-pass GEMM on the hi half), the attention takes q = hi + lo in the rel-pos table product and in Q.K^T and
+    # splits the softmax weights for P.V.  q's rounding is the one SAM's decomposed rel-pos terms amplify (tools/emulate_f16_sites.py:
+    # 57 % of the fp16 mode's error variance comes through q), this path removes it for +1/3 of the q|k|v GEMM's MFMA work
+    SITES_F16Q = frozenset(("f16attn", "f16q", "f16mlp"))
     parity_sites = PARITY_SITES
 
-    def _f16_weights(self, blk):
-        """fp16 copies of lin1 / lin2.  A bf16 value inside the fp16 NORMAL range (6.1e-5 .. 65504) converts exactly (8 significant
-        bits into 11); smaller ones land on fp16 subnormals and move by at most 2^-25 = 3e-8 - checked here, and irrelevant next to
-        weights of typical size 1e-2."""
-        if "lin1_h" not in blk:
-            for n in ("lin1", "lin2"):
-                w16 = ops.bf16_to_f16(blk[n].w)
-                err = float((w16.float() - blk[n].w.float()).abs().max())
-                if not (err <= 2.0 ** -24) or not bool(torch.isfinite(w16).all()):
-                    raise ops.IvlmError(f"{n}: weights outside the fp16 range (max conversion error {err:.3g}) - use the split "
-                                        f"(hi + lo) sites instead of f16mlp")
-                blk[n + "_h"] = w16
-        return blk["lin1_h"], blk["lin2_h"]
+    def _f16_weights(self, blk, names=("lin1", "lin2")):
+        """fp16 copies of a block's GEMM weights.  A bf16 value inside the fp16 NORMAL range (6.1e-5 .. 65504) converts exactly (8
+        significant bits into 11); smaller ones land on fp16 subnormals and move by at most 2^-25 = 3e-8 - checked here, and
+        irrelevant next to weights of typical size 1e-2."""
+        for n in names:
+            if n + "_h" not in blk:
+                blk[n + "_h"] = ops.f16_weight(blk[n].w, n)
+        return tuple(blk[n + "_h"] for n in names)
+
+    def _attention_f16(self, blk, xn, V, side, nwin, win=None, qx=False):
+        """_attention on fp16 operands: xn fp16 rows -> fp16 attention output [nwin*S, D].  qx ("exact q"): xn is [rows, 2D] =
+        [hi | lo] IEEE halves, win = (unpart, pad, q buffer [.., 2D], k|v buffer [.., 2D])."""
+        c = self.cfg
+        D = c.embed_dim
+        H, hd = c.num_heads, D // c.num_heads
+        S = side * side
+        (wq,) = self._f16_weights(blk, ("qkv",))
+        if "qkv_b_h" not in blk:
+            blk["qkv_b_h"] = ops.bf16_to_f16(blk["qkv"].b)
+            blk["q_b_split_h"] = torch.cat([blk["qkv_b_h"][:D], torch.zeros_like(blk["qkv_b_h"][:D])]).contiguous()
+            blk["kv_b_h"] = blk["qkv_b_h"][D:].contiguous()
+            if "rel_cat" not in blk:
+                blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
+            blk["rel_cat_h"] = ops.bf16_to_f16(blk["rel_cat"])
+        if qx:
+            bq, bkv = blk["qkv"].b[:D], blk["qkv"].b[D:]
+            if win is None:
+                q2 = ops.linear(xn, wq[:D], bq, a_split=True, out_split=True, out_f16=True)  # [rows, 2D] = [q hi | q lo]
+                kv = ops.linear(xn[:, :D], wq[D:], bkv, out_f16=True)                          # [rows, 2D] = [k | v]
+            else:
+                unpart, pad, q2, kv = win
+                ops.linear(xn, wq[:D], bq, out=q2, out_rows=unpart, a_split=True, out_split=True, out_f16=True)
+                ops.linear(xn[:, :D], wq[D:], bkv, out=kv, out_rows=unpart)
+                ops.fill_rows(q2, pad, blk["q_b_split_h"])
+                ops.fill_rows(kv, pad, blk["kv_b_h"])
+            q4, kv4 = q2.view(nwin, S, 2, H, hd), kv.view(nwin, S, 2, H, hd)
+            q, q_lo, k, v = (t.permute(0, 2, 1, 3) for t in (q4[:, :, 0], q4[:, :, 1], kv4[:, :, 0], kv4[:, :, 1]))
+            if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
+                o = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_cat_h"], side), q_lo=q_lo)
+            else:
+                rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat_h"], q_lo=q_lo)
+                o = ops.attention(q, k, v, hd ** -0.5, rel=rel, q_lo=q_lo)
+            return o.permute(0, 2, 1, 3).reshape(nwin * S, H * hd)
+        if win is None:
+            qkv = ops.linear(xn, wq, blk["qkv"].b, out_f16=True)
+        else:
+            unpart, pad, qkv = win
+            ops.linear(xn, wq, blk["qkv"].b, out=qkv, out_rows=unpart)
+            ops.fill_rows(qkv, pad, blk["qkv_b_h"])
+        qkv5 = qkv.view(nwin, S, 3, H, hd)
+        q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
+            o = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_cat_h"], side))
+        else:
+            rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat_h"])
+            o = ops.attention(q, k, v, hd ** -0.5, rel=rel)
+        return o.permute(0, 2, 1, 3).reshape(nwin * S, H * hd)
 
     def _attention_parity(self, blk, xn, V, side, nwin, win=None):
         """_attention with split operands: xn [rows, D or 2D] -> attention output [nwin*S, 2D] ([hi | lo] rows), or
@@ -317,16 +370,32 @@ class SamImageEncoder:
         x = self.patch(cols, residual=self.pos_embed, res_mod=g * g, out_f32=True)
         part, unpart, nw, gp, pad = self._window_maps(V)
         nwin = V * nw * nw
-        key = ("split" if sa else "bf16", V)
+        f16a = "f16attn" in sites
+        key = ("f16" if f16a else ("split" if sa else "bf16"), V)
         if key not in self._xw:
-            self._xw[key] = torch.empty(nwin * c.window * c.window, (6 if sa else 3) * D, dtype=BF16, device=x.device)
+            self._xw[key] = torch.empty(nwin * c.window * c.window, (6 if sa else 3) * D, dtype=torch.float16 if f16a else BF16,
+                                        device=x.device)
+        qx = f16a and "f16q" in sites
+        if qx and ("f16q", V) not in self._xw:  # window-ordered [q hi | q lo] and [k | v] buffers
+            self._xw[("f16q", V)] = tuple(torch.empty(nwin * c.window * c.window, 2 * D, dtype=torch.float16, device=x.device)
+                                          for _ in range(2))
         for blk in self.blocks:
-            xn = blk["norm1"](x, out_split="n1" in sites)
-            if blk["glob"]:
-                a = self._attention_parity(blk, xn, V, g, V)
+            if f16a:
+                xn = blk["norm1"](x, out_f16=True, out_split=qx)
+                (wp,) = self._f16_weights(blk, ("proj",))
+                if blk["glob"]:
+                    a = self._attention_f16(blk, xn, V, g, V, qx=qx)
+                    x = ops.linear(a, wp, blk["proj"].b, residual=x, out_f32=True)
+                else:
+                    a = self._attention_f16(blk, xn, V, c.window, nwin, qx=qx,
+                                            win=(unpart, pad) + (self._xw[("f16q", V)] if qx else (self._xw[key],)))
+                    x = ops.linear(a, wp, blk["proj"].b, residual=x, out=x, a_rows=unpart)
+            elif blk["glob"]:
+                a = self._attention_parity(blk, blk["norm1"](x, out_split="n1" in sites), V, g, V)
                 x = blk["proj"](a if (sp or not sa) else a[:, :D], residual=x, out_f32=True, a_split=sp)
             else:
-                a = self._attention_parity(blk, xn, V, c.window, nwin, win=(unpart, pad, self._xw[key]))
+                a = self._attention_parity(blk, blk["norm1"](x, out_split="n1" in sites), V, c.window, nwin,
+                                           win=(unpart, pad, self._xw[key]))
                 x = blk["proj"](a if (sp or not sa) else a[:, :D], residual=x, out=x, a_rows=unpart, a_split=sp)
             if "f16mlp" in sites:
                 w1, w2 = self._f16_weights(blk)

@@ -174,3 +174,115 @@ def test_relpos_gemm_formulation_matches_dot_kernel(hip_lib, cuda, SH, SW, B, H)
     ref_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh).reshape(B * H, S, SH)
     ref_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw).reshape(B * H, S, SW)
     assert torch.allclose(gh, ref_h, atol=2e-2, rtol=1e-2) and torch.allclose(gw, ref_w, atol=2e-2, rtol=1e-2)
+
+
+# ---- IEEE fp16 operands (the default precision of the towers): the same kernels on v_mfma_f32_16x16x32_f16 ---------------------------
+F16_CASES = [  # B, H, Sq, Sk, D, causal, q_pos0: the shapes of the path (CLIP, LLaMA prefill / chunked prefill)
+    (1, 16, 257, 257, 64, False, 0), (2, 4, 70, 70, 64, False, 0), (1, 32, 330, 330, 128, True, 0), (2, 4, 100, 333, 128, True, 233),
+]
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,D,causal,q_pos0", F16_CASES)
+def test_attention_f16_vs_torch(hip_lib, cuda, B, H, Sq, Sk, D, causal, q_pos0):
+    """fp16 q / k / v: only the softmax weights and the output are rounded (to fp16): 8 x closer to the fp64 result than the bf16
+    kernel on the same values (asserted)."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(B * 1000 + Sq + Sk + D)
+    q, k, v = (torch.randn(B, H, s_, D, generator=g).half() for s_ in (Sq, Sk, Sk))
+    scale = 1.0 / math.sqrt(D)
+    ref = _ref(q, k, v, scale, causal, q_pos0).double()  # (fp32 reference on the fp16 values: 1e-6)
+    got = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), scale, causal=causal, q_pos0=q_pos0, prescale_q=D == 64)
+    assert got.dtype == torch.float16 and got.shape == (B, H, Sq, D)
+    err = (got.double().cpu() - ref).abs().max().item()
+    bf = ops.attention(q.bfloat16().to(cuda), k.bfloat16().to(cuda), v.bfloat16().to(cuda), scale, causal=causal, q_pos0=q_pos0,
+                       prescale_q=D == 64)
+    err_bf = (bf.double().cpu() - ref).abs().max().item()
+    print(f"f16 attention max err {err:.2e} (bf16 operands of the same values: {err_bf:.2e})")
+    assert err < 2.5e-3 and err < err_bf / 3, (err, err_bf)
+
+
+@pytest.mark.parametrize("SH,SW,B,H", [(14, 14, 9, 4), (64, 64, 1, 2)])
+def test_relpos_attention_f16(hip_lib, cuda, SH, SW, B, H):
+    """SAM's attention with the decomposed rel-pos bias on fp16 operands: windows in table mode (the whole-window kernel and the
+    generic flash kernel), the global grid through the fp16 GEMM formulation of the terms."""
+    import torch
+
+    from interactvlm_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(SH + 7)
+    D, S = 80, SH * SW
+    q, k, v = (torch.randn(B, S, H, D, generator=g).half().permute(0, 2, 1, 3) for _ in range(3))  # SAM's [B, S, H, D] rows
+    tab_h = (torch.randn(2 * SH - 1, D, generator=g) * 0.2).bfloat16()
+    tab_w = (torch.randn(2 * SW - 1, D, generator=g) * 0.2).bfloat16()
+    idx_h = torch.arange(SH)[:, None] - torch.arange(SH)[None, :] + (SH - 1)
+    idx_w = torch.arange(SW)[:, None] - torch.arange(SW)[None, :] + (SW - 1)
+    Rh, Rw = tab_h.double()[idx_h], tab_w.double()[idx_w]
+    rq = q.double().reshape(B * H, SH, SW, D)
+    rel_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh)
+    rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw)
+    bias = (rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).reshape(B, H, S, S)
+    scale = D ** -0.5
+    sc = torch.einsum("bhqd,bhkd->bhqk", q.double() * scale, k.double()) + bias
+    ref = torch.einsum("bhqk,bhkd->bhqd", torch.softmax(sc, dim=-1), v.double())
+    cat = ops.bf16_to_f16(ops.relpos_tables_cat(tab_h.to(cuda), tab_w.to(cuda)))
+    qc, kc, vc = q.to(cuda), k.to(cuda), v.to(cuda)
+    lib = _lib.load()
+    if SH == 14:
+        outs = []
+        for v2 in (1, 0):
+            lib.ivlm_attention_window_kernel(v2)
+            outs.append(ops.attention(qc, kc, vc, scale, rel_tab=(cat, SH)))
+        lib.ivlm_attention_window_kernel(1)
+    else:
+        gh, gw = ops.relpos_bias(qc, tab_h.to(cuda), tab_w.to(cuda), SH, SW, cat=cat)
+        assert (gh.double().cpu() - rel_h.reshape(B * H, S, SH)).abs().max().item() < 2e-5  # (fp32 terms: exact products of fp16 q)
+        assert (gw.double().cpu() - rel_w.reshape(B * H, S, SW)).abs().max().item() < 2e-5
+        outs = [ops.attention(qc, kc, vc, scale, rel=(gh, gw))]
+    for o in outs:
+        err = (o.double().cpu() - ref).abs().max().item()
+        print(f"f16 rel-pos attention {SH}x{SW}: max err {err:.2e}")
+        assert o.dtype == torch.float16 and err < 4e-3, err
+
+
+@pytest.mark.parametrize("SH,SW,B,H", [(14, 14, 9, 4), (64, 64, 1, 2)])
+def test_relpos_attention_f16_exact_q(hip_lib, cuda, SH, SW, B, H):
+    """The "exact q" attention of the fp16 mode: q = hi + lo IEEE halves enters the rel-pos terms and the scores unrounded, the
+    softmax weights are split for P.V - against fp64 on the fp32 q (k / v fp16): closer than the single-fp16-q kernel (asserted)."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(SH + 11)
+    D, S = 80, SH * SW
+    q32 = torch.randn(B, S, H, D, generator=g).permute(0, 2, 1, 3)
+    k, v = (torch.randn(B, S, H, D, generator=g).half().permute(0, 2, 1, 3) for _ in range(2))
+    tab_h = (torch.randn(2 * SH - 1, D, generator=g) * 0.5).bfloat16()
+    tab_w = (torch.randn(2 * SW - 1, D, generator=g) * 0.5).bfloat16()
+    idx_h = torch.arange(SH)[:, None] - torch.arange(SH)[None, :] + (SH - 1)
+    idx_w = torch.arange(SW)[:, None] - torch.arange(SW)[None, :] + (SW - 1)
+    rq = q32.double().reshape(B * H, SH, SW, D)
+    rel_h = torch.einsum("bhwc,hkc->bhwk", rq, tab_h.double()[idx_h])
+    rel_w = torch.einsum("bhwc,wkc->bhwk", rq, tab_w.double()[idx_w])
+    bias = (rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).reshape(B, H, S, S)
+    scale = D ** -0.5
+    sc = torch.einsum("bhqd,bhkd->bhqk", q32.double() * scale, k.double()) + bias
+    ref = torch.einsum("bhqk,bhkd->bhqd", torch.softmax(sc, dim=-1), v.double())
+    q_hi = q32.half()
+    q_lo = (q32 - q_hi.float()).half()
+    cat = ops.bf16_to_f16(ops.relpos_tables_cat(tab_h.to(cuda), tab_w.to(cuda)))
+    qh, ql, kc, vc = q_hi.to(cuda), q_lo.to(cuda), k.to(cuda), v.to(cuda)
+    if SH == 14:
+        o2 = ops.attention(qh, kc, vc, scale, rel_tab=(cat, SH), q_lo=ql)
+        o1 = ops.attention(qh, kc, vc, scale, rel_tab=(cat, SH))
+    else:
+        rel = ops.relpos_bias(qh, tab_h.to(cuda), tab_w.to(cuda), SH, SW, cat=cat, q_lo=ql)
+        assert (rel[0].double().cpu() - rel_h.reshape(B * H, S, SH)).abs().max().item() < 3e-5
+        o2 = ops.attention(qh, kc, vc, scale, rel=rel, q_lo=ql)
+        o1 = ops.attention(qh, kc, vc, scale, rel=ops.relpos_bias(qh, tab_h.to(cuda), tab_w.to(cuda), SH, SW, cat=cat))
+    e2 = (o2.double().cpu() - ref).abs().max().item()
+    e1 = (o1.double().cpu() - ref).abs().max().item()
+    print(f"exact-q fp16 attention {SH}x{SW}: max err {e2:.2e} (single fp16 q: {e1:.2e})")
+    assert e2 < 1.5e-3 and e2 < e1, (e2, e1)

@@ -663,3 +663,35 @@ def test_row_stationary_prefill_tile(hip_lib, cuda, M, N, K, act):
     assert torch.allclose(got, ref, atol=2e-4, rtol=1e-4)
     gb = ops.linear(x, w, act=act)
     assert gb.dtype == torch.bfloat16 and torch.allclose(gb.float(), ref, atol=2e-2, rtol=1e-2)
+
+
+def test_gemm_f16_split_operand_and_output(hip_lib, cuda):
+    """fp16-mode "exact q" projection: A = [hi | lo] IEEE halves (layernorm(out_split, out_f16)), fp16 weight, the fp32 result written
+    as [hi | lo] IEEE halves - against fp64 on the fp32 activations; and the hi half alone is the plain fp16 row."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 1000, 1280, 1280
+    x = torch.randn(M, K, generator=g).to(cuda)
+    lw, lb = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().to(cuda), (0.1 * torch.randn(K, generator=g)).bfloat16().to(cuda)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(cuda)
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16().to(cuda)
+    xs = ops.layernorm(x, lw, lb, 1e-6, out_split=True, out_f16=True)
+    x1 = ops.layernorm(x, lw, lb, 1e-6, out_f16=True)
+    assert xs.dtype == torch.float16 and xs.shape == (M, 2 * K) and torch.equal(xs[:, :K], x1)
+    ref_n = torch.nn.functional.layer_norm(x.double(), (K,), lw.double(), lb.double(), 1e-6)
+    assert (xs[:, :K].double() + xs[:, K:].double() - ref_n).abs().max().item() < 2e-6
+    w16 = ops.f16_weight(w)
+    y = ops.linear(xs, w16, b, a_split=True, out_split=True, out_f16=True)
+    assert y.dtype == torch.float16 and y.shape == (M, 2 * N)
+    ref = ref_n @ w.double().t() + b.double()
+    err = (y[:, :N].double() + y[:, N:].double() - ref).abs().max().item()
+    y1 = ops.linear(x1, w16, b, out_f16=True)
+    err1 = (y1.double() - ref).abs().max().item()
+    print(f"fp16 split GEMM: max err {err:.2e} (single fp16 operand / output: {err1:.2e})")
+    assert err < 2e-5 and err1 > 10 * err
+    # scatter epilogue + strided hi-half operand (the k|v GEMM of the exact-q path reads the hi half in place)
+    y2 = ops.linear(xs[:, :K], w16, b, out_f16=True)
+    assert torch.equal(y2, y1)
