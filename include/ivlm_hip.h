@@ -273,13 +273,15 @@ int ivlm_attention_f16(const void *q, const void *k, const void *v, void *o, con
                        int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float *rel_h,
                        const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q,
                        ivlm_stream_t stream);
-/* ... with q as hi + lo IEEE halves (q_lo: same strides as q; the IVLM_F16_SPLIT rows of the q projection): the rel-pos table product
- * and Q.K^T take both halves, the softmax weights are split the same way for P.V (two MFMAs per fragment each) - q, whose rounding
- * the rel-pos terms amplify, enters the scores exactly; k / v / o stay single fp16.  SAM's shapes: D = 80, prescale_q, no mask;
- * windows in table mode (rel_w == NULL) or the 64 x 64 grid with the terms as arrays. */
+/* ... with q as hi + lo IEEE halves (q_lo: same strides as q; the IVLM_F16_SPLIT rows of the q projection) - q is the operand whose
+ * rounding SAM's decomposed rel-pos terms amplify.  level 1: the lo half enters the rel-pos terms only (table mode: the kernel's
+ * table product takes both halves; array mode: the caller computed rel_h / rel_w from hi + lo and this is ivlm_attention_f16);
+ * level 2: Q.K^T takes both halves too and the softmax weights are split the same way for P.V (two MFMAs per fragment each).
+ * k / v / o stay single fp16.  SAM's shapes: D = 80, prescale_q, no mask; windows in table mode (rel_w == NULL) or the 64 x 64
+ * grid with the terms as arrays. */
 int ivlm_attention_f16_qsplit(const void *q, const void *q_lo, const void *k, const void *v, void *o, const int64_t *strides_host,
                               int B, int H, int Sq, int Sk, int D, float scale, const float *rel_h, const float *rel_w, int rel_kh,
-                              int rel_kw, ivlm_stream_t stream);
+                              int rel_kw, int level, ivlm_stream_t stream);
 /* "Parity" precision of the same operator (fp32-operand attention on the bf16 matrix cores): q / k / v / o are given as hi + lo
  * bf16 planes (x = hi + lo to 2^-17: the [hi | lo] halves of IVLM_BF16_SPLIT rows; the *_lo tensors use the strides of the hi
  * ones), both products run as three MFMAs per fragment (hi.hi + hi.lo + lo.hi), q * scale and the rel-pos bias stay fp32.
@@ -320,6 +322,13 @@ int ivlm_relpos_gather(const void *G, int64_t g_head_stride, int npad, int B, in
  * add to the scores, so the fp16-operand path keeps them unrounded); g_head_stride in fp32 elements. */
 int ivlm_relpos_gather_f32(const void *G, int64_t g_head_stride, int npad, int B, int H, int SH, int SW, float *rel_h,
                            float *rel_w, ivlm_stream_t stream);
+
+/* The operands for fp16 q in ONE call: G = q . [rel_pos_h ; rel_pos_w]^T as a batched fp16 GEMM over the heads into the fp32 workspace
+ * G_ws (>= H * B * S * npad * 4 bytes; the terms add to the scores and are not rounded), then the gather.  q_lo != NULL: q = hi + lo
+ * IEEE halves (q_lo behind q in the same rows, e.g. the [hi | lo] halves of an IVLM_F16_SPLIT row: same strides) and the product
+ * takes both.  cat16: fp16 [npad, D] = [rel_pos_h ; rel_pos_w ; zeros]; q rows of all (b, s) uniformly strided (q_bs == S * q_rs). */
+int ivlm_relpos_bias_f16(const void *q, const void *q_lo, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void *cat16, int npad, int B,
+                         int H, int SH, int SW, int D, float *G_ws, size_t g_bytes, float *rel_h, float *rel_w, ivlm_stream_t stream);
 
 /* One decode step of HF LlamaAttention with a KV cache, for the newest token only: rotate-half RoPE of q,k at
  * position pos, append k,v (rounded to bf16) to kcache/vcache [tmax,H,D], o = softmax(q.K[0..pos]^T * scale).V[0..pos].

@@ -790,11 +790,16 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
 // SPLIT: hi + lo planes of q / k / v, three MFMAs per fragment, fp32 rel-pos terms, hi + lo output ("parity" precision); the hi + lo
 // K / V planes leave no LDS for the table-product scratch, so SPLIT reads the rel-pos terms from the fp32 arrays of
 // ivlm_relpos_bias_split (array mode) instead of computing them here (table mode).
-template <bool SPLIT, bool F16 = false, bool QLO = false>
+// QLV (with F16): q = hi + lo IEEE halves (a.q_lo).  1: the lo half enters the rel-pos table product only - the terms are what
+// amplifies q's rounding (a term is q . R with |R| ~ 6 x the |k| * scale of the score product: tools/emulate_f16_sites.py), Q.K^T and
+// P.V stay single fp16: 12 extra MFMAs per query tile; 2: the lo half also enters Q.K^T and the softmax weights are split for P.V
+// (3 % closer, +74 MFMAs per tile).
+template <bool SPLIT, bool F16 = false, int QLV = 0>
 __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArgs a) {
     static_assert(!(SPLIT && F16), "fp16 operands are single-pass");
-    static_assert(!QLO || F16, "QLO: q (and the softmax weights) as hi + lo IEEE halves, see attn_kernel");
-    constexpr bool QL = SPLIT || QLO;
+    static_assert(!QLV || F16, "QLV: q as hi + lo IEEE halves");
+    constexpr bool QLO = QLV == 2;          // lo half in Q.K^T, split softmax weights
+    constexpr bool QL = SPLIT || QLV != 0;  // a lo half of q is loaded
     constexpr uint32_t kOne16 = F16 ? 0x3C00u : 0x3F80u;  // 1.0 as a 16-bit operand
     constexpr bool TAB = !SPLIT;
     // SPLIT: 8 waves (two per SIMD, 240 registers: held under 256 with scheduling barriers in the fragment loops), the 13 query tiles
@@ -993,7 +998,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
                 for (int rt = 0; rt < 4; ++rt) {
                     const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(&Tb[ks * TPL + (rt * 16 + l15) * 32 + kswz]);
                     gacc[rt] = mma16<F16>(tf, qf[ks], gacc[rt]);
-                    if (QLO) gacc[rt] = mma16<F16>(tf, qfl[QLO ? ks : 0], gacc[rt]);
+                    if (QLV) gacc[rt] = mma16<F16>(tf, qfl[QLV ? ks : 0], gacc[rt]);
                 }
             }
 #pragma unroll
@@ -1218,13 +1223,13 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
 
 static int g_win_v2 = 1;  // 0: the generic flash kernel for windows too (A/B hook: ivlm_attention_window_kernel)
 
-template <bool SPLIT, bool F16 = false, bool QLO = false>
+template <bool SPLIT, bool F16 = false, int QLV = 0>
 static int launch_win(const AttnArgs& a, hipStream_t st) {
     constexpr int KS = 3, DT = 5, KPL = 13 * 16 * 32 + 32, VPL = 7 * 32 * 16 + 16;
     constexpr size_t lds = (size_t)(SPLIT ? 2 : 1) * (KS * KPL + DT * VPL) * 2 +
                            (SPLIT ? 0 : (size_t)13 * 64 * 16 + 13 * 16 * 65 * 4 + 3 * 64 * 32 * 2);
     static_assert(lds <= 160 * 1024, "window tiles must fit the LDS");
-    auto kfn = win_attn_kernel<SPLIT, F16, QLO>;
+    auto kfn = win_attn_kernel<SPLIT, F16, QLV>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1278,7 +1283,9 @@ template <int DQK, int DV>
 int launch_f16(const AttnArgs& a, hipStream_t st) {
     const bool rel = a.rel_h != nullptr;
     dim3 grid((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B);
-    if (a.q_lo) {  // "exact q" (QLO): SAM's global grid with the rel-pos terms as arrays (windows take the whole-window kernel)
+    if (a.q_lo && a.q_lo_level < 2 && a.rel_w) {
+        // level 1 with the terms as arrays: the lo half of q is already in them (ivlm_relpos_* on hi + lo) - the plain fp16 kernel
+    } else if (a.q_lo) {  // level 2 (QLO): SAM's global grid with the rel-pos terms as arrays (windows take the whole-window kernel)
         if constexpr (DV == 80) {
             if (!a.causal && rel && a.prescale_q && a.rel_w && a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw) {
                 attn_kernel<DQK, DV, false, 2, false, false, true, true><<<grid, 256, 0, st>>>(a);
@@ -1343,7 +1350,7 @@ int launch_d(const AttnArgs& a, hipStream_t st) {
         const bool win = g_win_v2 && a.rel_h && a.Sq <= 208 && a.Sq == a.Sk && !a.causal && a.prescale_q && a.H <= 65535 &&
                          a.B <= 65535 && a.rel_kh == a.rel_kw && 2 * a.rel_kh <= 32 && a.Sq == a.rel_kh * a.rel_kw;
         if (win && !a.q_lo && !a.rel_w) return a.f16 ? launch_win<false, true>(a, st) : launch_win<false>(a, st);
-        if (win && a.q_lo && !a.rel_w && a.f16) return launch_win<false, true, true>(a, st);
+        if (win && a.q_lo && !a.rel_w && a.f16) return a.q_lo_level >= 2 ? launch_win<false, true, 2>(a, st) : launch_win<false, true, 1>(a, st);
         if (win && a.q_lo && a.rel_w && !a.f16) return launch_win<true>(a, st);
     }
     if (a.f16) return launch_f16<DQK, DV>(a, st);
@@ -1609,6 +1616,36 @@ int ivlm_relpos_gather_f32(const void* G, int64_t g_head_stride, int npad, int B
                                ivlm_stream(stream), 2);
 }
 
+// fp16 q (optionally hi + lo halves): the terms through ONE batched GEMM over the heads against the fp16 [rel_pos_h ; rel_pos_w] table
+// (fp32 G: the terms add to the scores and are not rounded), then the Toeplitz gather
+int ivlm_relpos_bias_f16(const void* q, const void* q_lo, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* cat16, int npad, int B,
+                         int H, int SH, int SW, int D, float* G_ws, size_t g_bytes, float* rel_h, float* rel_w, ivlm_stream_t stream) {
+    ivlm_enter();
+    const int S = SH * SW;
+    if (!q || !cat16 || !G_ws || !rel_h || !rel_w || B <= 0 || H <= 0 || SH <= 0 || SW <= 0 || D <= 0 || (D & 7)) return IVLM_ERR_INVALID_ARG;
+    if (npad < 2 * SH - 1 + 2 * SW - 1 || (npad & 3)) return IVLM_ERR_INVALID_ARG;
+    if (q_bs != (int64_t)S * q_rs || ((q_rs | q_hs) & 7) || (reinterpret_cast<uintptr_t>(q) & 15)) return IVLM_ERR_UNSUPPORTED;  // rows of all (b, s) uniformly strided
+    const int64_t M = (int64_t)B * S;
+    if (M > 0x7fffffff || g_bytes < (size_t)H * M * npad * 4) return IVLM_ERR_WORKSPACE;
+    ivlm::GemmArgs g;
+    g.A = static_cast<const bf16_t*>(q); g.lda = q_rs;
+    g.W = static_cast<const bf16_t*>(cat16); g.ldw = D;
+    g.C = G_ws; g.ldc = npad;
+    g.M = (int)M; g.N = npad; g.K = D;
+    g.batch = H; g.strideA = q_hs; g.strideW = 0; g.strideC = M * npad;
+    g.out_f32 = 1;
+    g.f16 = 1;
+    if (q_lo) {
+        const int64_t off = static_cast<const bf16_t*>(q_lo) - static_cast<const bf16_t*>(q);
+        if (off < D || (off & 7)) return IVLM_ERR_INVALID_ARG;  // the lo plane lies behind the hi plane of the same rows
+        g.a_split = 1;
+        g.a_lo = off;
+    }
+    const int rc = ivlm::gemm_bf16(g, ivlm_stream(stream));
+    if (rc != IVLM_OK) return rc;
+    return ivlm::relpos_gather(reinterpret_cast<const bf16_t*>(G_ws), M * npad, npad, B, H, SH, SW, rel_h, rel_w, ivlm_stream(stream), 2);
+}
+
 int ivlm_attention_window_kernel(int v2) {  // benchmark/test hook: 1 (default) whole-window kernel, 0 generic flash kernel
     ivlm::g_win_v2 = v2;
     return 0;
@@ -1622,12 +1659,13 @@ int ivlm_attention_pingpong(int mode) {  // benchmark/test hook: -1 automatic, 0
 static int attention_16(const void* q, const void* k, const void* v, void* o, const int64_t* strides /*[12]*/, int B,
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float* rel_h,
                         const float* rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q, int f16, ivlm_stream_t stream,
-                        const void* q_lo = nullptr) {
+                        const void* q_lo = nullptr, int q_lo_level = 0) {
     ivlm_enter();
     if (!strides) return IVLM_ERR_INVALID_ARG;
     ivlm::AttnArgs a;
     a.f16 = f16;
     a.q_lo = static_cast<const bf16_t*>(q_lo);
+    a.q_lo_level = q_lo_level;
     if (reinterpret_cast<uintptr_t>(q_lo) & 15) return IVLM_ERR_INVALID_ARG;
     a.q = static_cast<const bf16_t*>(q);
     a.k = static_cast<const bf16_t*>(k);
@@ -1668,9 +1706,9 @@ int ivlm_attention_f16(const void* q, const void* k, const void* v, void* o, con
 // ... with q as hi + lo IEEE halves (q_lo: the strides of q): the "exact q" attention of the fp16 mode (SAM shapes), see ivlm_hip.h
 int ivlm_attention_f16_qsplit(const void* q, const void* q_lo, const void* k, const void* v, void* o, const int64_t* strides /*[12]*/,
                               int B, int H, int Sq, int Sk, int D, float scale, const float* rel_h, const float* rel_w, int rel_kh,
-                              int rel_kw, ivlm_stream_t stream) {
-    if (!q_lo) return IVLM_ERR_INVALID_ARG;
-    return attention_16(q, k, v, o, strides, B, H, Sq, Sk, D, scale, 0, 0, rel_h, rel_w, rel_kh, rel_kw, 1, 1, 1, stream, q_lo);
+                              int rel_kw, int level, ivlm_stream_t stream) {
+    if (!q_lo || (level != 1 && level != 2)) return IVLM_ERR_INVALID_ARG;
+    return attention_16(q, k, v, o, strides, B, H, Sq, Sk, D, scale, 0, 0, rel_h, rel_w, rel_kh, rel_kw, 1, 1, 1, stream, q_lo, level);
 }
 
 int ivlm_attention_bf16_split(const void* q, const void* q_lo, const void* k, const void* k_lo, const void* v, const void* v_lo,

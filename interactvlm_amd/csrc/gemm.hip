@@ -246,8 +246,10 @@ inline bool tile320_fits(const GemmArgs& g) {
     // faster on this tile ALONE (qkv 163 -> 155 us, encoder 29.64 -> 29.56 ms) but evaluate() is SLOWER with them on it (101.2 vs
     // 99.8 ms, alternating runs on one box; tile off everywhere: 100.5): a 256 x 320 tile holds its CU 25 % longer than a 256^2
     // one, and the decode / prefill kernels of the other stream - the critical path - wait for CUs at tile granularity.
-    if (!g.out_f32 || g.out_split) return false;
+    // (fp16 "exact q" projections: k|v, N = 2560, 16-bit output, and q on split rows with a split output, N = 1280 - exactly two /
+    //  one whole rounds of this tile where 256^2 tiles leave a quarter-filled round or fall back to 128^2)
     const long tm = (g.M + 255) / 256, tiles = tm * (g.N / 320);
+    if ((!g.out_f32 || g.out_split) && !(g.f16 && tiles % 256 == 0 && tiles <= 512)) return false;
     const double q = (double)tiles / (double)(((tiles + 255) / 256) * 256);
     return tiles >= 256 && q >= 0.85 && (double)(tm * 256) / (double)g.M < 1.1;
 }

@@ -542,7 +542,7 @@ def relpos_table64(tab_h, tab_w):
     return t
 
 
-def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, prescale_q=False, rel_tab=None, q_lo=None):
+def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, prescale_q=False, rel_tab=None, q_lo=None, q_lo_level=1):
     """q [B,H,Sq,D], k/v [Bk,H,Sk,D] (arbitrary strides, last dim contiguous; B % Bk == 0: K/V of batch
     b // (B//Bk)) -> o [B,H,Sq,D] as a view of a [B,Sq,H,D] buffer (so o.transpose(1,2) is contiguous).
     rel = (rel_h f32 [B*H,Sq,KH], rel_w f32 [B*H,Sq,KW]) adds SAM's decomposed rel-pos bias; rel_tab = (relpos_table64(...), side)
@@ -574,7 +574,7 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, presca
         assert dt == F16 and q_lo.dtype == F16 and q_lo.stride() == q.stride() and q_lo.shape == q.shape and not causal and B == Bk
         check(lib.ivlm_attention_f16_qsplit(q.data_ptr(), q_lo.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                             ctypes.cast(st, ctypes.c_void_p), B, H, Sq, Sk, D, float(scale), _p(rel_h), _p(rel_w),
-                                            kh, kw, _stream()), "attention_f16_qsplit")
+                                            kh, kw, int(q_lo_level), _stream()), "attention_f16_qsplit")
         return out
     fn = lib.ivlm_attention_f16 if dt == F16 else lib.ivlm_attention_bf16
     check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
@@ -677,31 +677,34 @@ def relpos_bias(q, tab_h, tab_w, SH, SW, cat=None, q_lo=None):
     rel_w = torch.empty(B * H, S, SW, dtype=torch.float32, device=q.device)
     # (measured, SAM ViT-H: global 64x64 grid 242 -> 139 us; 14x14 windows 54 -> 62 us - the GEMM's N = 54 wastes half a tile and
     #  the gather moves as many bytes as the dot kernel writes - so only grids of 32x32 and up take this path)
-    f16 = q.dtype == F16  # fp16 q against the fp16 table (cat), fp32 G and terms
-    if f16 and not (cat is not None and cat.dtype == F16 and min(SH, SW) >= 32):
-        raise IvlmError("relpos_bias: fp16 q needs the fp16 cat table and a grid of 32 x 32 or more (GEMM formulation)")
-    if (RELPOS_GEMM and cat is not None and min(SH, SW) >= 32 and q.dtype == cat.dtype and q.stride(0) == S * q.stride(2) and q.stride(2) % 8 == 0
-            and q.stride(1) % 8 == 0 and D % 8 == 0 and q.data_ptr() % 16 == 0):
+    if q.dtype == F16:  # fp16 q (optionally + q_lo) against the fp16 table: fp32 G and terms, one call
+        if not (cat is not None and cat.dtype == F16 and min(SH, SW) >= 32):
+            raise IvlmError("relpos_bias: fp16 q needs the fp16 cat table and a grid of 32 x 32 or more (GEMM formulation)")
         npad, M = cat.shape[0], B * S
-        # (fp16 q: G stays fp32 - the terms ADD to the scores, an fp16 rounding of a term of +-8 would be an absolute 2e-3)
-        G = torch.empty(H, M, npad, dtype=F32 if f16 else BF16, device=q.device)
-        call = lambda: check(lib.ivlm_gemm_bf16(q.data_ptr(), q.stride(2), cat.data_ptr(), D, G.data_ptr(), npad, 0, 0, 0, 0,
-                                                M, npad, D, 0, 1 if f16 else 0, H, q.stride(1), 0, M * npad, 0, 0, 0.0,
-                                                GEMM_F16 if f16 else 0, 0, 0, _stream()), "relpos gemm")
+        assert q_lo is None or (q_lo.dtype == F16 and q_lo.stride() == q.stride())
+        G = torch.empty(H, M, npad, dtype=F32, device=q.device)
+        call = lambda: check(lib.ivlm_relpos_bias_f16(q.data_ptr(), _p(q_lo), q.stride(0), q.stride(1), q.stride(2), cat.data_ptr(), npad,
+                                                      B, H, SH, SW, D, G.data_ptr(), G.numel() * 4, rel_h.data_ptr(), rel_w.data_ptr(),
+                                                      _stream()), "relpos_bias_f16")
         if TIMER.enabled:
             TIMER.time("gemm_bf16_mfma", 2.0 * H * M * npad * D, call, tag=("relpos", M, npad, D))
         else:
             call()
-        if q_lo is not None:  # fp16 "exact q": G += q_lo . T (the second product accumulates through the fp32 residual epilogue)
-            assert f16 and q_lo.dtype == F16 and q_lo.stride() == q.stride() and q_lo.data_ptr() % 16 == 0
-            check(lib.ivlm_gemm_bf16(q_lo.data_ptr(), q.stride(2), cat.data_ptr(), D, G.data_ptr(), npad, 0, G.data_ptr(), npad, 0,
-                                     M, npad, D, 0, 1, H, q.stride(1), 0, M * npad, M * npad, 0, 0.0, GEMM_F16 | GEMM_RES_F32, 0, 0,
-                                     _stream()), "relpos gemm (lo)")
-        check((lib.ivlm_relpos_gather_f32 if f16 else lib.ivlm_relpos_gather)(
-            G.data_ptr(), M * npad, npad, B, H, SH, SW, rel_h.data_ptr(), rel_w.data_ptr(), _stream()), "relpos_gather")
         return rel_h, rel_w
-    if f16:
-        raise IvlmError("relpos_bias: fp16 q with a layout the GEMM formulation cannot take")
+    if (RELPOS_GEMM and cat is not None and min(SH, SW) >= 32 and q.dtype == cat.dtype and q.stride(0) == S * q.stride(2) and q.stride(2) % 8 == 0
+            and q.stride(1) % 8 == 0 and D % 8 == 0 and q.data_ptr() % 16 == 0):
+        npad, M = cat.shape[0], B * S
+        G = torch.empty(H, M, npad, dtype=BF16, device=q.device)
+        call = lambda: check(lib.ivlm_gemm_bf16(q.data_ptr(), q.stride(2), cat.data_ptr(), D, G.data_ptr(), npad, 0, 0, 0, 0,
+                                                M, npad, D, 0, 0, H, q.stride(1), 0, M * npad, 0, 0, 0.0, 0, 0, 0, _stream()),
+                             "relpos gemm")
+        if TIMER.enabled:
+            TIMER.time("gemm_bf16_mfma", 2.0 * H * M * npad * D, call, tag=("relpos", M, npad, D))
+        else:
+            call()
+        check(lib.ivlm_relpos_gather(G.data_ptr(), M * npad, npad, B, H, SH, SW, rel_h.data_ptr(), rel_w.data_ptr(), _stream()),
+              "relpos_gather")
+        return rel_h, rel_w
     check(lib.ivlm_relpos_bias(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), tab_h.data_ptr(), tab_w.data_ptr(),
                                B, H, SH, SW, D, rel_h.data_ptr(), rel_w.data_ptr(), _stream()), "relpos_bias")
     return rel_h, rel_w

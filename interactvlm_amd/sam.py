@@ -214,7 +214,7 @@ class SamImageEncoder:
             return self._forward(images)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
-        key = tuple(images.shape) + (self.fp8, self.precision, self.parity_sites)
+        key = tuple(images.shape) + (self.fp8, self.precision, self.parity_sites, self.q_lo_level)
         ent = self._graphs.get(key)
         dev = images.device
         if ent is None:
@@ -260,6 +260,7 @@ class SamImageEncoder:
     # splits the softmax weights for P.V.  q's rounding is the one SAM's decomposed rel-pos terms amplify (tools/emulate_f16_sites.py:
     # 57 % of the fp16 mode's error variance comes through q), this path removes it for +1/3 of the q|k|v GEMM's MFMA work
     SITES_F16Q = frozenset(("f16attn", "f16q", "f16mlp"))
+    q_lo_level = 1
     parity_sites = PARITY_SITES
 
     def _f16_weights(self, blk, names=("lin1", "lin2")):
@@ -299,11 +300,12 @@ class SamImageEncoder:
                 ops.fill_rows(kv, pad, blk["kv_b_h"])
             q4, kv4 = q2.view(nwin, S, 2, H, hd), kv.view(nwin, S, 2, H, hd)
             q, q_lo, k, v = (t.permute(0, 2, 1, 3) for t in (q4[:, :, 0], q4[:, :, 1], kv4[:, :, 0], kv4[:, :, 1]))
+            lv = self.q_lo_level  # 1: q's lo half in the rel-pos terms only (what amplifies its rounding); 2: in Q.K^T too, split P
             if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
-                o = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_cat_h"], side), q_lo=q_lo)
+                o = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_cat_h"], side), q_lo=q_lo, q_lo_level=lv)
             else:
                 rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat_h"], q_lo=q_lo)
-                o = ops.attention(q, k, v, hd ** -0.5, rel=rel, q_lo=q_lo)
+                o = ops.attention(q, k, v, hd ** -0.5, rel=rel, q_lo=q_lo if lv == 2 else None, q_lo_level=lv)
             return o.permute(0, 2, 1, 3).reshape(nwin * S, H * hd)
         if win is None:
             qkv = ops.linear(xn, wq, blk["qkv"].b, out_f16=True)

@@ -25,7 +25,9 @@ def main():
         _lib.load().ivlm_attention_window_kernel(int(os.environ["WIN_V2"]))
     for mode in (os.environ.get("MODES", "default,parity").split(",")):
       for rik in ((True, False) if os.environ.get("AB_REL") else (True,)):
-        enc.precision = mode
+        # modes: default | parity | f16 | f16q (the fp16-operand site sets of SamImageEncoder)
+        enc.precision = "default" if mode == "default" else "parity"
+        enc.parity_sites = {"f16": enc.SITES_F16, "f16q": enc.SITES_F16Q, "parity-fast": enc.PARITY_SITES_FAST}.get(mode, enc.PARITY_SITES)
         enc.rel_in_kernel = rik
         enc.parity_window_arrays = os.environ.get("PWA", "1") == "1"
         if hasattr(enc, "_graphs"):

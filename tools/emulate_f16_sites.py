@@ -4,7 +4,7 @@ encoder output, and by how much, when an operand is rounded to IEEE fp16 (or bf1
 (oracle/nn.py sam_block, restated here with rounding hooks) runs in fp64 on one view of the headline ViT-H with seeded weights,
 once exactly and once per site set; prints the relative rms error of the [256, 64, 64] embedding.
 
-    sites: n1q / n1kv (norm1 out as seen by the q / the k|v columns of the q|k|v GEMM), q k v (GEMM outputs), qs (q * scale rounded again), rel (rel-pos terms),
+    sites: n1q / n1kv (norm1 out as seen by the q / the k|v columns of the q|k|v GEMM), qrel / qqk (the q GEMM output as seen by the rel-pos terms / by Q.K^T), k v (GEMM outputs), qs (q * scale rounded again), rel (rel-pos terms),
            p (softmax weights), o (attention output -> proj input), n2 (norm2 out), h (GELU hidden)
     python tools/emulate_f16_sites.py [f16|bf16] [depth]
 """
@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-SITES = ("n1q", "n1kv", "q", "k", "v", "qs", "rel", "p", "o", "n2", "h")
+SITES = ("n1q", "n1kv", "qrel", "qqk", "k", "v", "qs", "rel", "p", "o", "n2", "h")
 
 
 def main():
@@ -53,9 +53,10 @@ def main():
             q = qkv.reshape(3, B * H, Hh * Wd, hd)[0]
             qkv = lin(pre + ".qkv", r("n1kv", x)).reshape(B, Hh * Wd, 3, H, hd).permute(2, 0, 3, 1, 4)
             _, k, v = qkv.reshape(3, B * H, Hh * Wd, hd).unbind(0)
-            q, k, v = r("q", q), r("k", k), r("v", v)
+            k, v = r("k", k), r("v", v)
             Rh, Rw = rel_tab(Hh, w[pre + ".rel_pos_h"]), rel_tab(Wd, w[pre + ".rel_pos_w"])
-            rq = q.reshape(B * H, Hh, Wd, hd)
+            rq = r("qrel", q).reshape(B * H, Hh, Wd, hd)
+            q = r("qqk", q)
             rel_h = r("rel", torch.einsum("bhwc,hkc->bhwk", rq, Rh))
             rel_w = r("rel", torch.einsum("bhwc,wkc->bhwk", rq, Rw))
             out = torch.empty(B * H, Hh * Wd, hd, dtype=torch.float64, device=dev)
@@ -102,12 +103,11 @@ def main():
         print(f"{kind}, depth {depth}: relative rms error of the embedding per rounded site set", flush=True)
         for s in SITES:
             print(f"  {s:4s} {err((s,)):.2e}", flush=True)
-        A = ("n1q", "n1kv", "q", "k", "v", "qs", "p", "o", "n2", "h")  # everything the fp16 mode rounds (fp32 rel-pos terms)
+        A = ("n1q", "n1kv", "qrel", "qqk", "k", "v", "qs", "p", "o", "n2", "h")  # everything the fp16 mode rounds (fp32 rel-pos terms)
         wo = lambda *x: tuple(t for t in A if t not in x)
-        sets = {"all": A, "exact q path (n1q q qs)": wo("n1q", "q", "qs"), "... and p": wo("n1q", "q", "qs", "p"),
-                "... and p o": wo("n1q", "q", "qs", "p", "o"), "... and p o n1kv": wo("n1q", "q", "qs", "p", "o", "n1kv"),
-                "exact n1 (q|k|v GEMM on split rows)": wo("n1q", "n1kv"), "exact n1 and q, qs": wo("n1q", "n1kv", "q", "qs"),
-                "one q rounding": wo("qs"), "mlp only (n2 h)": ("n2", "h")}
+        sets = {"all": A, "exact q path (n1q qrel qqk qs)": wo("n1q", "qrel", "qqk", "qs"), "... and p": wo("n1q", "qrel", "qqk", "qs", "p"),
+                "exact n1q, q in the rel-pos terms only": wo("n1q", "qrel"), "... and p": wo("n1q", "qrel", "p"),
+                "... and p o": wo("n1q", "qrel", "p", "o"), "mlp only (n2 h)": ("n2", "h")}
         for name, a in sets.items():
             print(f"  {name:32s} {err(a):.2e}", flush=True)
 
