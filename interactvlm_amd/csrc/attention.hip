@@ -1294,17 +1294,12 @@ int launch_f16(const AttnArgs& a, hipStream_t st) {
         }
         return IVLM_ERR_UNSUPPORTED;
     }
-    if constexpr (DV == 128) {
-        if (a.causal && !rel) {
-            attn_kernel<DQK, DV, true, 0, false, false, true><<<grid, 256, 0, st>>>(a);
-            return ivlm_launch_status();
-        }
-    } else if constexpr (DV == 64) {
-        if (!a.causal && !rel) {
-            attn_kernel<DQK, DV, false, 0, false, false, true><<<grid, 256, 0, st>>>(a);
-            return ivlm_launch_status();
-        }
-    } else if constexpr (DV == 80) {
+    if (!rel) {  // plain / causal attention at every head dim (CLIP and LLaMA towers of any configuration)
+        if (a.causal) attn_kernel<DQK, DV, true, 0, false, false, true><<<grid, 256, 0, st>>>(a);
+        else attn_kernel<DQK, DV, false, 0, false, false, true><<<grid, 256, 0, st>>>(a);
+        return ivlm_launch_status();
+    }
+    if constexpr (DV == 80) {
         if (!a.causal && rel && a.prescale_q) {
             if (!a.rel_w) attn_kernel<DQK, DV, false, 4, false, false, true><<<grid, 256, 0, st>>>(a);
             else if (a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw) attn_kernel<DQK, DV, false, 2, false, false, true><<<grid, 256, 0, st>>>(a);

@@ -274,8 +274,17 @@ def test_towers_parity_mode_vs_oracle(hip_lib, cuda):
     enc.precision = "parity"
     e_par = rel(enc(x.to(cuda)), ref)
     e_par2 = rel(enc(x.to(cuda)), ref)  # graph replay
-    print(f"\n[SAM ViT-H width, 4 blocks] rel rms err: default {e_def:.2e}, parity {e_par:.2e}")
+    # fp16 operands (the model's default mode): plain, and with the exact q path
+    enc.parity_sites = enc.SITES_F16
+    e_f16 = rel(enc(x.to(cuda)), ref)
+    enc.parity_sites = enc.SITES_F16Q
+    e_f16q = rel(enc(x.to(cuda)), ref)
+    enc.q_lo_level = 2
+    e_f16q2 = rel(enc(x.to(cuda)), ref)
+    print(f"\n[SAM ViT-H width, 4 blocks] rel rms err: bf16 operands {e_def:.2e}, fp16 {e_f16:.2e}, fp16 + exact q {e_f16q:.2e} "
+          f"(lo half of q in Q.K^T too: {e_f16q2:.2e}), parity {e_par:.2e}")
     assert e_par < 1e-4 and e_par2 < 1e-4 and e_def > 10 * e_par
+    assert e_f16 < e_def / 5 and e_f16q < e_f16 and e_f16q2 < 1.05 * e_f16q
     del enc
 
     cc = Wt.ClipCfg(hidden=256, layers=4, heads=4, inter=512)
@@ -288,8 +297,10 @@ def test_towers_parity_mode_vs_oracle(hip_lib, cuda):
     fs = tower(xc.to(cuda))
     assert fs.shape == (2, 256, 512)
     e_par = rel(_join(fs, 256), refc)
-    print(f"[CLIP, 3 layers run] rel rms err: default {e_def:.2e}, parity {e_par:.2e}")
-    assert e_par < 5e-5 and e_def > 10 * e_par
+    tower.precision = "f16"
+    e_f16 = rel(_join(tower(xc.to(cuda)), 256), refc)
+    print(f"[CLIP, 3 layers run] rel rms err: bf16 operands {e_def:.2e}, fp16 {e_f16:.2e}, parity {e_par:.2e}")
+    assert e_par < 5e-5 and e_def > 10 * e_par and e_f16 < e_def / 5
 
     lc = Wt.LlamaCfg(hidden=512, layers=3, heads=4, inter=1024, vocab=1000)
     w = _bf16_weights(Wt.llama_spec(lc))
@@ -297,15 +308,22 @@ def test_towers_parity_mode_vs_oracle(hip_lib, cuda):
     emb = (torch.randn(90, 512, generator=g) * 0.5).to(torch.bfloat16).float()
     refl = O.llama(w, "model", emb[None], lc.layers, lc.heads)[0]
     errs = {}
-    for mode in ("default", "parity"):
+    for mode in ("default", "parity", "f16"):
         llm.set_precision(mode)
         h = [llm.forward(emb[:70].to(cuda), 0)]
         for t in range(70, 90):
             h.append(llm.forward(emb[t: t + 1].to(cuda), t))
         got = torch.cat(h, 0)
         errs[mode] = (rel(got[:70], refl[:70]), rel(got[70:], refl[70:]))
-    print(f"[LLaMA, 3 layers] rel rms err (prefill rows, decode rows): default {errs['default']}, parity {errs['parity']}")
+    print(f"[LLaMA, 3 layers] rel rms err (prefill rows, decode rows): bf16 operands {errs['default']}, fp16 operands + fp16 KV cache "
+          f"{errs['f16']}, parity {errs['parity']}")
     assert max(errs["parity"]) < 5e-5 and errs["default"][0] > 10 * errs["parity"][0]
+    assert errs["f16"][0] < errs["default"][0] / 5 and errs["f16"][1] < errs["default"][1] / 5
+    # a short chunk (2 .. 16 rows) in the non-bf16 modes goes token by token through the fp32-activation decode kernels
+    for mode in ("parity", "f16"):
+        llm.set_precision(mode)
+        h = torch.cat([llm.forward(emb[:70].to(cuda), 0), llm.forward(emb[70:78].to(cuda), 70)], 0)
+        assert rel(h, refl[:78]) < 2 * max(errs[mode]) + 1e-5
 
 
 def test_evaluate_parity_mode_vs_oracle(hip_lib, cuda):
@@ -329,12 +347,13 @@ def test_evaluate_parity_mode_vs_oracle(hip_lib, cuda):
     full_ids = torch.cat([ids[0], torch.tensor(forced)])
     ref = P.model_forward(w, cfg, im[0].float().cpu(), ic.float().cpu(), full_ids, cams[0], tables)["pred_contact"]
     errs = {}
-    for mode in ("default", "parity", "default"):
+    for mode in ("default", "bf16", "parity", "default"):
         m.set_precision(mode)
         out = m.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced)
         errs[mode] = float((out["pred_contact_3d"].float().cpu() - ref).abs().max())
-    print(f"\n[evaluate, tiny] max |dp| vs fp32 oracle: default {errs['default']:.2e}, parity {errs['parity']:.2e}")
-    assert errs["parity"] < 1e-4 and errs["default"] < 1e-3
+    print(f"\n[evaluate, tiny] max |dp| vs fp32 oracle: default (fp16 operands) {errs['default']:.2e}, bf16 {errs['bf16']:.2e}, "
+          f"parity {errs['parity']:.2e}")
+    assert errs["parity"] < 1e-4 and errs["default"] < 2e-4 and errs["bf16"] < 1e-3
     m.set_precision("parity")
     single = m.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced)["pred_contact_3d"]
     ic2, im2 = torch.cat([ic, ic]), torch.cat([im, im])
@@ -350,9 +369,9 @@ def test_full_depth_end_to_end_vs_oracle(hip_lib, cuda):
     a 32-layer LLaMA (width 1024: the fp32 oracle of the 7B width needs 27 GB of host weights - bench.py's
     `parity_vs_oracle_full_depth` leg does exactly that on the headline model), a 23-layer CLIP, the real mask decoder, 4 x 1024^2
     masks and the 6890-vertex lift: evaluate() against the fp32 CPU oracle on identical bf16-valued weights.
-    "parity" (and "parity-fast": the same with the SAM encoder's MLP on fp16 operands) precision must hold the north star's 1e-3 on
-    per-vertex probabilities with exactly equal vertex-id sets; "parity-encoder" (language towers in default precision) and the
-    default (bf16 MFMA operand) mode's error at this depth is printed and only sanity-bounded."""
+    EVERY listed mode except "bf16" must hold the north star's 1e-3 on per-vertex probabilities: the DEFAULT mode (fp16 operands,
+    exact q path) with a margin (< 7e-4 asserted; 4 - 6e-4 measured over seeds), "parity" / "parity-fast" with exactly equal
+    vertex-id sets; the bf16-operand mode's error at this depth (the reference's own GPU dtype class) is printed and sanity-bounded."""
     import time
 
     import torch
@@ -395,20 +414,21 @@ def test_full_depth_end_to_end_vs_oracle(hip_lib, cuda):
     ref, nviews = cref.lift_mesh_soft(masks.numpy()[None], tables[0].cpu().numpy().astype(np.int32), tables[1].cpu().numpy(), 6890)
     ref = torch.from_numpy(ref)
     err = {mode: float((c - ref).abs().max()) for mode, (c, _) in got.items()}
-    print(f"\n[full depth: SAM ViT-H 32 blocks x 4 views, 32-layer LLaMA, 23-layer CLIP] max |dp| vs fp32 oracle: default "
-          f"{err['default']:.2e}, parity-encoder {err['parity-encoder']:.2e}, parity-fast {err['parity-fast']:.2e}, parity "
-          f"{err['parity']:.2e} "
-          f"(oracle {time.time() - t0:.0f} s)")
+    print(f"\n[full depth: SAM ViT-H 32 blocks x 4 views, 32-layer LLaMA, 23-layer CLIP] max |dp| vs fp32 oracle: default (fp16 "
+          f"operands, exact q) {err['default']:.2e}, bf16 {err['bf16']:.2e}, parity-fast {err['parity-fast']:.2e}, parity "
+          f"{err['parity']:.2e} (oracle {time.time() - t0:.0f} s)")
     c, vis = got["parity"]
+    assert err["default"] < 7e-4  # the mode `value` of bench.py is quoted on: inside the north star's 1e-3 with a margin
     assert err["parity"] < 1e-3 and err["parity-fast"] < 1e-3
-    # (encoder-only parity leaves the bf16 rounding of the language towers in: 4e-4 .. 1.3e-3 over seeds, tools/diag_encoder_margin.py)
-    assert err["parity-encoder"] < 3e-3
-    assert torch.equal(got["parity-encoder"][1], vis) and torch.equal(got["parity-fast"][1], vis)
-    assert torch.equal(vis, torch.from_numpy(nviews[0] > 0))  # visibility set: bit-exact
-    for thr, op in ((0.5, torch.ge), (0.3, torch.gt)):  # metric / demo thresholds: equal off the (tiny) error band
-        band = (ref - thr).abs() <= err["parity"]
-        assert bool((op(c, thr) == op(ref, thr))[~band].all()) and int(band.sum()) <= 4
-    assert err["default"] < 5e-2
+    assert torch.equal(got["default"][1], vis) and torch.equal(got["parity-fast"][1], vis)
+    assert torch.equal(vis, torch.from_numpy(nviews[0] > 0))  # visibility set: bit-exact (every mode)
+    for mode in ("parity", "default"):
+        cm = got[mode][0]
+        for thr, op in ((0.5, torch.ge), (0.3, torch.gt)):  # metric / demo thresholds: equal off the error band of the mode
+            band = (ref - thr).abs() <= err[mode]
+            assert bool((op(cm, thr) == op(ref, thr))[~band].all())
+            assert mode != "parity" or int(band.sum()) <= 4
+    assert err["bf16"] < 5e-2
 
 
 @pytest.mark.parametrize("M,N,K,act", [(16384, 5120, 1280, "gelu"), (16384, 1280, 5120, "none"), (300, 512, 256, "none")])

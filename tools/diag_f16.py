@@ -21,7 +21,7 @@ def main():
     shapes = {"small-llm": small, "7b": synthetic.config_7b()}
     tables = synthetic.body_lift_tables(dev)
     cams = synthetic.human_cam_params()
-    modes = os.environ.get("MODES", "default,f16,f16q,parity-fast").split(",")
+    modes = os.environ.get("MODES", "bf16,f16,default,parity-fast").split(",")
     for name in os.environ.get("SHAPES", "small-llm,7b").split(","):
         cfg = shapes[name]
         ids, forced = synthetic.prompt_ids(cfg)
