@@ -304,6 +304,62 @@ def parity_vs_oracle(dev):
             "threshold": round(thr, 4), "visibility_set_equal": vis_equal, "threshold_sets": sets}
 
 
+def _sync(world, dev):
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.barrier()
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def timed_steps(step, warmup, steps, world, dev):
+    """The contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both
+    sides; the time is the MAX over the ranks (one all_reduce).  -> (seconds, result of the last step)"""
+    import torch.distributed as dist
+
+    res = None
+    for _ in range(warmup):
+        res = step()
+    _sync(world, dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    _sync(world, dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, res
+
+
+def one_gpu_same_workload(n_img, per_call, eval_chunk, rank, world, dev, res, dt, steps, prefetch=None):
+    """dp64 at N > 1: the SAME images on rank 0 alone, measured after the timed region (the other ranks idle at the barrier): the
+    strong-scaling denominator of this very run.  -> dict on rank 0, None elsewhere."""
+    from interactvlm_amd.dist import evaluate_sharded
+
+    one = None
+    if rank == 0:
+        if prefetch is not None:
+            for i in range(n_img):
+                prefetch(i)
+        evaluate_sharded(n_img, per_call, eval_chunk, rank=0, world=1)  # (world 1: no collective is entered)
+        if torch.device(dev).type == "cuda":
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ref1 = evaluate_sharded(n_img, per_call, eval_chunk, rank=0, world=1).cpu()
+        if torch.device(dev).type == "cuda":
+            torch.cuda.synchronize()
+        t_one = time.perf_counter() - t1
+        one = {"images_per_s": round(n_img / t_one, 4), "seconds": round(t_one, 3),
+               "speedup_of_this_run": round((n_img * steps / dt) / (n_img / t_one), 3),
+               "max_abs_dp_sharded_vs_one_gpu": float((res.cpu() - ref1).abs().max()),
+               "note": f"the same {n_img} images evaluated by rank 0 alone after the timed region (other ranks idle)"}
+    _sync(world, dev)
+    return one
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -409,38 +465,14 @@ def main():
         lo, hi = shard_range(N_IMG, rank, world)
         for i in range(lo, hi):
             dp_image(i)
-    for _ in range(args.warmup):
-        res = step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, res = timed_steps(step, args.warmup, args.steps, world, dev)
     items_per_step = world if workload == "b1" else N_IMG
     assert res.shape == (items_per_step, 6890)
 
     # ---- dp64 at N > 1: the SAME 64 images on rank 0 alone (the strong-scaling denominator, measured in the same run)
     one_gpu = None
     if workload == "dp64" and world > 1:
-        if rank == 0:
-            for i in range(N_IMG):
-                dp_image(i)
-            evaluate_sharded(N_IMG, PER_CALL, dp_chunk, rank=0, world=1)  # (world 1: no collective is entered)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            ref1 = evaluate_sharded(N_IMG, PER_CALL, dp_chunk, rank=0, world=1).cpu()
-            torch.cuda.synchronize()
-            t_one = time.perf_counter() - t1
-            one_gpu = {"images_per_s": round(N_IMG / t_one, 4), "seconds": round(t_one, 3),
-                       "speedup_of_this_run": round((N_IMG * args.steps / dt) / (N_IMG / t_one), 3),
-                       "max_abs_dp_sharded_vs_one_gpu": float((res - ref1).abs().max()),
-                       "note": "the same 64 images evaluated by rank 0 alone after the timed region (other ranks idle)"}
-        sync()
+        one_gpu = one_gpu_same_workload(N_IMG, PER_CALL, dp_chunk, rank, world, dev, res, dt, args.steps, prefetch=dp_image)
 
     # ---- variant (reported separately, never the headline): SAM embeddings of the 4 canonical body renders cached
     cached = None
