@@ -29,6 +29,29 @@ def llm_hidden(w, cfg, input_ids, image_features):
     return O.llama(w, "model", emb[None], cfg.llama.layers, cfg.llama.heads, cfg.llama.eps, cfg.llama.theta)[0]
 
 
+def greedy(w, cfg, images_clip, input_ids, max_new_tokens=32, eos_token_id=2):
+    """The reference's free-running generation (model/InteractVLM.py:524-531: HF greedy search, num_beams = 1, with
+    use_cache = False at :128, so that EVERY step is an uncached forward of the whole prefix with the image features spliced in -
+    llava_arch.py:98-123 - followed by lm_head on the last position and argmax): full re-forward, argmax, append, stop on EOS or
+    after max_new_tokens.  -> (output ids [L + n] (prompt + new tokens, like outputs.sequences), top-2 logit margins of the n steps
+    [n] - a comparison with another implementation is only meaningful where the margin exceeds that implementation's tolerance -,
+    the logits of every step [n, vocab])."""
+    feat = encode_images(w, cfg, images_clip)[0]
+    ids = input_ids.clone()
+    margins, logits_all = [], []
+    for _ in range(max_new_tokens):
+        hidden = llm_hidden(w, cfg, ids, feat)
+        logits = hidden[-1] @ w["lm_head.weight"].float().t()
+        top2 = torch.topk(logits, 2).values
+        margins.append(float(top2[0] - top2[1]))
+        logits_all.append(logits)
+        tok = int(torch.argmax(logits))
+        ids = torch.cat([ids, torch.tensor([tok], dtype=ids.dtype)])
+        if tok == eos_token_id:
+            break
+    return ids, torch.tensor(margins), torch.stack(logits_all)
+
+
 def sam_embed(w, cfg, images):
     """get_visual_embs (InteractVLM.py:251-261): images [V,3,S,S] -> [V,256,g,g]."""
     s = cfg.sam

@@ -25,6 +25,13 @@ def _bf16_weights(spec, seed=0):
     return {k: v.to(torch.bfloat16).float() for k, v in w.items()}
 
 
+# Stage bounds of the tower-level bf16-operand path (the towers' own "default"): ~1.5 x the measured figures (printed by the tests),
+# so that a regression of the bf16 path cannot hide inside a loose bound
+# measured (round 4): SAM small 1.48e-2 (vs the reference's fp32-WEIGHT golden: includes the checkpoint rounding), SAM blocks at
+# ViT-H width 8.9e-3, CLIP 3.7e-3, LLaMA 5.5e-3 / logits 4.2e-3
+BOUND_SAM_SMALL, BOUND_SAM_BLOCKS, BOUND_CLIP, BOUND_LLAMA = 2.2e-2, 1.4e-2, 6e-3, 8e-3
+
+
 def _rel_err(got, ref):
     import torch
 
@@ -89,7 +96,8 @@ def test_sam_encoder_small_vs_reference_golden(hip_lib, cuda, golden_dir):
     x = torch.from_numpy(synth.synth_normal("samenc/x", (2, 3, 480, 480), 1.0, 0)).to(torch.bfloat16).to(cuda)
     y = enc(x)  # [2, 900, 256] channels last
     ref = torch.from_numpy(d["out"]).permute(0, 2, 3, 1).reshape(2, 900, 256)
-    assert _rel_err(y, ref) < 5e-2, _rel_err(y, ref)
+    print(f"\n[SAM encoder small, bf16 operands vs the reference's fp32-weight output] rel err {_rel_err(y, ref):.2e}")
+    assert _rel_err(y, ref) < BOUND_SAM_SMALL, _rel_err(y, ref)
 
 
 def test_sam_encoder_vith_dimensions_vs_reference_golden(hip_lib, cuda, golden_dir):
@@ -110,7 +118,7 @@ def test_sam_encoder_vith_dimensions_vs_reference_golden(hip_lib, cuda, golden_d
     got = y[:, ::4, ::2, ::2]
     rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     print(f"\n[SAM ViT-H dims, depth 2] rel rms err vs reference = {rel:.4f}, max abs = {float((got - ref).abs().max()):.4f}")
-    assert rel < 3e-2 and float((got - ref).abs().max()) < 0.1 * float(ref.abs().max())
+    assert rel < 1.8e-2 and float((got - ref).abs().max()) < 0.1 * float(ref.abs().max())  # (measured 1.21e-2)
 
 
 def test_sam_block_full_dims_vs_oracle(hip_lib, cuda):
@@ -129,7 +137,8 @@ def test_sam_block_full_dims_vs_oracle(hip_lib, cuda):
     y = enc(x.to(cuda))
     ref = O.sam_image_encoder(w, Wt.SAM_PREFIX + ".image_encoder", x.float(), 2, 16, (1,))
     ref = ref.permute(0, 2, 3, 1).reshape(1, 4096, 256)
-    assert _rel_err(y, ref) < 5e-2, _rel_err(y, ref)
+    print(f"\n[SAM blocks at ViT-H width, bf16 operands vs oracle] rel err {_rel_err(y, ref):.2e}")
+    assert _rel_err(y, ref) < BOUND_SAM_BLOCKS, _rel_err(y, ref)
 
 
 def test_clip_and_llama_vs_oracle(hip_lib, cuda):
@@ -146,7 +155,8 @@ def test_clip_and_llama_vs_oracle(hip_lib, cuda):
     got = llava.ClipTower(w, cc, cuda)(x.to(cuda))
     ref = O.clip_vision(w, Wt.CLIP_PREFIX, x.float(), 4, 4)
     assert got.shape == (2, 256, 256)
-    assert _rel_err(got, ref) < 4e-2, _rel_err(got, ref)
+    print(f"\n[CLIP 4 layers, bf16 operands vs oracle] rel err {_rel_err(got, ref):.2e}")
+    assert _rel_err(got, ref) < BOUND_CLIP, _rel_err(got, ref)
 
     lc = Wt.LlamaCfg(hidden=512, layers=3, heads=4, inter=1024, vocab=1000)  # head dim 128 like LLaMA-2
     w = _bf16_weights(Wt.llama_spec(lc))
@@ -155,22 +165,25 @@ def test_clip_and_llama_vs_oracle(hip_lib, cuda):
     ref = O.llama(w, "model", emb[None], 3, 4)[0]
     full = llm.forward(emb.to(cuda), 0)
     assert full.dtype == torch.float32
-    assert _rel_err(full, ref) < 4e-2, _rel_err(full, ref)
+    print(f"[LLaMA 3 layers, bf16 operands vs oracle] rel err {_rel_err(full, ref):.2e}")
+    assert _rel_err(full, ref) < BOUND_LLAMA, _rel_err(full, ref)
     # prefill 50 + 20 single-token decode steps through the KV cache == one 70-token pass
     llm2 = llava.Llama(w, lc, cuda, max_len=128)
     h = [llm2.forward(emb[:50].to(cuda), 0)]
     for t in range(50, 70):
         h.append(llm2.forward(emb[t: t + 1].to(cuda), t))
     inc = torch.cat(h, 0)
-    assert _rel_err(inc, ref) < 4e-2
-    assert _rel_err(inc, full) < 2e-2  # decode rows: fp32 activations, exact products; prefill rows: bf16 MFMA operands
+    print(f"[LLaMA prefill 50 + 20 decode steps] vs oracle {_rel_err(inc, ref):.2e}, vs the one-pass result {_rel_err(inc, full):.2e}")
+    assert _rel_err(inc, ref) < BOUND_LLAMA
+    assert _rel_err(inc, full) < BOUND_LLAMA  # decode rows: fp32 activations, exact products; prefill rows: bf16 MFMA operands
     # the decode rows (fp32 activations end to end) sit closer to the fp32 oracle than the bf16-operand prefill rows do
     e_dec, e_pre = _rel_err(inc[50:], ref[50:]), _rel_err(full[50:], ref[50:])
     print(f"\n[llama] decode rows vs oracle {e_dec:.2e}, the same rows through the MFMA prefill {e_pre:.2e}")
     assert e_dec < 1.5 * e_pre + 1e-3
     lg = llm.logits(full[-1:]).cpu()
     ref_lg = ref[-1:] @ w["lm_head.weight"].T
-    assert _rel_err(lg, ref_lg) < 4e-2
+    print(f"[lm_head logits vs oracle] rel err {_rel_err(lg, ref_lg):.2e}")
+    assert _rel_err(lg, ref_lg) < BOUND_LLAMA
     from interactvlm_amd import ops
     assert int(ops.argmax(llm.logits(full[-1:]))[0]) == int(lg.argmax())
 
@@ -799,3 +812,65 @@ def test_forward_with_past_key_values_is_the_causal_lm_forward(hip_lib, cuda):
     o2 = m.forward(input_ids=cur, images=ic, past_key_values=None)
     assert o2.past_key_values is None and int(o2.logits[0, -1].argmax()) == got[-1]
     assert torch.allclose(o2.hidden_states[0, -1], o.hidden_states[0, -1], atol=2e-2, rtol=2e-2)
+
+
+def test_free_running_generation_vs_oracle_greedy(hip_lib, cuda, golden_dir):
+    """generate() / generate_batch() (KV-cached greedy search) against the ORACLE's restatement of the reference's
+    loop - uncached full re-forwards + argmax, stop on EOS / max_new_tokens (oracle.pipeline.greedy = InteractVLM.py:524-531 with
+    use_cache False) - token by token.  A step is compared wherever the oracle's top-2 logit margin exceeds the tolerance of the
+    HIP logits (measured here against the oracle's logits of the same prefix); once a below-tolerance step differs the prefixes
+    diverge legitimately and the comparison stops.  Also: one B = 16 evaluate_batch contact vector directly against the oracle."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synthetic
+    from interactvlm_amd import weights as Wt
+    from oracle import pipeline as P
+
+    torch.set_grad_enabled(False)
+    d, cfg, ids, images_clip, images, cams, tables = _toy(golden_dir)
+    w = {k: v.to(torch.bfloat16).float() for k, v in Wt.synth_weights(Wt.ivlm_spec(cfg)).items()}
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    bf = torch.bfloat16
+    n_new, compared = 10, 0
+    prompts = [ids[:40], torch.cat([ids[:30], ids[34:40]]), ids[:38]]
+    ics = [images_clip.to(bf), (images_clip * 0.5 + 0.1).to(bf), (-images_clip).to(bf)]
+    refs = [P.greedy(w, cfg, ics[b].float(), prompts[b], max_new_tokens=n_new, eos_token_id=2) for b in range(3)]
+    for graph in (True, False):
+        m.graph_decode = graph
+        outs = [m.generate(ics[b].to(cuda), prompts[b][None], max_new_tokens=n_new, eos_token_id=2) for b in range(3)]
+        outs_b = m.generate_batch(torch.cat(ics).to(cuda), prompts, max_new_tokens=n_new, eos_token_id=2)
+        for b in range(3):
+            ref_ids, margins, ref_logits = refs[b]
+            L = prompts[b].shape[0]
+            for name, (got_ids, hidden) in (("generate", outs[b]), ("generate_batch", outs_b[b])):
+                got = got_ids[0, L:].tolist()
+                want = ref_ids[L:].tolist()
+                # tolerance of the HIP logits: lm_head on the HIP hidden state of the step's last prefix row vs the oracle's logits
+                for t in range(min(len(got), len(want))):
+                    row = hidden[L + cfg.img_emb_len - 1 + t]  # (the prompt occupies L + img_emb_len positions: one id -> 256 rows)
+                    lg = row.float().cpu() @ w["lm_head.weight"].t()
+                    tol = 2.0 * float((lg - ref_logits[t]).abs().max())
+                    if float(margins[t]) <= tol:
+                        if got[t] != want[t]:
+                            break  # an undecidable step went the other way: the prefixes differ from here on
+                        continue
+                    assert got[t] == want[t], (name, graph, b, t, got, want, float(margins[t]), tol)
+                    compared += 1
+                else:
+                    assert len(got) == len(want), (name, got, want)  # same stop (EOS / max_new_tokens)
+    print(f"\n[free-running greedy vs oracle] {compared} decidable steps compared, all equal")
+    assert compared >= 40
+    # one B = 16 batched call: a contact vector straight against the oracle (not only against evaluate() of the same image)
+    from interactvlm_amd import synth
+    B = 16
+    ic = torch.from_numpy(synth.synth_normal("eb16/images_clip", (B, 3, 224, 224), 1.0, 0)).to(bf)
+    im = torch.from_numpy(synth.synth_normal("eb16/images", (B, 4, 3, 1024, 1024), 1.0, 0)).to(bf)
+    forced = ids[40:].tolist()
+    outs = m.evaluate_batch(ic.to(cuda), im.to(cuda), [ids[:40]] * B, [cams[0]] * B, [(1024, 1024)] * B, [(1024, 1024)] * B,
+                            forced_new_tokens=[forced] * B)
+    for b in (5, 15):
+        ref = P.model_forward(w, cfg, im[b].float(), ic[b: b + 1].float(), ids, cams[0], tables)["pred_contact"]
+        e = float((outs[b]["pred_contact_3d"].float().cpu() - ref).abs().max())
+        print(f"[evaluate_batch(16) image {b} vs oracle] max |dp| = {e:.2e}")
+        assert e < 1e-3
