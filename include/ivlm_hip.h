@@ -259,7 +259,10 @@ int ivlm_rmsnorm_fp8(const void *x, int x_dtype, const void *w, void *y, int64_t
  *   rel_h f32 [B*H,Sq,rel_kh], rel_w f32 [B*H,Sq,rel_kw] (or NULL): bias[q,k] = rel_h[q,k/rel_kw] + rel_w[q,k%rel_kw]
  *   TABLE MODE (rel_w == NULL, rel_h != NULL; D = 80, rel_kh == rel_kw == side, 2 * side <= 32, Sq == Sk == side^2: SAM's 14 x 14
  *   windows): rel_h points to the bf16 table [64, D] = [rel_pos_h (2 side - 1 rows) ; rel_pos_w (2 side - 1 rows) ; zeros] and the
- *   kernel computes the terms itself (one small MFMA product per query tile) - no ivlm_relpos_bias pass, no [B*H,Sq,2 side] arrays. */
+ *   kernel computes the terms itself (one small MFMA product per query tile) - no ivlm_relpos_bias pass, no [B*H,Sq,2 side] arrays.
+ *   The 64 x 64 grid (SAM's global blocks: rel_kh == rel_kw == 64, Sq == Sk == 4096) has a table mode too: rel_h points to the
+ *   [>= 254, D] table [rel_pos_h (127 rows) ; rel_pos_w (127 rows)] and every 128-query block computes its rel_h / rel_w terms
+ *   before its tile loop (39 MFMAs per query tile against 2816) - no G = q . T^T GEMM, no gather pass. */
 int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, const int64_t *strides_host, int B,
                         int H, int Sq, int Sk, int D, float scale, int causal, int q_pos0, const float *rel_h,
                         const float *rel_w, int rel_kh, int rel_kw, int kv_batch_div, int prescale_q,

@@ -105,10 +105,17 @@ __device__ __forceinline__ void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\
 // QLO (with F16; the "exact q" path of the fp16 mode): q arrives as hi + lo IEEE halves (a.q_lo: the [hi | lo] rows of the q projection
 // on split rows) - the rel-pos table product and Q.K^T take both halves (two MFMAs per fragment: q enters the scores exactly), and the
 // softmax weights are split the same way for P.V (two MFMAs per fragment).  k, v and the output stay single fp16.
-template <int DQK, int DV, bool CAUSAL, int REL, bool PP, bool SPLIT = false, bool F16 = false, bool QLO = false>
+// QLV 1: the lo half of q enters the in-kernel rel-pos table products only (REL 4 / REL 5), see win_attn_kernel.
+// REL 5 = REL 2 (SAM's 64 x 64 global grid, key tile = one grid row) with the decomposed rel-pos terms computed HERE from the
+// [rel_pos_h (127 rows) ; rel_pos_w (127 rows)] table instead of read from [B*H, S, 64] arrays: no batched G = q . T^T GEMM
+// (268 MB of fp32 G per global block), no gather pass (2 x 67 MB written, read back by this kernel).
+template <int DQK, int DV, bool CAUSAL, int REL, bool PP, bool SPLIT = false, bool F16 = false, int QLV = 0>
 __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) void attn_kernel(AttnArgs a) {
     static_assert(!(SPLIT && F16), "fp16 operands are single-pass");
-    static_assert(!QLO || (F16 && !SPLIT && !PP), "QLO: fp16 operands");
+    static_assert(!QLV || (F16 && !SPLIT && !PP), "QLV: fp16 operands");
+    static_assert(REL != 5 || (!SPLIT && !PP && DV == 80), "REL 5: SAM's global grid, the 4-wave block");
+    constexpr bool QLO = QLV == 2;
+    constexpr bool R2 = REL == 2 || REL == 5;  // rel_w seeds the accumulators, rel_h is one value per (query, key tile)
     constexpr uint32_t kOne16 = F16 ? 0x3C00u : 0x3F80u;  // 1.0 as a 16-bit operand
     // SPLIT: 8 waves of ONE 16-query tile each (the same 128 queries per block): two waves per SIMD to cover each other's LDS
     // and MFMA latencies - with two query tiles per wave the split kernel needs > 256 registers, i.e. one wave per SIMD (measured:
@@ -134,7 +141,7 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
     __shared__ __attribute__((aligned(16))) bf16_t Vs_[2][SPLIT ? 8 : VBUF];
     // REL 2: rel_h[query][key row] of the block's queries, one value per (query, key tile).  Read from global at its point of use it is a dependent load in every tile, and the s_waitcnt the
     // compiler puts in front of it also drains the K/V prefetches of the following tiles.
-    __shared__ __attribute__((aligned(16))) float Rh_[(REL == 2 && !SPLIT) ? kQBlk * kKV : 4];
+    __shared__ __attribute__((aligned(16))) float Rh_[(R2 && !SPLIT) ? kQBlk * kKV : 4];
     // REL 4: per-wave scratch of the rel-pos table product G^T = T . Q^T (64 table rows x 16 queries, row stride 65 floats)
     constexpr int kGW = 16 * 65;
     __shared__ float Gs_[(REL == 4 && !SPLIT) ? (NT / 64) * kGW : 4];
@@ -156,21 +163,24 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
     const bf16_t* __restrict__ Q = a.q + b * a.q_bs + h * a.q_hs;
     const bf16_t* __restrict__ K = a.k + bkv * a.k_bs + h * a.k_hs;
     const bf16_t* __restrict__ V = a.v + bkv * a.v_bs + h * a.v_hs;
-    const bf16_t* __restrict__ Ql = (SPLIT || QLO) ? a.q_lo + b * a.q_bs + h * a.q_hs : nullptr;
+    const bf16_t* __restrict__ Ql = (SPLIT || QLV) ? a.q_lo + b * a.q_bs + h * a.q_hs : nullptr;
     const bf16_t* __restrict__ Kl = SPLIT ? a.k_lo + bkv * a.k_bs + h * a.k_hs : nullptr;
     const bf16_t* __restrict__ Vl = SPLIT ? a.v_lo + bkv * a.v_bs + h * a.v_hs : nullptr;
 
     // ---- zero the pad chunks of K once (head dim < DQK), both buffers ------------------------------
-    if (DCH < KS * 4) {
-        constexpr int NPAD = KS * 4 - DCH;
-        for (int i = tid; i < 2 * kKV * NPAD; i += NT) {
-            const int buf = i / (kKV * NPAD), r = i % (kKV * NPAD);
-            const int key = r / NPAD, ch = DCH + r % NPAD;
-            const int phys = (ch & 3) ^ (((key >> 3) & 1) << 1);
-            *reinterpret_cast<u32x4_t*>(&Ks(buf)[(ch >> 2) * KPL + key * 32 + phys * 8]) = u32x4_t{0u, 0u, 0u, 0u};
-            if (SPLIT) *reinterpret_cast<u32x4_t*>(&Ks(buf)[KBUF + (ch >> 2) * KPL + key * 32 + phys * 8]) = u32x4_t{0u, 0u, 0u, 0u};
+    auto zero_pads = [&]() __attribute__((always_inline)) {
+        if (DCH < KS * 4) {
+            constexpr int NPAD = KS * 4 - DCH;
+            for (int i = tid; i < 2 * kKV * NPAD; i += NT) {
+                const int buf = i / (kKV * NPAD), r = i % (kKV * NPAD);
+                const int key = r / NPAD, ch = DCH + r % NPAD;
+                const int phys = (ch & 3) ^ (((key >> 3) & 1) << 1);
+                *reinterpret_cast<u32x4_t*>(&Ks(buf)[(ch >> 2) * KPL + key * 32 + phys * 8]) = u32x4_t{0u, 0u, 0u, 0u};
+                if (SPLIT) *reinterpret_cast<u32x4_t*>(&Ks(buf)[KBUF + (ch >> 2) * KPL + key * 32 + phys * 8]) = u32x4_t{0u, 0u, 0u, 0u};
+            }
         }
-    }
+    };
+    if (REL != 5) zero_pads();  // (REL 5 first uses the K buffers as the scratch of its table products)
 
     if (REL == 2) {  // rel_kh == 64 key rows (dispatch); rows of queries past Sq are clamped like the Q loads
         const int64_t bh = (int64_t)b * a.H + h;
@@ -185,8 +195,8 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
 
     // ---- Q fragments (B operand): lane holds Q[q0 + qt*16 + l15][(s*4+g)*8 .. +8] ---------------
     bf16x8_t qf[QT][KS];
-    constexpr bool QL = SPLIT || QLO;
-    bf16x8_t qfl[QT][QL ? KS : 1];  // SPLIT / QLO: the lo halves
+    constexpr bool QL = SPLIT || QLV != 0;
+    bf16x8_t qfl[QT][QL ? KS : 1];  // SPLIT / QLV: the lo halves
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         int qi = q0 + qt * 16 + l15;
@@ -243,7 +253,7 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
                 qf[qt][s_] = __builtin_bit_cast(bf16x8_t, uh);
             }
     };
-    if (REL != 4) prescale();
+    if (REL != 4 && REL != 5) prescale();
 
     f32x4_t o[QT][DT];
 #pragma unroll
@@ -360,7 +370,66 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
         }
         qrel[qt] = *reinterpret_cast<bf16x8_t*>(&u);
     };
-    if (REL == 4) {
+    if (REL == 5) {
+        // T = a.rel_h: 16-bit [>= 254, DV] = [rel_pos_h (rows 0 .. 126) ; rel_pos_w (rows 127 .. 253)] of the 64 x 64 grid.  A wave's 32
+        // queries lie in ONE grid row qh (32 | 64), at columns qw0 + 0 .. 31 (qw0 = 0 or 32):
+        //   rel_h[q][kh] = Q[q] . T_h[qh - kh + 63]: the 64 rows qh .. qh + 63 for all of them -> 4 row tiles, straight into the Rh block;
+        //   rel_w[q][kw] = Q[q] . T_w[qw - kw + 63]: rows qw .. qw + 63, per 16-query tile the 79 rows from its first column on ->
+        //   5 row tiles, through a per-wave scratch (overlaid on the K buffers, which are not yet in use) for the Toeplitz pick of
+        //   each lane's 16 key columns.  39 MFMAs per query tile (x 2 with a lo half of q) against 2816 of the tile loop.
+        constexpr int G = kKV;  // grid side = key tile = 64 (dispatch)
+        const bf16_t* tab = reinterpret_cast<const bf16_t*>(a.rel_h);
+        const int qh = q0 / G, qw0 = q0 - qh * G;
+        constexpr int kSW = 16 * 81;  // floats per wave: 16 queries x (80 rows + 1)
+        static_assert(REL != 5 || 4 * kSW * 4 <= 2 * KBUF * 2, "REL 5 scratch must fit the K buffers");
+        float* Sw = reinterpret_cast<float*>(Ks0) + wave * kSW;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4_t gh[4], gw[5];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) gh[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt) gw[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const int wbase = qw0 + qt * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int d0 = (ks * 4 + g) * 8;
+#pragma unroll
+                for (int rt = 0; rt < 9; ++rt) {
+                    int row = rt < 4 ? qh + rt * 16 + l15 : (2 * G - 1) + wbase + (rt - 4) * 16 + l15;
+                    row = row < 2 * (2 * G - 1) ? row : 2 * (2 * G - 1) - 1;  // (rows past the table are never picked)
+                    u32x4_t t4 = u32x4_t{0u, 0u, 0u, 0u};
+                    if (d0 < DV) t4 = *reinterpret_cast<const u32x4_t*>(tab + row * DV + d0);
+                    const bf16x8_t tf = __builtin_bit_cast(bf16x8_t, t4);
+                    f32x4_t& acc = rt < 4 ? gh[rt < 4 ? rt : 0] : gw[rt < 4 ? 0 : rt - 4];
+                    acc = mma16<F16>(tf, qf[qt][ks], acc);
+                    if (QL) acc = mma16<F16>(tf, qfl[qt][QL ? ks : 0], acc);
+                }
+            }
+            // (bf16 operands: the terms rounded to bf16, as the bf16 reference materialises them; fp16 operands: fp32 terms)
+            auto rnd = [](float x) __attribute__((always_inline)) { return F16 ? x : bf16_to_f32(f32_to_bf16(x)); };
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Rh[(wave * kQPerWave + qt * 16 + l15) * kKV + (G - 1) - (rt * 16 + g * 4 + r)] = rnd(gh[rt][r]);
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Sw[l15 * 81 + rt * 16 + g * 4 + r] = gw[rt][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rwf[qt][kt][r] = rnd(Sw[l15 * 81 + l15 + (G - 1) - (kt * 16 + g * 4 + r)]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();  // the scratch is reused by the next query tile
+        }
+        prescale();
+        __syncthreads();  // every wave is done with its scratch: the K buffers may be staged now
+        zero_pads();
+    } else if (REL == 4) {
         // The decomposed rel-pos terms computed HERE instead of by a kernel of their own (54 us and 120 MB of traffic per
         // windowed block): G^T = T . Q^T on the matrix cores - T = [rel_pos_h ; rel_pos_w ; 0] (64 rows, a.rel_h), Q the UNSCALED
         // query fragments already in registers - lands in C layout (lane = query l15, rows g*4+r of each 16-row tile), goes through
@@ -456,10 +525,10 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = REL == 2 ? rwf[qt][kt] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = R2 ? rwf[qt][kt] : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (REL != 2 && kt >= nkt) continue;  // keys past Sk: their scores are masked below (REL 2: Sk % 64 == 0)
+            if (!R2 && kt >= nkt) continue;  // keys past Sk: their scores are masked below (REL 2 / 5: Sk % 64 == 0)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8_t kf =
@@ -513,7 +582,7 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
         // causal diagonal) first overwrite their invalid raw scores with -1e30 in a pre-pass under one wave-uniform
         // branch; exp2 of those is exactly 0 because every query has a valid key in its first tile (key 0).
         const int kv0 = t * kKV;
-        bool edge = REL != 2 && kv0 + kKV > a.Sk;  // (REL 2 is dispatched only when Sk is a whole number of tiles)
+        bool edge = !R2 && kv0 + kKV > a.Sk;  // (REL 2 / 5 are dispatched only when Sk is a whole number of tiles)
         if (CAUSAL) edge = edge || (kv0 + kKV - 1 > q0 + a.q_pos0);
         if (REL == 3 || edge) {
             asm volatile("" ::: "memory");  // keep this a real branch (if-converted it costs 2 VALU per score on EVERY tile)
@@ -550,7 +619,7 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
             // log2-domain score y = x * sc2 + bias2 (monotonic in x): the maximum is taken on the raw scores, and the
             // subtraction of the running maximum rides in the same fma as the scaling: p = exp2(x * sc2 + (bias2 - m))
             float bias2 = 0.0f;
-            if (REL == 2) bias2 = Rh[(wave * kQPerWave + qt * 16 + l15) * kKV + t] * sc2;
+            if (R2) bias2 = Rh[(wave * kQPerWave + qt * 16 + l15) * kKV + t] * sc2;
             float mx = kNegBig;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -630,7 +699,7 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
         // ---- O^T += V^T . P^T  (key step outer: one uniform skip test per 32 keys, DT independent accumulators inner) ---
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            if (REL != 2 && 2 * s2 >= nkt) continue;  // all 32 keys of this step are past Sk (their P is 0)
+            if (!R2 && 2 * s2 >= nkt) continue;  // all 32 keys of this step are past Sk (their P is 0)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -1283,12 +1352,20 @@ template <int DQK, int DV>
 int launch_f16(const AttnArgs& a, hipStream_t st) {
     const bool rel = a.rel_h != nullptr;
     dim3 grid((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B);
+    if constexpr (DV == 80) {  // SAM's 64 x 64 grid in table mode (REL 5): the terms computed in the kernel, q_lo (level 1) in them
+        if (!a.causal && rel && a.prescale_q && !a.rel_w && a.rel_kh == kKV && a.rel_kw == kKV && a.Sq == kKV * kKV && a.Sk == a.Sq) {
+            if (a.q_lo && a.q_lo_level >= 2) return IVLM_ERR_UNSUPPORTED;
+            if (a.q_lo) attn_kernel<DQK, DV, false, 5, false, false, true, 1><<<grid, 256, 0, st>>>(a);
+            else attn_kernel<DQK, DV, false, 5, false, false, true, 0><<<grid, 256, 0, st>>>(a);
+            return ivlm_launch_status();
+        }
+    }
     if (a.q_lo && a.q_lo_level < 2 && a.rel_w) {
         // level 1 with the terms as arrays: the lo half of q is already in them (ivlm_relpos_* on hi + lo) - the plain fp16 kernel
     } else if (a.q_lo) {  // level 2 (QLO): SAM's global grid with the rel-pos terms as arrays (windows take the whole-window kernel)
         if constexpr (DV == 80) {
             if (!a.causal && rel && a.prescale_q && a.rel_w && a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw) {
-                attn_kernel<DQK, DV, false, 2, false, false, true, true><<<grid, 256, 0, st>>>(a);
+                attn_kernel<DQK, DV, false, 2, false, false, true, 2><<<grid, 256, 0, st>>>(a);
                 return ivlm_launch_status();
             }
         }
@@ -1322,7 +1399,10 @@ int launch_dp(const AttnArgs& a, hipStream_t st) {
     } else if (rel) {
         if (DV != 80) return IVLM_ERR_UNSUPPORTED;  // only SAM's ViT uses rel-pos; keeps the build small
         if (!a.prescale_q) return IVLM_ERR_UNSUPPORTED;
-        if (!a.rel_w)  // rel_h is the bf16 table [64, D]: the rel-pos terms are computed in the kernel (windows: 2 * side <= 32)
+        if (!a.rel_w && a.rel_kh == kKV && a.rel_kw == kKV && a.Sq == kKV * kKV && a.Sk == a.Sq) {  // the 64 x 64 grid in table mode
+            if constexpr (DV == 80 && !PP) attn_kernel<DQK, DV, false, 5, false><<<dim3(a.Sq / kQPerBlock, a.H, a.B), 256, 0, st>>>(a);
+            else return IVLM_ERR_UNSUPPORTED;
+        } else if (!a.rel_w)  // rel_h is the bf16 table [64, D]: the rel-pos terms are computed in the kernel (windows: 2 * side <= 32)
             attn_kernel<DQK, DV, false, DV == 80 ? 4 : 0, false><<<dim3((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B), 256, 0, st>>>(a);
         else if (a.rel_kw == kKV && a.Sk == a.rel_kh * a.rel_kw)
             attn_kernel<DQK, DV, false, DV == 80 ? 2 : 0, PP><<<grid, NT, 0, st>>>(a);
@@ -1538,10 +1618,11 @@ int attention_bf16(const AttnArgs& a, hipStream_t st) {
         return IVLM_ERR_UNSUPPORTED;  // 16-byte row chunks
     if ((a.o_rs | a.o_hs | a.o_bs) & 3) return IVLM_ERR_UNSUPPORTED;
     if (a.rel_h && (a.rel_kh <= 0 || a.rel_kw <= 0)) return IVLM_ERR_INVALID_ARG;
-    if (a.rel_h && !a.rel_w) {  // table mode: square windows whose 2 * side terms fit one MFMA k-step, queries = keys = side^2
-        if (a.rel_kh != a.rel_kw || 2 * a.rel_kh > 32 || a.Sq != a.rel_kh * a.rel_kw || a.Sk != a.Sq || a.D != 80 ||
+    if (a.rel_h && !a.rel_w) {  // table mode: square windows whose 2 * side terms fit one MFMA k-step, or the 64 x 64 grid (REL 5)
+        if (a.rel_kh != a.rel_kw || (2 * a.rel_kh > 32 && a.rel_kh != kKV) || a.Sq != a.rel_kh * a.rel_kw || a.Sk != a.Sq || a.D != 80 ||
             (reinterpret_cast<uintptr_t>(a.rel_h) & 15))
             return IVLM_ERR_UNSUPPORTED;
+        if (a.rel_kh == kKV && a.q_lo && !a.f16) return IVLM_ERR_UNSUPPORTED;  // (the split kernels take the terms as arrays)
     }
     if (a.f16) {  // fp16 operands: at most a lo plane of q ("exact q")
         if (a.k_lo || a.v_lo || a.o_lo) return IVLM_ERR_INVALID_ARG;

@@ -424,7 +424,12 @@ extern "C" int ivlm_sam_encode(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, c
             if ((rc = ivlm_launch_status())) return rc;
         }
         float *rh, *rw;
-        if (side >= 32) {  // rel-pos operands through one batched GEMM over the heads + Toeplitz gather
+        if (side == 64 && hdim == 80 && 2 * (2 * side - 1) <= npad) {
+            // the 64 x 64 grid: TABLE MODE too (REL 5 of attn_kernel) - every 128-query block computes its terms from rel_cat
+            // ([rel_pos_h (127 rows) ; rel_pos_w (127 rows)]) before its tile loop: no G GEMM, no gather
+            rh = reinterpret_cast<float*>(const_cast<void*>(Bk.rel_cat));
+            rw = nullptr;
+        } else if (side >= 32) {  // rel-pos operands through one batched GEMM over the heads + Toeplitz gather
             rh = relh_g; rw = relw_g;
             const int M = nb * S;
             GemmArgs gg;

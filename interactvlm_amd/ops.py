@@ -569,7 +569,8 @@ def attention(q, k, v, scale, causal=False, q_pos0=0, rel=None, out=None, presca
     if rel_tab is not None:  # table mode: rel_h = the bf16 table, rel_w = NULL
         rel_h, kh = rel_tab
         kw = kh
-        assert rel is None and rel_h.dtype == dt and rel_h.shape == (64, D) and rel_h.is_contiguous()
+        assert rel is None and rel_h.dtype == dt and rel_h.is_contiguous() and rel_h.shape[1] == D
+        assert rel_h.shape[0] == 64 if 2 * kh <= 32 else (kh == 64 and rel_h.shape[0] >= 254)  # windows | the 64 x 64 grid
     if q_lo is not None:  # fp16 "exact q": q = q + q_lo as IEEE halves (SAM shapes; the strides of q)
         assert dt == F16 and q_lo.dtype == F16 and q_lo.stride() == q.stride() and q_lo.shape == q.shape and not causal and B == Bk
         check(lib.ivlm_attention_f16_qsplit(q.data_ptr(), q_lo.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),

@@ -117,6 +117,7 @@ class SamImageEncoder:
     # stream stays fp32.
     fp8 = False
     rel_in_kernel = True  # window attention computes its rel-pos terms itself (ops.attention rel_tab=...); False: relpos kernel
+    rel_in_kernel_global = True  # ... and so does the global 64 x 64 attention (bf16 / fp16 operands; the split kernels take arrays)
     parity_window_arrays = True
 
     def enable_fp8(self, calib_images):
@@ -156,7 +157,7 @@ class SamImageEncoder:
             ops.fill_rows(qkv, pad, blk["qkv"].b)
         qkv5 = qkv.view(nwin, S, 3, H, hd)
         q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
+        if self.rel_in_kernel and (2 * side <= 32 or (side == 64 and self.rel_in_kernel_global)) and hd == 80:
             # windows: the decomposed rel-pos terms are computed inside the attention kernel (one small MFMA product per query
             # tile against the [rel_pos_h ; rel_pos_w] table) - no relpos pass, no [B*H, S, 2 side] fp32 arrays
             if "rel_cat" not in blk:
@@ -187,7 +188,7 @@ class SamImageEncoder:
             ops.fill_rows(qkv, pad, blk["qkv"].b)
         qkv5 = qkv.view(nw_, S, 3, H, hd)
         q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
+        if self.rel_in_kernel and (2 * side <= 32 or (side == 64 and self.rel_in_kernel_global)) and hd == 80:
             if "rel_cat" not in blk:
                 blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
             a = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_cat"], side)).permute(0, 2, 1, 3).reshape(nw_ * S, H * hd)
@@ -301,7 +302,7 @@ class SamImageEncoder:
             q4, kv4 = q2.view(nwin, S, 2, H, hd), kv.view(nwin, S, 2, H, hd)
             q, q_lo, k, v = (t.permute(0, 2, 1, 3) for t in (q4[:, :, 0], q4[:, :, 1], kv4[:, :, 0], kv4[:, :, 1]))
             lv = self.q_lo_level  # 1: q's lo half in the rel-pos terms only (what amplifies its rounding); 2: in Q.K^T too, split P
-            if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
+            if self.rel_in_kernel and (2 * side <= 32 or (side == 64 and self.rel_in_kernel_global)) and hd == 80:
                 o = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_cat_h"], side), q_lo=q_lo, q_lo_level=lv)
             else:
                 rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat_h"], q_lo=q_lo)
@@ -315,7 +316,7 @@ class SamImageEncoder:
             ops.fill_rows(qkv, pad, blk["qkv_b_h"])
         qkv5 = qkv.view(nwin, S, 3, H, hd)
         q, k, v = (qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        if self.rel_in_kernel and 2 * side <= 32 and hd == 80:
+        if self.rel_in_kernel and (2 * side <= 32 or (side == 64 and self.rel_in_kernel_global)) and hd == 80:
             o = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_cat_h"], side))
         else:
             rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat_h"])

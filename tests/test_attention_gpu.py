@@ -81,7 +81,7 @@ def test_attention_fused_qkv_layout_and_kv_broadcast(hip_lib, cuda):
 
 
 @pytest.mark.parametrize("SH,SW,B,H", [(14, 14, 3, 4), (64, 64, 1, 2)])
-def test_relpos_attention(hip_lib, cuda, SH, SW, B, H):
+def test_relpos_attention(hip_lib, cuda, SH, SW, B, H, attn_block_shape):
     """SAM decomposed relative-position bias (image_encoder.py:321-392)."""
     import torch
 
@@ -111,6 +111,13 @@ def test_relpos_attention(hip_lib, cuda, SH, SW, B, H):
     got = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), scale, rel=(gh, gw))
     err = (got.float().cpu() - ref).abs().max().item()
     assert err < 3e-2, f"max err {err}"
+    if SH == 64 and attn_block_shape == "4-wave":  # table mode of the global grid (REL 5): the terms computed in the kernel
+        cat = ops.relpos_tables_cat(tab_h.to(cuda), tab_w.to(cuda))
+        got_t = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), scale, rel_tab=(cat, SH))
+        err_t = (got_t.float().cpu() - ref).abs().max().item()
+        d = (got_t.float() - got.float()).abs().max().item()
+        print(f"\n[64 x 64 grid, bf16] table mode vs reference {err_t:.2e} (array mode {err:.2e}), table vs array mode {d:.2e}")
+        assert err_t < 3e-2 and d < 2e-2
 
 
 def test_attention_rescale_branch_forced(hip_lib, cuda):
@@ -240,7 +247,7 @@ def test_relpos_attention_f16(hip_lib, cuda, SH, SW, B, H):
         gh, gw = ops.relpos_bias(qc, tab_h.to(cuda), tab_w.to(cuda), SH, SW, cat=cat)
         assert (gh.double().cpu() - rel_h.reshape(B * H, S, SH)).abs().max().item() < 2e-5  # (fp32 terms: exact products of fp16 q)
         assert (gw.double().cpu() - rel_w.reshape(B * H, S, SW)).abs().max().item() < 2e-5
-        outs = [ops.attention(qc, kc, vc, scale, rel=(gh, gw))]
+        outs = [ops.attention(qc, kc, vc, scale, rel=(gh, gw)), ops.attention(qc, kc, vc, scale, rel_tab=(cat, SH))]  # arrays | table mode
     for o in outs:
         err = (o.double().cpu() - ref).abs().max().item()
         print(f"f16 rel-pos attention {SH}x{SW}: max err {err:.2e}")
@@ -285,6 +292,11 @@ def test_relpos_attention_f16_exact_q(hip_lib, cuda, SH, SW, B, H):
         o1 = ops.attention(qh, kc, vc, scale, rel=rel)  # (level 1 with the terms as arrays IS the plain fp16 kernel)
         assert torch.equal(o1, ops.attention(qh, kc, vc, scale, rel=rel, q_lo=ql, q_lo_level=1))
         o0 = ops.attention(qh, kc, vc, scale, rel=ops.relpos_bias(qh, tab_h.to(cuda), tab_w.to(cuda), SH, SW, cat=cat))
+        # table mode of the grid (REL 5) with the lo half of q in its table products == level 1 with the terms as arrays
+        ot = ops.attention(qh, kc, vc, scale, rel_tab=(cat, SH), q_lo=ql, q_lo_level=1)
+        dt = (ot.double() - o1.double()).abs().max().item()
+        print(f"[64 x 64 grid, fp16 exact q] table mode vs array mode: {dt:.2e}")
+        assert dt < 1e-3 and (ot.double().cpu() - ref).abs().max().item() < 2.5e-3
     e2, e1, e0 = ((o.double().cpu() - ref).abs().max().item() for o in (o2, o1, o0))
     print(f"exact-q fp16 attention {SH}x{SW}: max err level 2 {e2:.2e}, level 1 (rel-pos terms only) {e1:.2e}, single fp16 q {e0:.2e}")
     assert e2 < 1.5e-3 and e1 < 2.5e-3 and e2 <= e1 < e0, (e2, e1, e0)

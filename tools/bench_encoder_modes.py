@@ -29,6 +29,7 @@ def main():
         enc.precision = "default" if mode == "default" else "parity"
         enc.parity_sites = {"f16": enc.SITES_F16, "f16q": enc.SITES_F16Q, "parity-fast": enc.PARITY_SITES_FAST}.get(mode, enc.PARITY_SITES)
         enc.rel_in_kernel = rik
+        enc.rel_in_kernel_global = os.environ.get("GLOB_TAB", "1") == "1"  # REL 5: the global blocks' rel-pos terms in the kernel
         enc.parity_window_arrays = os.environ.get("PWA", "1") == "1"
         if hasattr(enc, "_graphs"):
             enc._graphs.clear()
