@@ -88,6 +88,15 @@ size_t ivlm_lift_plan_workspace_bytes(int V, int64_t HW, int Nv);
 int ivlm_lift_plan_build(const int32_t *vid, const float *bary, int V, int64_t HW, int Nv,
                          int32_t *row_ptr, int32_t *ent_pix, float *ent_w, int64_t cap, int32_t *nnz_out,
                          void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* The same inversion for a pixel -> point map of ObjectPCAfford3DPredictor (components.py:318-347; pid i32 [V,HW], -1 = no point):
+ * a point-major CSR with weights 1, rows ordered by pixel; cap >= V*HW.  Evaluated by ivlm_lift_mesh_plan with mode 2 (the map's
+ * own values are averaged: per view over the pixels of a point, then over the views that see it; no sigmoid, no clip): no
+ * atomics, no workspace, bit-reproducible - the p2pmap files are cached per path by the predictor, so a map that comes back is
+ * inverted once. */
+int ivlm_lift_points_plan_build(const int32_t *pid, int V, int64_t HW, int Np, int32_t *row_ptr, int32_t *ent_pix, float *ent_w,
+                                int64_t cap, int32_t *nnz_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* Benchmark hook: blocks per CU of the streaming lift kernels (ivlm_lift_mesh_dense / ivlm_lift_points); returns the previous value. */
+int ivlm_lift_stream_blocks_per_cu(int bpc);
 
 /* HumanContact3DPredictor.forward (model/components.py:220-277), deterministic vertex-major
  * gather over a lift plan:  m = sigmoid(clamp(logit,+-clampv)); per view votes/cnt; mean over

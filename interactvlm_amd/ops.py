@@ -162,6 +162,32 @@ class LiftPlan:
     def bytes(self) -> int:
         return self.nnz * 8 + self.row_ptr.numel() * 4
 
+    @classmethod
+    def from_points(cls, pid: torch.Tensor, num_points: int):
+        """Point-major CSR of a pixel -> point map (pid i32 [V,H,W], -1 = no point): weights 1, evaluated with mode 2."""
+        lib = _lib.load()
+        pid = _req(pid, torch.int32, "pid")
+        assert pid.dim() == 3, "pid must be [V,H,W]"
+        self = cls.__new__(cls)
+        V, H, W = pid.shape
+        self.V, self.HW, self.hw_shape, self.num_vertices = V, H * W, (H, W), int(num_points)
+        dev = pid.device
+        cap = V * H * W
+        self.row_ptr = torch.empty(V * self.num_vertices + 1, dtype=torch.int32, device=dev)
+        ent_pix = torch.empty(cap, dtype=torch.int32, device=dev)
+        ent_w = torch.empty(cap, dtype=torch.float32, device=dev)
+        nnz = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws_bytes = lib.ivlm_lift_plan_workspace_bytes(V, self.HW, self.num_vertices)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(lib.ivlm_lift_points_plan_build(pid.data_ptr(), V, self.HW, self.num_vertices, self.row_ptr.data_ptr(),
+                                              ent_pix.data_ptr(), ent_w.data_ptr(), cap, nnz.data_ptr(), ws.data_ptr(), ws_bytes,
+                                              _stream()), "lift_points_plan_build")
+        self.nnz = int(nnz.item())
+        keep = max(self.nnz, 1)
+        self.ent_pix = ent_pix[:keep].clone()
+        self.ent_w = ent_w[:keep].clone()
+        return self
+
 
 def lift_mesh_plan(logits: torch.Tensor, plan: LiftPlan, mode: int = 0, param: float = 20.0, want_nviews=False):
     """logits f32 [B,V,H,W] -> contacts f32 [B,Nv] (and nviews) via the CSR plan."""
@@ -249,6 +275,12 @@ def lift_points(probs, pid, num_points: int, want_nviews=False):
     check(lib.ivlm_lift_points(probs.data_ptr(), pid.data_ptr(), batched, B, V, HW, n, out.data_ptr(), _p(nviews),
                                ws.data_ptr(), ws.numel(), _stream()), "lift_points")
     return (out, nviews) if want_nviews else out
+
+
+def lift_points_plan(probs, plan: LiftPlan, want_nviews=False):
+    """probs f32 [B,V,H,W] -> f32 [B,Np] through a point-major plan (``LiftPlan.from_points``): the deterministic, atomic-free
+    counterpart of ``lift_points`` for a pixel -> point map that is used more than once."""
+    return lift_mesh_plan(probs, plan, mode=2, param=0.0, want_nviews=want_nviews)
 
 
 def postprocess_masks(low_res, input_size, original_size, img_size: int = 1024, apply_sigmoid: bool = False, sigmoid_gt=None,

@@ -31,7 +31,8 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     assert lib.ivlm_lift_mesh_plan(None, None, None, None, 1, 4, 16, 8, 0, 20.0, None, None, None) == -1
     assert lib.ivlm_postprocess_masks(None, 0, 1, 4, 4, 16, 16, 16, 16, 16, 0, None, None) == -1
-    assert lib.ivlm_lift_mesh_dense_workspace_bytes(2, 4, 6890) == 2 * 4 * 6890 * 2 * 4
+    assert lib.ivlm_lift_mesh_dense_workspace_bytes(2, 4, 6890) == 2 * 4 * 6890 * 2 * 4 * 128  # one [2][Nv] slab per block: 128 per (image, view)
+    assert lib.ivlm_lift_mesh_dense_workspace_bytes(0, 4, 6890) == 0
 
 
 def test_ops_fail_loudly_on_cpu_tensors():

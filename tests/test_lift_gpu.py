@@ -168,6 +168,24 @@ def test_points_full_size_vs_oracle(hip_lib, cuda):
     got_s = ops.lift_points(_t(probs, cuda), _t(pid[0], cuda, torch.int32), NP)
     exp_s, _ = cref.lift_points(probs, np.stack([pid[0], pid[0]]), NP)
     np.testing.assert_allclose(got_s.cpu().numpy(), exp_s, atol=2e-5, rtol=0)
+    # the point-major plan of a map (what the predictor builds when a p2pmap set comes back): same means, same visibility,
+    # no atomics -> bit-reproducible
+    for b in range(B):
+        plan = ops.LiftPlan.from_points(_t(pid[b], cuda, torch.int32), NP)
+        assert plan.nnz == int(((pid[b] >= 0) & (pid[b] < NP)).sum())
+        gp, gn = ops.lift_points_plan(_t(probs[b: b + 1], cuda), plan, want_nviews=True)
+        np.testing.assert_allclose(gp.cpu().numpy(), exp[b: b + 1], atol=2e-5, rtol=0)
+        assert np.array_equal(gn.cpu().numpy(), exp_n[b: b + 1])
+        assert torch.equal(gp, ops.lift_points_plan(_t(probs[b: b + 1], cuda), plan))
+    # a map with unseen points and an empty view
+    pid_e = pid[0].copy()
+    pid_e[1] = -1
+    pid_e[pid_e == 7] = -1
+    plan = ops.LiftPlan.from_points(_t(pid_e, cuda, torch.int32), NP)
+    ge, gne = ops.lift_points_plan(_t(probs[:1], cuda), plan, want_nviews=True)
+    ee, ene = cref.lift_points(probs[:1], pid_e[None], NP)
+    np.testing.assert_allclose(ge.cpu().numpy(), ee, atol=2e-5, rtol=0)
+    assert np.array_equal(gne.cpu().numpy(), ene) and float(ge[0, 7]) == 0.0
 
 
 def test_edge_cases(hip_lib, cuda):
@@ -329,3 +347,9 @@ def test_predictor_modules_match_reference_api(hip_lib, cuda, tmp_path):
     o = pc([_t(probs[0], cuda), _t(probs[1], cuda)], None, paths)
     exp_p, _ = cref.lift_points(probs, pid, 2048)
     np.testing.assert_allclose(o.cpu().numpy(), exp_p, atol=2e-6)
+    # the same p2pmap files again: the predictor inverts them once into point-major plans (deterministic gather) - same results
+    o2 = pc([_t(probs[0], cuda), _t(probs[1], cuda)], None, paths)
+    assert len(pc._plans) == 2
+    np.testing.assert_allclose(o2.cpu().numpy(), exp_p, atol=2e-6)
+    o3 = pc([_t(probs[1], cuda)], None, paths[1:])
+    assert torch.equal(o3[0], o2[1])

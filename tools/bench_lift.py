@@ -72,7 +72,28 @@ def main():
     pid = torch.from_numpy(synth.synth_point_maps(B, V, H, W, NP, seed=0)).to(dev, torch.int32)
     pr = torch.rand(B, V, H, W, device=dev)
     t = timeit(lambda: ops.lift_points(pr, pid, NP), a.iters)
-    res["points"] = {"us": t * 1e6, "alg_GBps": B * ALG_BYTES_PC / t / 1e9}
+    res["points"] = {"us": t * 1e6, "alg_GBps": B * ALG_BYTES_PC / t / 1e9,
+                     "note": "streaming kernel (single-use maps): memset + vote kernel + finalize, back to back"}
+    # a RENDERED pixel -> point map (what the p2pmap files hold: utils_obj_pc.py:88-113 - splats of ~5 pixels, coherent along a row):
+    # 2048 points of the stand-in body under the four object cameras, radius 0.005 NDC
+    from interactvlm_amd import render
+    from interactvlm_amd.constants import OBJS_VIEW_DICT
+    bv, _ = synthetic.body_mesh()
+    pts = render.normalize_mesh(bv[torch.linspace(0, bv.shape[0] - 1, NP).long()].to(dev)).contiguous()
+    cams = OBJS_VIEW_DICT["4MV-Z_HM"]["cam_params"]
+    pid_r = torch.stack([render.rasterize_points(pts, cams[n], 0.005, (H, W)) for n in list(cams)[:V]])[None].contiguous()
+    t = timeit(lambda: ops.lift_points(pr[:1], pid_r, NP), a.iters)
+    res["points_rendered_map"] = {"us": t * 1e6, "alg_GBps": ALG_BYTES_PC / t / 1e9, "foreground": float((pid_r >= 0).float().mean()),
+                                  "note": "streaming kernel on a rasterised 2048-point cloud (runs of equal ids are summed in registers)"}
+    pplan_r = ops.LiftPlan.from_points(pid_r[0], NP)
+    t = timeit(lambda: ops.lift_points_plan(pr[:1], pplan_r), a.iters)
+    res["points_rendered_map_plan"] = {"us": t * 1e6, "alg_GBps": ALG_BYTES_PC / t / 1e9, "nnz": pplan_r.nnz}
+    pplan = ops.LiftPlan.from_points(pid[0], NP)
+    tp = timeit(lambda: ops.lift_points_plan(pr[:1], pplan), a.iters)
+    tb = timeit(lambda: ops.LiftPlan.from_points(pid[0], NP), iters=3, warm=1)
+    res["points_plan"] = {"us": tp * 1e6, "alg_GBps": ALG_BYTES_PC / tp / 1e9, "nnz": pplan.nnz, "plan_bytes": pplan.bytes(),
+                          "actual_GBps": (pplan.bytes() + pplan.nnz * 4) / tp / 1e9, "plan_build_ms": tb * 1e3,
+                          "note": "point-major plan of a cached p2pmap set (second sight on): one gather launch, no atomics"}
     low = torch.randn(B * V, 1, 256, 256, device=dev)
     t = timeit(lambda: ops.postprocess_masks(low, (1024, 1024), (1024, 1024)), a.iters)
     res["postprocess"] = {"us": t * 1e6, "alg_GBps": B * ALG_BYTES_POST / t / 1e9}
