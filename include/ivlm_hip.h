@@ -403,10 +403,21 @@ int ivlm_llama_prefill(const ivlm_llama_cfg *cfg, const ivlm_llama_layer *layers
  * workspace: ivlm_llama_decode_workspace_bytes, ZEROED by the caller at the start of every generation (arrival counters and
  * the tokens-decoded word of the fused attention + o_proj launch; its int32 word [activations..] status stays 0 unless a bounded
  * device-side wait expired).  advance != 0: *pos_dev += 1 at the end of the step (graph-replay friendly). */
+/* The prefill in the DEFAULT precision of the host model: IEEE fp16 MFMA operands; layers16_host = the same struct with qkv / o / gu /
+ * down pointing to fp16 copies of the bf16 weights (ln1 / ln2 unchanged), kcache16 / vcache16 hold IEEE halves.  T > 16 (shorter
+ * chunks: ivlm_llama_decode_step_f16kv token by token).  Workspace: ivlm_llama_prefill_workspace_bytes. */
+int ivlm_llama_prefill_f16(const ivlm_llama_cfg *cfg, const ivlm_llama_layer *layers16_host, const void *final_norm, void *kcache16,
+                           void *vcache16, const float *cos_tab, const float *sin_tab, const float *x_in, int T, int pos0,
+                           float *hidden_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
 size_t ivlm_llama_decode_workspace_bytes(const ivlm_llama_cfg *cfg);
 int ivlm_llama_decode_step(const ivlm_llama_cfg *cfg, const ivlm_llama_layer *layers_host, const void *final_norm, void *kcache,
                            void *vcache, const float *cos_tab, const float *sin_tab, const float *x_in, int32_t *pos_dev,
                            int advance, float *hidden_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* The decode step against the fp16 KV cache of ivlm_llama_prefill_f16: bf16 weights (layers_host), fp32 activations, K / V rows appended
+ * and read as IEEE halves; attention and o_proj as separate launches. */
+int ivlm_llama_decode_step_f16kv(const ivlm_llama_cfg *cfg, const ivlm_llama_layer *layers_host, const void *final_norm, void *kcache16,
+                                 void *vcache16, const float *cos_tab, const float *sin_tab, const float *x_in, int32_t *pos_dev,
+                                 int advance, float *hidden_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
 /* CLIPVisionTower.forward + feature_select('patch', layer -2) (clip_encoder.py:31-60): images bf16 [B,3,S,S] -> bf16
  * [B, tokens-1, hidden] (the mm_projector's operand).  layers_run = the encoder layers actually needed (23 of 24 for layer -2);
  * patch_w bf16 [hidden, kpad] (conv weight as GEMM rows, K zero-padded to kpad % 64 == 0), pos bf16 [tokens, hidden], cls_row
@@ -424,6 +435,12 @@ typedef struct {
 size_t ivlm_clip_encode_workspace_bytes(const ivlm_clip_cfg *cfg, int B);
 int ivlm_clip_encode(const ivlm_clip_cfg *cfg, const ivlm_clip_head *head, const ivlm_clip_layer *layers_host, const void *images,
                      int B, void *features_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* The same stage in the DEFAULT precision of the host model: IEEE fp16 MFMA operands (fp16 LayerNorm / q|k|v / quick-GELU outputs,
+ * fp16 attention).  layers16_host: the same struct with qkv_w / out_w / fc1_w / fc2_w pointing to fp16 copies (ivlm_bf16_to_f16) of
+ * the bf16 weights, biases and LayerNorm weights unchanged.  features_split_out: bf16 [B, tokens-1, 2*hidden] = [hi | lo] rows of the
+ * fp32 features (the mm_projector takes them with IVLM_GEMM_A_SPLIT).  Workspace: ivlm_clip_encode_workspace_bytes. */
+int ivlm_clip_encode_f16(const ivlm_clip_cfg *cfg, const ivlm_clip_head *head, const ivlm_clip_layer *layers16_host, const void *images,
+                         int B, void *features_split_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
 
 /* ImageEncoderViT.forward (image_encoder.py:110-125; Block :177-193, Attention :235-260, window partition :263-318, decomposed
  * rel-pos :354-392, neck :92-108): images bf16 [V,3,img,img] -> embeddings fp32 [V, grid*grid, out_chans] (channels last).
@@ -459,7 +476,20 @@ typedef struct {
 int ivlm_sam_encode_parity_f16mlp(const ivlm_sam_cfg *cfg, const ivlm_sam_head *head, const ivlm_sam_block *blocks_host,
                                   const ivlm_sam_mlp_f16 *mlp16_host, const void *images, int V, float *embeddings_out,
                                   void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
-/* bf16 -> IEEE fp16 (round to nearest even, saturating), n elements: weight copies for IVLM_GEMM_F16 / ivlm_sam_encode_parity_f16mlp */
+/* The stage in the DEFAULT precision of the host model - IEEE fp16 MFMA operands in one pass (an eighth of the bf16 operand rounding at
+ * the same matrix-core rate) with the q path exact: norm1 as [hi | lo] halves, q = W_q . (hi + lo) from its own GEMM as [hi | lo]
+ * halves, its lo half in the rel-pos table products of the attention kernels (fp32 rel-pos terms), k | v / proj / mlp on single fp16
+ * operands, the neck on hi + lo bf16 operands.  4 - 6e-4 end to end against the fp32 oracle at depth 32 (bf16 operands: 6e-3 .. 1e-2)
+ * for ~10 % more encoder time.  blocks16_host[l] = fp16 copies (ivlm_bf16_to_f16) of block l's qkv_w / proj_w / lin1_w / lin2_w, of
+ * its q|k|v bias and of rel_cat.  SAM ViT shapes (head dim 80, 64 x 64 grid, windows of 2 * side <= 32). */
+typedef struct {
+    const void *qkv_w16, *proj_w16, *lin1_w16, *lin2_w16, *qkv_b16, *rel_cat16;
+} ivlm_sam_block_f16;
+size_t ivlm_sam_encode_f16_workspace_bytes(const ivlm_sam_cfg *cfg, int V);
+int ivlm_sam_encode_f16(const ivlm_sam_cfg *cfg, const ivlm_sam_head *head, const ivlm_sam_block *blocks_host,
+                        const ivlm_sam_block_f16 *blocks16_host, const void *images, int V, float *embeddings_out, void *workspace,
+                        size_t workspace_bytes, ivlm_stream_t stream);
+/* bf16 -> IEEE fp16 (round to nearest even, saturating), n elements: weight copies for IVLM_GEMM_F16 / the *_f16 stages */
 int ivlm_bf16_to_f16(const void *src_bf16, void *dst_f16, int64_t n, ivlm_stream_t stream);
 
 /* PromptEncoder.forward(text_embeds) + MaskDecoder.forward(multimask_output=False) (prompt_encoder.py:140-186,

@@ -59,8 +59,10 @@ struct Carver {
 
 int lin(const void* A, int a_f32, int64_t lda, const void* W, int64_t ldw, void* C, int out_f32, int64_t ldc, const void* res,
         int res_f32, int M, int N, int K, int act, const void* rms_w, float eps, float* splitk_ws, size_t splitk_bytes,
-        hipStream_t st) {
+        hipStream_t st, int f16 = 0, int out_f16 = 0) {
     GemmArgs g;
+    g.f16 = f16;          // A and W are IEEE halves (the fp16-operand prefill)
+    g.out_f16 = out_f16;  // a 16-bit output is written as IEEE halves
     g.A = static_cast<const bf16_t*>(A);
     g.a_f32 = a_f32;
     g.W = static_cast<const bf16_t*>(W);
@@ -106,9 +108,9 @@ extern "C" size_t ivlm_llama_prefill_workspace_bytes(const ivlm_llama_cfg* c, in
     return b + 256;
 }
 
-extern "C" int ivlm_llama_prefill(const ivlm_llama_cfg* c, const ivlm_llama_layer* layers_host, const void* final_norm,
-                                  void* kcache, void* vcache, const float* cos_tab, const float* sin_tab, const float* x_in, int T,
-                                  int pos0, float* hidden_out, void* workspace, size_t workspace_bytes, ivlm_stream_t stream) {
+static int llama_prefill(const ivlm_llama_cfg* c, const ivlm_llama_layer* layers_host, const void* final_norm, void* kcache,
+                         void* vcache, const float* cos_tab, const float* sin_tab, const float* x_in, int T, int pos0, float* hidden_out,
+                         void* workspace, size_t workspace_bytes, ivlm_stream_t stream, const int f16) {
     ivlm_enter();
     if (!cfg_ok(c) || !layers_host || !final_norm || !kcache || !vcache || !x_in || !hidden_out || !workspace || T <= 0 || pos0 < 0 ||
         pos0 + T > c->max_len)
@@ -133,10 +135,11 @@ extern "C" int ivlm_llama_prefill(const ivlm_llama_cfg* c, const ivlm_llama_laye
         const ivlm_llama_layer& L = layers_host[l];
         bf16_t* kc = static_cast<bf16_t*>(kcache) + l * cache_layer;
         bf16_t* vc = static_cast<bf16_t*>(vcache) + l * cache_layer;
-        if ((rc = rmsnorm(x, 1, static_cast<const bf16_t*>(L.ln1), y, 0, T, Hd, c->eps, st))) return rc;
-        if ((rc = lin(y, 0, Hd, L.qkv, Hd, qkv, 0, 3 * Hd, nullptr, 0, T, 3 * Hd, Hd, ACT_NONE, nullptr, 0.f, sk, skb, st))) return rc;
-        if ((rc = rope_kv(qkv, 3 * Hd, T, H, D, pos0, c->theta, kc, vc, st, cos_tab, sin_tab))) return rc;
+        if ((rc = rmsnorm(x, 1, static_cast<const bf16_t*>(L.ln1), y, f16 ? 4 : 0, T, Hd, c->eps, st))) return rc;
+        if ((rc = lin(y, 0, Hd, L.qkv, Hd, qkv, 0, 3 * Hd, nullptr, 0, T, 3 * Hd, Hd, ACT_NONE, nullptr, 0.f, sk, skb, st, f16, f16))) return rc;
+        if ((rc = rope_kv(qkv, 3 * Hd, T, H, D, pos0, c->theta, kc, vc, st, cos_tab, sin_tab, f16))) return rc;
         AttnArgs a{};
+        a.f16 = f16;
         a.q = qkv; a.k = kc; a.v = vc; a.o = att;
         a.q_bs = 0; a.q_hs = D; a.q_rs = 3 * Hd;
         a.k_bs = 0; a.k_hs = D; a.k_rs = Hd;
@@ -148,14 +151,33 @@ extern "C" int ivlm_llama_prefill(const ivlm_llama_cfg* c, const ivlm_llama_laye
         a.kv_batch_div = 1; a.prescale_q = 0;
         if ((rc = attention_bf16(a, st))) return rc;
         float* x1 = (x == xa) ? xb : xa;
-        if ((rc = lin(att, 0, Hd, L.o, Hd, x1, 1, Hd, x, 1, T, Hd, Hd, ACT_NONE, nullptr, 0.f, sk, skb, st))) return rc;
-        if ((rc = rmsnorm(x1, 1, static_cast<const bf16_t*>(L.ln2), y, 0, T, Hd, c->eps, st))) return rc;
-        if ((rc = lin(y, 0, Hd, L.gu, Hd, hh, 0, I, nullptr, 0, T, 2 * I, Hd, ACT_SWIGLU, nullptr, 0.f, sk, skb, st))) return rc;
+        if ((rc = lin(att, 0, Hd, L.o, Hd, x1, 1, Hd, x, 1, T, Hd, Hd, ACT_NONE, nullptr, 0.f, sk, skb, st, f16, 0))) return rc;
+        if ((rc = rmsnorm(x1, 1, static_cast<const bf16_t*>(L.ln2), y, f16 ? 4 : 0, T, Hd, c->eps, st))) return rc;
+        if ((rc = lin(y, 0, Hd, L.gu, Hd, hh, 0, I, nullptr, 0, T, 2 * I, Hd, ACT_SWIGLU, nullptr, 0.f, sk, skb, st, f16, f16))) return rc;
         float* x2 = (x1 == xa) ? xb : xa;
-        if ((rc = lin(hh, 0, I, L.down, I, x2, 1, Hd, x1, 1, T, Hd, I, ACT_NONE, nullptr, 0.f, sk, skb, st))) return rc;
+        if ((rc = lin(hh, 0, I, L.down, I, x2, 1, Hd, x1, 1, T, Hd, I, ACT_NONE, nullptr, 0.f, sk, skb, st, f16, 0))) return rc;
         x = x2;
     }
     return rmsnorm(x, 1, static_cast<const bf16_t*>(final_norm), hidden_out, 1, T, Hd, c->eps, st);
+}
+
+extern "C" int ivlm_llama_prefill(const ivlm_llama_cfg* c, const ivlm_llama_layer* layers_host, const void* final_norm,
+                                  void* kcache, void* vcache, const float* cos_tab, const float* sin_tab, const float* x_in, int T,
+                                  int pos0, float* hidden_out, void* workspace, size_t workspace_bytes, ivlm_stream_t stream) {
+    return llama_prefill(c, layers_host, final_norm, kcache, vcache, cos_tab, sin_tab, x_in, T, pos0, hidden_out, workspace,
+                         workspace_bytes, stream, 0);
+}
+
+// The default precision of the host model (interactvlm_amd/llava.py Llama._layer_f16): IEEE fp16 MFMA operands in one pass - the
+// qkv / o / gu / down pointers of layers16_host are fp16 copies of the bf16 weights (ivlm_bf16_to_f16: exact inside the fp16
+// range; ln1 / ln2 stay the bf16 norm weights), RMSNorm / q|k|v / SwiGLU outputs and the KV cache are fp16.  Needs T > 16.
+extern "C" int ivlm_llama_prefill_f16(const ivlm_llama_cfg* c, const ivlm_llama_layer* layers16_host, const void* final_norm,
+                                      void* kcache16, void* vcache16, const float* cos_tab, const float* sin_tab, const float* x_in,
+                                      int T, int pos0, float* hidden_out, void* workspace, size_t workspace_bytes,
+                                      ivlm_stream_t stream) {
+    if (T <= 16) return IVLM_ERR_UNSUPPORTED;  // (the fp16 tile GEMMs; short chunks go through ivlm_llama_decode_step_f16kv)
+    return llama_prefill(c, layers16_host, final_norm, kcache16, vcache16, cos_tab, sin_tab, x_in, T, pos0, hidden_out, workspace,
+                         workspace_bytes, stream, 1);
 }
 
 extern "C" size_t ivlm_llama_decode_workspace_bytes(const ivlm_llama_cfg* c) {
@@ -165,10 +187,9 @@ extern "C" size_t ivlm_llama_decode_workspace_bytes(const ivlm_llama_cfg* c) {
     return al(3 * h * 4) + al(in * 4) + 2 * al(h * 4) + al(h * 4) + al(L * 32 * 4) + 256 + al(L * h * 4) + 256;
 }
 
-extern "C" int ivlm_llama_decode_step(const ivlm_llama_cfg* c, const ivlm_llama_layer* layers_host, const void* final_norm,
-                                      void* kcache, void* vcache, const float* cos_tab, const float* sin_tab, const float* x_in,
-                                      int32_t* pos_dev, int advance, float* hidden_out, void* workspace, size_t workspace_bytes,
-                                      ivlm_stream_t stream) {
+static int llama_decode_step(const ivlm_llama_cfg* c, const ivlm_llama_layer* layers_host, const void* final_norm, void* kcache,
+                             void* vcache, const float* cos_tab, const float* sin_tab, const float* x_in, int32_t* pos_dev, int advance,
+                             float* hidden_out, void* workspace, size_t workspace_bytes, ivlm_stream_t stream, const int cache_f16) {
     ivlm_enter();
     if (!cfg_ok(c) || !layers_host || !final_norm || !kcache || !vcache || !cos_tab || !sin_tab || !x_in || !pos_dev || !hidden_out ||
         !workspace)
@@ -192,7 +213,7 @@ extern "C" int ivlm_llama_decode_step(const ivlm_llama_cfg* c, const ivlm_llama_
         IVLM_HIP_TRY(hipGetDevice(&dev));
         IVLM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const bool fuse = c->fuse_attn_oproj && (Hd == 512 || Hd == 1024 || Hd == 4096 || Hd == 5120) && H + Hd / 32 <= cus;
+    const bool fuse = !cache_f16 && c->fuse_attn_oproj && (Hd == 512 || Hd == 1024 || Hd == 4096 || Hd == 5120) && H + Hd / 32 <= cus;
     const int64_t cache_layer = (int64_t)c->max_len * Hd;
     const float scale = 1.0f / sqrtf((float)D);
     const float* x = x_in;
@@ -208,7 +229,9 @@ extern "C" int ivlm_llama_decode_step(const ivlm_llama_cfg* c, const ivlm_llama_
                                   c->theta, scale, cos_tab, sin_tab, pos_dev, words + 1, counters + l * 32, words, st);
             if (rc) return rc;
         } else {
-            if ((rc = llama_decode_attn(qkv, 1, kc, vc, c->max_len, att, H, D, 0, c->theta, scale, st, cos_tab, sin_tab, pos_dev))) return rc;
+            if ((rc = llama_decode_attn(qkv, 1, kc, vc, c->max_len, att, H, D, 0, c->theta, scale, st, cos_tab, sin_tab, pos_dev, nullptr,
+                                        nullptr, cache_f16)))
+                return rc;
             if ((rc = lin(att, 1, Hd, L.o, Hd, x1, 1, Hd, x, 1, 1, Hd, Hd, ACT_NONE, nullptr, 0.f, nullptr, 0, st))) return rc;
         }
         if ((rc = lin(x1, 1, Hd, L.gu, Hd, hh, 1, I, nullptr, 0, 1, 2 * I, Hd, ACT_SWIGLU, L.ln2, c->eps, nullptr, 0, st))) return rc;
@@ -219,6 +242,24 @@ extern "C" int ivlm_llama_decode_step(const ivlm_llama_cfg* c, const ivlm_llama_
     if ((rc = rmsnorm(x, 1, static_cast<const bf16_t*>(final_norm), hidden_out, 1, 1, Hd, c->eps, st))) return rc;
     bump_kernel<<<1, 1, 0, st>>>(fuse ? words + 1 : nullptr, advance ? pos_dev : nullptr);  // tokens decoded += 1 (position += 1)
     return ivlm_launch_status();
+}
+
+extern "C" int ivlm_llama_decode_step(const ivlm_llama_cfg* c, const ivlm_llama_layer* layers_host, const void* final_norm,
+                                      void* kcache, void* vcache, const float* cos_tab, const float* sin_tab, const float* x_in,
+                                      int32_t* pos_dev, int advance, float* hidden_out, void* workspace, size_t workspace_bytes,
+                                      ivlm_stream_t stream) {
+    return llama_decode_step(c, layers_host, final_norm, kcache, vcache, cos_tab, sin_tab, x_in, pos_dev, advance, hidden_out, workspace,
+                             workspace_bytes, stream, 0);
+}
+
+// ... against the fp16 KV cache ivlm_llama_prefill_f16 fills: the bf16 weights of layers_host (fp32 activations, exact products, as
+// in every mode), K / V rows appended and read as IEEE halves (separate attention / o_proj launches).
+extern "C" int ivlm_llama_decode_step_f16kv(const ivlm_llama_cfg* c, const ivlm_llama_layer* layers_host, const void* final_norm,
+                                            void* kcache16, void* vcache16, const float* cos_tab, const float* sin_tab,
+                                            const float* x_in, int32_t* pos_dev, int advance, float* hidden_out, void* workspace,
+                                            size_t workspace_bytes, ivlm_stream_t stream) {
+    return llama_decode_step(c, layers_host, final_norm, kcache16, vcache16, cos_tab, sin_tab, x_in, pos_dev, advance, hidden_out,
+                             workspace, workspace_bytes, stream, 1);
 }
 
 // =====================================================================================================================
@@ -303,9 +344,8 @@ extern "C" size_t ivlm_clip_encode_workspace_bytes(const ivlm_clip_cfg* c, int B
            al(rows * c->inter * 2) + al(8 * rows * std::max<size_t>(3 * h, c->inter) * 4) + al(rows * 4) + 512;
 }
 
-extern "C" int ivlm_clip_encode(const ivlm_clip_cfg* c, const ivlm_clip_head* hd, const ivlm_clip_layer* layers_host,
-                                const void* images, int B, void* features_out, void* workspace, size_t workspace_bytes,
-                                ivlm_stream_t stream) {
+static int clip_encode(const ivlm_clip_cfg* c, const ivlm_clip_head* hd, const ivlm_clip_layer* layers_host, const void* images, int B,
+                       void* features_out, void* workspace, size_t workspace_bytes, ivlm_stream_t stream, const int f16) {
     ivlm_enter();
     if (!c || !hd || !layers_host || !images || !features_out || !workspace || B <= 0) return IVLM_ERR_INVALID_ARG;
     if (workspace_bytes < ivlm_clip_encode_workspace_bytes(c, B)) return IVLM_ERR_WORKSPACE;
@@ -338,26 +378,44 @@ extern "C" int ivlm_clip_encode(const ivlm_clip_cfg* c, const ivlm_clip_head* hd
                                  (int64_t)T * Hd, D, Hd};
     for (int l = 0; l < c->layers_run; ++l) {
         const ivlm_clip_layer& L = layers_host[l];
-        if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(L.ln1_w), static_cast<const bf16_t*>(L.ln1_b), y, 0, R, Hd, c->eps, st))) return rc;
-        if ((rc = gemm(y, Hd, L.qkv_w, Hd, qkv, 0, 3 * Hd, L.qkv_b, nullptr, 0, 0, 0, R, 3 * Hd, Hd, ACT_NONE, nullptr, nullptr, sk, skb, st))) return rc;
-        if ((rc = ivlm_attention_bf16(qkv, qkv + Hd, qkv + 2 * Hd, att, strides, B, H, T, T, D, 1.0f / sqrtf((float)D), 0, 0, nullptr,
-                                      nullptr, 0, 0, 1, 1, stream)))
+        const int k16 = f16 ? 4 : 0;  // (LayerNorm output kind: IEEE halves | bf16)
+        if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(L.ln1_w), static_cast<const bf16_t*>(L.ln1_b), y, k16, R, Hd, c->eps, st))) return rc;
+        if ((rc = gemm(y, Hd, L.qkv_w, Hd, qkv, 0, 3 * Hd, L.qkv_b, nullptr, 0, 0, 0, R, 3 * Hd, Hd, ACT_NONE, nullptr, nullptr, sk, skb, st, 0, 0, f16, f16))) return rc;
+        if ((rc = (f16 ? ivlm_attention_f16 : ivlm_attention_bf16)(qkv, qkv + Hd, qkv + 2 * Hd, att, strides, B, H, T, T, D,
+                                                                  1.0f / sqrtf((float)D), 0, 0, nullptr, nullptr, 0, 0, 1, 1, stream)))
             return rc;
         float* x1 = (x == xa) ? xb : xa;
-        if ((rc = gemm(att, Hd, L.out_w, Hd, x1, 1, Hd, L.out_b, x, 1, Hd, 0, R, Hd, Hd, ACT_NONE, nullptr, nullptr, sk, skb, st))) return rc;
-        if ((rc = layernorm(x1, 1, static_cast<const bf16_t*>(L.ln2_w), static_cast<const bf16_t*>(L.ln2_b), y, 0, R, Hd, c->eps, st))) return rc;
-        if ((rc = gemm(y, Hd, L.fc1_w, Hd, hh, 0, I, L.fc1_b, nullptr, 0, 0, 0, R, I, Hd, ACT_QUICK_GELU, nullptr, nullptr, sk, skb, st))) return rc;
+        if ((rc = gemm(att, Hd, L.out_w, Hd, x1, 1, Hd, L.out_b, x, 1, Hd, 0, R, Hd, Hd, ACT_NONE, nullptr, nullptr, sk, skb, st, 0, 0, f16, 0))) return rc;
+        if ((rc = layernorm(x1, 1, static_cast<const bf16_t*>(L.ln2_w), static_cast<const bf16_t*>(L.ln2_b), y, k16, R, Hd, c->eps, st))) return rc;
+        if ((rc = gemm(y, Hd, L.fc1_w, Hd, hh, 0, I, L.fc1_b, nullptr, 0, 0, 0, R, I, Hd, ACT_QUICK_GELU, nullptr, nullptr, sk, skb, st, 0, 0, f16, f16))) return rc;
         float* x2 = (x1 == xa) ? xb : xa;
-        if ((rc = gemm(hh, I, L.fc2_w, I, x2, 1, Hd, L.fc2_b, x1, 1, Hd, 0, R, Hd, I, ACT_NONE, nullptr, nullptr, sk, skb, st))) return rc;
+        if ((rc = gemm(hh, I, L.fc2_w, I, x2, 1, Hd, L.fc2_b, x1, 1, Hd, 0, R, Hd, I, ACT_NONE, nullptr, nullptr, sk, skb, st, 0, 0, f16, 0))) return rc;
         x = x2;
     }
-    // drop the CLS row of every image, fp32 stream -> bf16 features (the mm_projector's operand)
+    // drop the CLS row of every image, fp32 stream -> bf16 features (the mm_projector's operand); fp16 mode: [hi | lo] bf16 rows
+    // of width 2 * hidden (the projector takes split rows there: 0.03 % of the image's FLOPs)
+    const int fw = f16 ? 2 * Hd : Hd;
     for (int b = 0; b < B; ++b)
-        if ((rc = gather_rows(static_cast<bf16_t*>(features_out) + (size_t)b * (T - 1) * Hd, 0, Hd, x + ((size_t)b * T + 1) * Hd, 1, Hd,
+        if ((rc = gather_rows(static_cast<bf16_t*>(features_out) + (size_t)b * (T - 1) * fw, f16 ? 2 : 0, fw, x + ((size_t)b * T + 1) * Hd, 1, Hd,
                               nullptr, nullptr, 0, 0, T - 1, Hd, st)))
             return rc;
     (void)prow;
     return IVLM_OK;
+}
+
+extern "C" int ivlm_clip_encode(const ivlm_clip_cfg* c, const ivlm_clip_head* hd, const ivlm_clip_layer* layers_host,
+                                const void* images, int B, void* features_out, void* workspace, size_t workspace_bytes,
+                                ivlm_stream_t stream) {
+    return clip_encode(c, hd, layers_host, images, B, features_out, workspace, workspace_bytes, stream, 0);
+}
+
+// The default precision of the host model (interactvlm_amd/llava.py ClipTower, precision "f16"): IEEE fp16 MFMA operands - the
+// qkv_w / out_w / fc1_w / fc2_w pointers of layers16_host are fp16 copies of the bf16 weights (biases and LayerNorm weights stay
+// bf16); features_out: bf16 [B, tokens-1, 2*hidden] = [hi | lo] rows of the fp32 features (the mm_projector's split operand).
+extern "C" int ivlm_clip_encode_f16(const ivlm_clip_cfg* c, const ivlm_clip_head* hd, const ivlm_clip_layer* layers16_host,
+                                    const void* images, int B, void* features_split_out, void* workspace, size_t workspace_bytes,
+                                    ivlm_stream_t stream) {
+    return clip_encode(c, hd, layers16_host, images, B, features_split_out, workspace, workspace_bytes, stream, 1);
 }
 
 extern "C" size_t ivlm_sam_encode_workspace_bytes(const ivlm_sam_cfg* c, int V) {
@@ -414,6 +472,9 @@ extern "C" int ivlm_sam_encode(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, c
     const float scale = 1.0f / sqrtf((float)hdim);
     for (int l = 0; l < c->depth; ++l) {
         const ivlm_sam_block& Bk = blocks_host[l];
+        // rel_cat is READ by the attention kernels' table mode (windows: 64 rows; the 64 x 64 grid: 254 rows; zero-padded to a
+        // multiple of 64 rows - ABI version 4): a NULL table would silently drop the rel-pos bias
+        if (!Bk.rel_cat || !Bk.rel_h || !Bk.rel_w) return IVLM_ERR_INVALID_ARG;
         if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(Bk.norm1_w), static_cast<const bf16_t*>(Bk.norm1_b), xn, 0, R, D, 1e-6f, st))) return rc;
         const int side = Bk.global_attn ? g : wsz, S = side * side, nb = Bk.global_attn ? V : nwin;
         if (Bk.global_attn) {
@@ -594,6 +655,106 @@ extern "C" int ivlm_sam_encode_parity_f16mlp(const ivlm_sam_cfg* c, const ivlm_s
     ivlm_enter();
     if (!mlp16_host) return IVLM_ERR_INVALID_ARG;
     return sam_encode_parity(c, hd, blocks_host, mlp16_host, images, V, embeddings_out, workspace, workspace_bytes, stream);
+}
+
+// =====================================================================================================================
+// ivlm_sam_encode_f16: the stage in the DEFAULT precision of the host model (interactvlm_amd/sam.py SamImageEncoder._forward_parity
+// with SITES_F16Q, bit-identical to it): IEEE fp16 MFMA operands in one pass with the q path exact -
+//   norm1 -> [hi | lo] halves; q = W_q . (hi + lo) as its own GEMM, written as [hi | lo] halves; k | v: one GEMM on the hi half;
+//   attention on fp16 q / k / v with the lo half of q in the rel-pos table products (windows: whole-window kernel; the 64 x 64
+//   grid: REL 5), fp32 rel-pos terms; proj / mlp1 / mlp2 on fp16 operands; the neck on hi + lo bf16 operands.
+// blocks16_host[l]: fp16 copies of block l's four GEMM weights, of its q|k|v bias and of rel_cat (ivlm_bf16_to_f16).
+// =====================================================================================================================
+extern "C" size_t ivlm_sam_encode_f16_workspace_bytes(const ivlm_sam_cfg* c, int V) {
+    if (!c || V <= 0) return 0;
+    const size_t g2 = (size_t)c->grid * c->grid, rows = (size_t)V * g2, D = c->embed_dim;
+    const int nw = (c->grid + c->window - 1) / c->window;
+    const size_t wrows = (size_t)V * nw * nw * c->window * c->window, qrows = std::max(rows, wrows);
+    size_t b = al(rows * 3 * c->patch * c->patch * 2) + al(rows * D * 4) + al(rows * 2 * D * 2) + 2 * al(qrows * 2 * D * 2) +
+               al(qrows * D * 2) + al(rows * c->mlp_dim * 2);
+    b += al(wrows * 4) + al(rows * 4) + al(2 * D * 2);            // part / unpart maps, the [q bias | 0] row of the padded positions
+    b += al(rows * c->out_chans * 4) + al(rows * 2 * c->out_chans * 2) + al(rows * 18 * c->out_chans * 2);
+    return b + 1024;
+}
+
+extern "C" int ivlm_sam_encode_f16(const ivlm_sam_cfg* c, const ivlm_sam_head* hd, const ivlm_sam_block* blocks_host,
+                                   const ivlm_sam_block_f16* blocks16_host, const void* images, int V, float* embeddings_out,
+                                   void* workspace, size_t workspace_bytes, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!c || !hd || !blocks_host || !blocks16_host || !images || !embeddings_out || !workspace || V <= 0) return IVLM_ERR_INVALID_ARG;
+    if (workspace_bytes < ivlm_sam_encode_f16_workspace_bytes(c, V)) return IVLM_ERR_WORKSPACE;
+    hipStream_t st = ivlm_stream(stream);
+    const int g = c->grid, D = c->embed_dim, H = c->heads, hdim = D / H, wsz = c->window, OC = c->out_chans, MD = c->mlp_dim;
+    const int nw = (g + wsz - 1) / wsz, g2 = g * g, R = V * g2, nwin = V * nw * nw, WS = wsz * wsz, WR = nwin * WS;
+    const int Kp = 3 * c->patch * c->patch;
+    if (hdim != 80 || g != 64 || 2 * wsz > 32) return IVLM_ERR_UNSUPPORTED;  // (table-mode attention: SAM's head dim, grid and windows)
+    Carver cv{static_cast<char*>(workspace), workspace_bytes};
+    bf16_t* cols = static_cast<bf16_t*>(cv.take((size_t)R * Kp * 2));
+    float* x = static_cast<float*>(cv.take((size_t)R * D * 4));
+    bf16_t* xn = static_cast<bf16_t*>(cv.take((size_t)R * 2 * D * 2));
+    const size_t qrows = std::max(R, WR);
+    bf16_t* q2 = static_cast<bf16_t*>(cv.take(qrows * 2 * D * 2));   // [q hi | q lo]
+    bf16_t* kv = static_cast<bf16_t*>(cv.take(qrows * 2 * D * 2));   // [k | v]
+    bf16_t* att = static_cast<bf16_t*>(cv.take(qrows * D * 2));
+    bf16_t* hh = static_cast<bf16_t*>(cv.take((size_t)R * MD * 2));
+    int32_t* part = static_cast<int32_t*>(cv.take((size_t)WR * 4));
+    int32_t* unpart = static_cast<int32_t*>(cv.take((size_t)R * 4));
+    bf16_t* brow = static_cast<bf16_t*>(cv.take((size_t)2 * D * 2));
+    float* n0 = static_cast<float*>(cv.take((size_t)R * OC * 4));
+    bf16_t* n1 = static_cast<bf16_t*>(cv.take((size_t)R * 2 * OC * 2));
+    bf16_t* c3 = static_cast<bf16_t*>(cv.take((size_t)R * 18 * OC * 2));
+    if (!cv.ok) return IVLM_ERR_WORKSPACE;
+    int rc;
+    sam_window_maps_kernel<<<256, 256, 0, st>>>(V, g, wsz, nw, part, unpart);
+    if ((rc = ivlm_launch_status())) return rc;
+    if ((rc = im2col_nchw(static_cast<const bf16_t*>(images), cols, V, 3, c->img_size, c->img_size, c->patch, c->patch, Kp, st))) return rc;
+    if ((rc = gemm(cols, Kp, hd->patch_w, Kp, x, 1, D, hd->patch_b, hd->pos_embed, 0, D, g2, R, D, Kp, ACT_NONE, nullptr, nullptr, nullptr, 0, st))) return rc;
+    const float scale = 1.0f / sqrtf((float)hdim);
+    for (int l = 0; l < c->depth; ++l) {
+        const ivlm_sam_block& Bk = blocks_host[l];
+        const ivlm_sam_block_f16& B16 = blocks16_host[l];
+        if (!B16.qkv_w16 || !B16.proj_w16 || !B16.lin1_w16 || !B16.lin2_w16 || !B16.qkv_b16 || !B16.rel_cat16) return IVLM_ERR_INVALID_ARG;
+        const bf16_t* wq = static_cast<const bf16_t*>(B16.qkv_w16);
+        const bf16_t* bq = static_cast<const bf16_t*>(Bk.qkv_b);
+        if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(Bk.norm1_w), static_cast<const bf16_t*>(Bk.norm1_b), xn, 5, R, D, 1e-6f, st))) return rc;
+        const int side = Bk.global_attn ? g : wsz, S = side * side, nb = Bk.global_attn ? V : nwin;
+        const int32_t* omap = Bk.global_attn ? nullptr : unpart;
+        // q = W_q . (hi + lo) -> [hi | lo] halves;  k | v = W_kv . hi  (real rows only; windows: scattered to their window positions)
+        if ((rc = gemm(xn, 2 * D, wq, D, q2, 0, 2 * D, bq, nullptr, 0, 0, 0, R, D, D, ACT_NONE, omap, nullptr, nullptr, 0, st, 1, 1, 1, 1))) return rc;
+        if ((rc = gemm(xn, 2 * D, wq + (size_t)D * D, D, kv, 0, 2 * D, bq + D, nullptr, 0, 0, 0, R, 2 * D, D, ACT_NONE, omap, nullptr, nullptr, 0, st, 0, 0, 1, 1))) return rc;
+        if (!Bk.global_attn) {  // the padded window positions: q = [bias | 0], k | v = bias
+            IVLM_HIP_TRY(hipMemsetAsync(brow, 0, (size_t)2 * D * 2, st));
+            IVLM_HIP_TRY(hipMemcpyAsync(brow, B16.qkv_b16, (size_t)D * 2, hipMemcpyDeviceToDevice, st));
+            fill_pad_rows_kernel<<<2048, 256, 0, st>>>(q2, 2 * D, part, WR, brow, 2 * D);
+            fill_pad_rows_kernel<<<2048, 256, 0, st>>>(kv, 2 * D, part, WR, static_cast<const bf16_t*>(B16.qkv_b16) + D, 2 * D);
+            if ((rc = ivlm_launch_status())) return rc;
+        }
+        AttnArgs a{};
+        a.f16 = 1;
+        a.q = q2; a.q_lo = q2 + D; a.q_lo_level = 1;
+        a.k = kv; a.v = kv + D; a.o = att;
+        a.q_bs = a.k_bs = a.v_bs = (int64_t)S * 2 * D;
+        a.q_hs = a.k_hs = a.v_hs = hdim;
+        a.q_rs = a.k_rs = a.v_rs = 2 * D;
+        a.o_bs = (int64_t)S * D; a.o_hs = hdim; a.o_rs = D;
+        a.B = nb; a.H = H; a.Sq = S; a.Sk = S; a.D = hdim;
+        a.scale = scale; a.causal = 0; a.q_pos0 = 0;
+        a.rel_h = reinterpret_cast<const float*>(B16.rel_cat16); a.rel_w = nullptr; a.rel_kh = side; a.rel_kw = side;  // table mode
+        a.kv_batch_div = 1; a.prescale_q = 1;
+        if ((rc = attention_bf16(a, st))) return rc;
+        if ((rc = gemm(att, D, B16.proj_w16, D, x, 1, D, Bk.proj_b, x, 1, D, 0, R, D, D, ACT_NONE, nullptr, omap, nullptr, 0, st, 0, 0, 1, 0))) return rc;
+        if ((rc = layernorm(x, 1, static_cast<const bf16_t*>(Bk.norm2_w), static_cast<const bf16_t*>(Bk.norm2_b), xn, 4, R, D, 1e-6f, st))) return rc;
+        if ((rc = gemm(xn, D, B16.lin1_w16, D, hh, 0, MD, Bk.lin1_b, nullptr, 0, 0, 0, R, MD, D, ACT_GELU, nullptr, nullptr, nullptr, 0, st, 0, 0, 1, 1))) return rc;
+        if ((rc = gemm(hh, MD, B16.lin2_w16, MD, x, 1, D, Bk.lin2_b, x, 1, D, 0, R, D, MD, ACT_NONE, nullptr, nullptr, nullptr, 0, st, 0, 0, 1, 0))) return rc;
+    }
+    // neck: 1x1 conv, LayerNorm2d, 3x3 conv, LayerNorm2d on hi + lo bf16 operands (as the parity stage)
+    if ((rc = gather_rows(xn, 2, 2 * D, x, 1, D, nullptr, nullptr, 0, 0, R, D, st))) return rc;
+    if ((rc = gemm(xn, 2 * D, hd->neck0_w, D, n0, 1, OC, nullptr, nullptr, 0, 0, 0, R, OC, D, ACT_NONE, nullptr, nullptr, nullptr, 0, st, 1, 0))) return rc;
+    if ((rc = layernorm(n0, 1, static_cast<const bf16_t*>(hd->neck1_w), static_cast<const bf16_t*>(hd->neck1_b), n1, 2, R, OC, 1e-6f, st))) return rc;
+    if ((rc = im2col3x3_nhwc(n1, c3, V, g, g, OC, st, 2 * OC, 18 * OC))) return rc;
+    if ((rc = im2col3x3_nhwc(n1 + OC, c3 + 9 * OC, V, g, g, OC, st, 2 * OC, 18 * OC))) return rc;
+    if ((rc = gemm(c3, 18 * OC, hd->neck2_w, 9 * OC, n0, 1, OC, nullptr, nullptr, 0, 0, 0, R, OC, 9 * OC, ACT_NONE, nullptr, nullptr, nullptr, 0, st, 1, 0))) return rc;
+    return layernorm(n0, 1, static_cast<const bf16_t*>(hd->neck3_w), static_cast<const bf16_t*>(hd->neck3_b), embeddings_out, 1, R, OC, 1e-6f, st);
 }
 
 // =====================================================================================================================

@@ -281,13 +281,15 @@ class SamImageEncoder:
         H, hd = c.num_heads, D // c.num_heads
         S = side * side
         (wq,) = self._f16_weights(blk, ("qkv",))
-        if "qkv_b_h" not in blk:
-            blk["qkv_b_h"] = ops.bf16_to_f16(blk["qkv"].b)
+        if "q_b_split_h" not in blk:
+            if "qkv_b_h" not in blk:
+                blk["qkv_b_h"] = ops.bf16_to_f16(blk["qkv"].b)
             blk["q_b_split_h"] = torch.cat([blk["qkv_b_h"][:D], torch.zeros_like(blk["qkv_b_h"][:D])]).contiguous()
             blk["kv_b_h"] = blk["qkv_b_h"][D:].contiguous()
             if "rel_cat" not in blk:
                 blk["rel_cat"] = ops.relpos_tables_cat(blk["rel_h"], blk["rel_w"])
-            blk["rel_cat_h"] = ops.bf16_to_f16(blk["rel_cat"])
+            if "rel_cat_h" not in blk:
+                blk["rel_cat_h"] = ops.bf16_to_f16(blk["rel_cat"])
         if qx:
             bq, bkv = blk["qkv"].b[:D], blk["qkv"].b[D:]
             if win is None:

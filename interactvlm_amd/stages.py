@@ -49,6 +49,40 @@ class LlamaStages:
                                      int(pos0), out.data_ptr(), ws.data_ptr(), nbytes, self._stream()), "llama_prefill")
         return out
 
+    def _layers16(self):
+        """the layer table with qkv / o / gu / down pointing to the fp16 copies of the weights (ivlm_llama_prefill_f16)"""
+        if not hasattr(self, "layers16"):
+            Ls = [self.llm._f16(L) for L in self.llm.layers]
+            self.layers16 = (LlamaLayer * len(Ls))(*[LlamaLayer(L["ln1"].data_ptr(), L["qkv_h"].data_ptr(), L["o_h"].data_ptr(),
+                                                                 L["ln2"].data_ptr(), L["gu_h"].data_ptr(), L["down_h"].data_ptr())
+                                                      for L in Ls])
+        return self.layers16
+
+    def prefill_f16(self, x, pos0=0):
+        """The default precision of the host model: fp16 MFMA operands, fp16 KV cache (the instance's cache storage seen as fp16)."""
+        lib = _lib.load()
+        llm = self.llm
+        T = x.shape[0]
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        nbytes = lib.ivlm_llama_prefill_workspace_bytes(C.byref(self.cfg), T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(lib.ivlm_llama_prefill_f16(C.byref(self.cfg), self._layers16(), llm.norm.data_ptr(), llm.kcache.data_ptr(),
+                                         llm.vcache.data_ptr(), llm.rope[0].data_ptr(), llm.rope[1].data_ptr(), x.data_ptr(), T,
+                                         int(pos0), out.data_ptr(), ws.data_ptr(), nbytes, self._stream()), "llama_prefill_f16")
+        return out
+
+    def decode_step_f16kv(self, x, pos_dev, advance=True):
+        """One decode step against the fp16 KV cache (bf16 weights, fp32 activations)."""
+        lib = _lib.load()
+        llm = self.llm
+        out = torch.empty_like(x)
+        check(lib.ivlm_llama_decode_step_f16kv(C.byref(self.cfg), self.layers, llm.norm.data_ptr(), llm.kcache.data_ptr(),
+                                               llm.vcache.data_ptr(), llm.rope[0].data_ptr(), llm.rope[1].data_ptr(), x.data_ptr(),
+                                               pos_dev.data_ptr(), 1 if advance else 0, out.data_ptr(), self._dws.data_ptr(),
+                                               self._dws.numel(), self._stream()), "llama_decode_step_f16kv")
+        return out
+
     def start_generation(self):
         self._dws.zero_()
 
@@ -91,14 +125,26 @@ class ClipStages:
             ClipLayerC(p(L["ln1"].w), p(L["ln1"].b), p(L["qkv_w"]), p(L["qkv_b"]), p(L["out"].w), p(L["out"].b), p(L["ln2"].w),
                        p(L["ln2"].b), p(L["fc1"].w), p(L["fc1"].b), p(L["fc2"].w), p(L["fc2"].b)) for L in tower.layers])
 
-    def __call__(self, images):
+    def __call__(self, images, precision="bf16"):
+        """precision 'f16' (the host model's default): ``ivlm_clip_encode_f16`` -> [B, tokens-1, 2*hidden] split rows."""
         lib = _lib.load()
         images = images.to(torch.bfloat16).contiguous()
         B = images.shape[0]
         c = self.t.cfg
-        out = torch.empty(B, c.tokens - 1, c.hidden, dtype=torch.bfloat16, device=images.device)
+        f16 = precision == "f16"
+        out = torch.empty(B, c.tokens - 1, (2 if f16 else 1) * c.hidden, dtype=torch.bfloat16, device=images.device)
         nbytes = lib.ivlm_clip_encode_workspace_bytes(C.byref(self.cfg), B)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device)
+        if f16:
+            if not hasattr(self, "layers16"):
+                p = lambda t: t.data_ptr()
+                Ls = [self.t._f16(L) for L in self.t.layers]
+                self.layers16 = (ClipLayerC * len(Ls))(*[
+                    ClipLayerC(p(L["ln1"].w), p(L["ln1"].b), p(L["qkv_h"]), p(L["qkv_b"]), p(L["out_h"]), p(L["out"].b), p(L["ln2"].w),
+                               p(L["ln2"].b), p(L["fc1_h"]), p(L["fc1"].b), p(L["fc2_h"]), p(L["fc2"].b)) for L in Ls])
+            check(lib.ivlm_clip_encode_f16(C.byref(self.cfg), C.byref(self.head), self.layers16, images.data_ptr(), B, out.data_ptr(),
+                                           ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "clip_encode_f16")
+            return out
         check(lib.ivlm_clip_encode(C.byref(self.cfg), C.byref(self.head), self.layers, images.data_ptr(), B, out.data_ptr(),
                                    ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "clip_encode")
         return out
@@ -120,6 +166,10 @@ class SamBlockC(C.Structure):
 
 class SamMlpF16C(C.Structure):
     _fields_ = [("lin1_w16", C.c_void_p), ("lin2_w16", C.c_void_p)]
+
+
+class SamBlockF16C(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w16", "proj_w16", "lin1_w16", "lin2_w16", "qkv_b16", "rel_cat16")]
 
 
 class SamEncodeStages:
@@ -152,6 +202,23 @@ class SamEncodeStages:
         c = self.e.cfg
         out = torch.empty(V, c.grid * c.grid, c.out_chans, dtype=torch.float32, device=images.device)
         st = torch.cuda.current_stream().cuda_stream
+        if precision == "f16":  # the host model's default: fp16 operands, exact q path (ivlm_sam_encode_f16)
+            from . import ops
+            if not hasattr(self, "blocks16"):
+                rows = []
+                for b in self.e.blocks:
+                    w = self.e._f16_weights(b, ("qkv", "proj", "lin1", "lin2"))
+                    if "qkv_b_h" not in b:
+                        b["qkv_b_h"] = ops.bf16_to_f16(b["qkv"].b)
+                    if "rel_cat_h" not in b:
+                        b["rel_cat_h"] = ops.bf16_to_f16(b["rel_cat"])
+                    rows.append(SamBlockF16C(*[t.data_ptr() for t in w], b["qkv_b_h"].data_ptr(), b["rel_cat_h"].data_ptr()))
+                self.blocks16 = (SamBlockF16C * c.depth)(*rows)
+            nbytes = lib.ivlm_sam_encode_f16_workspace_bytes(C.byref(self.cfg), V)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device)
+            check(lib.ivlm_sam_encode_f16(C.byref(self.cfg), C.byref(self.head), self.blocks, self.blocks16, images.data_ptr(), V,
+                                          out.data_ptr(), ws.data_ptr(), nbytes, st), "sam_encode_f16")
+            return out
         if precision == "parity-encoder":
             if not hasattr(self, "mlp16"):
                 w16 = [self.e._f16_weights(b) for b in self.e.blocks]

@@ -50,6 +50,27 @@ def test_llama_prefill_and_decode_step_equal_python_path(hip_lib, cuda, hidden, 
         assert torch.equal(hb[1 + t], ha[1 + t]), (t, float((hb[1 + t] - ha[1 + t]).abs().max()))
     n = T0 + n_new
     assert torch.equal(b.kcache[:, :n], a.kcache[:, :n]) and torch.equal(b.vcache[:, :n], a.vcache[:, :n])
+    if not fuse:
+        # the DEFAULT precision of the host model: ivlm_llama_prefill_f16 / ivlm_llama_decode_step_f16kv (fp16 MFMA operands, fp16
+        # KV cache) == the Python-sequenced "f16" path bit for bit
+        a2 = llava.Llama(w, lc, cuda, max_len=512)
+        a2.set_precision("f16")
+        h2 = [a2.forward(emb[:T0], 0)]
+        for t in range(n_new):
+            h2.append(a2.forward(emb[T0 + t: T0 + t + 1], T0 + t))
+        b2 = llava.Llama(w, lc, cuda, max_len=512)
+        b2.set_precision("f16")  # (only so that its cache view is the fp16 one below)
+        st2 = stages.LlamaStages(b2)
+        g2 = [st2.prefill_f16(emb[:T0], 0)]
+        st2.start_generation()
+        pos2 = torch.tensor([T0], dtype=torch.int32, device=cuda)
+        for t in range(n_new):
+            g2.append(st2.decode_step_f16kv(emb[T0 + t: T0 + t + 1].contiguous(), pos2, advance=True))
+        for t in range(n_new + 1):
+            assert torch.equal(g2[t], h2[t]), (t, float((g2[t] - h2[t]).abs().max()))
+        ka, kb = a2._caches()[0], b2._caches()[0]
+        assert ka.dtype == torch.float16 and torch.equal(kb[:, :n], ka[:, :n]) and torch.equal(b2._caches()[1][:, :n], a2._caches()[1][:, :n])
+        assert not torch.equal(h2[0], ha[0])  # (and it is a different rounding than the bf16 path)
     # errors: a workspace that is too small is reported, not overrun
     import ctypes as C
     from interactvlm_amd import _lib
@@ -74,6 +95,12 @@ def test_clip_encode_stage_equals_python_path(hip_lib, cuda):
     ref = tower._forward(x)
     got = stages.ClipStages(tower)(x)
     assert got.shape == ref.shape and torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+    # the default precision of the host model: ivlm_clip_encode_f16 == ClipTower in "f16" precision (split feature rows)
+    tower.precision = "f16"
+    ref16 = tower._forward(x)
+    got16 = stages.ClipStages(tower)(x, precision="f16")
+    assert got16.shape == ref16.shape == (3, 256, 512) and torch.equal(got16, ref16)
+    assert not torch.equal(ref16[..., :256], ref)
 
 
 @pytest.mark.parametrize("V", [1, 4])
@@ -108,6 +135,12 @@ def test_sam_encode_stage_equals_python_path(hip_lib, cuda, V):
     assert torch.equal(got_f, ref_f), float((got_f - ref_f).abs().max())
     assert not torch.equal(ref_f, ref_p)
     assert float((ref_f - ref_p).abs().max()) < 0.25 * float((ref - ref_p).abs().max())  # (much closer to all-split than default is)
+    # the DEFAULT precision of the host model (fp16 operands, exact q path): ivlm_sam_encode_f16 == the Python path with SITES_F16Q
+    enc.parity_sites = enc.SITES_F16Q
+    ref_q = enc._forward(x)
+    got_q = stages.SamEncodeStages(enc)(x, precision="f16")
+    assert torch.equal(got_q, ref_q), float((got_q - ref_q).abs().max())
+    assert float((ref_q - ref_p).abs().max()) < 0.25 * float((ref - ref_p).abs().max())
 
 
 @pytest.mark.parametrize("V", [4, 1])
