@@ -186,6 +186,30 @@ def check_against_spec(state: Dict[str, torch.Tensor], cfg: Wt.IvlmCfg, ignore: 
         raise CheckpointError("\n".join(msg))
 
 
+def warn_if_difde_copies_differ(state, cfg) -> bool:
+    """A '-DifDe' checkpoint whose three decoder key sets differ evaluates differently here (cfg.difde_load == "separate": every
+    decoder its own tensors) and in the reference's inference construction (all three = object_mask_decoder.*, see
+    weights.IvlmCfg.difde_load): say so once, and which semantics is applied."""
+    import warnings
+
+    if "DifDe" not in cfg.token_type:
+        return False
+    pre = Wt.SAM_PREFIX
+    differ = []
+    for k in state:
+        if k.startswith(pre + ".mask_decoder."):
+            tail = k[len(pre + ".mask_decoder."):]
+            for other in ("human_mask_decoder", "object_mask_decoder"):
+                o = state.get(f"{pre}.{other}.{tail}")
+                if o is not None and not torch.equal(o, state[k]):
+                    differ.append(other)
+    if differ:
+        warnings.warn(f"'-DifDe' checkpoint: {sorted(set(differ))} differ from mask_decoder.* - applying difde_load="
+                      f"{cfg.difde_load!r} ({'each decoder its own tensors, selected by dataset name' if cfg.difde_load == 'separate' else 'all three decoders = object_mask_decoder.*, what the reference constructs at inference'}); "
+                      f"set IvlmCfg.difde_load to choose")
+    return bool(differ)
+
+
 def load_weights(version_dir: str, clip_dir: str, tokenizer_ids: Optional[dict] = None,
                  ignore: Iterable[str] = TOLERATED_PREFIXES):
     """(cfg, state) ready for ``InteractVLMForCausalLM(cfg, state, device)``."""
@@ -197,6 +221,7 @@ def load_weights(version_dir: str, clip_dir: str, tokenizer_ids: Optional[dict] 
     except KeyError as e:
         raise CheckpointError(f"{version_dir}: tensor {e} needed to size the towers is missing") from None
     check_against_spec(state, cfg, ignore)
+    warn_if_difde_copies_differ(state, cfg)
     return cfg, state
 
 

@@ -579,7 +579,9 @@ class Llama:
         return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
 
     def logits(self, hidden_rows):
-        """lm_head on fp32 [n, hidden] -> f32 [n, vocab] (n <= 16: exact fp32 activations on the weight-streaming kernels)."""
+        """lm_head on fp32 [n, hidden] -> f32 [n, vocab].  n <= 16: exact fp32 activations on the weight-streaming kernels; more rows:
+        one tile GEMM on [hi | lo] bf16 operands (fp32-equivalent activations, the weight matrix read once - ADVICE r3: 16-row
+        chunks re-streamed the 262 MB of lm_head once per chunk)."""
         if hidden_rows.shape[0] > 16:
-            hidden_rows = ops.gather_rows(hidden_rows, out_kind="bf16")
+            return ops.linear(ops.split_rows(hidden_rows.contiguous()), self.lm_head, out_f32=True, a_split=True)
         return ops.linear(hidden_rows, self.lm_head, out_f32=True)

@@ -109,8 +109,15 @@ class InteractVLMForCausalLM:
         vm.prompt_encoder = vm.mask_decoder  # text path of the prompt encoder is folded into the decoder object
         self.use_diff_decoder = "DifDe" in c.token_type
         if self.use_diff_decoder:  # separately trained decoder copies, picked per sample by dataset name (InteractVLM.py:46-52)
-            vm.human_mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid, decoder="human_mask_decoder")
-            vm.object_mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid, decoder="object_mask_decoder")
+            assert c.difde_load in ("separate", "reference"), c.difde_load
+            if c.difde_load == "reference":  # the reference's load-into-aliases-then-deepcopy: all three = the key set loaded last
+                vm.mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid, decoder="object_mask_decoder")
+                vm.prompt_encoder = vm.mask_decoder
+                if os.environ.get("IVLM_NO_GRAPHS"):
+                    vm.mask_decoder.use_graph = False
+            names = ("object_mask_decoder",) * 2 if c.difde_load == "reference" else ("human_mask_decoder", "object_mask_decoder")
+            vm.human_mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid, decoder=names[0])
+            vm.object_mask_decoder = SamMaskDecoder(w, dev, grid=c.sam.grid, decoder=names[1])
             if os.environ.get("IVLM_NO_GRAPHS"):
                 vm.human_mask_decoder.use_graph = vm.object_mask_decoder.use_graph = False
         if self.use_fusion:
@@ -231,7 +238,7 @@ class InteractVLMForCausalLM:
         if pos0 + x.shape[0] > self.llm.max_len:
             raise ops.IvlmError(f"sequence of {pos0 + x.shape[0]} positions exceeds the KV cache (max_len={self.llm.max_len})")
         h = self.llm.forward(x, pos0)
-        logits = torch.cat([self.llm.logits(h[i: i + 16]) for i in range(0, h.shape[0], 16)], 0)  # fp32 rows, exact products
+        logits = self.llm.logits(h)  # fp32 rows (> 16 rows: ONE tile GEMM over hi + lo operands - lm_head is streamed once)
         cache = SimpleNamespace(length=pos0 + x.shape[0]) if (use_cache or past_key_values is not None) else None
         return SimpleNamespace(loss=None, logits=logits[None], past_key_values=cache, hidden_states=h[None], attentions=None)
 

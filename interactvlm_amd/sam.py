@@ -304,7 +304,8 @@ class SamImageEncoder:
             q4, kv4 = q2.view(nwin, S, 2, H, hd), kv.view(nwin, S, 2, H, hd)
             q, q_lo, k, v = (t.permute(0, 2, 1, 3) for t in (q4[:, :, 0], q4[:, :, 1], kv4[:, :, 0], kv4[:, :, 1]))
             lv = self.q_lo_level  # 1: q's lo half in the rel-pos terms only (what amplifies its rounding); 2: in Q.K^T too, split P
-            if self.rel_in_kernel and (2 * side <= 32 or (side == 64 and self.rel_in_kernel_global)) and hd == 80:
+            # (level 2 on the 64 x 64 grid takes the terms as arrays: its kernel has no table mode)
+            if self.rel_in_kernel and (2 * side <= 32 or (side == 64 and self.rel_in_kernel_global and lv < 2)) and hd == 80:
                 o = ops.attention(q, k, v, hd ** -0.5, rel_tab=(blk["rel_cat_h"], side), q_lo=q_lo, q_lo_level=lv)
             else:
                 rel = ops.relpos_bias(q, blk["rel_h"], blk["rel_w"], side, side, cat=blk["rel_cat_h"], q_lo=q_lo)

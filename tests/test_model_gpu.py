@@ -780,6 +780,45 @@ def test_difde_decoders_selected_by_dataset_name(hip_lib, cuda):
         del m2
 
 
+def test_difde_reference_load_semantics_switch(hip_lib, cuda):
+    """a '-DifDe' checkpoint whose three decoder copies DIFFER.  Default (difde_load = "separate"): each decoder its own
+    tensors.  difde_load = "reference": the reference's from_pretrained-into-aliased-modules-then-deepcopy construction
+    (InteractVLM.py:30-32, evaluate.py:557-563) - all three decoders hold object_mask_decoder.*; the loader warns that the copies
+    differ and says which semantics is applied."""
+    import dataclasses
+    import warnings
+
+    import torch
+
+    from interactvlm_amd import checkpoint
+    from interactvlm_amd import model as M
+    from interactvlm_amd import synth, synthetic
+    from interactvlm_amd import weights as Wt
+
+    cfg = dataclasses.replace(synthetic.config_tiny(), token_type="Gen-DifDe")
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))  # (the three decoders are distinct tensors: keyed random draws)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert checkpoint.warn_if_difde_copies_differ(w, cfg)
+    assert any("difde_load='separate'" in str(r.message) for r in rec)
+    tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
+    ids, forced = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=8)
+    cams = synthetic.human_cam_params()
+    ic, im = synthetic.images(cfg, cuda)
+    ev = lambda m_: m_.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], contact_type="hcontact", forced_new_tokens=forced)
+    sep = ev(M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables))
+    ref_sem = ev(M.InteractVLMForCausalLM(dataclasses.replace(cfg, difde_load="reference"), w, cuda, lift_tables=tables))
+    # "reference": hcontact goes through a decoder holding object_mask_decoder.* == a plain model whose mask_decoder.* are those tensors
+    pre = Wt.SAM_PREFIX
+    w_obj = {k: v for k, v in w.items() if "human_mask_decoder" not in k and "object_mask_decoder" not in k}
+    for k, v in w.items():
+        if k.startswith(pre + ".object_mask_decoder."):
+            w_obj[pre + ".mask_decoder." + k[len(pre + ".object_mask_decoder."):]] = v
+    plain = ev(M.InteractVLMForCausalLM(dataclasses.replace(cfg, token_type="Gen"), w_obj, cuda, lift_tables=tables))
+    assert torch.equal(ref_sem["pred_contact_3d"], plain["pred_contact_3d"])
+    assert not torch.equal(sep["pred_contact_3d"], ref_sem["pred_contact_3d"])  # (the copies differ: so do the two semantics)
+
+
 def test_forward_with_past_key_values_is_the_causal_lm_forward(hip_lib, cuda):
     """forward(past_key_values=...) (InteractVLM.py:263-266 -> llava_llama.py:55-135): a greedy loop driven through it - full
     sequence first, then one id at a time against the cache handle - yields the ids and hidden states of generate(); with
