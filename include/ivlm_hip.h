@@ -527,6 +527,24 @@ int ivlm_sam_decode(const ivlm_sam_dec *weights, int V, int grid, int n_text, co
 /* The split-K rule of the small-M tile GEMMs (number of K slices, 1 = none): shared by the sequencers and the Python host. */
 int ivlm_gemm_splitk_choice(int M, int N, int K, int act, int has_rms);
 
+/* Batch-1 decode linear over LOSSLESSLY packed bf16 weights ("bf12", 1.5 bytes per weight instead of 2; the decode step of
+ * InteractVLM.evaluate's greedy search, model/InteractVLM.py:524-531, is pure weight streaming).  A row of W [N, K] is stored as
+ *   P  u8 [N, ldp >= K]      sign << 7 | mantissa (7 bits)
+ *   E  u8 [N, lde >= K/2]    two 4-bit codes per byte (low nibble = even column): exponent field - ebase[row] in 1 .. 15;
+ *                            0 = the weight is zero or outside the row's window (then P = 0)
+ *   ebase i32 [N]            row maximum of the exponent field - 15, clamped at 0
+ *   patch_ptr i32 [N+1], patch_col i32, patch_val bf16: CSR of the nonzero weights outside the window, with their exact values
+ * - every weight is reconstructed bit for bit (ivlm_unpack_bf12).  y = act(W . x (* rsqrt(mean(x^2) + eps) with rms_w: the fused
+ * RMSNorm of ivlm_gemm_bf16's M = 1 path) + bias) + residual; x fp32 [K], exact bf16 x fp32 products, fp32 accumulation; act as
+ * ivlm_gemm_bf16 (SWIGLU: rows interleaved (gate_j, up_j), out [N/2]); flags: IVLM_GEMM_RES_F32.  K % 16 == 0, K <= 15360. */
+int ivlm_gemv1_bf12(const float *x, const void *P, int64_t ldp, const void *E, int64_t lde, const int32_t *ebase,
+                    const int32_t *patch_ptr, const int32_t *patch_col, const void *patch_val, void *C, const void *bias,
+                    const void *residual, int N, int K, int act, int out_f32, const void *rms_w, float rms_eps, int flags,
+                    ivlm_stream_t stream);
+/* The packed matrix back as bf16 [N, K] (the losslessness check; not on the path). */
+int ivlm_unpack_bf12(const void *P, int64_t ldp, const void *E, int64_t lde, const int32_t *ebase, const int32_t *patch_ptr,
+                     const int32_t *patch_col, const void *patch_val, int N, int K, void *w_out, ivlm_stream_t stream);
+
 /* torch.argmax(logits, -1) of HF greedy search (first maximal index); x f32 [rows, cols] -> out i32 [rows]. */
 int ivlm_argmax_f32(const float *x, int rows, int cols, int32_t *out, ivlm_stream_t stream);
 

@@ -526,6 +526,71 @@ def linear_fp8w(x, wq, scale_w, bias=None, act="none", residual=None, out_f32=Tr
     return out
 
 
+class PackedBf12:
+    """A bf16 weight matrix [N, K] in the lossless 12-bit layout of ``ivlm_gemv1_bf12`` (1.5 bytes per weight): P bytes (sign |
+    mantissa), E nibbles (exponent code relative to the row's window), per-row exponent base, CSR patches for the (rare) nonzero
+    weights outside the window.  Built once per matrix on the device (weight preparation, like the q|k|v concatenation)."""
+
+    def __init__(self, w):
+        assert w.dtype == BF16 and w.dim() == 2 and w.is_cuda and w.shape[1] % 16 == 0
+        if not bool(torch.isfinite(w).all()):
+            raise IvlmError("PackedBf12: inf / nan weights cannot be packed")
+        N, K = w.shape
+        bits = w.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+        ef = (bits >> 7) & 0xFF
+        eb = (ef.max(dim=1).values - 15).clamp_(min=0)
+        code = ef - eb[:, None]
+        inwin = code >= 1  # (code <= 15 by construction)
+        esc = (~inwin) & ((bits & 0x7FFF) != 0)  # nonzero weights below the window (incl. bf16 subnormals): exact patches
+        self.P = torch.where(inwin, ((bits >> 8) & 0x80) | (bits & 0x7F), torch.zeros_like(bits)).to(torch.uint8).contiguous()
+        code = torch.where(inwin, code, torch.zeros_like(code))
+        self.E = (code[:, 0::2] | (code[:, 1::2] << 4)).to(torch.uint8).contiguous()
+        self.ebase = eb.to(torch.int32).contiguous()
+        rows, cols = esc.nonzero(as_tuple=True)  # (row-major order: sorted by row)
+        self.patch_ptr = torch.zeros(N + 1, dtype=torch.int32, device=w.device)
+        if rows.numel():
+            self.patch_ptr[1:] = torch.bincount(rows, minlength=N).cumsum(0).to(torch.int32)
+        self.patch_col = (cols.to(torch.int32) if rows.numel() else torch.zeros(1, dtype=torch.int32, device=w.device)).contiguous()
+        self.patch_val = (w[rows, cols] if rows.numel() else torch.zeros(1, dtype=BF16, device=w.device)).contiguous()
+        self.shape, self.n_patches = (N, K), int(rows.numel())
+
+    def bytes(self):
+        return self.P.numel() + self.E.numel() + 4 * self.ebase.numel() + 4 * self.patch_ptr.numel() + 6 * self.n_patches
+
+    def _args(self):
+        return (self.P.data_ptr(), self.P.stride(0), self.E.data_ptr(), self.E.stride(0), self.ebase.data_ptr(),
+                self.patch_ptr.data_ptr(), self.patch_col.data_ptr(), self.patch_val.data_ptr())
+
+    def unpack(self):
+        """-> bf16 [N, K], bit-identical to the matrix that was packed."""
+        out = torch.empty(self.shape, dtype=BF16, device=self.P.device)
+        check(_lib.load().ivlm_unpack_bf12(*self._args(), self.shape[0], self.shape[1], out.data_ptr(), _stream()), "unpack_bf12")
+        return out
+
+
+def linear_bf12(x, wp: PackedBf12, bias=None, act="none", residual=None, out_f32=True, rms=None):
+    """act(x @ W.T + bias) + residual for ONE fp32 row x against a ``PackedBf12`` weight: the batch-1 decode linears streaming
+    1.5 instead of 2 bytes per weight (same exact bf16 x fp32 products and fp32 accumulation as ``linear`` on fp32 x)."""
+    lib = _lib.load()
+    N, K = wp.shape
+    assert x.dtype == F32 and x.is_contiguous() and x.numel() == K
+    n_out = N // 2 if act == "swiglu" else N
+    out = torch.empty(1, n_out, dtype=F32 if out_f32 else BF16, device=x.device)
+    flags = 0
+    if residual is not None:
+        assert residual.dtype in (BF16, F32) and residual.is_contiguous() and residual.numel() == N
+        if residual.dtype == F32:
+            flags |= GEMM_RES_F32
+    call = lambda: check(lib.ivlm_gemv1_bf12(x.data_ptr(), *wp._args(), out.data_ptr(), _p(bias), _p(residual), N, K, ACT[act],
+                                             1 if out_f32 else 0, _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, flags,
+                                             _stream()), "gemv1_bf12")
+    if TIMER.enabled:  # work = the ALGORITHMIC bytes (the bf16 matrix), like the other decode linears
+        TIMER.time("gemv_bf16", 2.0 * N * K, call, tag=(1, N, K, act, "bf12"))
+    else:
+        call()
+    return out
+
+
 def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False, fp8_scale=None, out_f16=False):
     lib = _lib.load()
     x = _req(x, None, "x")

@@ -695,3 +695,45 @@ def test_gemm_f16_split_operand_and_output(hip_lib, cuda):
     # scatter epilogue + strided hi-half operand (the k|v GEMM of the exact-q path reads the hi half in place)
     y2 = ops.linear(xs[:, :K], w16, b, out_f16=True)
     assert torch.equal(y2, y1)
+
+
+@pytest.mark.parametrize("N,K,act,rms,res", [(12288, 4096, "none", True, False), (4096, 4096, "none", False, True),
+                                             (22016, 4096, "swiglu", True, False), (4096, 11008, "none", False, True),
+                                             (32003, 4096, "none", False, False), (40, 512, "none", True, True)])
+def test_gemv_bf12_is_lossless_and_equals_the_bf16_gemv(hip_lib, cuda, N, K, act, rms, res):
+    """The 12-bit packed weight layout of the batch-1 decode linears: every weight (zeros, subnormals, the far tail below the row's
+    exponent window: patches) is reconstructed BIT FOR BIT, and the linear on the packed matrix equals the bf16 GEMV on the original
+    one up to fp32 summation order (both: exact bf16 x fp32 products) - checked against fp64."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(N + K)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    # adversarial entries: exact zeros, negative zero, bf16 subnormals, values 20 - 40 binades under the row maximum, one huge row
+    w[0, :8] = torch.tensor([0.0, -0.0, 1e-40, -3e-39, 1e-12, -1e-9, 2e-7, 1e-30]).bfloat16()
+    w[1, 5] = 3e4
+    w[min(7, N - 1)] = 0
+    w = w.to(cuda)
+    wp = ops.PackedBf12(w)
+    assert torch.equal(wp.unpack().view(torch.int16), torch.where(w == 0, torch.zeros_like(w), w).view(torch.int16))  # (-0.0 packs as +0.0)
+    assert wp.n_patches >= 6 and (N < 1000 or wp.bytes() < 0.77 * w.numel() * 2)  # (1.5 of 2 bytes per weight + row tables / patches)
+    x = (torch.randn(1, K, generator=g) * 2.0).to(cuda)
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().to(cuda) if rms else None
+    r = torch.randn(1, N, generator=g).to(cuda) if res else None
+    kw = dict(act=act, residual=r, rms=(gam, 1e-5) if rms else None)
+    got = ops.linear_bf12(x, wp, **kw)
+    ref16 = ops.linear(x, w, out_f32=True, **kw)
+    xd = x.double()
+    if rms:
+        xd = xd * torch.rsqrt((xd * xd).mean() + 1e-5) * gam.double()
+    y = xd @ w.double().t()
+    if act == "swiglu":
+        y = torch.nn.functional.silu(y[:, 0::2]) * y[:, 1::2]
+    if res:
+        y = y + r.double()
+    scale = float(y.abs().max())
+    e12, e16 = float((got.double() - y).abs().max()) / scale, float((ref16.double() - y).abs().max()) / scale
+    print(f"\\n[bf12 GEMV {N}x{K} {act}] vs fp64: packed {e12:.2e}, bf16 GEMV {e16:.2e}; patches {wp.n_patches}")
+    assert got.shape == ref16.shape and e12 < 3e-6 and e16 < 3e-6
+    assert float((got - ref16).abs().max()) / scale < 3e-6
