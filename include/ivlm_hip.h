@@ -311,6 +311,9 @@ int ivlm_attention_f32(const float *q, const float *k, const float *v, float *o,
 /* Benchmark/test hook: -1 (default) picks per shape; 0 forces the 4-wave / 128-query block, 1 the 8-wave ping-pong block
  * (256 queries; one wave group on the matrix unit while the other does its softmax on the VALU). */
 int ivlm_attention_pingpong(int mode);
+/* Benchmark hook: 1 (default) = the table-mode kernel of the 64 x 64 grid maps all query blocks of a (view, head) to one XCD (its L2
+ * fetches that head's K / V once); 0 = plain block order.  Returns the previous value. */
+int ivlm_attention_xcd_map(int on);
 /* Benchmark/test hook: 1 (default) = SAM's windows in table mode run on the whole-window kernel (one block per (window, head), K / V
  * of the window resident in LDS, one-pass softmax); 0 = the generic flash kernel for them too. */
 int ivlm_attention_window_kernel(int v2);

@@ -156,8 +156,28 @@ __global__ __launch_bounds__((PP || SPLIT) ? 512 : 256, (PP || SPLIT) ? 1 : 2) v
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q_blk0 = blockIdx.x * kQBlk;
+    int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x;
+    if (REL == 5) {
+        // 1-D launch, XCD-aware: consecutive block ids go to the 8 XCDs round-robin, and the 32 query blocks of a (view, head) read
+        // the SAME 1.3 MB of K / V - all of them on ONE XCD, so that its L2 fetches them once instead of every XCD fetching them
+        // (PMC: 800 MB of fabric traffic per launch of which 670 MB were those eight-fold K / V fetches)
+        const int nq = a.Sq / kQBlk, npairs = a.B * a.H;
+        const int i = blockIdx.x, xcd = i & 7, j = i >> 3;
+        const int full = (npairs / 8) * 8;
+        int pair = (j / nq) * 8 + xcd;
+        qblk = j % nq;
+        if (!a.xcd_map) {  // (A/B hook ivlm_attention_xcd_map(0): plain order, a pair's query blocks spread over all XCDs)
+            pair = i / nq;
+            qblk = i % nq;
+        } else if (pair >= full) {  // tail pairs (B * H not a multiple of 8): plain order
+            const int t = i - full * nq;
+            pair = full + t / nq;
+            qblk = t % nq;
+        }
+        b = pair / a.H;
+        h = pair - b * a.H;
+    }
+    const int q_blk0 = qblk * kQBlk;
     const int q0 = q_blk0 + wave * kQPerWave;
     const int bkv = b / a.kv_batch_div;
     const bf16_t* __restrict__ Q = a.q + b * a.q_bs + h * a.q_hs;
@@ -1290,6 +1310,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 1024, 1) void win_attn_kernel(AttnArg
     }
 }
 
+static int g_xcd_map = 1;  // REL 5: XCD-aware block map (A/B hook: ivlm_attention_xcd_map)
 static int g_win_v2 = 1;  // 0: the generic flash kernel for windows too (A/B hook: ivlm_attention_window_kernel)
 
 template <bool SPLIT, bool F16 = false, int QLV = 0>
@@ -1355,8 +1376,9 @@ int launch_f16(const AttnArgs& a, hipStream_t st) {
     if constexpr (DV == 80) {  // SAM's 64 x 64 grid in table mode (REL 5): the terms computed in the kernel, q_lo (level 1) in them
         if (!a.causal && rel && a.prescale_q && !a.rel_w && a.rel_kh == kKV && a.rel_kw == kKV && a.Sq == kKV * kKV && a.Sk == a.Sq) {
             if (a.q_lo && a.q_lo_level >= 2) return IVLM_ERR_UNSUPPORTED;
-            if (a.q_lo) attn_kernel<DQK, DV, false, 5, false, false, true, 1><<<grid, 256, 0, st>>>(a);
-            else attn_kernel<DQK, DV, false, 5, false, false, true, 0><<<grid, 256, 0, st>>>(a);
+            const dim3 g1((a.Sq / kQPerBlock) * a.H * a.B);  // (REL 5: 1-D, XCD-aware block map in the kernel)
+            if (a.q_lo) attn_kernel<DQK, DV, false, 5, false, false, true, 1><<<g1, 256, 0, st>>>(a);
+            else attn_kernel<DQK, DV, false, 5, false, false, true, 0><<<g1, 256, 0, st>>>(a);
             return ivlm_launch_status();
         }
     }
@@ -1400,7 +1422,7 @@ int launch_dp(const AttnArgs& a, hipStream_t st) {
         if (DV != 80) return IVLM_ERR_UNSUPPORTED;  // only SAM's ViT uses rel-pos; keeps the build small
         if (!a.prescale_q) return IVLM_ERR_UNSUPPORTED;
         if (!a.rel_w && a.rel_kh == kKV && a.rel_kw == kKV && a.Sq == kKV * kKV && a.Sk == a.Sq) {  // the 64 x 64 grid in table mode
-            if constexpr (DV == 80 && !PP) attn_kernel<DQK, DV, false, 5, false><<<dim3(a.Sq / kQPerBlock, a.H, a.B), 256, 0, st>>>(a);
+            if constexpr (DV == 80 && !PP) attn_kernel<DQK, DV, false, 5, false><<<dim3((a.Sq / kQPerBlock) * a.H * a.B), 256, 0, st>>>(a);
             else return IVLM_ERR_UNSUPPORTED;
         } else if (!a.rel_w)  // rel_h is the bf16 table [64, D]: the rel-pos terms are computed in the kernel (windows: 2 * side <= 32)
             attn_kernel<DQK, DV, false, DV == 80 ? 4 : 0, false><<<dim3((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B), 256, 0, st>>>(a);
@@ -1611,7 +1633,9 @@ int relpos_gather(const bf16_t* G, int64_t g_hs, int npad, int B, int H, int SH,
     return ivlm_launch_status();
 }
 
-int attention_bf16(const AttnArgs& a, hipStream_t st) {
+int attention_bf16(const AttnArgs& a_in, hipStream_t st) {
+    AttnArgs a = a_in;
+    a.xcd_map = g_xcd_map;
     if (!a.q || !a.k || !a.v || !a.o || a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return IVLM_ERR_INVALID_ARG;
     if (a.H > 65535 || a.B > 65535 || a.kv_batch_div <= 0) return IVLM_ERR_INVALID_ARG;
     if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.q_hs | a.k_hs | a.v_hs | a.q_bs | a.k_bs | a.v_bs) & 7)
@@ -1720,6 +1744,12 @@ int ivlm_relpos_bias_f16(const void* q, const void* q_lo, int64_t q_bs, int64_t 
     const int rc = ivlm::gemm_bf16(g, ivlm_stream(stream));
     if (rc != IVLM_OK) return rc;
     return ivlm::relpos_gather(reinterpret_cast<const bf16_t*>(G_ws), M * npad, npad, B, H, SH, SW, rel_h, rel_w, ivlm_stream(stream), 2);
+}
+
+int ivlm_attention_xcd_map(int on) {  // benchmark hook: XCD-aware block map of the 64 x 64 grid's table-mode kernel (default 1)
+    const int prev = ivlm::g_xcd_map;
+    ivlm::g_xcd_map = on ? 1 : 0;
+    return prev;
 }
 
 int ivlm_attention_window_kernel(int v2) {  // benchmark/test hook: 1 (default) whole-window kernel, 0 generic flash kernel

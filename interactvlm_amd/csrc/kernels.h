@@ -102,6 +102,7 @@ struct AttnArgs {
     // "parity" precision: lo planes of q / k / v / o (x = hi + lo; same strides as the hi tensors).  All four set or none.
     const bf16_t *q_lo = nullptr, *k_lo = nullptr, *v_lo = nullptr;
     bf16_t* o_lo = nullptr;
+    int xcd_map = 1;     // (set by attention_bf16 from the A/B hook)
     int q_lo_level = 0;  // fp16 with q_lo: 1 = the lo half of q enters the rel-pos terms only, 2 = also Q.K^T (+ split softmax weights)
     int f16 = 0;  // 1: q / k / v / o (and the table-mode rel-pos table) are IEEE fp16: same tiles, the f16 matrix instruction
 };

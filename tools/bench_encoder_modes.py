@@ -20,6 +20,9 @@ def main():
     enc = sam.SamImageEncoder(w, c, dev)
     _, im = synthetic.images(cfg, dev)
     n = int(os.environ.get("N", "5"))
+    if os.environ.get("XCD_MAP") is not None:
+        from interactvlm_amd import _lib
+        _lib.load().ivlm_attention_xcd_map(int(os.environ["XCD_MAP"]))
     if os.environ.get("WIN_V2") is not None:
         from interactvlm_amd import _lib
         _lib.load().ivlm_attention_window_kernel(int(os.environ["WIN_V2"]))
