@@ -226,6 +226,9 @@ int ivlm_gemm_bf16_splitk(const void *A, int64_t lda, const void *W, int64_t ldw
 int ivlm_gemv_tuning(int max_blocks_per_cu, int rows2_min_n);
 /* Benchmark hook of the batch-1 decode GEMV (gemv1_kernel): waves per weight row (1 or 2); 0 = default (1). */
 void ivlm_gemv1_tuning(int ksplit);
+/* A/B hook: dynamic LDS (bytes, <= 128 KB) requested by batch-1 GEMV grids of at most one block per CU (the 4096-row matrices): above
+   80 KB only one block fits a CU, so the dispatcher has to give every CU exactly one.  0 = off. */
+void ivlm_gemv1_lds_floor(int bytes);
 /* Benchmark/test hook for the skinny-M dispatch: rows M in [min_m, 16] against matrices with K, N >= 1024 go to the
  * split-K MFMA kernel (csrc/gemv_mfma.hip) instead of the wave-per-row GEMV / tile GEMM; 0 restores the automatic choice. */
 int ivlm_gemv_mfma_min_m(int min_m);
@@ -358,6 +361,16 @@ int ivlm_llama_decode_attn(const void *qkv, int io_dtype, void *kcache, void *vc
 int ivlm_llama_decode_attn_f16(const void *qkv, void *kcache, void *vcache, int tmax, void *o, int H, int D, int pos,
                                const int32_t *pos_dev, float theta, float scale, const float *cos_tab, const float *sin_tab,
                                ivlm_stream_t stream);
+/* Split-KV variant (fp32 qkv / o; cache_dtype IVLM_BF16 or IVLM_F16): the keys of a head are cut into S ranges (grid H x S, default
+ * S = 8, A/B hook ivlm_llama_decode_attn_splits), each block publishes (o, max, sum) of its range and the block that arrives last for
+ * a head merges them in range order - no block ever waits for another.  Same result as ivlm_llama_decode_attn[_f16] up to the fp32
+ * summation order.  scratch: ivlm_llama_decode_attn_splitkv_scratch_bytes(H, D) bytes, 16-byte aligned, ZEROED once by the caller
+ * (per-head arrival counters, left at zero by every launch), never shared by launches that can run concurrently. */
+size_t ivlm_llama_decode_attn_splitkv_scratch_bytes(int H, int D);
+int ivlm_llama_decode_attn_splitkv(const float *qkv, int cache_dtype, void *kcache, void *vcache, int tmax, float *o, int H, int D,
+                                   int pos, const int32_t *pos_dev, float theta, float scale, const float *cos_tab,
+                                   const float *sin_tab, void *scratch, size_t scratch_bytes, ivlm_stream_t stream);
+int ivlm_llama_decode_attn_splits(int splits); /* 1..16 */
 int ivlm_llama_decode_attn_batch_f16(const void *qkv, int64_t ldq, void *kcache, void *vcache, int64_t cache_stride, int tmax,
                                      void *o, int64_t ldo, int B, int H, int D, const int32_t *pos_dev, float theta, float scale,
                                      const float *cos_tab, const float *sin_tab, ivlm_stream_t stream);

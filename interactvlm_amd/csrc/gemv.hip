@@ -306,16 +306,23 @@ __global__ __launch_bounds__(64 * kG1Waves, 8) void gemv1_kernel(GemmArgs g) {
     }
     __syncthreads();
     float acc = 0.0f;
+    // rows longer than one batch of U chunks per lane (down_proj: K = 11008): each half of the batch is refilled with the NEXT batch's
+    // chunks as soon as it is consumed, so the wave always has U / 2 .. U loads in flight instead of a full round trip per batch
+    // (same chunk order: identical sums)
+    constexpr int UH = U / 2;
     for (int c = c_lo + lane; c < c_hi; c += 64 * U) {
-        if (c != c_lo + lane) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (c + 64 * u < c_hi) w[u] = __builtin_nontemporal_load(wp + c + 64 * u);
-        }
+        for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int cc = c + 64 * u;
-            if (cc < c_hi) acc += dot8f(w[u], xf[cc], xf[nchunk + cc]);
+            for (int u = hf * UH; u < (hf + 1) * UH; ++u) {
+                const int cc = c + 64 * u;
+                if (cc < c_hi) acc += dot8f(w[u], xf[cc], xf[nchunk + cc]);
+            }
+#pragma unroll
+            for (int u = hf * UH; u < (hf + 1) * UH; ++u) {
+                const int nc = c + 64 * (U + u);
+                if (nc < c_hi) w[u] = __builtin_nontemporal_load(wp + nc);
+            }
         }
     }
     acc = wave_sum(acc);
@@ -452,17 +459,21 @@ __global__ __launch_bounds__(64 * kG1Waves, 8) void gemv1_fp8w_kernel(GemmArgs g
 }
 
 int g_gemv1_ksplit = 0;  // 0 = rule below (A/B hook: ivlm_gemv1_tuning)
+int g_gemv1_lds_floor = 0;  // dynamic LDS requested by grids of <= one block per CU (A/B hook: ivlm_gemv1_lds_floor)
 
 template <bool RMS, int KS>
 static void launch_gemv1_ks(const GemmArgs& g, hipStream_t st) {
     static bool set = false;
     auto kfn = gemv1_kernel<RMS, KS>;
     if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         set = true;
     }
     const int rows_per_block = kG1Waves / KS;
-    ivlm_launch(kfn, dim3((g.N + rows_per_block - 1) / rows_per_block), dim3(64 * kG1Waves), (size_t)g.K * 4, st, g);
+    const int blocks = (g.N + rows_per_block - 1) / rows_per_block;
+    size_t lds = (size_t)g.K * 4;
+    if (blocks <= 256 && (size_t)g_gemv1_lds_floor > lds) lds = (size_t)g_gemv1_lds_floor;
+    ivlm_launch(kfn, dim3(blocks), dim3(64 * kG1Waves), lds, st, g);
 }
 
 static int launch_gemv1(const GemmArgs& g, hipStream_t st) {
@@ -651,6 +662,7 @@ extern "C" int ivlm_gemv_tuning(int max_blocks_per_cu, int rows2_min_n) {  // be
 }
 
 extern "C" void ivlm_gemv1_tuning(int ksplit) { ivlm::g_gemv1_ksplit = ksplit; }
+extern "C" void ivlm_gemv1_lds_floor(int bytes) { ivlm::g_gemv1_lds_floor = bytes < 0 ? 0 : (bytes > 128 * 1024 ? 128 * 1024 : bytes); }
 
 extern "C" int ivlm_gemv_fp8w(const float* x, const void* Wq, int64_t ldw, const float* scale_w, void* C, const void* bias,
                               const void* residual, int N, int K, int act, int out_f32, const void* rms_w, float rms_eps, int flags,

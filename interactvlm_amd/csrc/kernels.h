@@ -165,6 +165,12 @@ int llama_decode_attn_batch(const void* qkv, int io_f32, int64_t ldq, bf16_t* kc
                             const float* cos_tab, const float* sin_tab, hipStream_t st, bf16_t* kcache_lo = nullptr,
                             bf16_t* vcache_lo = nullptr, int cache_f16 = 0);
 
+// split-KV variant (fp32 qkv / o, no lo planes): grid H x S, scratch zeroed once by the caller (decode.hip)
+size_t llama_decode_attn_splitkv_scratch_bytes(int H, int D);
+int llama_decode_attn_splitkv(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* o, int H, int D, int pos, float theta,
+                              float scale, hipStream_t st, const float* cos_tab, const float* sin_tab, const int32_t* pos_dev,
+                              int cache_f16, void* scratch, size_t scratch_bytes);
+
 // fused decode attention + o_proj (decode_fused.hip)
 int llama_attn_oproj(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* attn_scratch, const bf16_t* wo,
                      const float* x, float* x_out, int H, int D, float theta, float scale, const float* cos_tab,

@@ -992,10 +992,17 @@ def mask_dot(up, hyper, B, gh, gw):
     return low
 
 
-def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, table=None, lo=None):
+def decode_attn_scratch(H, D, device):
+    """Zeroed scratch of the split-KV decode attention (per-head arrival counters + range partials): one per model / stream."""
+    n = int(_lib.load().ivlm_llama_decode_attn_splitkv_scratch_bytes(H, D))
+    return torch.zeros(n, dtype=torch.uint8, device=device)
+
+
+def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, table=None, lo=None, scratch=None):
     """qkv bf16 | fp32 [1, 3*H*D] of the newest token -> o (same dtype) [1, H*D]; RoPE + cache append fused.
     pos: python int, or an int32 device tensor [1] (read by the kernel: HIP-graph friendly).  kcache [Tmax, H, D].
-    lo = (kcache_lo, vcache_lo): "parity" precision, K / V cached as hi + lo planes (fp32 qkv only)."""
+    lo = (kcache_lo, vcache_lo): "parity" precision, K / V cached as hi + lo planes (fp32 qkv only).
+    scratch (decode_attn_scratch; fp32 qkv, no lo planes): the split-KV kernel - H x S blocks instead of H."""
     lib = _lib.load()
     assert qkv.dtype in (BF16, F32) and qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
     if out is None:
@@ -1003,6 +1010,14 @@ def llama_decode_attn(qkv, kcache, vcache, H, D, pos, theta, scale, out=None, ta
     dev_pos = isinstance(pos, torch.Tensor)
     if dev_pos:
         assert pos.dtype == torch.int32 and pos.is_cuda
+    if scratch is not None and lo is None and qkv.dtype == F32:
+        assert kcache.dtype in (BF16, F16) and vcache.dtype == kcache.dtype
+        check(lib.ivlm_llama_decode_attn_splitkv(qkv.data_ptr(), 4 if kcache.dtype == F16 else IVLM_BF16,
+                                                 kcache.data_ptr(), vcache.data_ptr(), kcache.shape[0], out.data_ptr(), H, D,
+                                                 0 if dev_pos else int(pos), pos.data_ptr() if dev_pos else 0, float(theta),
+                                                 float(scale), _p(table[0]) if table else 0, _p(table[1]) if table else 0,
+                                                 scratch.data_ptr(), scratch.numel(), _stream()), "llama_decode_attn_splitkv")
+        return out
     if lo is not None:
         assert qkv.dtype == F32 and lo[0].is_contiguous() and lo[1].is_contiguous() and lo[0].shape == kcache.shape
         check(lib.ivlm_llama_decode_attn_split(qkv.data_ptr(), kcache.data_ptr(), lo[0].data_ptr(), vcache.data_ptr(),

@@ -913,3 +913,100 @@ def test_free_running_generation_vs_oracle_greedy(hip_lib, cuda, golden_dir):
         e = float((outs[b]["pred_contact_3d"].float().cpu() - ref).abs().max())
         print(f"[evaluate_batch(16) image {b} vs oracle] max |dp| = {e:.2e}")
         assert e < 1e-3
+
+
+@pytest.mark.parametrize("cache_dtype", ["bf16", "f16"])
+def test_decode_attn_splitkv_equals_one_block_kernel(hip_lib, cuda, cache_dtype):
+    """The split-KV decode attention (H x S blocks, the last block of a head merges the range partials) against the one-block-per-head
+    kernel: same output up to the fp32 summation order, the SAME appended cache rows, at positions that leave ranges empty (0, 5),
+    fill exactly one tile, straddle tiles, need several tiles per range (3000), and past the slab (zeros, nothing appended); for every
+    split count; repeated launches on one scratch (the counters are left at zero); device and host positions."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    H, D, Tmax = 8, 128, 3072
+    dt = torch.bfloat16 if cache_dtype == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(11)
+    kc0 = torch.randn(Tmax, H, D, generator=g).to(dt).to(cuda)
+    vc0 = torch.randn(Tmax, H, D, generator=g).to(dt).to(cuda)
+    tab = ops.rope_table(Tmax, D, 10000.0, cuda)
+    scratch = ops.decode_attn_scratch(H, D, cuda)
+    try:
+        for splits in (8, 1, 3, 16):
+            assert hip_lib.ivlm_llama_decode_attn_splits(splits) == 0
+            for pos in (0, 5, 95, 96, 650, 767, 768, 3000, Tmax - 1):
+                qkv = torch.randn(1, 3 * H * D, generator=g).to(cuda)
+                k1, v1, k2, v2 = kc0.clone(), vc0.clone(), kc0.clone(), vc0.clone()
+                ref = ops.llama_decode_attn(qkv, k1, v1, H, D, pos, 10000.0, D ** -0.5, table=tab)
+                p_arg = torch.tensor([pos], dtype=torch.int32, device=cuda) if pos % 2 else pos
+                got = ops.llama_decode_attn(qkv, k2, v2, H, D, p_arg, 10000.0, D ** -0.5, table=tab, scratch=scratch)
+                assert torch.equal(k1, k2) and torch.equal(v1, v2), (splits, pos)
+                err = float((got - ref).abs().max())
+                assert err < 2e-6 * max(1.0, float(ref.abs().max())), (splits, pos, err)
+            assert int(scratch[:H * 4].view(torch.int32).abs().max()) == 0
+        assert hip_lib.ivlm_llama_decode_attn_splits(17) != 0 and hip_lib.ivlm_llama_decode_attn_splits(0) != 0
+        # past the slab: zeros, nothing appended
+        small_k, small_v = kc0[:64].clone(), vc0[:64].clone()
+        out = ops.llama_decode_attn(torch.randn(1, 3 * H * D, generator=g).to(cuda), small_k, small_v, H, D,
+                                    torch.tensor([64], dtype=torch.int32, device=cuda), 10000.0, D ** -0.5, table=tab, scratch=scratch)
+        assert float(out.abs().max()) == 0.0 and torch.equal(small_k, kc0[:64]) and torch.equal(small_v, vc0[:64])
+        # small heads (D = 16: one 16-byte chunk per row), H not a power of two
+        H2, D2 = 5, 16
+        kk = torch.randn(256, H2, D2, generator=g).to(dt).to(cuda)
+        vv = torch.randn(256, H2, D2, generator=g).to(dt).to(cuda)
+        tab2 = ops.rope_table(256, D2, 10000.0, cuda)
+        sc2 = ops.decode_attn_scratch(H2, D2, cuda)
+        q2 = torch.randn(1, 3 * H2 * D2, generator=g).to(cuda)
+        ka, va, kb, vb = kk.clone(), vv.clone(), kk.clone(), vv.clone()
+        r2 = ops.llama_decode_attn(q2, ka, va, H2, D2, 200, 10000.0, D2 ** -0.5, table=tab2)
+        g2 = ops.llama_decode_attn(q2, kb, vb, H2, D2, 200, 10000.0, D2 ** -0.5, table=tab2, scratch=sc2)
+        assert torch.equal(ka, kb) and float((g2 - r2).abs().max()) < 2e-6 * max(1.0, float(r2.abs().max()))
+    finally:
+        hip_lib.ivlm_llama_decode_attn_splits(8)
+
+
+@pytest.mark.parametrize("precision", ["f16", "default"])
+def test_graph_decode_with_splitkv_attention_matches_one_block_kernel(hip_lib, cuda, precision):
+    """A replayed decode graph with the opt-in split-KV attention (`decode_splitkv`) against eager steps on the one-block-per-head
+    kernel: same argmax ids, hidden states and KV cache to fp32 summation order; two generations on one graph / scratch."""
+    import torch
+
+    from interactvlm_amd import llava, ops
+    from interactvlm_amd import weights as Wt
+
+    lc = Wt.LlamaCfg(hidden=512, layers=3, heads=4, inter=1024, vocab=1003)
+    w = _bf16_weights(Wt.llama_spec(lc))
+    g = torch.Generator().manual_seed(5)
+    T0, n_new = 150, 12
+    emb = (torch.randn(T0, 512, generator=g) * 0.5).to(torch.bfloat16).float().to(cuda)
+    toks = torch.randint(3, 1000, (n_new,), generator=g).to(torch.int32).to(cuda)
+    llm_a = llava.Llama(w, lc, cuda, max_len=256)
+    llm_a.set_precision(precision)
+    llm_a.forward(emb, 0)
+    hid_a, arg_a = [], []
+    for s in range(n_new):
+        h = llm_a.forward(llm_a.embed_ids(toks[s: s + 1]), T0 + s)
+        hid_a.append(h)
+        arg_a.append(int(ops.argmax(llm_a.logits(h))[0]))
+    llm_b = llava.Llama(w, lc, cuda, max_len=256)
+    llm_b.set_precision(precision)
+    llm_b.decode_splitkv = True
+    llm_b.forward(emb, 0)
+    dg = llm_b.decode_graph()
+    assert llm_b._dec_scratch is not None
+    for rep in range(2):
+        dg["pos"].fill_(T0)
+        dg["pos64"].fill_(T0)
+        hid_b, arg_b = [], []
+        for s in range(n_new):
+            dg["tok"].copy_(toks[s: s + 1])
+            dg["graph"].replay()
+            hid_b.append(dg["hidden"].clone())
+            arg_b.append(int(dg["nxt"][0]))
+        assert _rel_err(torch.cat(hid_b), torch.cat(hid_a).float().cpu()) < 1e-5
+        assert arg_a == arg_b
+        # layer 0 appends rows computed from identical inputs: the same bits; deeper layers see the other summation order
+        (ka, va), (kb, vb) = llm_a._caches(), llm_b._caches()
+        assert torch.equal(ka[0, :T0 + n_new], kb[0, :T0 + n_new]) and torch.equal(va[0, :T0 + n_new], vb[0, :T0 + n_new])
+        assert float((ka[:, :T0 + n_new].float() - kb[:, :T0 + n_new].float()).abs().max()) < 1e-2

@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--fuse", action="store_true", help="attention + o_proj in one launch (opt-in)")
     ap.add_argument("--legacy", action="store_true", help="persistent GEMV kernel also for the M = 1 fp32 rows")
+    ap.add_argument("--prefill", type=int, default=330, help="positions in the cache before the timed steps (the headline prompt: 256 image tokens + text)")
+    ap.add_argument("--precision", default="f16", help="tower precision: f16 (the default mode of the model) | default (bf16)")
+    ap.add_argument("--splits", type=int, default=0, help="split-KV ranges per head (0 = library default)")
     ap.add_argument("--tiles", type=int, default=0, help="skinny MFMA tiles per block (0 = automatic)")
     a = ap.parse_args()
     from interactvlm_amd import llava, synthetic
@@ -37,8 +40,13 @@ def main():
         del t
     llm = llava.Llama(w, cfg, dev, max_len=1024)
     llm.fuse_attn_oproj = a.fuse
+    if a.precision != "default":
+        llm.set_precision(a.precision)
+    if a.splits:
+        assert _lib.load().ivlm_llama_decode_attn_splits(a.splits) == 0
+        llm.decode_splitkv = True
     del w
-    T0 = 330
+    T0 = a.prefill
     x = (torch.randn(T0, cfg.hidden, device=dev) * 0.5)
     nbytes = sum(L[k].numel() * 2 for L in llm.layers for k in ("qkv", "o", "gu", "down")) + llm.lm_head.numel() * 2
     if a.batch == 1:

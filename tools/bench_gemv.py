@@ -19,9 +19,10 @@ def main():
     bf = torch.bfloat16
     f32x = "--bf16x" not in sys.argv
     lib = _lib.load()
-    for per_cu, r2 in ((0, 0), (3, 0), (6, 0), (8, 0), (0, 1024), (3, 1024), (8, 1024)):
-      lib.ivlm_gemv_tuning(per_cu, r2)
-      print(f"--- blocks/CU {per_cu or 4}, rows2 above N = {r2 or 8192}, x {'fp32' if f32x else 'bf16'}")
+    for floor, ks in ((0, 0), (84 * 1024, 0), (0, 2), (0, 0), (84 * 1024, 0)):
+      lib.ivlm_gemv1_lds_floor(floor)
+      lib.ivlm_gemv1_tuning(ks)
+      print(f"--- batch-1 kernel: LDS floor {floor}, ksplit {ks or 1}, x {'fp32' if f32x else 'bf16'}")
       for name, N, K, act, rms in SHAPES:
         run_shape(dev, bf, f32x, name, N, K, act, rms)
 
