@@ -281,7 +281,7 @@ int ivlm_attention_bf16(const void *q, const void *k, const void *v, void *o, co
                         ivlm_stream_t stream);
 /* The same operator on IEEE fp16 tensors (q / k / v / o, and in table mode the fp16 [64, D] table): identical tiles and layouts on
  * v_mfma_f32_16x16x32_f16; q * scale, the softmax weights and the output are rounded to fp16 (11 significant bits: an eighth of
- * the bf16 rounding error at the same matrix-core rate), saturating at +-65504.  The default precision of the three towers
+ * the bf16 rounding error at the same matrix-core rate); a value past +-65504 becomes inf (not clamped: the caller can see it).  The default precision of the three towers
  * (image_encoder.py:235-260; HF CLIP / LLaMA attention).  Shapes of the path: D = 64 (plain), D = 80 with rel_h (prescale_q = 1),
  * D = 128 causal. */
 int ivlm_attention_f16(const void *q, const void *k, const void *v, void *o, const int64_t *strides_host, int B,
@@ -505,7 +505,7 @@ size_t ivlm_sam_encode_f16_workspace_bytes(const ivlm_sam_cfg *cfg, int V);
 int ivlm_sam_encode_f16(const ivlm_sam_cfg *cfg, const ivlm_sam_head *head, const ivlm_sam_block *blocks_host,
                         const ivlm_sam_block_f16 *blocks16_host, const void *images, int V, float *embeddings_out, void *workspace,
                         size_t workspace_bytes, ivlm_stream_t stream);
-/* bf16 -> IEEE fp16 (round to nearest even, saturating), n elements: weight copies for IVLM_GEMM_F16 / the *_f16 stages */
+/* bf16 -> IEEE fp16 (round to nearest even; |x| > 65504 -> inf), n elements: weight copies for IVLM_GEMM_F16 / the *_f16 stages */
 int ivlm_bf16_to_f16(const void *src_bf16, void *dst_f16, int64_t n, ivlm_stream_t stream);
 
 /* PromptEncoder.forward(text_embeds) + MaskDecoder.forward(multimask_output=False) (prompt_encoder.py:140-186,

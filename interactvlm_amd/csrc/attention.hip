@@ -48,7 +48,7 @@ __device__ __forceinline__ f32x4_t mma16(const bf16x8_t a, const bf16x8_t b, con
     else
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-// two fp32 -> one packed 16-bit pair (RNE; the fp16 form saturates at +-65504), and back
+// two fp32 -> one packed 16-bit pair (RNE; fp16 overflows to inf), and back
 template <bool F16>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     if constexpr (F16) return pack_f16x2(lo, hi);

@@ -33,7 +33,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
         case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
         case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
-        case ACT_RELU: return fmaxf(x, 0.0f);
+        case ACT_RELU: return x < 0.0f ? 0.0f : x;  // (torch.relu semantics: a NaN stays a NaN; fmaxf would turn it into 0)
         case ACT_SILU: return x / (1.0f + __expf(-x));
         case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
         default: return x;

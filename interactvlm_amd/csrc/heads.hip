@@ -56,13 +56,16 @@ __global__ __launch_bounds__(256) void uncertainty_mlp_kernel(const float* __res
     for (int i = 0; i < kH2; ++i) h2[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < kH1; ++j) {
-        const float a = fmaxf(bf16_round(h1[j] + B1[j]), 0.f);  // relu(linear1) on bf16 values
+        const float a0 = bf16_round(h1[j] + B1[j]), a = a0 < 0.f ? 0.f : a0;  // relu(linear1) on bf16 values (NaN stays NaN)
 #pragma unroll
         for (int i = 0; i < kH2; ++i) h2[i] = fmaf(a, W2t[j][i], h2[i]);
     }
     float y = 0.f;
 #pragma unroll
-    for (int i = 0; i < kH2; ++i) y = fmaf(fmaxf(bf16_round(h2[i] + B2[i]), 0.f), W3[i], y);
+    for (int i = 0; i < kH2; ++i) {
+        const float a2 = bf16_round(h2[i] + B2[i]);
+        y = fmaf(a2 < 0.f ? 0.f : a2, W3[i], y);
+    }
     y = bf16_round(y + bf16_to_f32(b3[0]));
     // nn.Softplus(beta = 1, threshold = 20) on the bf16 value, fp32 inside, rounded to bf16
     out[r] = bf16_round(y > 20.f ? y : log1pf(expf(y)));

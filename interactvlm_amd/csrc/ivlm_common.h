@@ -76,16 +76,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
-// two fp32 -> packed IEEE half pair (round to nearest even; saturating at +-65504 instead of overflowing to inf)
+// two fp32 -> packed IEEE half pair (round to nearest even).  NOT saturating: a value past +-65504 becomes inf and the result of the
+// call NaN - which the model's guard sees and recomputes with bf16 operands (model.py evaluate); a clamp would return a plausible,
+// wrong answer instead
 typedef __attribute__((ext_vector_type(2))) _Float16 ivlm_f16x2_t;
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
-    const ivlm_f32x2_t v = {__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+    const ivlm_f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ivlm_f16x2_t));
 }
 // 16-bit output pair of the GEMM epilogues: bf16 or (f16 != 0) fp16
 __device__ __forceinline__ uint32_t pack_16x2(float lo, float hi, int f16) { return f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
 
-// one 16-bit storage element <-> fp32, operand kind chosen at compile time: F16 = IEEE half (saturating stores), else bf16
+// one 16-bit storage element <-> fp32, operand kind chosen at compile time: F16 = IEEE half (overflow -> inf, see pack_f16x2), else bf16
 template <bool F16>
 __device__ __forceinline__ float h16_to_f32(uint16_t v) {
     if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v);
@@ -93,7 +95,7 @@ __device__ __forceinline__ float h16_to_f32(uint16_t v) {
 }
 template <bool F16>
 __device__ __forceinline__ uint16_t f32_to_h16(float f) {
-    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
+    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)f);
     else return f32_to_bf16(f);
 }
 template <bool F16>

@@ -24,6 +24,10 @@ constexpr int kStream = 1024;  // block of the streaming (pixel-major) kernels: 
 // =============================================================================================
 // plan build
 // =============================================================================================
+// torch.clamp / np.clip semantics: a NaN stays a NaN (fminf / fmaxf alone would turn it into a bound, and a NaN mask logit into a
+// plausible contact value)
+__device__ __forceinline__ float clamp_nan(float x, float lo, float hi) { return x != x ? x : fminf(fmaxf(x, lo), hi); }
+
 __device__ __forceinline__ bool triple_ok(int a, int b, int c, int nv) {
     return ((unsigned)a < (unsigned)nv) & ((unsigned)b < (unsigned)nv) & ((unsigned)c < (unsigned)nv);
 }
@@ -238,7 +242,7 @@ __device__ __forceinline__ void lift_plan_body(Fetch fetch, const int32_t* __res
                 for (int k = 0; k < 4; ++k) x[k] = fetch(v, p[k]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (MODE == 0) x[k] = fminf(fmaxf(x[k], -param), param);
+                    if (MODE == 0) x[k] = clamp_nan(x[k], -param, param);
                     const float m = MODE == 2 ? x[k] : sigmoid_f32(x[k]);  // (MODE 2: the map holds the values to average)
                     if (i + 64 * k < e && (MODE != 1 || m > param)) {
                         votes += w[k] * m;
@@ -254,7 +258,7 @@ __device__ __forceinline__ void lift_plan_body(Fetch fetch, const int32_t* __res
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int k = 0; k < kWaves && v0 + k < V; ++k)
-                if (s_ratio[k] >= 0.0f) {
+                if (!(s_ratio[k] < 0.0f)) {  // (seen; a NaN ratio - NaN logits - counts and makes the vertex NaN, as in the reference)
                     pred += s_ratio[k];
                     seen_views += 1.0f;
                 }
@@ -263,7 +267,7 @@ __device__ __forceinline__ void lift_plan_body(Fetch fetch, const int32_t* __res
     }
     if (threadIdx.x == 0) {
         if (seen_views > 0.0f) pred = pred / seen_views;           // components.py:240-241
-        if (MODE == 0) pred = fminf(fmaxf(pred, 0.0f), 1.0f);      // components.py:242 (soft only)
+        if (MODE == 0) pred = clamp_nan(pred, 0.0f, 1.0f);      // components.py:242 (soft only)
         out[(int64_t)b * nv + vert] = pred;
         if (nviews) nviews[(int64_t)b * nv + vert] = seen_views;
     }
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(kStream) void lift_dense_kernel(const float* __rest
             const int a = ids[3 * j], bb = ids[3 * j + 1], c = ids[3 * j + 2];
             if (!triple_ok(a, bb, c, nv)) continue;
             float x = xs[j];
-            if (MODE == 0) x = fminf(fmaxf(x, -param), param);
+            if (MODE == 0) x = clamp_nan(x, -param, param);
             const float m = sigmoid_f32(x);
             if (MODE == 1 && !(m > param)) continue;
             if (a != ca || bb != cb || c != cc) {
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void lift_finalize_kernel(const float* __re
     }
     if (cg != 0 || i >= n) return;
     if (seen > 0.0f) pred /= seen;
-    if (MODE == 0) pred = fminf(fmaxf(pred, 0.0f), 1.0f);
+    if (MODE == 0) pred = clamp_nan(pred, 0.0f, 1.0f);
     out[(int64_t)b * n + i] = pred;
     if (nviews) nviews[(int64_t)b * n + i] = seen;
 }

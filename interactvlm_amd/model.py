@@ -197,6 +197,41 @@ class InteractVLMForCausalLM:
         self.set_precision(getattr(self, "_precision_before_fp8", "default"))
 
     fp8 = False
+    # evaluate / evaluate_batch: recompute a non-finite result of an fp16-operand mode with bf16 operands (IVLM_NONFINITE_GUARD=0: off)
+    nonfinite_guard = os.environ.get("IVLM_NONFINITE_GUARD", "1") != "0"
+
+    def _guard_applies(self):
+        return (self.nonfinite_guard and not self.fp8 and self.precision in ("default", "f16", "parity-fast")
+                and not getattr(self, "_in_guard", False))
+
+    def _guarded(self, fn, args, kwargs):
+        """fp16 operands have 5 exponent bits (max 65504; bf16: 8, as fp32), and the kernels do not clamp: an activation outside
+        that range becomes inf and everything downstream NaN.  One flag per call - the tower outputs (LLaMA hidden states, SAM
+        embeddings) and the contacts are all finite - read back where the caller would read the result anyway: a call that fails it
+        is recomputed in the `bf16` mode (same arithmetic, fp32's exponent range) and reported."""
+        self._in_guard = True
+        self._finite_flags = []
+        try:
+            out = fn(*args, **kwargs)
+            outs = out if isinstance(out, list) else [out]
+            flags = self._finite_flags + [torch.isfinite(o["pred_contact_3d"]).all() for o in outs
+                                          if o.get("pred_contact_3d") is not None]
+            if flags and not bool(torch.stack(flags).all()):
+                import warnings
+
+                warnings.warn(f"non-finite contacts in precision mode {self.precision!r} (an activation left fp16's exponent "
+                              "range): this call is recomputed with bf16 operands; consider model.set_precision('bf16')")
+                mode = self.precision
+                self.set_precision("bf16")
+                try:
+                    out = fn(*args, **kwargs)
+                finally:
+                    self.set_precision(mode)
+                for o in (out if isinstance(out, list) else [out]):
+                    o["recomputed_in_bf16"] = True
+            return out
+        finally:
+            self._in_guard = False
 
     def get_visual_embs(self, pixel_values):
         """[B,V,3,S,S] -> image embeddings; returned in the reference's [B,V,256,g,g] shape (a strided view of the
@@ -324,6 +359,8 @@ class InteractVLMForCausalLM:
                        sigmoid_gt=None, llava_features=None):
         """[SEG] rows -> pred_mask [V,H,W] fp32 for one sample (InteractVLM.py:416-442 / 585-612).  llava_features: the hidden
         rows the fusion head attends to when ``use_fusion`` (ModifiedSAM.forward, InteractVLM.py:41-44)."""
+        if getattr(self, "_in_guard", False):  # (evaluate / evaluate_batch under the fp16 exponent-range guard: see _guarded)
+            self._finite_flags.append(torch.isfinite(hidden).all() & torch.isfinite(image_embeddings).all())
         rows = rows_mask.nonzero().flatten()
         V = self.multiview_channels
         if rows.numel() == 0:
@@ -584,6 +621,10 @@ class InteractVLMForCausalLM:
         may then be lists, one entry per prompt.
         image_embeddings: pre-computed SAM embeddings, one [V, g*g, 256] tensor for all samples (the four
         canonical body renders of hcontact are the same for every image) or a list of B; ``images`` is then not encoded."""
+        if self._guard_applies():  # (fp16 exponent range: see _guarded)
+            return self._guarded(self.evaluate_batch, (images_clip, images, input_ids_list, cam_params, resize_list,
+                                                       original_size_list, contact_type, max_new_tokens, forced_new_tokens,
+                                                       eos_token_id, lift2d_dict_path, image_embeddings), {})
         B = len(input_ids_list)
         if B > 16:  # larger batches run as consecutive calls of <= 16 sequences (the decode kernels' row limit)
             if images_clip.shape[0] == 1:
@@ -661,6 +702,10 @@ class InteractVLMForCausalLM:
         (``precompute_visual_embs``).  For hcontact the SAM inputs are the SAME four canonical body renders for
         every sample (run_demo.py:279-292, datasets/hcontact_3d.py:268-271), so they can be encoded once."""
         assert input_ids.shape[0] == 1, "the reference only ever calls evaluate with batch 1 (evaluate.py:479)"
+        if self._guard_applies():
+            return self._guarded(self.evaluate, (images_clip, images, input_ids, cam_params, resize_list, original_size_list,
+                                                 lift2d_dict_path, contact_type, max_new_tokens, tokenizer, forced_new_tokens,
+                                                 eos_token_id, image_embeddings), {})
         # The SAM ViT-H encoder (MFMA-bound, ~60 ms) does not depend on the language model (CLIP -> prefill -> decode:
         # HBM-bound weight streaming that leaves the matrix cores idle): run it on a second HIP stream and join
         # before the mask decoder.  The reference runs them back to back (InteractVLM.py:524-531, 578).

@@ -610,7 +610,7 @@ def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False, fp8_scale=None,
 
 
 def bf16_to_f16(w):
-    """bf16 tensor -> IEEE fp16 copy (RNE, saturating): the weight operands of ``linear`` on fp16 activations."""
+    """bf16 tensor -> IEEE fp16 copy (RNE; out of range -> inf): the weight operands of ``linear`` on fp16 activations."""
     w = w.contiguous()
     assert w.dtype == torch.bfloat16
     out = torch.empty(w.shape, dtype=torch.float16, device=w.device)

@@ -353,3 +353,43 @@ def test_predictor_modules_match_reference_api(hip_lib, cuda, tmp_path):
     np.testing.assert_allclose(o2.cpu().numpy(), exp_p, atol=2e-6)
     o3 = pc([_t(probs[1], cuda)], None, paths[1:])
     assert torch.equal(o3[0], o2[1])
+
+
+def test_nan_logits_stay_nan_like_the_reference(hip_lib, cuda):
+    """torch.clamp / the per-view ratio of the reference propagate a NaN mask logit into every vertex it votes for
+    (components.py:242-277; the oracle: np.clip, votes / cnt); fminf / fmaxf and a `ratio >= 0` test would silently turn it into a
+    plausible contact.  Plan, streaming and point-map kernels against the oracle, NaN positions included."""
+    import torch
+
+    from interactvlm_amd import ops
+    from oracle import lift as OL
+
+    V, H, W, NV = 4, 64, 64, 500
+    g = np.random.default_rng(5)
+    vid = g.integers(0, NV, (V, H, W, 3)).astype(np.int32)
+    vid[g.random((V, H, W)) < 0.5] = -1
+    bary = g.dirichlet((1, 1, 1), (V, H, W)).astype(np.float32)
+    lg = (g.standard_normal((2, V, H, W)) * 3).astype(np.float32)
+    lg[0, 1, 10:12, 5:40] = np.nan
+    lg[1, 3, 33, :] = np.nan
+    exp, exp_nv = OL.lift_mesh_soft(lg, vid, bary, NV)
+    assert np.isnan(exp).any() and not np.isnan(exp).all()
+    tv, tb, tl = _t(vid, cuda), _t(bary, cuda), _t(lg, cuda)
+    got, nv1 = ops.lift_mesh_plan(tl, ops.LiftPlan(tv, tb, NV), 0, 20.0, want_nviews=True)
+    got2 = ops.lift_mesh_dense(tl, tv, tb, NV, 0, 20.0)
+    for o in (got, got2):
+        o = o.cpu().numpy()
+        assert np.array_equal(np.isnan(o), np.isnan(exp))
+        np.testing.assert_allclose(o, exp, atol=TOL, rtol=0)  # (equal_nan)
+    assert np.array_equal(nv1.cpu().numpy(), exp_nv)
+    # point maps (mean of the probabilities over the pixels of a point)
+    pid = g.integers(-1, 300, (V, H, W)).astype(np.int32)
+    pr = 1.0 / (1.0 + np.exp(-lg[:1, :, :, :]))
+    expp = OL.lift_points(pr, pid[None], 300)
+    expp = expp[0] if isinstance(expp, tuple) else expp
+    gp = ops.lift_points(_t(pr, cuda), _t(pid, cuda), 300).cpu().numpy()
+    gpp = ops.lift_points_plan(_t(pr, cuda), ops.LiftPlan.from_points(_t(pid, cuda), 300)).cpu().numpy()
+    assert np.array_equal(np.isnan(gpp), np.isnan(expp))
+    np.testing.assert_allclose(gpp, expp, atol=2e-5, rtol=0)
+    assert np.isnan(expp).any() and np.array_equal(np.isnan(gp), np.isnan(expp))
+    np.testing.assert_allclose(gp, expp, atol=2e-5, rtol=0)

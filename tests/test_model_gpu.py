@@ -1010,3 +1010,51 @@ def test_graph_decode_with_splitkv_attention_matches_one_block_kernel(hip_lib, c
         (ka, va), (kb, vb) = llm_a._caches(), llm_b._caches()
         assert torch.equal(ka[0, :T0 + n_new], kb[0, :T0 + n_new]) and torch.equal(va[0, :T0 + n_new], vb[0, :T0 + n_new])
         assert float((ka[:, :T0 + n_new].float() - kb[:, :T0 + n_new].float()).abs().max()) < 1e-2
+
+
+def test_nonfinite_result_of_an_fp16_mode_is_recomputed_in_bf16(hip_lib, cuda, golden_dir):
+    """fp16 operands have 5 exponent bits: weights that push an activation past 65504 (here gate / up projections scaled by 2^11, so
+    that SiLU(gate) * up of the prefill overflows) make the default mode's contacts NaN.  evaluate() notices (one flag on the
+    result), recomputes the call with bf16 operands (same arithmetic, fp32's exponent range), warns and marks the result; the
+    unguarded model returns the NaNs; an in-range model is never touched by the guard."""
+    import warnings
+
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import weights as Wt
+
+    d, cfg, ids, images_clip, images, cams, tables = _toy(golden_dir)
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    bf = torch.bfloat16
+    ic, im = images_clip.to(bf).to(cuda), images.to(bf).to(cuda)
+    args = (ic, im, ids[None, :40], cams, [(1024, 1024)], [(1024, 1024)])
+    kw = dict(forced_new_tokens=ids[40:].tolist())
+    m0 = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # an in-range model: no warning, no recomputation
+        ok = m0.evaluate(*args, **kw)
+    assert "recomputed_in_bf16" not in ok and bool(torch.isfinite(ok["pred_contact_3d"]).all())
+    del m0
+    w2 = dict(w)
+    for n in ("gate_proj", "up_proj"):
+        k = f"model.layers.0.mlp.{n}.weight"
+        w2[k] = (w[k].float() * 2048.0).to(bf)
+    m = M.InteractVLMForCausalLM(cfg, w2, cuda, lift_tables=tables)
+    assert m.precision == "default" and m.nonfinite_guard
+    m.nonfinite_guard = False
+    raw = m.evaluate(*args, **kw)
+    assert not bool(torch.isfinite(raw["pred_contact_3d"]).all())  # the premise: this model overflows fp16
+    m.nonfinite_guard = True
+    with pytest.warns(UserWarning, match="recomputed with bf16 operands"):
+        out = m.evaluate(*args, **kw)
+    assert out.get("recomputed_in_bf16") is True and m.precision == "default"
+    assert bool(torch.isfinite(out["pred_contact_3d"]).all())
+    with pytest.warns(UserWarning, match="recomputed with bf16 operands"):
+        outs = m.evaluate_batch(ic.repeat(2, 1, 1, 1), im.repeat(2, 1, 1, 1, 1), [ids[:40], ids[:40]], [cams[0]] * 2,
+                                [(1024, 1024)] * 2, [(1024, 1024)] * 2, forced_new_tokens=ids[40:].tolist())
+    assert all(o.get("recomputed_in_bf16") and bool(torch.isfinite(o["pred_contact_3d"]).all()) for o in outs)
+    m.set_precision("bf16")
+    ref = m.evaluate(*args, **kw)
+    assert torch.equal(out["pred_contact_3d"], ref["pred_contact_3d"]) and torch.equal(out["output_ids"], ref["output_ids"])
+    assert float((outs[1]["pred_contact_3d"] - ref["pred_contact_3d"]).abs().max()) < 1e-3
