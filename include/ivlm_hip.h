@@ -557,7 +557,17 @@ int ivlm_gemv1_bf12(const float *x, const void *P, int64_t ldp, const void *E, i
                     const int32_t *patch_ptr, const int32_t *patch_col, const void *patch_val, void *C, const void *bias,
                     const void *residual, int N, int K, int act, int out_f32, const void *rms_w, float rms_eps, int flags,
                     ivlm_stream_t stream);
-/* The packed matrix back as bf16 [N, K] (the losslessness check; not on the path). */
+/* The same product with the dots on the matrix cores: Pf / Ef hold the bytes of P / E in the order the lanes of
+ * v_mfma_f32_16x16x32_bf16 consume them - [N/16][K/64][64 lanes][16 | 8 bytes], lane = q*16 + r, byte h*8 + i of a lane = weight
+ * k = sp*64 + h*32 + q*8 + i of row rb*16 + r (E: two codes per byte, low nibble = even k) - the weights are the B operand, x enters
+ * as three bf16 rows hi + lo + lo2 (24 significant bits: the fp32 activation exactly), fp32 accumulation.  Two VALU operations per
+ * weight instead of five.  N % 16 == 0, K % 64 == 0, K <= 17066 (6 K bytes of LDS); x 16-byte aligned. */
+int ivlm_gemv1_bf12m(const float *x, const void *Pf, const void *Ef, const int32_t *ebase, const int32_t *patch_ptr,
+                     const int32_t *patch_col, const void *patch_val, void *C, const void *bias, const void *residual, int N, int K,
+                     int act, int out_f32, const void *rms_w, float rms_eps, int flags, ivlm_stream_t stream);
+/* A/B hook: grids of at most this many 16-row blocks run 16 waves per block (default 256 = one block per CU), larger ones 8. */
+void ivlm_gemv1_bf12m_tuning(int wide_max_blocks);
+/* The packed matrix (row layout) back as bf16 [N, K] (the losslessness check; not on the path). */
 int ivlm_unpack_bf12(const void *P, int64_t ldp, const void *E, int64_t lde, const int32_t *ebase, const int32_t *patch_ptr,
                      const int32_t *patch_col, const void *patch_val, int N, int K, void *w_out, ivlm_stream_t stream);
 

@@ -173,6 +173,198 @@ __global__ __launch_bounds__(64 * kWaves, 8) void gemv1_p12_kernel(GemmArgs g, P
     else static_cast<bf16_t*>(g.C)[row] = f32_to_bf16(v);
 }
 
+// =====================================================================================================================================
+// MFMA variant ("fragment layout"): the same 12-bit weights, dots on the matrix cores.
+//
+// gemv1_p12_kernel spends five VALU operations per weight (four to rebuild the fp32 number + the FMA): it is issue-bound, not HBM-bound
+// (2.56 instead of 0.75 x 2.67 ms per token).  Here a lane rebuilds bf16 PAIRS (byte permute, and-or, multiply, and-or: two operations
+// per weight) and v_mfma_f32_16x16x32_bf16 does the products: B operand = 16 weight rows x 32 k, A operand = x as THREE bf16 rows
+// (hi + lo + lo2 of x * 2^100: 24 significant bits, i.e. the fp32 activation exactly), so lane j < 16 finds sum_k w[j][k] (hi + lo + lo2)[k]
+// in its own accumulator registers d[0] + d[1] + d[2]: exact bf16 x bf16 products, fp32 accumulation - the arithmetic of gemv1_kernel
+// up to the summation order.  Rows 3 .. 15 of A repeat lo2 and are ignored.
+//
+// A block = 16 weight rows x 8 waves; a wave owns a contiguous range of 64-weight "step pairs" (two MFMA steps) of those rows and the
+// 16 partial sums of every wave meet in LDS in wave order.  The planes are stored in the order the lanes consume them, so every wave
+// instruction fetches 1 KB (P) / 512 B (E) contiguous:
+//     P [N/16][K/64][64 lanes][16 B]   lane = q * 16 + r (r = row in the block, q = k-quarter): bytes h * 8 + i = weight
+//                                      k = sp * 64 + h * 32 + q * 8 + i of row rb * 16 + r            (h: MFMA step of the pair)
+//     E [N/16][K/64][64 lanes][ 8 B]   the same weights' codes, two per byte (low nibble = even k)
+// (ops.PackedBf12 builds both layouts from the same P / E bytes; code 0 <-> bf16 zero, patches and ebase as above.)
+struct P12M {
+    const u32x4_t* P;
+    const u32x2_t* E;
+    const int32_t* ebase;
+    const int32_t* patch_ptr;
+    const int32_t* patch_col;
+    const bf16_t* patch_val;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8m_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4m_t;
+
+// two weights -> one dword of two bf16 numbers 1.m x 2^(code - 127) (code 0, P 0 -> 0): pd = [b1 b1 b0 b0] (each P byte twice: the sign
+// lands on bit 15 / 31, the mantissa on bits 6..0 / 22..16), e = the byte with the two codes (-> exponent-field bits 10..7 / 26..23)
+__device__ __forceinline__ uint32_t pair_p12m(uint32_t pd, uint32_t e) {
+    return (pd & 0x807f807fu) | ((e * 0x00080080u) & 0x07800780u);
+}
+// the eight weights of a lane for one MFMA step: P dwords x0 (k 0..3), x1 (k 4..7), code bytes in e
+__device__ __forceinline__ bf16x8m_t frag_p12m(uint32_t x0, uint32_t x1, uint32_t e) {
+    u32x4_t d;
+    d[0] = pair_p12m(__builtin_amdgcn_perm(0u, x0, 0x01010000u), e & 0xffu);
+    d[1] = pair_p12m(__builtin_amdgcn_perm(0u, x0, 0x03030202u), (e >> 8) & 0xffu);
+    d[2] = pair_p12m(__builtin_amdgcn_perm(0u, x1, 0x01010000u), (e >> 16) & 0xffu);
+    d[3] = pair_p12m(__builtin_amdgcn_perm(0u, x1, 0x03030202u), e >> 24);
+    return __builtin_bit_cast(bf16x8m_t, d);
+}
+
+// kWavesM = 8: 512-thread blocks, three fit a CU at <= 80 registers (1024-thread blocks: two only at <= 64, which this loop does not fit
+// without spills), so one block's prologue / tail runs under the others' streaming - the matrices with more row blocks than CUs.
+// kWavesM = 16: when there is at most one block per CU anyway (N <= 4096: o_proj, down_proj) all 16 wave slots of its SIMDs' share
+// belong to that block: twice the loads in flight.
+// U: step pairs in flight per lane, U x (16 + 8) bytes (8 with two 8-wave blocks per CU was measured slower than 4 with three: 2.66 vs
+// 2.44 ms per token)
+template <bool RMS, int kWavesM, int U>
+__global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12m_kernel(GemmArgs g, P12M p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // x * 2^100 as three bf16 planes [3][K]
+    __shared__ float s_red[kWavesM];
+    __shared__ float s_part[kWavesM][16];
+    __shared__ float s_patch[16];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = g.K, nsp = K >> 6;
+    const int per = (nsp + kWavesM - 1) / kWavesM;
+    const int s0 = wave * per, s1 = min(nsp, s0 + per);
+    const int64_t base = (int64_t)blockIdx.x * nsp * 64 + lane;
+    const u32x4_t* pp = p.P + base;
+    const u32x2_t* ep = p.E + base;
+    u32x4_t w[U];
+    u32x2_t e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int sp = min(s0 + u, nsp - 1);
+        w[u] = __builtin_nontemporal_load(pp + (int64_t)sp * 64);
+        e[u] = __builtin_nontemporal_load(ep + (int64_t)sp * 64);
+    }
+    // ---- stage x * 2^100 (x * gamma * 2^100) as hi + lo + lo2 bf16 planes, sum(x^2) of the unscaled row ----
+    const float xs = __builtin_ldexpf(1.0f, kXScaleExp);
+    float ssq = 0.0f;
+    uint32_t* xw = reinterpret_cast<uint32_t*>(smem);
+    for (int c = threadIdx.x; c < (K >> 2); c += 64 * kWavesM) {
+        const f32x4v_t xv4 = reinterpret_cast<const f32x4v_t*>(g.A)[c];
+        float v[4] = {xv4[0], xv4[1], xv4[2], xv4[3]};
+        if (RMS) {
+            const u32x2_t gv = *(reinterpret_cast<const u32x2_t*>(g.rms_w) + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ssq += v[j] * v[j];
+            v[0] *= __uint_as_float(gv[0] << 16);
+            v[1] *= __uint_as_float(gv[0] & 0xffff0000u);
+            v[2] *= __uint_as_float(gv[1] << 16);
+            v[3] *= __uint_as_float(gv[1] & 0xffff0000u);
+        }
+        uint32_t hi[2], lo[2], l2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float a = v[2 * j] * xs, b = v[2 * j + 1] * xs;
+            const float ah = bf16_to_f32(f32_to_bf16(a)), bh = bf16_to_f32(f32_to_bf16(b));
+            hi[j] = pack_bf16x2(ah, bh);
+            a -= ah;
+            b -= bh;
+            const float al = bf16_to_f32(f32_to_bf16(a)), bl = bf16_to_f32(f32_to_bf16(b));
+            lo[j] = pack_bf16x2(al, bl);
+            l2[j] = pack_bf16x2(a - al, b - bl);
+        }
+        *reinterpret_cast<u32x2_t*>(xw + 2 * c) = u32x2_t{hi[0], hi[1]};
+        *reinterpret_cast<u32x2_t*>(xw + (K >> 1) + 2 * c) = u32x2_t{lo[0], lo[1]};
+        *reinterpret_cast<u32x2_t*>(xw + K + 2 * c) = u32x2_t{l2[0], l2[1]};
+    }
+    if (RMS) {
+        ssq = wave_sum(ssq);
+        if (lane == 0) s_red[wave] = ssq;
+    }
+    __syncthreads();
+    // A fragments: lane (i = lane & 15: plane min(i, 2); q = lane >> 4) reads k = step * 32 + q * 8 .. + 7 of its plane
+    const int plane = min(lane & 15, 2);
+    const u32x4_t* xa = reinterpret_cast<const u32x4_t*>(smem) + ((plane * K) >> 3) + (lane >> 4);
+    f32x4m_t d = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto step_pair = [&](const u32x4_t& pw, const u32x2_t& ew, int sp) {
+        const bf16x8m_t a0 = __builtin_bit_cast(bf16x8m_t, xa[sp * 8]);
+        const bf16x8m_t a1 = __builtin_bit_cast(bf16x8m_t, xa[sp * 8 + 4]);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, frag_p12m(pw[0], pw[1], ew[0]), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, frag_p12m(pw[2], pw[3], ew[1]), d, 0, 0, 0);
+    };
+    constexpr int UH = U / 2;
+    for (int sp = s0; sp < s1; sp += U) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int u = hf * UH; u < (hf + 1) * UH; ++u)
+                if (sp + u < s1) step_pair(w[u], e[u], sp + u);
+#pragma unroll
+            for (int u = hf * UH; u < (hf + 1) * UH; ++u) {
+                const int nx = sp + U + u;
+                if (nx < s1) {
+                    w[u] = __builtin_nontemporal_load(pp + (int64_t)nx * 64);
+                    e[u] = __builtin_nontemporal_load(ep + (int64_t)nx * 64);
+                }
+            }
+        }
+    }
+    if (lane < 16) s_part[wave][lane] = d[0] + d[1] + d[2];
+    // ---- the tail: wave w owns the patches of row w (and w + 8 in the 8-wave form) of the block (the nonzero weights outside the row's exponent window:
+    //      exact bf16 values, on average < 1 per row) against (hi + lo + lo2)[col] = the fp32 activation * 2^100 (the three parts add up
+    //      exactly); the 16 finishing lanes of wave 0 fetch their row's exponent base / bias / residual meanwhile ----
+    const bool fin = wave == 0 && lane < 16;
+    const int row = blockIdx.x * 16 + (lane & 15);  // (N % 16 == 0: every row is live)
+    int eb = 0;
+    bf16_t bias_raw = 0;
+    uint32_t res_raw = 0;
+    if (fin) {
+        eb = p.ebase[row];
+        if (g.bias) bias_raw = g.bias[row];
+        if (g.residual) res_raw = g.res_f32 ? reinterpret_cast<const uint32_t*>(g.residual)[row] : (uint32_t)g.residual[row] << 16;
+    }
+    const bf16_t* xb = reinterpret_cast<const bf16_t*>(smem);
+#pragma unroll
+    for (int h = 0; h < 16 / kWavesM; ++h) {
+        const int r = wave + kWavesM * h;
+        const int pp0 = p.patch_ptr[blockIdx.x * 16 + r], pp1 = p.patch_ptr[blockIdx.x * 16 + r + 1];  // (wave-uniform)
+        float pacc = 0.0f;
+        if (pp0 < pp1) {
+            for (int i = pp0 + lane; i < pp1; i += 64) {
+                const int col = p.patch_col[i];
+                const float xv = (bf16_to_f32(xb[col]) + bf16_to_f32(xb[K + col])) + bf16_to_f32(xb[2 * K + col]);
+                pacc = fmaf(bf16_to_f32(p.patch_val[i]), xv, pacc);
+            }
+            pacc = wave_sum(pacc);
+        }
+        if (lane == 0) s_patch[r] = pacc;
+    }
+    __syncthreads();
+    if (!fin) return;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kWavesM; ++i) acc += s_part[i][lane];
+    acc = __builtin_ldexpf(acc, eb - kXScaleExp) + __builtin_ldexpf(s_patch[lane], -kXScaleExp);
+    if (RMS) {
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kWavesM; ++i) q += s_red[i];
+        acc *= rsqrtf(q / (float)K + g.rms_eps);
+    }
+    float v = acc + bf16_to_f32(bias_raw);
+    if (g.act == ACT_SWIGLU) {  // rows (gate_j, up_j) interleaved: the even lane finishes the pair
+        const float up = __shfl_down(v, 1, 64);
+        if (lane & 1) return;
+        const float o = (v / (1.0f + __expf(-v))) * up;
+        const int64_t idx = row >> 1;
+        if (g.out_f32) static_cast<float*>(g.C)[idx] = o;
+        else static_cast<bf16_t*>(g.C)[idx] = f32_to_bf16(o);
+        return;
+    }
+    v = act1(v, g.act) + __uint_as_float(res_raw);
+    if (g.out_f32) static_cast<float*>(g.C)[row] = v;
+    else static_cast<bf16_t*>(g.C)[row] = f32_to_bf16(v);
+}
+
 // exact reconstruction of the bf16 matrix (the losslessness check of the tests; not on the path): one thread per weight
 __global__ __launch_bounds__(256) void unpack_p12_kernel(P12 p, int N, int K, bf16_t* __restrict__ out) {
     const int64_t total = (int64_t)N * K;
@@ -255,3 +447,54 @@ extern "C" int ivlm_unpack_bf12(const void* P, int64_t ldp, const void* E, int64
     unpack_p12_patch_kernel<<<N, 256, 0, st>>>(p, N, K, static_cast<bf16_t*>(w_out));
     return ivlm_launch_status();
 }
+
+int g_p12m_wide_max_blocks = 256;  // A/B hook: ivlm_gemv1_bf12m_tuning
+
+// MFMA variant on the fragment layout (see gemv1_p12m_kernel): Pf / Ef = the P / E bytes of ivlm_gemv1_bf12 re-ordered as
+// [N/16][K/64][64 lanes][16 | 8 bytes]; N % 16 == 0, K % 64 == 0, 6 K bytes of LDS.  Same contract otherwise.
+extern "C" int ivlm_gemv1_bf12m(const float* x, const void* Pf, const void* Ef, const int32_t* ebase, const int32_t* patch_ptr,
+                                const int32_t* patch_col, const void* patch_val, void* C, const void* bias, const void* residual, int N,
+                                int K, int act, int out_f32, const void* rms_w, float rms_eps, int flags, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!x || !C || !Pf || !Ef || !ebase || !patch_ptr || !patch_col || !patch_val || N <= 0 || K <= 0) return IVLM_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(Pf) & 15) || (reinterpret_cast<uintptr_t>(Ef) & 7) || (reinterpret_cast<uintptr_t>(x) & 15))
+        return IVLM_ERR_INVALID_ARG;
+    if ((N & 15) || (K & 63) || (size_t)K * 6 > 100 * 1024) return IVLM_ERR_UNSUPPORTED;
+    if (act == ACT_SWIGLU && residual) return IVLM_ERR_UNSUPPORTED;
+    GemmArgs g;
+    g.A = reinterpret_cast<const bf16_t*>(x);
+    g.a_f32 = 1;
+    g.C = C;
+    g.bias = static_cast<const bf16_t*>(bias);
+    g.residual = static_cast<const bf16_t*>(residual);
+    g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
+    g.M = 1; g.N = N; g.K = K;
+    g.lda = K;
+    g.act = act;
+    g.out_f32 = out_f32;
+    g.rms_w = static_cast<const bf16_t*>(rms_w);
+    g.rms_eps = rms_eps;
+    P12M p{static_cast<const u32x4_t*>(Pf), static_cast<const u32x2_t*>(Ef), ebase, patch_ptr, patch_col,
+           static_cast<const bf16_t*>(patch_val)};
+    hipStream_t st = ivlm_stream(stream);
+    const dim3 grid(N / 16);
+    const bool wide = grid.x <= (unsigned)g_p12m_wide_max_blocks;  // at most one block per CU: 16 waves per block
+    auto go = [&](auto kfn, int waves, bool& set) {
+        if (!set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+            set = true;
+        }
+        ivlm_launch(kfn, grid, dim3(64 * waves), (size_t)K * 6, st, g, p);
+    };
+    static bool set[4] = {false, false, false, false};
+    if (rms_w) {
+        if (wide) go(gemv1_p12m_kernel<true, 16, 4>, 16, set[0]);
+        else go(gemv1_p12m_kernel<true, 8, 4>, 8, set[1]);
+    } else {
+        if (wide) go(gemv1_p12m_kernel<false, 16, 4>, 16, set[2]);
+        else go(gemv1_p12m_kernel<false, 8, 4>, 8, set[3]);
+    }
+    return ivlm_launch_status();
+}
+
+extern "C" void ivlm_gemv1_bf12m_tuning(int wide_max_blocks) { g_p12m_wide_max_blocks = wide_max_blocks < 0 ? 0 : wide_max_blocks; }

@@ -208,12 +208,11 @@ class Llama:
         # GEMV was the persistent kernel; with gemv1_kernel the separate launches are as fast (2.67 vs 2.68 ms/token, same
         # end to end), so the simpler graph is the default and the fused launch stays opt-in (tests cover both)
         self.fuse_attn_oproj = bool(os.environ.get("IVLM_FUSE_ATTN_OPROJ"))
-        # OPT-IN experiment: the batch-1 decode linears over LOSSLESSLY packed weights (ops.PackedBf12: 1.5 bytes per weight, every
-        # bf16 value reconstructed bit for bit; copies made on the first decode step, +10 GB for 7B).  The step is HBM-bound on the
-        # weight bytes, but unpacking costs 4 integer operations per weight and the kernel turns VALU-bound: decode ALONE 2.67 ->
-        # 2.56 ms per token (25 % fewer bytes, 4 % less time), evaluate() end to end 9.63 -> 9.55 images/s (SLOWER: alternating runs
-        # on one box) - so it stays off.  DESIGN.md has the instruction counts.
-        self.decode_packed = os.environ.get("IVLM_DECODE_PACKED", "0") == "1"
+        # The batch-1 decode linears stream LOSSLESSLY packed weights (ops.PackedBf12: 1.5 bytes per weight, every bf16 value
+        # reconstructed bit for bit, dots on the matrix cores: ivlm_gemv1_bf12m; copies made on the first decode step, +10 GB for
+        # 7B): 2.69 -> 2.44 ms per token.  Matrices whose shape the fragment layout does not take (rows % 16, columns % 64) and the
+        # lm_head stay on the bf16 kernel.  IVLM_DECODE_PACKED=0 / decode_packed = False: bf16 weights everywhere.
+        self.decode_packed = os.environ.get("IVLM_DECODE_PACKED", "1") != "0"
 
     # ---- "parity" precision (opt-in): the prefill GEMMs take hi + lo bf16 activation operands, the attention three MFMAs per
     # fragment, and K / V are cached as hi + lo planes (also read by the decode kernels) - no activation is rounded to bf16.
@@ -583,16 +582,21 @@ class Llama:
                 x = ops.linear_fp8w(h, L["down_q"], L["down_s"], residual=x)
             return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
         kc_, vc_ = self._caches()
-        if self.decode_packed and fz is None and c.hidden % 16 == 0 and c.inter % 16 == 0 and max(c.hidden, c.inter) * 4 <= 60 * 1024:
+        if self.decode_packed and fz is None:
+            def lin(x_, L, n, **kw):  # (packed where the fragment layout takes the matrix, bf16 otherwise)
+                if n + "_p" not in L:
+                    N_, K_ = L[n].shape
+                    L[n + "_p"] = ops.PackedBf12(L[n]) if ops.PackedBf12.takes(N_, K_) else None
+                wp = L[n + "_p"]
+                return ops.linear_bf12(x_, wp, **kw) if wp is not None else ops.linear(x_, L[n], out_f32=True, **kw)
+
             for li, L in enumerate(self.layers):
-                if "qkv_p" not in L:
-                    for n in ("qkv", "o", "gu", "down"):
-                        L[n + "_p"] = ops.PackedBf12(L[n])
-                qkv = ops.linear_bf12(x, L["qkv_p"], rms=(L["ln1"], c.eps))
-                a = ops.llama_decode_attn(qkv, kc_[li], vc_[li], H, hd, pos, c.theta, hd ** -0.5, table=self.rope, lo=self._lo(li))
-                x = ops.linear_bf12(a, L["o_p"], residual=x)
-                h = ops.linear_bf12(x, L["gu_p"], act="swiglu", rms=(L["ln2"], c.eps))
-                x = ops.linear_bf12(h, L["down_p"], residual=x)
+                qkv = lin(x, L, "qkv", rms=(L["ln1"], c.eps))
+                a = ops.llama_decode_attn(qkv, kc_[li], vc_[li], H, hd, pos, c.theta, hd ** -0.5, table=self.rope, lo=self._lo(li),
+                                          scratch=self._attn_scratch())
+                x = lin(a, L, "o", residual=x)
+                h = lin(x, L, "gu", act="swiglu", rms=(L["ln2"], c.eps))
+                x = lin(h, L, "down", residual=x)
             return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
         for li, L in enumerate(self.layers):
             qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps), out_f32=True)
@@ -613,8 +617,4 @@ class Llama:
         chunks re-streamed the 262 MB of lm_head once per chunk)."""
         if hidden_rows.shape[0] > 16:
             return ops.linear(ops.split_rows(hidden_rows.contiguous()), self.lm_head, out_f32=True, a_split=True)
-        if hidden_rows.shape[0] == 1 and self.decode_packed and self.cfg.hidden % 16 == 0 and self.cfg.hidden * 4 <= 60 * 1024:
-            if not hasattr(self, "lm_head_p"):
-                self.lm_head_p = ops.PackedBf12(self.lm_head)
-            return ops.linear_bf12(hidden_rows.contiguous(), self.lm_head_p)
         return ops.linear(hidden_rows, self.lm_head, out_f32=True)

@@ -531,7 +531,12 @@ class PackedBf12:
     mantissa), E nibbles (exponent code relative to the row's window), per-row exponent base, CSR patches for the (rare) nonzero
     weights outside the window.  Built once per matrix on the device (weight preparation, like the q|k|v concatenation)."""
 
-    def __init__(self, w):
+    @staticmethod
+    def takes(N, K):
+        """shapes the fragment layout (the MFMA kernel) takes: 16-row blocks, 64-column step pairs, x as three bf16 planes in LDS"""
+        return N % 16 == 0 and K % 64 == 0 and K * 6 <= 100 * 1024
+
+    def __init__(self, w, fragments=True):
         assert w.dtype == BF16 and w.dim() == 2 and w.is_cuda and w.shape[1] % 16 == 0
         if not bool(torch.isfinite(w).all()):
             raise IvlmError("PackedBf12: inf / nan weights cannot be packed")
@@ -553,18 +558,38 @@ class PackedBf12:
         self.patch_col = (cols.to(torch.int32) if rows.numel() else torch.zeros(1, dtype=torch.int32, device=w.device)).contiguous()
         self.patch_val = (w[rows, cols] if rows.numel() else torch.zeros(1, dtype=BF16, device=w.device)).contiguous()
         self.shape, self.n_patches = (N, K), int(rows.numel())
+        # fragment layout of the MFMA kernel (ivlm_gemv1_bf12m): the SAME bytes in the order the lanes consume them -
+        # [N/16][K/64][lane = q*16 + r][h*8 + i] for weight k = sp*64 + h*32 + q*8 + i of row rb*16 + r.  Kept INSTEAD of the row layout.
+        self.frag = fragments and self.takes(N, K)
+        if self.frag:
+            self.P = self.P.view(N // 16, 16, K // 64, 2, 4, 8).permute(0, 2, 4, 1, 3, 5).contiguous()
+            self.E = self.E.view(N // 16, 16, K // 64, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).contiguous()
 
     def bytes(self):
         return self.P.numel() + self.E.numel() + 4 * self.ebase.numel() + 4 * self.patch_ptr.numel() + 6 * self.n_patches
 
+    def _rows(self):
+        """(P [N, K], E [N, K/2]) in the row layout"""
+        if not self.frag:
+            return self.P, self.E
+        N, K = self.shape
+        return (self.P.permute(0, 3, 1, 4, 2, 5).reshape(N, K).contiguous(), self.E.permute(0, 3, 1, 4, 2, 5).reshape(N, K // 2).contiguous())
+
     def _args(self):
-        return (self.P.data_ptr(), self.P.stride(0), self.E.data_ptr(), self.E.stride(0), self.ebase.data_ptr(),
+        P, E = self._rows()
+        self._keep = (P, E)
+        return (P.data_ptr(), P.stride(0), E.data_ptr(), E.stride(0), self.ebase.data_ptr(),
                 self.patch_ptr.data_ptr(), self.patch_col.data_ptr(), self.patch_val.data_ptr())
+
+    def _args_frag(self):
+        return (self.P.data_ptr(), self.E.data_ptr(), self.ebase.data_ptr(), self.patch_ptr.data_ptr(), self.patch_col.data_ptr(),
+                self.patch_val.data_ptr())
 
     def unpack(self):
         """-> bf16 [N, K], bit-identical to the matrix that was packed."""
         out = torch.empty(self.shape, dtype=BF16, device=self.P.device)
         check(_lib.load().ivlm_unpack_bf12(*self._args(), self.shape[0], self.shape[1], out.data_ptr(), _stream()), "unpack_bf12")
+        self._keep = None
         return out
 
 
@@ -581,9 +606,14 @@ def linear_bf12(x, wp: PackedBf12, bias=None, act="none", residual=None, out_f32
         assert residual.dtype in (BF16, F32) and residual.is_contiguous() and residual.numel() == N
         if residual.dtype == F32:
             flags |= GEMM_RES_F32
-    call = lambda: check(lib.ivlm_gemv1_bf12(x.data_ptr(), *wp._args(), out.data_ptr(), _p(bias), _p(residual), N, K, ACT[act],
-                                             1 if out_f32 else 0, _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, flags,
-                                             _stream()), "gemv1_bf12")
+    if wp.frag:  # MFMA kernel on the fragment layout
+        call = lambda: check(lib.ivlm_gemv1_bf12m(x.data_ptr(), *wp._args_frag(), out.data_ptr(), _p(bias), _p(residual), N, K,
+                                                  ACT[act], 1 if out_f32 else 0, _p(rms[0]) if rms else 0,
+                                                  float(rms[1]) if rms else 0.0, flags, _stream()), "gemv1_bf12m")
+    else:
+        call = lambda: check(lib.ivlm_gemv1_bf12(x.data_ptr(), *wp._args(), out.data_ptr(), _p(bias), _p(residual), N, K, ACT[act],
+                                                 1 if out_f32 else 0, _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0,
+                                                 flags, _stream()), "gemv1_bf12")
     if TIMER.enabled:  # work = the ALGORITHMIC bytes (the bf16 matrix), like the other decode linears
         TIMER.time("gemv_bf16", 2.0 * N * K, call, tag=(1, N, K, act, "bf12"))
     else:

@@ -699,7 +699,9 @@ def test_gemm_f16_split_operand_and_output(hip_lib, cuda):
 
 @pytest.mark.parametrize("N,K,act,rms,res", [(12288, 4096, "none", True, False), (4096, 4096, "none", False, True),
                                              (22016, 4096, "swiglu", True, False), (4096, 11008, "none", False, True),
-                                             (32003, 4096, "none", False, False), (40, 512, "none", True, True)])
+                                             (32003, 4096, "none", False, False), (40, 512, "none", True, True),
+                                             (48, 1024, "swiglu", True, False), (16, 64, "none", False, True),
+                                             (5120, 13824, "none", False, True)])
 def test_gemv_bf12_is_lossless_and_equals_the_bf16_gemv(hip_lib, cuda, N, K, act, rms, res):
     """The 12-bit packed weight layout of the batch-1 decode linears: every weight (zeros, subnormals, the far tail below the row's
     exponent window: patches) is reconstructed BIT FOR BIT, and the linear on the packed matrix equals the bf16 GEMV on the original
@@ -715,15 +717,21 @@ def test_gemv_bf12_is_lossless_and_equals_the_bf16_gemv(hip_lib, cuda, N, K, act
     w[1, 5] = 3e4
     w[min(7, N - 1)] = 0
     w = w.to(cuda)
-    wp = ops.PackedBf12(w)
-    assert torch.equal(wp.unpack().view(torch.int16), torch.where(w == 0, torch.zeros_like(w), w).view(torch.int16))  # (-0.0 packs as +0.0)
-    assert wp.n_patches >= 6 and (N < 1000 or wp.bytes() < 0.77 * w.numel() * 2)  # (1.5 of 2 bytes per weight + row tables / patches)
     x = (torch.randn(1, K, generator=g) * 2.0).to(cuda)
     gam = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().to(cuda) if rms else None
     r = torch.randn(1, N, generator=g).to(cuda) if res else None
     kw = dict(act=act, residual=r, rms=(gam, 1e-5) if rms else None)
-    got = ops.linear_bf12(x, wp, **kw)
     ref16 = ops.linear(x, w, out_f32=True, **kw)
+    got = None
+    for fragments in (False, True):  # row layout (VALU kernel) and fragment layout (MFMA kernel: N % 16 == 0, K % 64 == 0)
+        wp = ops.PackedBf12(w, fragments=fragments)
+        assert wp.frag == (fragments and N % 16 == 0 and K % 64 == 0)
+        assert torch.equal(wp.unpack().view(torch.int16), torch.where(w == 0, torch.zeros_like(w), w).view(torch.int16))  # (-0.0 -> +0.0)
+        assert wp.n_patches >= 6 and (N < 1000 or wp.bytes() < 0.77 * w.numel() * 2)  # (1.5 of 2 bytes per weight + tables / patches)
+        y_ = ops.linear_bf12(x, wp, **kw)
+        if got is not None:
+            assert float((y_ - got).abs().max()) <= 3e-6 * max(1.0, float(got.abs().max()))
+        got = y_
     xd = x.double()
     if rms:
         xd = xd * torch.rsqrt((xd * xd).mean() + 1e-5) * gam.double()

@@ -446,8 +446,9 @@ def test_gemm_fp16_operands_and_output(hip_lib, cuda, M, N, K, act):
     w = wb.to(torch.float16)  # exact above the fp16 subnormal range, off by <= 2^-25 below it
     assert float((w.float() - wb.float()).abs().max()) <= 2.0 ** -25
     assert torch.equal(ops.bf16_to_f16(wb.to(cuda)).cpu(), w)  # ivlm_bf16_to_f16: RNE like torch's conversion
-    big = torch.tensor([1e6, -3e38, 65504.0, 7.0, 1e-9, -0.0, 3.0], dtype=torch.bfloat16)  # ... saturating, odd length (tail path)
-    assert torch.equal(ops.bf16_to_f16(big.to(cuda)).cpu(), big.float().clamp(-65504, 65504).to(torch.float16))
+    # out of range -> inf, like torch's conversion (NOT clamped: an overflow must stay visible, DESIGN.md par. 3); odd length (tail path)
+    big = torch.tensor([1e6, -3e38, 65504.0, 7.0, 1e-9, -0.0, 3.0], dtype=torch.bfloat16)
+    assert torch.equal(ops.bf16_to_f16(big.to(cuda)).cpu(), big.to(torch.float16))
     b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
     r = torch.randn(M, N, generator=g)
     ref = x.double() @ w.double().T + b.double()

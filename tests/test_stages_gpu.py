@@ -19,6 +19,7 @@ def test_llama_prefill_and_decode_step_equal_python_path(hip_lib, cuda, hidden, 
     emb = (torch.randn(T0 + n_new, hidden, generator=g) * 0.5).to(torch.bfloat16).float().to(cuda)
     # Python-sequenced reference: prefill, then decode steps through the captured graph (fused attention + o_proj where it applies)
     a = llava.Llama(w, lc, cuda, max_len=512)
+    a.decode_packed = False  # (the C sequencers of this test stream the bf16 weights: compare like with like, bit for bit)
     a.fuse_attn_oproj = fuse  # (attention + o_proj in one launch: opt-in on both sides)
     ha = [a.forward(emb[:T0], 0)]
     dg = a.decode_graph()
@@ -54,6 +55,7 @@ def test_llama_prefill_and_decode_step_equal_python_path(hip_lib, cuda, hidden, 
         # the DEFAULT precision of the host model: ivlm_llama_prefill_f16 / ivlm_llama_decode_step_f16kv (fp16 MFMA operands, fp16
         # KV cache) == the Python-sequenced "f16" path bit for bit
         a2 = llava.Llama(w, lc, cuda, max_len=512)
+        a2.decode_packed = False
         a2.set_precision("f16")
         h2 = [a2.forward(emb[:T0], 0)]
         for t in range(n_new):

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--prefill", type=int, default=330, help="positions in the cache before the timed steps (the headline prompt: 256 image tokens + text)")
     ap.add_argument("--precision", default="f16", help="tower precision: f16 (the default mode of the model) | default (bf16)")
     ap.add_argument("--splits", type=int, default=0, help="split-KV ranges per head (0 = library default)")
+    ap.add_argument("--wide", type=int, default=-1, help="ivlm_gemv1_bf12m_tuning: 16-wave blocks up to this many row blocks (-1 = default)")
     ap.add_argument("--tiles", type=int, default=0, help="skinny MFMA tiles per block (0 = automatic)")
     a = ap.parse_args()
     from interactvlm_amd import llava, synthetic
@@ -42,6 +43,8 @@ def main():
     llm.fuse_attn_oproj = a.fuse
     if a.precision != "default":
         llm.set_precision(a.precision)
+    if a.wide != -1:
+        _lib.load().ivlm_gemv1_bf12m_tuning(a.wide)
     if a.splits:
         assert _lib.load().ivlm_llama_decode_attn_splits(a.splits) == 0
         llm.decode_splitkv = True
