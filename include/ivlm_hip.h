@@ -565,7 +565,8 @@ int ivlm_gemv1_bf12(const float *x, const void *P, int64_t ldp, const void *E, i
 int ivlm_gemv1_bf12m(const float *x, const void *Pf, const void *Ef, const int32_t *ebase, const int32_t *patch_ptr,
                      const int32_t *patch_col, const void *patch_val, void *C, const void *bias, const void *residual, int N, int K,
                      int act, int out_f32, const void *rms_w, float rms_eps, int flags, ivlm_stream_t stream);
-/* A/B hook: grids of at most this many 16-row blocks run 16 waves per block (default 256 = one block per CU), larger ones 8. */
+/* A/B hook: grids of at most this many 16-row blocks run 16 waves per block (default 256 = one block per CU), larger ones 8;
+   a negative value: the same limit without the 8-deep prefetch of long rows. */
 void ivlm_gemv1_bf12m_tuning(int wide_max_blocks);
 /* The packed matrix (row layout) back as bf16 [N, K] (the losslessness check; not on the path). */
 int ivlm_unpack_bf12(const void *P, int64_t ldp, const void *E, int64_t lde, const int32_t *ebase, const int32_t *patch_ptr,

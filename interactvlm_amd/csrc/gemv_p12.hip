@@ -244,6 +244,32 @@ __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12
         w[u] = __builtin_nontemporal_load(pp + (int64_t)sp * 64);
         e[u] = __builtin_nontemporal_load(ep + (int64_t)sp * 64);
     }
+    // The tail's operands.  kWavesM == 16 (one block per CU: nothing else would hide a round trip after the last MFMA): fetched NOW,
+    // behind the weights - raw bits only, a conversion here would be a use and make the wave wait, in order, for every load issued
+    // so far.  kWavesM == 8 (three blocks per CU, 80 registers): fetched in the tail, under the other blocks' streaming.
+    constexpr bool EARLY = kWavesM == 16;  // (for the 8-wave form too: measured no faster)
+    const bool fin = wave == 0 && lane < 16;
+    const int row = blockIdx.x * 16 + (lane & 15);  // (N % 16 == 0: every row is live)
+    int eb = 0;
+    uint32_t bias_raw = 0, res_raw = 0;  // raw bits (16 or 32 of them); shifted / converted in the tail
+    auto load_fin = [&]() {
+        if (fin) {
+            eb = p.ebase[row];
+            if (g.bias) bias_raw = g.bias[row];
+            if (g.residual) res_raw = g.res_f32 ? reinterpret_cast<const uint32_t*>(g.residual)[row] : (uint32_t)g.residual[row];
+        }
+    };
+    int e_pp0 = 0, e_pp1 = 0, e_col = 0;
+    uint32_t e_val = 0;
+    if (EARLY) {
+        e_pp0 = p.patch_ptr[blockIdx.x * 16 + wave];
+        e_pp1 = p.patch_ptr[blockIdx.x * 16 + wave + 1];
+        if (e_pp0 + lane < e_pp1) {
+            e_col = p.patch_col[e_pp0 + lane];
+            e_val = p.patch_val[e_pp0 + lane];
+        }
+        load_fin();
+    }
     // ---- stage x * 2^100 (x * gamma * 2^100) as hi + lo + lo2 bf16 planes, sum(x^2) of the unscaled row ----
     const float xs = __builtin_ldexpf(1.0f, kXScaleExp);
     float ssq = 0.0f;
@@ -312,28 +338,26 @@ __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12
     // ---- the tail: wave w owns the patches of row w (and w + 8 in the 8-wave form) of the block (the nonzero weights outside the row's exponent window:
     //      exact bf16 values, on average < 1 per row) against (hi + lo + lo2)[col] = the fp32 activation * 2^100 (the three parts add up
     //      exactly); the 16 finishing lanes of wave 0 fetch their row's exponent base / bias / residual meanwhile ----
-    const bool fin = wave == 0 && lane < 16;
-    const int row = blockIdx.x * 16 + (lane & 15);  // (N % 16 == 0: every row is live)
-    int eb = 0;
-    bf16_t bias_raw = 0;
-    uint32_t res_raw = 0;
-    if (fin) {
-        eb = p.ebase[row];
-        if (g.bias) bias_raw = g.bias[row];
-        if (g.residual) res_raw = g.res_f32 ? reinterpret_cast<const uint32_t*>(g.residual)[row] : (uint32_t)g.residual[row] << 16;
+    if (!EARLY) load_fin();
+    if (EARLY) {  // pin the first USE of the early loads here (the compiler hoists a shift / an address computation to the load, and
+                  // with it the in-order wait for everything issued before)
+        asm volatile("" : "+v"(e_col), "+v"(e_val), "+v"(eb), "+v"(bias_raw), "+v"(res_raw));
     }
     const bf16_t* xb = reinterpret_cast<const bf16_t*>(smem);
+    auto xat = [&](int col) { return (bf16_to_f32(xb[col]) + bf16_to_f32(xb[K + col])) + bf16_to_f32(xb[2 * K + col]); };
 #pragma unroll
     for (int h = 0; h < 16 / kWavesM; ++h) {
         const int r = wave + kWavesM * h;
-        const int pp0 = p.patch_ptr[blockIdx.x * 16 + r], pp1 = p.patch_ptr[blockIdx.x * 16 + r + 1];  // (wave-uniform)
+        const int pp0 = EARLY ? e_pp0 : p.patch_ptr[blockIdx.x * 16 + r];  // (wave-uniform)
+        const int pp1 = EARLY ? e_pp1 : p.patch_ptr[blockIdx.x * 16 + r + 1];
         float pacc = 0.0f;
         if (pp0 < pp1) {
-            for (int i = pp0 + lane; i < pp1; i += 64) {
-                const int col = p.patch_col[i];
-                const float xv = (bf16_to_f32(xb[col]) + bf16_to_f32(xb[K + col])) + bf16_to_f32(xb[2 * K + col]);
-                pacc = fmaf(bf16_to_f32(p.patch_val[i]), xv, pacc);
+            int i = pp0 + lane;
+            if (EARLY) {
+                if (i < pp1) pacc = __uint_as_float(e_val << 16) * xat(e_col);
+                i += 64;
             }
+            for (; i < pp1; i += 64) pacc = fmaf(bf16_to_f32(p.patch_val[i]), xat(p.patch_col[i]), pacc);
             pacc = wave_sum(pacc);
         }
         if (lane == 0) s_patch[r] = pacc;
@@ -350,7 +374,7 @@ __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12
         for (int i = 0; i < kWavesM; ++i) q += s_red[i];
         acc *= rsqrtf(q / (float)K + g.rms_eps);
     }
-    float v = acc + bf16_to_f32(bias_raw);
+    float v = acc + __uint_as_float(bias_raw << 16);
     if (g.act == ACT_SWIGLU) {  // rows (gate_j, up_j) interleaved: the even lane finishes the pair
         const float up = __shfl_down(v, 1, 64);
         if (lane & 1) return;
@@ -360,7 +384,7 @@ __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12
         else static_cast<bf16_t*>(g.C)[idx] = f32_to_bf16(o);
         return;
     }
-    v = act1(v, g.act) + __uint_as_float(res_raw);
+    v = act1(v, g.act) + __uint_as_float(g.res_f32 ? res_raw : res_raw << 16);
     if (g.out_f32) static_cast<float*>(g.C)[row] = v;
     else static_cast<bf16_t*>(g.C)[row] = f32_to_bf16(v);
 }
@@ -448,7 +472,8 @@ extern "C" int ivlm_unpack_bf12(const void* P, int64_t ldp, const void* E, int64
     return ivlm_launch_status();
 }
 
-int g_p12m_wide_max_blocks = 256;  // A/B hook: ivlm_gemv1_bf12m_tuning
+int g_p12m_wide_max_blocks = 256;  // A/B hooks: ivlm_gemv1_bf12m_tuning
+int g_p12m_deep = 1;
 
 // MFMA variant on the fragment layout (see gemv1_p12m_kernel): Pf / Ef = the P / E bytes of ivlm_gemv1_bf12 re-ordered as
 // [N/16][K/64][64 lanes][16 | 8 bytes]; N % 16 == 0, K % 64 == 0, 6 K bytes of LDS.  Same contract otherwise.
@@ -486,15 +511,23 @@ extern "C" int ivlm_gemv1_bf12m(const float* x, const void* Pf, const void* Ef, 
         }
         ivlm_launch(kfn, grid, dim3(64 * waves), (size_t)K * 6, st, g, p);
     };
-    static bool set[4] = {false, false, false, false};
+    static bool set[6] = {false, false, false, false, false, false};
+    // (one block per CU and a long row - down_proj: 8 step pairs in flight per lane, so that most of the block's 264 KB is requested
+    //  BEFORE the x staging, which otherwise runs with only the first 96 KB on their way)
+    const bool deep = wide && (K >> 6) > 4 * 16 && g_p12m_deep;
     if (rms_w) {
-        if (wide) go(gemv1_p12m_kernel<true, 16, 4>, 16, set[0]);
+        if (deep) go(gemv1_p12m_kernel<true, 16, 8>, 16, set[4]);
+        else if (wide) go(gemv1_p12m_kernel<true, 16, 4>, 16, set[0]);
         else go(gemv1_p12m_kernel<true, 8, 4>, 8, set[1]);
     } else {
-        if (wide) go(gemv1_p12m_kernel<false, 16, 4>, 16, set[2]);
+        if (deep) go(gemv1_p12m_kernel<false, 16, 8>, 16, set[5]);
+        else if (wide) go(gemv1_p12m_kernel<false, 16, 4>, 16, set[2]);
         else go(gemv1_p12m_kernel<false, 8, 4>, 8, set[3]);
     }
     return ivlm_launch_status();
 }
 
-extern "C" void ivlm_gemv1_bf12m_tuning(int wide_max_blocks) { g_p12m_wide_max_blocks = wide_max_blocks < 0 ? 0 : wide_max_blocks; }
+extern "C" void ivlm_gemv1_bf12m_tuning(int wide_max_blocks) {
+    g_p12m_deep = wide_max_blocks >= 0;  // (negative: |value| as the limit, without the 8-deep form)
+    g_p12m_wide_max_blocks = wide_max_blocks < 0 ? -wide_max_blocks : wide_max_blocks;
+}
