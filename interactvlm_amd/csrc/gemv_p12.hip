@@ -217,6 +217,7 @@ __device__ __forceinline__ bf16x8m_t frag_p12m(uint32_t x0, uint32_t x1, uint32_
     return __builtin_bit_cast(bf16x8m_t, d);
 }
 
+// (4-wave blocks, six per CU: 2.53 instead of 2.39 ms per token.)
 // kWavesM = 8: 512-thread blocks, three fit a CU at <= 80 registers (1024-thread blocks: two only at <= 64, which this loop does not fit
 // without spills), so one block's prologue / tail runs under the others' streaming - the matrices with more row blocks than CUs.
 // kWavesM = 16: when there is at most one block per CU anyway (N <= 4096: o_proj, down_proj) all 16 wave slots of its SIMDs' share
