@@ -434,6 +434,27 @@ int ivlm_llama_decode_step(const ivlm_llama_cfg *cfg, const ivlm_llama_layer *la
 int ivlm_llama_decode_step_f16kv(const ivlm_llama_cfg *cfg, const ivlm_llama_layer *layers_host, const void *final_norm, void *kcache16,
                                  void *vcache16, const float *cos_tab, const float *sin_tab, const float *x_in, int32_t *pos_dev,
                                  int advance, float *hidden_out, void *workspace, size_t workspace_bytes, ivlm_stream_t stream);
+/* The decode step of the host model's default configuration: the four linears of every layer stream LOSSLESSLY packed weights
+ * (ivlm_gemv1_bf12m: 1.5 bytes per weight, dots on the matrix cores; each matrix as built by the host: fragment-layout planes + per-row
+ * exponent bases + CSR patches), fp32 activations, KV cache of IEEE halves (cache_dtype IVLM_F16: after ivlm_llama_prefill_f16) or
+ * bf16 (IVLM_BF16: after ivlm_llama_prefill).  hidden % 64 == 0, inter % 64 == 0 (every matrix must take the fragment layout), else
+ * IVLM_ERR_UNSUPPORTED.  Workspace: ivlm_llama_decode_workspace_bytes.  Same arithmetic as ivlm_llama_decode_step[_f16kv] up to the fp32
+ * summation order. */
+typedef struct {
+    const void *Pf, *Ef;          /* fragment-layout planes (ivlm_gemv1_bf12m) */
+    const int32_t *ebase;         /* [rows] */
+    const int32_t *patch_ptr;     /* [rows + 1] */
+    const int32_t *patch_col;
+    const void *patch_val;        /* bf16 */
+} ivlm_bf12m;
+typedef struct {
+    const void *ln1, *ln2;        /* bf16 [hidden] */
+    ivlm_bf12m qkv, o, gu, down;  /* rows: 3 hidden | hidden | 2 inter (gate / up interleaved) | hidden */
+} ivlm_llama_layer_bf12;
+int ivlm_llama_decode_step_bf12(const ivlm_llama_cfg *cfg, const ivlm_llama_layer_bf12 *layers_host, const void *final_norm,
+                                void *kcache, void *vcache, int cache_dtype, const float *cos_tab, const float *sin_tab,
+                                const float *x_in, int32_t *pos_dev, int advance, float *hidden_out, void *workspace,
+                                size_t workspace_bytes, ivlm_stream_t stream);
 /* CLIPVisionTower.forward + feature_select('patch', layer -2) (clip_encoder.py:31-60): images bf16 [B,3,S,S] -> bf16
  * [B, tokens-1, hidden] (the mm_projector's operand).  layers_run = the encoder layers actually needed (23 of 24 for layer -2);
  * patch_w bf16 [hidden, kpad] (conv weight as GEMM rows, K zero-padded to kpad % 64 == 0), pos bf16 [tokens, hidden], cls_row

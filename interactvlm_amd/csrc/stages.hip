@@ -262,6 +262,55 @@ extern "C" int ivlm_llama_decode_step_f16kv(const ivlm_llama_cfg* c, const ivlm_
                              workspace, workspace_bytes, stream, 1);
 }
 
+// The same step with the four linears of a layer on losslessly packed weights (ivlm_gemv1_bf12m): the default decode path of the host
+// model.  Separate attention / o_proj launches; fp16 or bf16 KV cache.
+extern "C" int ivlm_llama_decode_step_bf12(const ivlm_llama_cfg* c, const ivlm_llama_layer_bf12* layers_host, const void* final_norm,
+                                           void* kcache, void* vcache, int cache_dtype, const float* cos_tab, const float* sin_tab,
+                                           const float* x_in, int32_t* pos_dev, int advance, float* hidden_out, void* workspace,
+                                           size_t workspace_bytes, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!cfg_ok(c) || !layers_host || !final_norm || !kcache || !vcache || !cos_tab || !sin_tab || !x_in || !pos_dev || !hidden_out ||
+        !workspace || (cache_dtype != IVLM_BF16 && cache_dtype != IVLM_F16))
+        return IVLM_ERR_INVALID_ARG;
+    if (workspace_bytes < ivlm_llama_decode_workspace_bytes(c)) return IVLM_ERR_WORKSPACE;
+    const int Hd = c->hidden, H = c->heads, D = Hd / H, I = c->inter;
+    if ((Hd & 63) || (I & 63)) return IVLM_ERR_UNSUPPORTED;
+    hipStream_t st = ivlm_stream(stream);
+    Carver cv{static_cast<char*>(workspace), workspace_bytes};
+    float* qkv = static_cast<float*>(cv.take((size_t)3 * Hd * 4));
+    float* hh = static_cast<float*>(cv.take((size_t)I * 4));
+    float* xa = static_cast<float*>(cv.take((size_t)Hd * 4));
+    float* xb = static_cast<float*>(cv.take((size_t)Hd * 4));
+    float* att = static_cast<float*>(cv.take((size_t)Hd * 4));
+    if (!cv.ok) return IVLM_ERR_WORKSPACE;
+    auto gemv = [&](const float* x, const ivlm_bf12m& m, float* out, const float* res, int N, int K, int act, const void* rms) {
+        return ivlm_gemv1_bf12m(x, m.Pf, m.Ef, m.ebase, m.patch_ptr, m.patch_col, m.patch_val, out, nullptr, res, N, K, act, 1, rms,
+                                rms ? c->eps : 0.0f, res ? IVLM_GEMM_RES_F32 : 0, stream);
+    };
+    const int64_t cache_layer = (int64_t)c->max_len * Hd;
+    const float scale = 1.0f / sqrtf((float)D);
+    const float* x = x_in;
+    int rc;
+    for (int l = 0; l < c->layers; ++l) {
+        const ivlm_llama_layer_bf12& L = layers_host[l];
+        bf16_t* kc = static_cast<bf16_t*>(kcache) + l * cache_layer;
+        bf16_t* vc = static_cast<bf16_t*>(vcache) + l * cache_layer;
+        if ((rc = gemv(x, L.qkv, qkv, nullptr, 3 * Hd, Hd, ACT_NONE, L.ln1))) return rc;
+        if ((rc = llama_decode_attn(qkv, 1, kc, vc, c->max_len, att, H, D, 0, c->theta, scale, st, cos_tab, sin_tab, pos_dev, nullptr,
+                                    nullptr, cache_dtype == IVLM_F16)))
+            return rc;
+        float* x1 = (x == xa) ? xb : xa;
+        if ((rc = gemv(att, L.o, x1, x, Hd, Hd, ACT_NONE, nullptr))) return rc;
+        if ((rc = gemv(x1, L.gu, hh, nullptr, 2 * I, Hd, ACT_SWIGLU, L.ln2))) return rc;
+        float* x2 = (x1 == xa) ? xb : xa;
+        if ((rc = gemv(hh, L.down, x2, x1, Hd, I, ACT_NONE, nullptr))) return rc;
+        x = x2;
+    }
+    if ((rc = rmsnorm(x, 1, static_cast<const bf16_t*>(final_norm), hidden_out, 1, 1, Hd, c->eps, st))) return rc;
+    bump_kernel<<<1, 1, 0, st>>>(nullptr, advance ? pos_dev : nullptr);
+    return ivlm_launch_status();
+}
+
 // =====================================================================================================================
 // Vision stages: ivlm_clip_encode (CLIPVisionTower.forward + feature_select, clip_encoder.py:31-60) and ivlm_sam_encode
 // (ImageEncoderViT.forward, image_encoder.py:110-125) as C++ sequencers - the launch order of interactvlm_amd/llava.py

@@ -20,6 +20,14 @@ class LlamaLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1", "qkv", "o", "ln2", "gu", "down")]
 
 
+class Bf12M(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("Pf", "Ef", "ebase", "patch_ptr", "patch_col", "patch_val")]
+
+
+class LlamaLayerBf12(C.Structure):
+    _fields_ = [("ln1", C.c_void_p), ("ln2", C.c_void_p), ("qkv", Bf12M), ("o", Bf12M), ("gu", Bf12M), ("down", Bf12M)]
+
+
 class LlamaStages:
     """Wraps a ``llava.Llama`` instance's weights / caches / rope tables as the C structs and calls the C sequencers."""
 
@@ -81,6 +89,37 @@ class LlamaStages:
                                                llm.vcache.data_ptr(), llm.rope[0].data_ptr(), llm.rope[1].data_ptr(), x.data_ptr(),
                                                pos_dev.data_ptr(), 1 if advance else 0, out.data_ptr(), self._dws.data_ptr(),
                                                self._dws.numel(), self._stream()), "llama_decode_step_f16kv")
+        return out
+
+    def _layers_bf12(self):
+        """the layer table of the packed decode step: every matrix as ops.PackedBf12 in the fragment layout (packed here if the
+        host model has not decoded yet)"""
+        if not hasattr(self, "layers_bf12"):
+            from . import ops
+
+            rows = []
+            for L in self.llm.layers:
+                for n in ("qkv", "o", "gu", "down"):
+                    if L.get(n + "_p") is None:
+                        L[n + "_p"] = ops.PackedBf12(L[n])
+                    if not L[n + "_p"].frag:
+                        raise ops.IvlmError("decode_step_bf12: a matrix does not take the fragment layout (rows % 16, columns % 64)")
+                rows.append(LlamaLayerBf12(L["ln1"].data_ptr(), L["ln2"].data_ptr(),
+                                           *[Bf12M(*L[n + "_p"]._args_frag()) for n in ("qkv", "o", "gu", "down")]))
+            self.layers_bf12 = (LlamaLayerBf12 * len(rows))(*rows)
+        return self.layers_bf12
+
+    def decode_step_bf12(self, x, pos_dev, advance=True):
+        """One decode step on losslessly packed weights (the host model's default decode path) against the instance's KV cache in the
+        element type of its precision mode (fp16 after prefill_f16, bf16 after prefill)."""
+        lib = _lib.load()
+        llm = self.llm
+        out = torch.empty_like(x)
+        cache_dt = 4 if llm.precision == "f16" else 1  # IVLM_F16 | IVLM_BF16
+        check(lib.ivlm_llama_decode_step_bf12(C.byref(self.cfg), self._layers_bf12(), llm.norm.data_ptr(), llm.kcache.data_ptr(),
+                                              llm.vcache.data_ptr(), cache_dt, llm.rope[0].data_ptr(), llm.rope[1].data_ptr(),
+                                              x.data_ptr(), pos_dev.data_ptr(), 1 if advance else 0, out.data_ptr(),
+                                              self._dws.data_ptr(), self._dws.numel(), self._stream()), "llama_decode_step_bf12")
         return out
 
     def start_generation(self):

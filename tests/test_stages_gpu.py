@@ -164,3 +164,53 @@ def test_sam_decode_stage_equals_python_path(hip_lib, cuda, V):
     assert low.shape == low_r.shape and iou.shape == iou_r.shape
     assert torch.equal(low, low_r), float((low - low_r).abs().max())
     assert torch.equal(iou, iou_r), float((iou - iou_r).abs().max())
+
+
+@pytest.mark.parametrize("precision", ["f16", "default"])
+def test_llama_decode_step_bf12_equals_python_packed_path(hip_lib, cuda, precision):
+    """ivlm_llama_decode_step_bf12 (the four linears of a layer on losslessly packed weights, dots on the matrix cores) == the host
+    model's default decode path (`decode_packed`) bit for bit: hidden states and the appended KV rows, fp16 and bf16 cache; a
+    configuration whose matrices do not take the fragment layout is refused."""
+    import ctypes as C
+
+    import torch
+
+    from interactvlm_amd import llava, stages
+    from interactvlm_amd import weights as Wt
+
+    lc = Wt.LlamaCfg(hidden=1024, heads=8, layers=3, inter=2752, vocab=1000)  # (2752 = 43 x 64: uneven step pairs over the waves)
+    w = {k: v.to(torch.bfloat16).float() for k, v in Wt.synth_weights(Wt.llama_spec(lc)).items()}
+    g = torch.Generator().manual_seed(9)
+    T0, n_new = 70, 5
+    emb = (torch.randn(T0 + n_new, 1024, generator=g) * 0.5).to(torch.bfloat16).float().to(cuda)
+    a = llava.Llama(w, lc, cuda, max_len=128)
+    a.set_precision(precision)
+    assert a.decode_packed
+    ha = [a.forward(emb[:T0], 0)] + [a.forward(emb[T0 + t: T0 + t + 1], T0 + t) for t in range(n_new)]
+    assert all(a.layers[0][n + "_p"].frag for n in ("qkv", "o", "gu", "down"))
+    b = llava.Llama(w, lc, cuda, max_len=128)
+    b.set_precision(precision)
+    st = stages.LlamaStages(b)
+    hb = [st.prefill_f16(emb[:T0], 0) if precision == "f16" else st.prefill(emb[:T0], 0)]
+    st.start_generation()
+    pos = torch.tensor([T0], dtype=torch.int32, device=cuda)
+    for t in range(n_new):
+        hb.append(st.decode_step_bf12(emb[T0 + t: T0 + t + 1].contiguous(), pos, advance=True))
+    assert int(pos[0]) == T0 + n_new
+    for t in range(n_new + 1):
+        assert torch.equal(hb[t], ha[t]), (t, float((hb[t] - ha[t]).abs().max()))
+    n = T0 + n_new
+    (ka, va), (kb, vb) = a._caches(), b._caches()
+    assert torch.equal(ka[:, :n], kb[:, :n]) and torch.equal(va[:, :n], vb[:, :n])
+    # the bf16-weight step gives the same numbers up to the fp32 summation order (lossless packing, exact products on both)
+    c2 = llava.Llama(w, lc, cuda, max_len=128)
+    c2.set_precision(precision)
+    c2.decode_packed = False
+    hc = [c2.forward(emb[:T0], 0)] + [c2.forward(emb[T0 + t: T0 + t + 1], T0 + t) for t in range(n_new)]
+    assert float((torch.cat(hc) - torch.cat(ha)).abs().max()) < 2e-5 * float(torch.cat(ha).abs().max())
+    # inter % 64 != 0: refused, not mis-read
+    bad = stages.LlamaCfg(lc.layers, 1024, 8, 1376, 128, lc.eps, lc.theta, 0)
+    rc = hip_lib.ivlm_llama_decode_step_bf12(C.byref(bad), st._layers_bf12(), b.norm.data_ptr(), b.kcache.data_ptr(), b.vcache.data_ptr(),
+                                             1, b.rope[0].data_ptr(), b.rope[1].data_ptr(), emb.data_ptr(), pos.data_ptr(), 0,
+                                             hb[0].data_ptr(), st._dws.data_ptr(), st._dws.numel(), 0)
+    assert rc != 0
