@@ -616,6 +616,10 @@ def main():
               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(va / PEAK_HBM_GBPS, 4), "traffic": None,
               "algorithmic_bytes": int(gv["work"] / gv["launches"]), "launches_per_image": gv["launches"] // nsteps,
               "avg_us": round(gv["avg_us"], 2), "ms_per_image": round(gv["total_s"] / nsteps * 1e3, 2)}
+        if getattr(model.llm, "decode_packed", False):
+            rv["kernel"] = "gemv1_p12m_kernel + gemv1_kernel (decode linears: weight streaming; lm_head on bf16 weights)"
+            rv["weight_storage"] = ("lossless 12-bit (ivlm_gemv1_bf12m): `achieved` counts the ALGORITHMIC bytes (2 per weight, SURVEY 8d); "
+                                    "the kernels move 0.75 of them (`traffic`: the PMC figure)")
         return rg, rl, rv
 
     roof_gemv = None

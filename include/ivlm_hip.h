@@ -586,6 +586,16 @@ int ivlm_gemv1_bf12(const float *x, const void *P, int64_t ldp, const void *E, i
 int ivlm_gemv1_bf12m(const float *x, const void *Pf, const void *Ef, const int32_t *ebase, const int32_t *patch_ptr,
                      const int32_t *patch_col, const void *patch_val, void *C, const void *bias, const void *residual, int N, int K,
                      int act, int out_f32, const void *rms_w, float rms_eps, int flags, ivlm_stream_t stream);
+/* The o_proj of a decode step with the split-KV attention's merge in its prologue: the activation row x[h][d] = sum_s e^(m_s - M)
+ * o_s[d] / sum_s e^(m_s - M) l_s is computed, while it is staged, from parts[K / D heads][4 ranges][D + 4] fp32 (o unnormalised | max |
+ * sum | pad) written by ivlm_llama_decode_attn_parts - 128 attention blocks instead of 32 (a head's K / V rows are otherwise streamed by
+ * ONE CU at its ~25 GB/s), no merge launch, no counters: the kernel boundary is the synchronisation. */
+int ivlm_llama_decode_attn_parts(const float *qkv, int cache_dtype, void *kcache, void *vcache, int tmax, float *parts, int H, int D,
+                                 int pos, const int32_t *pos_dev, float theta, float scale, const float *cos_tab, const float *sin_tab,
+                                 ivlm_stream_t stream);
+int ivlm_gemv1_bf12m_parts(const float *parts, int D, const void *Pf, const void *Ef, const int32_t *ebase, const int32_t *patch_ptr,
+                           const int32_t *patch_col, const void *patch_val, void *C, const void *bias, const void *residual, int N, int K,
+                           int act, int out_f32, int flags, ivlm_stream_t stream);
 /* A/B hook: grids of at most this many 16-row blocks run 16 waves per block (default 256 = one block per CU), larger ones 8;
    a negative value: the same limit without the 8-deep prefetch of long rows. */
 void ivlm_gemv1_bf12m_tuning(int wide_max_blocks);

@@ -49,7 +49,10 @@ constexpr int kT = 256, kG = kT / 16, kU = 6, kTile = kG * kU;  // 96 keys per t
 constexpr int kMaxSplits = 16;
 }  // namespace splitkv
 
-template <bool CF16>
+// PARTS: the block only writes its (o, m, l) - rows of D + 4 floats, plain stores - and the CONSUMER merges them (the o_proj GEMV reads the
+// S partials of a head while it stages its activation row: ivlm_gemv1_bf12m_parts; the kernel boundary is the synchronisation, no
+// counter, no merge round trips).
+template <bool CF16, bool PARTS = false>
 __global__ __launch_bounds__(splitkv::kT) void llama_decode_attn_splitkv_kernel(
     const float* __restrict__ qkv, bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache, float* __restrict__ o, int H, int D,
     int pos_arg, float theta, float scale, const float* __restrict__ ct, const float* __restrict__ stab,
@@ -60,7 +63,13 @@ __global__ __launch_bounds__(splitkv::kT) void llama_decode_attn_splitkv_kernel(
     const int t = threadIdx.x;
     const int pos = pos_dev ? __builtin_amdgcn_readfirstlane(*pos_dev) : pos_arg;
     if (pos >= tmax || pos >= kMaxT) {  // past the slab: nothing appended, zeros out (as the one-block kernel)
-        if (sp == 0 && t < D) o[(int64_t)h * D + t] = 0.0f;
+        if (PARTS) {  // (o = 0, m = 0, l = 1 for range 0 and l = 0 for the others: the merge gives exactly 0)
+            float* mine = part + ((int64_t)h * S + sp) * (D + 4);
+            if (t < D) mine[t] = 0.0f;
+            else if (t == 128) { mine[D] = 0.0f; mine[D + 1] = sp == 0 ? 1.0f : 0.0f; }
+        } else if (sp == 0 && t < D) {
+            o[(int64_t)h * D + t] = 0.0f;
+        }
         return;
     }
     const int nkeys = pos + 1;
@@ -225,6 +234,19 @@ __global__ __launch_bounds__(splitkv::kT) void llama_decode_attn_splitkv_kernel(
     }
     __syncthreads();
     // ---- publish (o, m, l); the last block of the head merges --------------------------------------------------------------------
+    if (PARTS) {
+        float* mine = part + ((int64_t)h * S + sp) * (D + 4);
+        if (t < D) {
+            float r = 0.0f;
+#pragma unroll
+            for (int g2 = 0; g2 < kG; ++g2) r += partl[g2][t];
+            mine[t] = r;
+        } else if (t == 128) {
+            mine[D] = mx;
+            mine[D + 1] = tot;
+        }
+        return;
+    }
     float* mine = part + ((int64_t)h * S + sp) * (D + 2);
     if (t < D) {
         float r = 0.0f;
@@ -333,6 +355,23 @@ size_t llama_decode_attn_splitkv_scratch_bytes(int H, int D) {
 }
 
 int g_splitkv_splits = 8;  // A/B hook: ivlm_llama_decode_attn_splits
+
+// the PARTS form: S = 4 ranges, partials [H][4][D + 4] fp32 for ivlm_gemv1_bf12m_parts
+int llama_decode_attn_parts(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* parts, int H, int D, int pos, float theta,
+                            float scale, hipStream_t st, const float* cos_tab, const float* sin_tab, const int32_t* pos_dev,
+                            int cache_f16) {
+    if (!qkv || !kcache || !vcache || !parts || H <= 0 || D <= 0 || D > kMaxD || (D & 15) || tmax <= 0) return IVLM_ERR_INVALID_ARG;
+    if (!pos_dev && (pos < 0 || pos >= kMaxT || pos >= tmax)) return IVLM_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(parts) & 15) return IVLM_ERR_INVALID_ARG;
+    constexpr int S = 4;
+    if (cache_f16)
+        llama_decode_attn_splitkv_kernel<true, true><<<dim3(H, S), splitkv::kT, 0, st>>>(qkv, kcache, vcache, nullptr, H, D, pos, theta, scale,
+                                                                                         cos_tab, sin_tab, pos_dev, tmax, parts, nullptr);
+    else
+        llama_decode_attn_splitkv_kernel<false, true><<<dim3(H, S), splitkv::kT, 0, st>>>(qkv, kcache, vcache, nullptr, H, D, pos, theta, scale,
+                                                                                          cos_tab, sin_tab, pos_dev, tmax, parts, nullptr);
+    return ivlm_launch_status();
+}
 
 int llama_decode_attn_splitkv(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* o, int H, int D, int pos, float theta,
                               float scale, hipStream_t st, const float* cos_tab, const float* sin_tab, const int32_t* pos_dev,
@@ -454,4 +493,16 @@ extern "C" int ivlm_llama_decode_attn_splits(int splits) {
     if (splits < 1 || splits > ivlm::splitkv::kMaxSplits) return IVLM_ERR_INVALID_ARG;
     ivlm::g_splitkv_splits = splits;
     return IVLM_OK;
+}
+
+// Split-KV attention WITHOUT the merge: four key ranges per head, partials parts[H][4][D + 4] fp32 (o unnormalised | max | sum | pad) for
+// the o_proj GEMV that merges them while it stages its activation row (ivlm_gemv1_bf12m_parts).  parts: 16-byte aligned,
+// H * 4 * (D + 4) floats; no other state.
+extern "C" int ivlm_llama_decode_attn_parts(const float* qkv, int cache_dtype, void* kcache, void* vcache, int tmax, float* parts, int H,
+                                            int D, int pos, const int32_t* pos_dev, float theta, float scale, const float* cos_tab,
+                                            const float* sin_tab, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (cache_dtype != IVLM_BF16 && cache_dtype != IVLM_F16) return IVLM_ERR_INVALID_ARG;
+    return ivlm::llama_decode_attn_parts(qkv, static_cast<bf16_t*>(kcache), static_cast<bf16_t*>(vcache), tmax, parts, H, D, pos, theta,
+                                         scale, ivlm_stream(stream), cos_tab, sin_tab, pos_dev, cache_dtype == IVLM_F16);
 }

@@ -197,6 +197,8 @@ struct P12M {
     const int32_t* patch_ptr;
     const int32_t* patch_col;
     const bf16_t* patch_val;
+    const float* parts;  // PARTS form: x = the merge of the split-KV attention partials [K / pD heads][4][pD + 4] (decode.hip)
+    int pD;
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8m_t;
@@ -224,7 +226,9 @@ __device__ __forceinline__ bf16x8m_t frag_p12m(uint32_t x0, uint32_t x1, uint32_
 // belong to that block: twice the loads in flight.
 // U: step pairs in flight per lane, U x (16 + 8) bytes (8 with two 8-wave blocks per CU was measured slower than 4 with three: 2.66 vs
 // 2.44 ms per token)
-template <bool RMS, int kWavesM, int U>
+// PARTS: the activation row is not read from g.A but merged, while it is staged, from the four (o, max, sum) partials per head that
+// llama_decode_attn_parts wrote: x[h][d] = sum_s e^(m_s - M) o_s[d] / sum_s e^(m_s - M) l_s (the o_proj of the decode step).
+template <bool RMS, int kWavesM, int U, bool PARTS = false>
 __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12m_kernel(GemmArgs g, P12M p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // x * 2^100 as three bf16 planes [3][K]
     __shared__ float s_red[kWavesM];
@@ -276,7 +280,31 @@ __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12
     float ssq = 0.0f;
     uint32_t* xw = reinterpret_cast<uint32_t*>(smem);
     for (int c = threadIdx.x; c < (K >> 2); c += 64 * kWavesM) {
-        const f32x4v_t xv4 = reinterpret_cast<const f32x4v_t*>(g.A)[c];
+        f32x4v_t xv4;
+        if (PARTS) {
+            const int k = c << 2, hd = k / p.pD, d0 = k - hd * p.pD, ps = p.pD + 4;
+            const float* ph = p.parts + (int64_t)hd * 4 * ps;
+            float m[4], l[4];
+            f32x4v_t o4[4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                m[s2] = ph[s2 * ps + p.pD];
+                l[s2] = ph[s2 * ps + p.pD + 1];
+                o4[s2] = *reinterpret_cast<const f32x4v_t*>(ph + s2 * ps + d0);
+            }
+            const float M = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+            float den = 0.0f;
+            xv4 = f32x4v_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const float wgt = __expf(m[s2] - M);
+                den = fmaf(wgt, l[s2], den);
+                xv4 += o4[s2] * wgt;
+            }
+            xv4 = xv4 * (1.0f / den);
+        } else {
+            xv4 = reinterpret_cast<const f32x4v_t*>(g.A)[c];
+        }
         float v[4] = {xv4[0], xv4[1], xv4[2], xv4[3]};
         if (RMS) {
             const u32x2_t gv = *(reinterpret_cast<const u32x2_t*>(g.rms_w) + c);
@@ -478,13 +506,17 @@ int g_p12m_deep = 1;
 
 // MFMA variant on the fragment layout (see gemv1_p12m_kernel): Pf / Ef = the P / E bytes of ivlm_gemv1_bf12 re-ordered as
 // [N/16][K/64][64 lanes][16 | 8 bytes]; N % 16 == 0, K % 64 == 0, 6 K bytes of LDS.  Same contract otherwise.
-extern "C" int ivlm_gemv1_bf12m(const float* x, const void* Pf, const void* Ef, const int32_t* ebase, const int32_t* patch_ptr,
-                                const int32_t* patch_col, const void* patch_val, void* C, const void* bias, const void* residual, int N,
-                                int K, int act, int out_f32, const void* rms_w, float rms_eps, int flags, ivlm_stream_t stream) {
+static int gemv1_bf12m(const float* x, const float* parts, int pD, const void* Pf, const void* Ef, const int32_t* ebase,
+                      const int32_t* patch_ptr, const int32_t* patch_col, const void* patch_val, void* C, const void* bias,
+                      const void* residual, int N, int K, int act, int out_f32, const void* rms_w, float rms_eps, int flags,
+                      ivlm_stream_t stream) {
     ivlm_enter();
-    if (!x || !C || !Pf || !Ef || !ebase || !patch_ptr || !patch_col || !patch_val || N <= 0 || K <= 0) return IVLM_ERR_INVALID_ARG;
-    if ((reinterpret_cast<uintptr_t>(Pf) & 15) || (reinterpret_cast<uintptr_t>(Ef) & 7) || (reinterpret_cast<uintptr_t>(x) & 15))
+    if ((!x && !parts) || !C || !Pf || !Ef || !ebase || !patch_ptr || !patch_col || !patch_val || N <= 0 || K <= 0)
         return IVLM_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(Pf) & 15) || (reinterpret_cast<uintptr_t>(Ef) & 7) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+        (reinterpret_cast<uintptr_t>(parts) & 15))
+        return IVLM_ERR_INVALID_ARG;
+    if (parts && (pD <= 0 || (pD & 3) || K % pD != 0 || rms_w)) return IVLM_ERR_INVALID_ARG;
     if ((N & 15) || (K & 63) || (size_t)K * 6 > 100 * 1024) return IVLM_ERR_UNSUPPORTED;
     if (act == ACT_SWIGLU && residual) return IVLM_ERR_UNSUPPORTED;
     GemmArgs g;
@@ -501,7 +533,7 @@ extern "C" int ivlm_gemv1_bf12m(const float* x, const void* Pf, const void* Ef, 
     g.rms_w = static_cast<const bf16_t*>(rms_w);
     g.rms_eps = rms_eps;
     P12M p{static_cast<const u32x4_t*>(Pf), static_cast<const u32x2_t*>(Ef), ebase, patch_ptr, patch_col,
-           static_cast<const bf16_t*>(patch_val)};
+           static_cast<const bf16_t*>(patch_val), parts, pD};
     hipStream_t st = ivlm_stream(stream);
     const dim3 grid(N / 16);
     const bool wide = grid.x <= (unsigned)g_p12m_wide_max_blocks;  // at most one block per CU: 16 waves per block
@@ -512,7 +544,12 @@ extern "C" int ivlm_gemv1_bf12m(const float* x, const void* Pf, const void* Ef, 
         }
         ivlm_launch(kfn, grid, dim3(64 * waves), (size_t)K * 6, st, g, p);
     };
-    static bool set[6] = {false, false, false, false, false, false};
+    static bool set[8] = {false, false, false, false, false, false, false, false};
+    if (parts) {  // (the o_proj of a decode step: K = hidden, never the 8-deep form)
+        if (wide) go(gemv1_p12m_kernel<false, 16, 4, true>, 16, set[6]);
+        else go(gemv1_p12m_kernel<false, 8, 4, true>, 8, set[7]);
+        return ivlm_launch_status();
+    }
     // (one block per CU and a long row - down_proj: 8 step pairs in flight per lane, so that most of the block's 264 KB is requested
     //  BEFORE the x staging, which otherwise runs with only the first 96 KB on their way)
     const bool deep = wide && (K >> 6) > 4 * 16 && g_p12m_deep;
@@ -526,6 +563,24 @@ extern "C" int ivlm_gemv1_bf12m(const float* x, const void* Pf, const void* Ef, 
         else go(gemv1_p12m_kernel<false, 8, 4>, 8, set[3]);
     }
     return ivlm_launch_status();
+}
+
+extern "C" int ivlm_gemv1_bf12m(const float* x, const void* Pf, const void* Ef, const int32_t* ebase, const int32_t* patch_ptr,
+                                const int32_t* patch_col, const void* patch_val, void* C, const void* bias, const void* residual, int N,
+                                int K, int act, int out_f32, const void* rms_w, float rms_eps, int flags, ivlm_stream_t stream) {
+    if (!x) return IVLM_ERR_INVALID_ARG;
+    return gemv1_bf12m(x, nullptr, 0, Pf, Ef, ebase, patch_ptr, patch_col, patch_val, C, bias, residual, N, K, act, out_f32, rms_w, rms_eps,
+                       flags, stream);
+}
+
+// ... with the activation row merged from the split-KV attention partials parts[K / D][4][D + 4] of ivlm_llama_decode_attn_parts (the
+// o_proj of a decode step: no RMSNorm prologue)
+extern "C" int ivlm_gemv1_bf12m_parts(const float* parts, int D, const void* Pf, const void* Ef, const int32_t* ebase,
+                                      const int32_t* patch_ptr, const int32_t* patch_col, const void* patch_val, void* C, const void* bias,
+                                      const void* residual, int N, int K, int act, int out_f32, int flags, ivlm_stream_t stream) {
+    if (!parts) return IVLM_ERR_INVALID_ARG;
+    return gemv1_bf12m(nullptr, parts, D, Pf, Ef, ebase, patch_ptr, patch_col, patch_val, C, bias, residual, N, K, act, out_f32, nullptr,
+                       0.0f, flags, stream);
 }
 
 extern "C" void ivlm_gemv1_bf12m_tuning(int wide_max_blocks) {

@@ -171,6 +171,10 @@ int llama_decode_attn_splitkv(const float* qkv, bf16_t* kcache, bf16_t* vcache, 
                               float scale, hipStream_t st, const float* cos_tab, const float* sin_tab, const int32_t* pos_dev,
                               int cache_f16, void* scratch, size_t scratch_bytes);
 
+int llama_decode_attn_parts(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* parts, int H, int D, int pos, float theta,
+                            float scale, hipStream_t st, const float* cos_tab, const float* sin_tab, const int32_t* pos_dev,
+                            int cache_f16);
+
 // fused decode attention + o_proj (decode_fused.hip)
 int llama_attn_oproj(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* attn_scratch, const bf16_t* wo,
                      const float* x, float* x_out, int H, int D, float theta, float scale, const float* cos_tab,

@@ -184,7 +184,9 @@ extern "C" size_t ivlm_llama_decode_workspace_bytes(const ivlm_llama_cfg* c) {
     if (!cfg_ok(c)) return 0;
     const size_t h = c->hidden, in = c->inter, L = c->layers;
     // activations | fused-launch state: per-layer arrival counters (128 B apart), status + step words, per-layer attention rows
-    return al(3 * h * 4) + al(in * 4) + 2 * al(h * 4) + al(h * 4) + al(L * 32 * 4) + 256 + al(L * h * 4) + 256;
+    // + the split-KV attention partials of the packed step [heads][4][head_dim + 4] fp32
+    return al(3 * h * 4) + al(in * 4) + 2 * al(h * 4) + al(h * 4) + al(L * 32 * 4) + 256 + al(L * h * 4) + 256 +
+           al((size_t)c->heads * 4 * (h / c->heads + 4) * 4);
 }
 
 static int llama_decode_step(const ivlm_llama_cfg* c, const ivlm_llama_layer* layers_host, const void* final_norm, void* kcache,
@@ -282,6 +284,12 @@ extern "C" int ivlm_llama_decode_step_bf12(const ivlm_llama_cfg* c, const ivlm_l
     float* xa = static_cast<float*>(cv.take((size_t)Hd * 4));
     float* xb = static_cast<float*>(cv.take((size_t)Hd * 4));
     float* att = static_cast<float*>(cv.take((size_t)Hd * 4));
+    cv.take((size_t)c->layers * 32 * 4);  // (the regions of the other forms of the step: same workspace, same offsets)
+    cv.take(256);
+    cv.take((size_t)c->layers * Hd * 4);
+    float* parts = static_cast<float*>(cv.take((size_t)H * 4 * (D + 4) * 4));
+    const bool split = !c->fuse_attn_oproj;  // split-KV attention merged by the o_proj prologue (the host model's default);
+                                             // fuse_attn_oproj != 0 selects the one-block attention + separate o_proj instead
     if (!cv.ok) return IVLM_ERR_WORKSPACE;
     auto gemv = [&](const float* x, const ivlm_bf12m& m, float* out, const float* res, int N, int K, int act, const void* rms) {
         return ivlm_gemv1_bf12m(x, m.Pf, m.Ef, m.ebase, m.patch_ptr, m.patch_col, m.patch_val, out, nullptr, res, N, K, act, 1, rms,
@@ -296,11 +304,20 @@ extern "C" int ivlm_llama_decode_step_bf12(const ivlm_llama_cfg* c, const ivlm_l
         bf16_t* kc = static_cast<bf16_t*>(kcache) + l * cache_layer;
         bf16_t* vc = static_cast<bf16_t*>(vcache) + l * cache_layer;
         if ((rc = gemv(x, L.qkv, qkv, nullptr, 3 * Hd, Hd, ACT_NONE, L.ln1))) return rc;
-        if ((rc = llama_decode_attn(qkv, 1, kc, vc, c->max_len, att, H, D, 0, c->theta, scale, st, cos_tab, sin_tab, pos_dev, nullptr,
-                                    nullptr, cache_dtype == IVLM_F16)))
-            return rc;
         float* x1 = (x == xa) ? xb : xa;
-        if ((rc = gemv(att, L.o, x1, x, Hd, Hd, ACT_NONE, nullptr))) return rc;
+        if (split) {
+            if ((rc = llama_decode_attn_parts(qkv, kc, vc, c->max_len, parts, H, D, 0, c->theta, scale, st, cos_tab, sin_tab, pos_dev,
+                                              cache_dtype == IVLM_F16)))
+                return rc;
+            if ((rc = ivlm_gemv1_bf12m_parts(parts, D, L.o.Pf, L.o.Ef, L.o.ebase, L.o.patch_ptr, L.o.patch_col, L.o.patch_val, x1, nullptr,
+                                             x, Hd, Hd, ACT_NONE, 1, IVLM_GEMM_RES_F32, stream)))
+                return rc;
+        } else {
+            if ((rc = llama_decode_attn(qkv, 1, kc, vc, c->max_len, att, H, D, 0, c->theta, scale, st, cos_tab, sin_tab, pos_dev, nullptr,
+                                        nullptr, cache_dtype == IVLM_F16)))
+                return rc;
+            if ((rc = gemv(att, L.o, x1, x, Hd, Hd, ACT_NONE, nullptr))) return rc;
+        }
         if ((rc = gemv(x1, L.gu, hh, nullptr, 2 * I, Hd, ACT_SWIGLU, L.ln2))) return rc;
         float* x2 = (x1 == xa) ? xb : xa;
         if ((rc = gemv(hh, L.down, x2, x1, Hd, I, ACT_NONE, nullptr))) return rc;

@@ -213,6 +213,7 @@ class Llama:
         # 7B): 2.69 -> 2.44 ms per token.  Matrices whose shape the fragment layout does not take (rows % 16, columns % 64) and the
         # lm_head stay on the bf16 kernel.  IVLM_DECODE_PACKED=0 / decode_packed = False: bf16 weights everywhere.
         self.decode_packed = os.environ.get("IVLM_DECODE_PACKED", "1") != "0"
+        self.decode_attn_parts = os.environ.get("IVLM_DECODE_ATTN_PARTS", "1") != "0"  # (with decode_packed: see _decode_step)
 
     # ---- "parity" precision (opt-in): the prefill GEMMs take hi + lo bf16 activation operands, the attention three MFMAs per
     # fragment, and K / V are cached as hi + lo planes (also read by the decode kernels) - no activation is rounded to bf16.
@@ -590,11 +591,22 @@ class Llama:
                 wp = L[n + "_p"]
                 return ops.linear_bf12(x_, wp, **kw) if wp is not None else ops.linear(x_, L[n], out_f32=True, **kw)
 
+            # attention as 4 key ranges per head whose (o, max, sum) partials the o_proj merges in its prologue (128 blocks instead of
+            # 32, no merge launch): when o_proj is packed and K / V are single planes (not the hi + lo planes of "parity")
+            split = self.decode_attn_parts and self._lo(0) is None
+            if split and getattr(self, "_parts", None) is None:
+                self._parts = torch.zeros(H * 4 * (hd + 4), dtype=F32, device=self.norm.device)
             for li, L in enumerate(self.layers):
                 qkv = lin(x, L, "qkv", rms=(L["ln1"], c.eps))
-                a = ops.llama_decode_attn(qkv, kc_[li], vc_[li], H, hd, pos, c.theta, hd ** -0.5, table=self.rope, lo=self._lo(li),
-                                          scratch=self._attn_scratch())
-                x = lin(a, L, "o", residual=x)
+                if "o_p" not in L:
+                    L["o_p"] = ops.PackedBf12(L["o"]) if ops.PackedBf12.takes(*L["o"].shape) else None
+                if split and L["o_p"] is not None:
+                    ops.llama_decode_attn_parts(qkv, kc_[li], vc_[li], H, hd, pos, c.theta, hd ** -0.5, self._parts, table=self.rope)
+                    x = ops.linear_bf12(None, L["o_p"], residual=x, parts=(self._parts, hd))
+                else:
+                    a = ops.llama_decode_attn(qkv, kc_[li], vc_[li], H, hd, pos, c.theta, hd ** -0.5, table=self.rope,
+                                              lo=self._lo(li), scratch=self._attn_scratch())
+                    x = lin(a, L, "o", residual=x)
                 h = lin(x, L, "gu", act="swiglu", rms=(L["ln2"], c.eps))
                 x = lin(h, L, "down", residual=x)
             return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)

@@ -593,20 +593,29 @@ class PackedBf12:
         return out
 
 
-def linear_bf12(x, wp: PackedBf12, bias=None, act="none", residual=None, out_f32=True, rms=None):
+def linear_bf12(x, wp: PackedBf12, bias=None, act="none", residual=None, out_f32=True, rms=None, parts=None):
     """act(x @ W.T + bias) + residual for ONE fp32 row x against a ``PackedBf12`` weight: the batch-1 decode linears streaming
     1.5 instead of 2 bytes per weight (same exact bf16 x fp32 products and fp32 accumulation as ``linear`` on fp32 x)."""
     lib = _lib.load()
     N, K = wp.shape
-    assert x.dtype == F32 and x.is_contiguous() and x.numel() == K
+    if parts is not None:  # x = the merge of the split-KV attention partials (parts tensor, head dim): fragment layout only
+        pt, pD = parts
+        assert x is None and wp.frag and rms is None and pt.dtype == F32 and pt.numel() >= (K // pD) * 4 * (pD + 4)
+        dev = pt.device
+    else:
+        assert x.dtype == F32 and x.is_contiguous() and x.numel() == K
+        dev = x.device
     n_out = N // 2 if act == "swiglu" else N
-    out = torch.empty(1, n_out, dtype=F32 if out_f32 else BF16, device=x.device)
+    out = torch.empty(1, n_out, dtype=F32 if out_f32 else BF16, device=dev)
     flags = 0
     if residual is not None:
         assert residual.dtype in (BF16, F32) and residual.is_contiguous() and residual.numel() == N
         if residual.dtype == F32:
             flags |= GEMM_RES_F32
-    if wp.frag:  # MFMA kernel on the fragment layout
+    if parts is not None:
+        call = lambda: check(lib.ivlm_gemv1_bf12m_parts(pt.data_ptr(), pD, *wp._args_frag(), out.data_ptr(), _p(bias), _p(residual), N, K,
+                                                        ACT[act], 1 if out_f32 else 0, flags, _stream()), "gemv1_bf12m_parts")
+    elif wp.frag:  # MFMA kernel on the fragment layout
         call = lambda: check(lib.ivlm_gemv1_bf12m(x.data_ptr(), *wp._args_frag(), out.data_ptr(), _p(bias), _p(residual), N, K,
                                                   ACT[act], 1 if out_f32 else 0, _p(rms[0]) if rms else 0,
                                                   float(rms[1]) if rms else 0.0, flags, _stream()), "gemv1_bf12m")
@@ -1020,6 +1029,21 @@ def mask_dot(up, hyper, B, gh, gw):
     low = torch.empty(B, 4 * gh, 4 * gw, dtype=F32, device=up.device)
     check(lib.ivlm_mask_dot(up.data_ptr(), hyper.data_ptr(), _dtc(up), low.data_ptr(), B, gh, gw, C, _stream()), "mask_dot")
     return low
+
+
+def llama_decode_attn_parts(qkv, kcache, vcache, H, D, pos, theta, scale, parts, table=None):
+    """Split-KV decode attention WITHOUT the merge: RoPE + cache append + four key ranges per head -> parts fp32 [H, 4, D + 4] (o
+    unnormalised | max | sum | pad) for ``linear_bf12(..., parts=)`` (the o_proj merges them while it stages its activation row)."""
+    lib = _lib.load()
+    assert qkv.dtype == F32 and qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
+    assert parts.dtype == F32 and parts.is_contiguous() and parts.numel() >= H * 4 * (D + 4) and kcache.dtype in (BF16, F16)
+    dev_pos = isinstance(pos, torch.Tensor)
+    check(lib.ivlm_llama_decode_attn_parts(qkv.data_ptr(), 4 if kcache.dtype == F16 else IVLM_BF16, kcache.data_ptr(), vcache.data_ptr(),
+                                           kcache.shape[0], parts.data_ptr(), H, D, 0 if dev_pos else int(pos),
+                                           pos.data_ptr() if dev_pos else 0, float(theta), float(scale),
+                                           _p(table[0]) if table else 0, _p(table[1]) if table else 0, _stream()),
+          "llama_decode_attn_parts")
+    return parts
 
 
 def decode_attn_scratch(H, D, device):

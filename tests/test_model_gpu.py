@@ -992,6 +992,7 @@ def test_graph_decode_with_splitkv_attention_matches_one_block_kernel(hip_lib, c
     llm_b = llava.Llama(w, lc, cuda, max_len=256)
     llm_b.set_precision(precision)
     llm_b.decode_splitkv = True
+    llm_b.decode_attn_parts = False  # (the default form - partials merged by the packed o_proj - has its own test below)
     llm_b.forward(emb, 0)
     dg = llm_b.decode_graph()
     assert llm_b._dec_scratch is not None
@@ -1058,3 +1059,44 @@ def test_nonfinite_result_of_an_fp16_mode_is_recomputed_in_bf16(hip_lib, cuda, g
     ref = m.evaluate(*args, **kw)
     assert torch.equal(out["pred_contact_3d"], ref["pred_contact_3d"]) and torch.equal(out["output_ids"], ref["output_ids"])
     assert float((outs[1]["pred_contact_3d"] - ref["pred_contact_3d"]).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("cache_dtype", ["bf16", "f16"])
+def test_decode_attn_parts_merged_by_the_oproj_prologue(hip_lib, cuda, cache_dtype):
+    """The default decode step's attention: four key ranges per head publish (o, max, sum) partials (ivlm_llama_decode_attn_parts) and the
+    packed o_proj GEMV merges them while it stages its activation row (ivlm_gemv1_bf12m_parts).  Against the one-block attention +
+    the packed GEMV on its output: the same appended cache rows, x + W_o a to fp32 summation order - at positions that leave ranges
+    empty, fill exactly one tile, need several tiles, and past the slab (attention row = 0: the residual comes back unchanged)."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    H, D, Tmax = 8, 128, 2048
+    hidden = H * D
+    dt = torch.bfloat16 if cache_dtype == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(21)
+    kc0 = torch.randn(Tmax, H, D, generator=g).to(dt).to(cuda)
+    vc0 = torch.randn(Tmax, H, D, generator=g).to(dt).to(cuda)
+    tab = ops.rope_table(Tmax, D, 10000.0, cuda)
+    wo = (torch.randn(hidden, hidden, generator=g) / hidden ** 0.5).bfloat16().to(cuda)
+    wp = ops.PackedBf12(wo)
+    assert wp.frag
+    parts = torch.zeros(H * 4 * (D + 4), dtype=torch.float32, device=cuda)
+    for pos in (0, 5, 95, 96, 330, 383, 384, 700, 1999, Tmax - 1):
+        qkv = torch.randn(1, 3 * hidden, generator=g).to(cuda)
+        res = torch.randn(1, hidden, generator=g).to(cuda)
+        k1, v1, k2, v2 = kc0.clone(), vc0.clone(), kc0.clone(), vc0.clone()
+        a = ops.llama_decode_attn(qkv, k1, v1, H, D, pos, 10000.0, D ** -0.5, table=tab)
+        ref = ops.linear_bf12(a, wp, residual=res)
+        p_arg = torch.tensor([pos], dtype=torch.int32, device=cuda) if pos % 2 else pos
+        ops.llama_decode_attn_parts(qkv, k2, v2, H, D, p_arg, 10000.0, D ** -0.5, parts, table=tab)
+        got = ops.linear_bf12(None, wp, residual=res, parts=(parts, D))
+        assert torch.equal(k1, k2) and torch.equal(v1, v2), pos
+        err = float((got - ref).abs().max())
+        assert err < 3e-6 * max(1.0, float(ref.abs().max())), (pos, err)
+    sk, sv = kc0[:64].clone(), vc0[:64].clone()
+    res = torch.randn(1, hidden, generator=g).to(cuda)
+    ops.llama_decode_attn_parts(torch.randn(1, 3 * hidden, generator=g).to(cuda), sk, sv, H, D,
+                                torch.tensor([64], dtype=torch.int32, device=cuda), 10000.0, D ** -0.5, parts, table=tab)
+    out = ops.linear_bf12(None, wp, residual=res, parts=(parts, D))
+    assert torch.equal(out, res) and torch.equal(sk, kc0[:64]) and torch.equal(sv, vc0[:64])

@@ -51,8 +51,10 @@ def main():
             sel = [r for r in rows if r["kernel"].startswith(prefix)]
             n = sum(r["launches"] for r in sel)
             return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in sel) / max(n, 1)) if sel else None
-        json.dump({"gemm_bf16_kernel": agg(("ivlm::gemm_bf16_kernel", "ivlm::gemm256_kernel")), "lift_plan_kernel": agg("lift_plan"),
-                   "gemv_kernel": agg(("ivlm::gemv_kernel", "ivlm::gemv1_kernel")), "note": "avg HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB"},
+        json.dump({"gemm_bf16_kernel": agg(("ivlm::gemm_bf16_kernel", "ivlm::gemm256_kernel", "ivlm::gemm320_kernel")),
+                   "lift_plan_kernel": agg("lift_plan"),
+                   "gemv_kernel": agg(("ivlm::gemv_kernel", "ivlm::gemv1_kernel", "ivlm::gemv1_p12m_kernel", "ivlm::gemv1_p12_kernel")),
+                   "note": "avg HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB"},
                   open(sys.argv[3], "w"), indent=1)
 
 
