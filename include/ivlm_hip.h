@@ -596,6 +596,7 @@ int ivlm_llama_decode_attn_parts(const float *qkv, int cache_dtype, void *kcache
 int ivlm_gemv1_bf12m_parts(const float *parts, int D, const void *Pf, const void *Ef, const int32_t *ebase, const int32_t *patch_ptr,
                            const int32_t *patch_col, const void *patch_val, void *C, const void *bias, const void *residual, int N, int K,
                            int act, int out_f32, int flags, ivlm_stream_t stream);
+int ivlm_decode_parts_tuning(int ranges); /* A/B hook: 2 or 4 (default) key ranges per head for the pair above */
 /* A/B hook: grids of at most this many 16-row blocks run 16 waves per block (default 256 = one block per CU), larger ones 8;
    a negative value: the same limit without the 8-deep prefetch of long rows. */
 void ivlm_gemv1_bf12m_tuning(int wide_max_blocks);

@@ -356,14 +356,15 @@ size_t llama_decode_attn_splitkv_scratch_bytes(int H, int D) {
 
 int g_splitkv_splits = 8;  // A/B hook: ivlm_llama_decode_attn_splits
 
-// the PARTS form: S = 4 ranges, partials [H][4][D + 4] fp32 for ivlm_gemv1_bf12m_parts
+// the PARTS form: S = 4 ranges (A/B: 2), partials [H][S][D + 4] fp32 for ivlm_gemv1_bf12m_parts
+extern int g_decode_parts_S;
 int llama_decode_attn_parts(const float* qkv, bf16_t* kcache, bf16_t* vcache, int tmax, float* parts, int H, int D, int pos, float theta,
                             float scale, hipStream_t st, const float* cos_tab, const float* sin_tab, const int32_t* pos_dev,
                             int cache_f16) {
     if (!qkv || !kcache || !vcache || !parts || H <= 0 || D <= 0 || D > kMaxD || (D & 15) || tmax <= 0) return IVLM_ERR_INVALID_ARG;
     if (!pos_dev && (pos < 0 || pos >= kMaxT || pos >= tmax)) return IVLM_ERR_INVALID_ARG;
     if (reinterpret_cast<uintptr_t>(parts) & 15) return IVLM_ERR_INVALID_ARG;
-    constexpr int S = 4;
+    const int S = g_decode_parts_S;
     if (cache_f16)
         llama_decode_attn_splitkv_kernel<true, true><<<dim3(H, S), splitkv::kT, 0, st>>>(qkv, kcache, vcache, nullptr, H, D, pos, theta, scale,
                                                                                          cos_tab, sin_tab, pos_dev, tmax, parts, nullptr);

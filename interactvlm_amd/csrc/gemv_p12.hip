@@ -197,8 +197,8 @@ struct P12M {
     const int32_t* patch_ptr;
     const int32_t* patch_col;
     const bf16_t* patch_val;
-    const float* parts;  // PARTS form: x = the merge of the split-KV attention partials [K / pD heads][4][pD + 4] (decode.hip)
-    int pD;
+    const float* parts;  // PARTS form: x = the merge of the split-KV attention partials [K / pD heads][pS][pD + 4] (decode.hip)
+    int pD, pS;
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8m_t;
@@ -283,21 +283,22 @@ __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12
         f32x4v_t xv4;
         if (PARTS) {
             const int k = c << 2, hd = k / p.pD, d0 = k - hd * p.pD, ps = p.pD + 4;
-            const float* ph = p.parts + (int64_t)hd * 4 * ps;
+            const float* ph = p.parts + (int64_t)hd * p.pS * ps;
             float m[4], l[4];
             f32x4v_t o4[4];
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
-                m[s2] = ph[s2 * ps + p.pD];
-                l[s2] = ph[s2 * ps + p.pD + 1];
-                o4[s2] = *reinterpret_cast<const f32x4v_t*>(ph + s2 * ps + d0);
+                const int sc = s2 < p.pS ? s2 : 0;  // (pS = 2: ranges 2, 3 repeat range 0 with weight 0)
+                m[s2] = ph[sc * ps + p.pD];
+                l[s2] = ph[sc * ps + p.pD + 1];
+                o4[s2] = *reinterpret_cast<const f32x4v_t*>(ph + sc * ps + d0);
             }
             const float M = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
             float den = 0.0f;
             xv4 = f32x4v_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
-                const float wgt = __expf(m[s2] - M);
+                const float wgt = s2 < p.pS ? __expf(m[s2] - M) : 0.0f;
                 den = fmaf(wgt, l[s2], den);
                 xv4 += o4[s2] * wgt;
             }
@@ -503,6 +504,9 @@ extern "C" int ivlm_unpack_bf12(const void* P, int64_t ldp, const void* E, int64
 
 int g_p12m_wide_max_blocks = 256;  // A/B hooks: ivlm_gemv1_bf12m_tuning
 int g_p12m_deep = 1;
+namespace ivlm {
+int g_decode_parts_S = 4;  // key ranges per head of the split-KV attention / o_proj pair (A/B hook: ivlm_decode_parts_tuning; 2 or 4)
+}
 
 // MFMA variant on the fragment layout (see gemv1_p12m_kernel): Pf / Ef = the P / E bytes of ivlm_gemv1_bf12 re-ordered as
 // [N/16][K/64][64 lanes][16 | 8 bytes]; N % 16 == 0, K % 64 == 0, 6 K bytes of LDS.  Same contract otherwise.
@@ -533,7 +537,7 @@ static int gemv1_bf12m(const float* x, const float* parts, int pD, const void* P
     g.rms_w = static_cast<const bf16_t*>(rms_w);
     g.rms_eps = rms_eps;
     P12M p{static_cast<const u32x4_t*>(Pf), static_cast<const u32x2_t*>(Ef), ebase, patch_ptr, patch_col,
-           static_cast<const bf16_t*>(patch_val), parts, pD};
+           static_cast<const bf16_t*>(patch_val), parts, pD, g_decode_parts_S};
     hipStream_t st = ivlm_stream(stream);
     const dim3 grid(N / 16);
     const bool wide = grid.x <= (unsigned)g_p12m_wide_max_blocks;  // at most one block per CU: 16 waves per block
@@ -586,4 +590,10 @@ extern "C" int ivlm_gemv1_bf12m_parts(const float* parts, int D, const void* Pf,
 extern "C" void ivlm_gemv1_bf12m_tuning(int wide_max_blocks) {
     g_p12m_deep = wide_max_blocks >= 0;  // (negative: |value| as the limit, without the 8-deep form)
     g_p12m_wide_max_blocks = wide_max_blocks < 0 ? -wide_max_blocks : wide_max_blocks;
+}
+
+extern "C" int ivlm_decode_parts_tuning(int ranges) {
+    if (ranges != 2 && ranges != 4) return IVLM_ERR_INVALID_ARG;
+    g_decode_parts_S = ranges;
+    return IVLM_OK;
 }

@@ -43,6 +43,8 @@ def main():
     llm.fuse_attn_oproj = a.fuse
     if a.precision != "default":
         llm.set_precision(a.precision)
+    if os.environ.get("PARTS_S"):
+        assert _lib.load().ivlm_decode_parts_tuning(int(os.environ["PARTS_S"])) == 0
     if a.wide != -1:
         _lib.load().ivlm_gemv1_bf12m_tuning(a.wide)
     if a.splits:

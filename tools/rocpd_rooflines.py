@@ -37,7 +37,7 @@ def main():
             nrows = vocab if label == "lm_head" else nrows
             b = nrows * K * 2
         elif nrows == hidden:  # o_proj (K = hidden) and down_proj (K = inter) share a grid: told apart by the packed form, else averaged
-            if packed and m.group(2).endswith("16, 8"):
+            if packed and ", 16, 8" in m.group(2):
                 label, b = "down", hidden * inter * 2
             elif packed and inter > 4096:
                 label, b = "o", hidden * hidden * 2
