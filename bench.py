@@ -756,7 +756,9 @@ def main():
             "kernel_timing": "HIP events attached to each kernel launch (hipExtLaunchKernelGGL), on the launch stream",
             "precision": "default mode: the checkpoint's bf16 weights, IEEE fp16 MFMA operands (dtype: 11 significant bits against "
                          "bf16's 8, same MFMA rate), fp32 accumulation and residual streams, fp32 activations on the decode and "
-                         "mask-decoder paths; see precision_modes",
+                         "mask-decoder paths; the decode linears stream the SAME bf16 weights in a lossless 12-bit packing (every "
+                         "value rebuilt bit for bit; products on the matrix cores against hi + lo + lo2 bf16 parts of the fp32 "
+                         "activation: exact); see precision_modes",
             "precision_modes": precision_modes,
             "algorithmic_tflop_per_image": round(fl["total"] / 1e12, 2),
             # `roofline` = the kernel family with the largest share of GPU time (decode GEMV: HBM-bound);

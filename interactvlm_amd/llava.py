@@ -210,8 +210,8 @@ class Llama:
         self.fuse_attn_oproj = bool(os.environ.get("IVLM_FUSE_ATTN_OPROJ"))
         # The batch-1 decode linears stream LOSSLESSLY packed weights (ops.PackedBf12: 1.5 bytes per weight, every bf16 value
         # reconstructed bit for bit, dots on the matrix cores: ivlm_gemv1_bf12m; copies made on the first decode step, +10 GB for
-        # 7B): 2.69 -> 2.44 ms per token.  Matrices whose shape the fragment layout does not take (rows % 16, columns % 64) and the
-        # lm_head stay on the bf16 kernel.  IVLM_DECODE_PACKED=0 / decode_packed = False: bf16 weights everywhere.
+        # 7B): 2.69 -> 2.34 ms per token.  Matrices whose shape the fragment layout does not take (rows % 16, columns % 64) stay
+        # on the bf16 kernel (the lm_head's rows are padded with zeros).  IVLM_DECODE_PACKED=0 / decode_packed = False: bf16 weights everywhere.
         self.decode_packed = os.environ.get("IVLM_DECODE_PACKED", "1") != "0"
         self.decode_attn_parts = os.environ.get("IVLM_DECODE_ATTN_PARTS", "1") != "0"  # (with decode_packed: see _decode_step)
 
@@ -629,4 +629,8 @@ class Llama:
         chunks re-streamed the 262 MB of lm_head once per chunk)."""
         if hidden_rows.shape[0] > 16:
             return ops.linear(ops.split_rows(hidden_rows.contiguous()), self.lm_head, out_f32=True, a_split=True)
+        if hidden_rows.shape[0] == 1 and self.decode_packed and ops.PackedBf12.takes(16, self.cfg.hidden):
+            if getattr(self, "lm_head_p", None) is None:  # (the decode step's lm_head: 12-bit weights, rows padded to 16 with zeros)
+                self.lm_head_p = ops.PackedBf12(self.lm_head, pad_rows=True)
+            return ops.linear_bf12(hidden_rows.contiguous(), self.lm_head_p)
         return ops.linear(hidden_rows, self.lm_head, out_f32=True)

@@ -536,8 +536,13 @@ class PackedBf12:
         """shapes the fragment layout (the MFMA kernel) takes: 16-row blocks, 64-column step pairs, x as three bf16 planes in LDS"""
         return N % 16 == 0 and K % 64 == 0 and K * 6 <= 100 * 1024
 
-    def __init__(self, w, fragments=True):
+    def __init__(self, w, fragments=True, pad_rows=False):
+        """pad_rows: zero rows are appended up to a multiple of 16 so that the fragment layout takes the matrix (lm_head: 32003 rows);
+        ``rows`` keeps the true count, ``linear_bf12`` returns that many outputs."""
         assert w.dtype == BF16 and w.dim() == 2 and w.is_cuda and w.shape[1] % 16 == 0
+        self.rows = w.shape[0]
+        if pad_rows and w.shape[0] % 16:
+            w = torch.cat([w, torch.zeros(16 - w.shape[0] % 16, w.shape[1], dtype=BF16, device=w.device)])
         if not bool(torch.isfinite(w).all()):
             raise IvlmError("PackedBf12: inf / nan weights cannot be packed")
         N, K = w.shape
@@ -586,11 +591,11 @@ class PackedBf12:
                 self.patch_val.data_ptr())
 
     def unpack(self):
-        """-> bf16 [N, K], bit-identical to the matrix that was packed."""
+        """-> bf16 [rows, K], bit-identical to the matrix that was packed."""
         out = torch.empty(self.shape, dtype=BF16, device=self.P.device)
         check(_lib.load().ivlm_unpack_bf12(*self._args(), self.shape[0], self.shape[1], out.data_ptr(), _stream()), "unpack_bf12")
         self._keep = None
-        return out
+        return out[: self.rows]
 
 
 def linear_bf12(x, wp: PackedBf12, bias=None, act="none", residual=None, out_f32=True, rms=None, parts=None):
@@ -627,7 +632,7 @@ def linear_bf12(x, wp: PackedBf12, bias=None, act="none", residual=None, out_f32
         TIMER.time("gemv_bf16", 2.0 * N * K, call, tag=(1, N, K, act, "bf12"))
     else:
         call()
-    return out
+    return out if wp.rows == N or act == "swiglu" else out[:, : wp.rows]
 
 
 def rmsnorm(x, weight, eps=1e-5, out_f32=False, out_split=False, fp8_scale=None, out_f16=False):

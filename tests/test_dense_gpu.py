@@ -732,6 +732,12 @@ def test_gemv_bf12_is_lossless_and_equals_the_bf16_gemv(hip_lib, cuda, N, K, act
         if got is not None:
             assert float((y_ - got).abs().max()) <= 3e-6 * max(1.0, float(got.abs().max()))
         got = y_
+    if N % 16 and K % 64 == 0 and not res:  # rows padded to 16 with zeros (the lm_head): fragment layout, N outputs
+        wpad = ops.PackedBf12(w, pad_rows=True)
+        assert wpad.frag and wpad.rows == N and wpad.shape[0] % 16 == 0
+        assert torch.equal(wpad.unpack().view(torch.int16), torch.where(w == 0, torch.zeros_like(w), w).view(torch.int16))
+        y_ = ops.linear_bf12(x, wpad, **kw)
+        assert y_.shape == got.shape and float((y_ - got).abs().max()) <= 3e-6 * max(1.0, float(got.abs().max()))
     xd = x.double()
     if rms:
         xd = xd * torch.rsqrt((xd * xd).mean() + 1e-5) * gam.double()
