@@ -596,6 +596,14 @@ int ivlm_llama_decode_attn_parts(const float *qkv, int cache_dtype, void *kcache
 int ivlm_gemv1_bf12m_parts(const float *parts, int D, const void *Pf, const void *Ef, const int32_t *ebase, const int32_t *patch_ptr,
                            const int32_t *patch_col, const void *patch_val, void *C, const void *bias, const void *residual, int N, int K,
                            int act, int out_f32, int flags, ivlm_stream_t stream);
+/* The linears of the BATCHED decode step (M <= 16 fp32 activation rows: one token of each sequence) on the same planes: the weight
+ * fragments are rebuilt once and meet all M rows (x = hi + lo bf16 operands to 2^-17, two MFMAs per fragment, fp32 accumulation);
+ * blocks of 1 - 3 tiles of 16 weight rows x 8 waves over K.  out[M, N] = act(x . W^T + bias) + residual; N % 16 == 0, K % 64 == 0. */
+int ivlm_gemv16_bf12m(const float *x, int64_t lda, int M, const void *Pf, const void *Ef, const int32_t *ebase,
+                      const int32_t *patch_ptr, const int32_t *patch_col, const void *patch_val, void *C, int64_t ldc, const void *bias,
+                      const void *residual, int64_t ldr, int N, int K, int act, int out_f32, const void *rms_w, float rms_eps, int flags,
+                      ivlm_stream_t stream);
+void ivlm_gemv16_bf12m_tuning(int tiles_per_block); /* A/B hook: 1 - 3, 0 = automatic */
 int ivlm_decode_parts_tuning(int ranges); /* A/B hook: 2 or 4 (default) key ranges per head for the pair above */
 /* A/B hook: grids of at most this many 16-row blocks run 16 waves per block (default 256 = one block per CU), larger ones 8;
    a negative value: the same limit without the 8-deep prefetch of long rows. */

@@ -419,6 +419,160 @@ __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12
     else static_cast<bf16_t*>(g.C)[row] = f32_to_bf16(v);
 }
 
+// =====================================================================================================================================
+// M <= 16 activation rows (the batched decode step, BASELINE configs[2]: one token of each of B sequences) on the same packed weights:
+// the structure of skinny_mfma_kernel (gemv_mfma.hip) - block = T tiles of 16 weight rows x 8 waves over K, activation fragments loaded
+// straight from L2 (fp32 rows, split into hi + lo bf16 operands in registers: x = hi + lo to 2^-17, two MFMAs per weight fragment), the 8
+// partial 16 x 16 tiles summed through LDS in wave order - with the weight fragments rebuilt from the fragment-layout planes (1 KB
+// contiguous per wave instruction instead of 16 rows x 64 B, 0.75 x the bytes; two VALU operations per weight, shared by all M rows).
+// A operand = the 16 weight rows, B operand = the activation rows: lane holds C[weight row 4 kg + i][activation row r].
+__device__ __forceinline__ void split_pair_p12(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16x2(a, b);
+    lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+
+template <bool RMS, int T>
+__global__ __launch_bounds__(512, 2) void skinny_p12m_kernel(GemmArgs g, P12M p) {
+    constexpr int kW = 8, U = 2;  // waves per block; step pairs in flight per lane (4 MFMA k-steps)
+    __shared__ float s_part[kW][16][17];  // [wave][m][n]
+    __shared__ float s_ssq[kW][16];
+    __shared__ float s_fin[16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int K = g.K, nsp = K >> 6;
+    const int per = (nsp + kW - 1) / kW;
+    const int s0 = wave * per, s1 = min(nsp, s0 + per);
+    const int ntiles = g.N >> 4;
+    const u32x4_t* pp[T];
+    const u32x2_t* ep[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t rb = min((int)blockIdx.x * T + t, ntiles - 1);
+        pp[t] = p.P + rb * nsp * 64 + lane;
+        ep[t] = p.E + rb * nsp * 64 + lane;
+    }
+    const bool xrow = r < g.M;
+    const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const float*>(g.A) + (int64_t)(xrow ? r : 0) * g.lda);
+    const u32x4_t* gp = reinterpret_cast<const u32x4_t*>(g.rms_w);
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+    const float xs = __builtin_ldexpf(1.0f, kXScaleExp);
+    f32x4m_t acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4m_t{0.0f, 0.0f, 0.0f, 0.0f};
+    float ssq = 0.0f;
+    for (int sp = s0; sp < s1; sp += U) {
+        u32x4_t pw[U][T], xa[U][2], xb[U][2], gm[U][2];
+        u32x2_t ew[U][T];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = sp + u < s1;
+            const int spc = ok ? sp + u : s0;  // clamped (unconditional) weight loads keep the buffers in registers
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                pw[u][t] = __builtin_nontemporal_load(pp[t] + (int64_t)spc * 64);
+                ew[u][t] = __builtin_nontemporal_load(ep[t] + (int64_t)spc * 64);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // the lane's 8 fp32 activations of MFMA step 2 spc + h: k = spc * 64 + h * 32 + kg * 8 ..
+                const int c = spc * 8 + h * 4 + kg;  // 8-element chunk index
+                xa[u][h] = (ok && xrow) ? xp[2 * c] : zero;
+                xb[u][h] = (ok && xrow) ? xp[2 * c + 1] : zero;
+                if (RMS) gm[u][h] = gp[c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[j] = __uint_as_float(xa[u][h][j]);
+                    f[4 + j] = __uint_as_float(xb[u][h][j]);
+                }
+                if (RMS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ssq += f[2 * j] * f[2 * j] + f[2 * j + 1] * f[2 * j + 1];
+                        f[2 * j] *= __uint_as_float(gm[u][h][j] << 16);
+                        f[2 * j + 1] *= __uint_as_float(gm[u][h][j] & 0xffff0000u);
+                    }
+                }
+                u32x4_t hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t h2, l2;
+                    split_pair_p12(f[2 * j] * xs, f[2 * j + 1] * xs, h2, l2);
+                    hi[j] = h2;
+                    lo[j] = l2;
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const bf16x8m_t wf = frag_p12m(pw[u][t][2 * h], pw[u][t][2 * h + 1], ew[u][t][h]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8m_t, hi), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8m_t, lo), acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // lane holds C[m = r][n = 4 * kg + i] of this wave's K slice, per tile
+    if (RMS) {
+        ssq += __shfl_xor(ssq, 16);
+        ssq += __shfl_xor(ssq, 32);
+        if (kg == 0) s_ssq[wave][r] = ssq;
+    }
+    const int m = threadIdx.x >> 4, n = threadIdx.x & 15;
+    const float* xg = reinterpret_cast<const float*>(g.A);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int nt = ((int)blockIdx.x * T + t) * 16;
+        if (t > 0) __syncthreads();  // the previous tile's s_fin readers are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_part[wave][r][kg * 4 + i] = acc[t][i];
+        __syncthreads();
+        if (threadIdx.x < 256 && nt < g.N) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) v += s_part[w][m][n];
+            const int nn = nt + n;  // (N % 16 == 0)
+            v = __builtin_ldexpf(v, p.ebase[nn] - kXScaleExp);
+            if (m < g.M) {  // the nonzero weights outside the row's exponent window: exact bf16 values x fp32 activations
+                for (int i = p.patch_ptr[nn]; i < p.patch_ptr[nn + 1]; ++i) {
+                    const int col = p.patch_col[i];
+                    float xv = xg[(int64_t)m * g.lda + col];
+                    if (RMS) xv *= bf16_to_f32(g.rms_w[col]);
+                    v = fmaf(bf16_to_f32(p.patch_val[i]), xv, v);
+                }
+            }
+            if (RMS) {
+                float q = 0.0f;
+#pragma unroll
+                for (int w = 0; w < kW; ++w) q += s_ssq[w][m];
+                v *= rsqrtf(q / (float)K + g.rms_eps);
+            }
+            s_fin[m][n] = v + (g.bias ? bf16_to_f32(g.bias[nn]) : 0.0f);
+        }
+        __syncthreads();
+        if (threadIdx.x >= 256 || m >= g.M || nt >= g.N) continue;
+        float v = s_fin[m][n];
+        int64_t col = nt + n;
+        if (g.act == ACT_SWIGLU) {  // rows (gate_j, up_j) interleaved: even n pairs with n + 1
+            if (n & 1) continue;
+            const float up = s_fin[m][n + 1];
+            v = (v / (1.0f + __expf(-v))) * up;
+            col >>= 1;
+        } else {
+            v = act1(v, g.act);
+            if (g.residual) {
+                const int64_t idx = (int64_t)m * g.ldr + col;
+                v += g.res_f32 ? reinterpret_cast<const float*>(g.residual)[idx] : bf16_to_f32(g.residual[idx]);
+            }
+        }
+        if (g.out_f32) static_cast<float*>(g.C)[(int64_t)m * g.ldc + col] = v;
+        else static_cast<bf16_t*>(g.C)[(int64_t)m * g.ldc + col] = f32_to_bf16(v);
+    }
+}
+
 // exact reconstruction of the bf16 matrix (the losslessness check of the tests; not on the path): one thread per weight
 __global__ __launch_bounds__(256) void unpack_p12_kernel(P12 p, int N, int K, bf16_t* __restrict__ out) {
     const int64_t total = (int64_t)N * K;
@@ -502,6 +656,7 @@ extern "C" int ivlm_unpack_bf12(const void* P, int64_t ldp, const void* E, int64
     return ivlm_launch_status();
 }
 
+int g_skinny_p12m_tiles = 0;       // 0 = rule in ivlm_gemv16_bf12m (A/B hook: ivlm_gemv16_bf12m_tuning)
 int g_p12m_wide_max_blocks = 256;  // A/B hooks: ivlm_gemv1_bf12m_tuning
 int g_p12m_deep = 1;
 namespace ivlm {
@@ -597,3 +752,57 @@ extern "C" int ivlm_decode_parts_tuning(int ranges) {
     g_decode_parts_S = ranges;
     return IVLM_OK;
 }
+
+// The batched decode step's linears (M <= 16 fp32 activation rows) on the fragment-layout planes: out[M, N] = act(x . W^T + bias) +
+// residual; x = hi + lo bf16 operands (2^-17), fp32 accumulation.  N % 16 == 0, K % 64 == 0; lda / ldc / ldr in elements.
+extern "C" int ivlm_gemv16_bf12m(const float* x, int64_t lda, int M, const void* Pf, const void* Ef, const int32_t* ebase,
+                                 const int32_t* patch_ptr, const int32_t* patch_col, const void* patch_val, void* C, int64_t ldc,
+                                 const void* bias, const void* residual, int64_t ldr, int N, int K, int act, int out_f32,
+                                 const void* rms_w, float rms_eps, int flags, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!x || !C || !Pf || !Ef || !ebase || !patch_ptr || !patch_col || !patch_val || M <= 0 || M > 16 || N <= 0 || K <= 0)
+        return IVLM_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(Pf) & 15) || (reinterpret_cast<uintptr_t>(Ef) & 7) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+        (lda & 3) || lda < K)
+        return IVLM_ERR_INVALID_ARG;
+    if ((N & 15) || (K & 63)) return IVLM_ERR_UNSUPPORTED;
+    if (act == ACT_SWIGLU && residual) return IVLM_ERR_UNSUPPORTED;
+    GemmArgs g;
+    g.A = reinterpret_cast<const bf16_t*>(x);
+    g.a_f32 = 1;
+    g.C = C;
+    g.bias = static_cast<const bf16_t*>(bias);
+    g.residual = static_cast<const bf16_t*>(residual);
+    g.res_f32 = (flags & IVLM_GEMM_RES_F32) ? 1 : 0;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldc = ldc; g.ldr = ldr;
+    g.act = act;
+    g.out_f32 = out_f32;
+    g.rms_w = static_cast<const bf16_t*>(rms_w);
+    g.rms_eps = rms_eps;
+    P12M p{static_cast<const u32x4_t*>(Pf), static_cast<const u32x2_t*>(Ef), ebase, patch_ptr, patch_col,
+           static_cast<const bf16_t*>(patch_val), nullptr, 0, 0};
+    hipStream_t st = ivlm_stream(stream);
+    const int tiles = N / 16;
+    int T = g_skinny_p12m_tiles;
+    if (T <= 0) {  // fewest (blocks per CU) x (tiles per block), then the most tiles (least activation re-reading): as skinny_tiles()
+        int best_cost = 1 << 30;
+        for (int t : {1, 2, 3}) {
+            const int blocks = (tiles + t - 1) / t, cost = ((blocks + 255) / 256) * t;
+            if (cost <= best_cost) { T = t; best_cost = cost; }
+        }
+    }
+    const dim3 grid((tiles + T - 1) / T), block(512);
+    if (rms_w) {
+        if (T == 1) ivlm_launch(skinny_p12m_kernel<true, 1>, grid, block, 0, st, g, p);
+        else if (T == 2) ivlm_launch(skinny_p12m_kernel<true, 2>, grid, block, 0, st, g, p);
+        else ivlm_launch(skinny_p12m_kernel<true, 3>, grid, block, 0, st, g, p);
+    } else {
+        if (T == 1) ivlm_launch(skinny_p12m_kernel<false, 1>, grid, block, 0, st, g, p);
+        else if (T == 2) ivlm_launch(skinny_p12m_kernel<false, 2>, grid, block, 0, st, g, p);
+        else ivlm_launch(skinny_p12m_kernel<false, 3>, grid, block, 0, st, g, p);
+    }
+    return ivlm_launch_status();
+}
+
+extern "C" void ivlm_gemv16_bf12m_tuning(int tiles_per_block) { g_skinny_p12m_tiles = tiles_per_block > 3 ? 3 : tiles_per_block; }

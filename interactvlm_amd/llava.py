@@ -214,6 +214,7 @@ class Llama:
         # on the bf16 kernel (the lm_head's rows are padded with zeros).  IVLM_DECODE_PACKED=0 / decode_packed = False: bf16 weights everywhere.
         self.decode_packed = os.environ.get("IVLM_DECODE_PACKED", "1") != "0"
         self.decode_attn_parts = os.environ.get("IVLM_DECODE_ATTN_PARTS", "1") != "0"  # (with decode_packed: see _decode_step)
+        self.decode_packed_batch = os.environ.get("IVLM_DECODE_PACKED_BATCH", "1") != "0"  # (the batched step: ivlm_gemv16_bf12m)
 
     # ---- "parity" precision (opt-in): the prefill GEMMs take hi + lo bf16 activation operands, the attention three MFMAs per
     # fragment, and K / V are cached as hi + lo planes (also read by the decode kernels) - no activation is rounded to bf16.
@@ -514,13 +515,23 @@ class Llama:
         H, hd = c.heads, c.hidden // c.heads
         if x.shape[0] > 16:
             raise ops.IvlmError("decode_step_batch: at most 16 sequences per step (weight-streaming kernels)")
+        packed = self.decode_packed and self.decode_packed_batch and x.shape[0] > 1
+
+        def lin(x_, L, n, **kw):  # (the packed planes of the batch-1 step where the fragment layout takes the matrix, bf16 otherwise)
+            if packed:
+                if n + "_p" not in L:
+                    L[n + "_p"] = ops.PackedBf12(L[n]) if ops.PackedBf12.takes(*L[n].shape) else None
+                if L[n + "_p"] is not None and L[n + "_p"].frag:
+                    return ops.linear_bf12(x_, L[n + "_p"], **kw)
+            return ops.linear(x_, L[n], out_f32=True, **kw)
+
         for li, L in enumerate(self.layers):
-            qkv = ops.linear(x, L["qkv"], rms=(L["ln1"], c.eps), out_f32=True)
+            qkv = lin(x, L, "qkv", rms=(L["ln1"], c.eps))
             a = ops.llama_decode_attn_batch(qkv, kc[li], vc[li], H, hd, pos_dev, c.theta, hd ** -0.5, table=self.rope,
                                             lo=(lo[0][li], lo[1][li]) if lo is not None else None)
-            x = ops.linear(a, L["o"], residual=x, out_f32=True)
-            h = ops.linear(x, L["gu"], act="swiglu", rms=(L["ln2"], c.eps), out_f32=True)
-            x = ops.linear(h, L["down"], residual=x, out_f32=True)
+            x = lin(a, L, "o", residual=x)
+            h = lin(x, L, "gu", act="swiglu", rms=(L["ln2"], c.eps))
+            x = lin(h, L, "down", residual=x)
         return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
 
     def decode_graph_batch(self, B):

@@ -608,10 +608,25 @@ def linear_bf12(x, wp: PackedBf12, bias=None, act="none", residual=None, out_f32
         assert x is None and wp.frag and rms is None and pt.dtype == F32 and pt.numel() >= (K // pD) * 4 * (pD + 4)
         dev = pt.device
     else:
-        assert x.dtype == F32 and x.is_contiguous() and x.numel() == K
+        assert x.dtype == F32 and x.is_contiguous() and x.dim() == 2 and x.shape[1] == K and 1 <= x.shape[0] <= 16
         dev = x.device
     n_out = N // 2 if act == "swiglu" else N
-    out = torch.empty(1, n_out, dtype=F32 if out_f32 else BF16, device=dev)
+    M = 1 if parts is not None else x.shape[0]
+    out = torch.empty(M, n_out, dtype=F32 if out_f32 else BF16, device=dev)
+    if M > 1:  # the batched decode step: M activation rows meet every rebuilt weight fragment (fragment layout only)
+        assert wp.frag and wp.rows == N
+        flags = 0
+        if residual is not None:
+            assert residual.dtype in (BF16, F32) and residual.is_contiguous() and tuple(residual.shape) == (M, N)
+            flags = GEMM_RES_F32 if residual.dtype == F32 else 0
+        call = lambda: check(lib.ivlm_gemv16_bf12m(x.data_ptr(), K, M, *wp._args_frag(), out.data_ptr(), n_out, _p(bias), _p(residual), N,
+                                                   N, K, ACT[act], 1 if out_f32 else 0, _p(rms[0]) if rms else 0,
+                                                   float(rms[1]) if rms else 0.0, flags, _stream()), "gemv16_bf12m")
+        if TIMER.enabled:
+            TIMER.time("gemv_bf16", 2.0 * N * K, call, tag=(M, N, K, act, "bf12"))
+        else:
+            call()
+        return out
     flags = 0
     if residual is not None:
         assert residual.dtype in (BF16, F32) and residual.is_contiguous() and residual.numel() == N

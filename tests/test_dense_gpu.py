@@ -732,6 +732,25 @@ def test_gemv_bf12_is_lossless_and_equals_the_bf16_gemv(hip_lib, cuda, N, K, act
         if got is not None:
             assert float((y_ - got).abs().max()) <= 3e-6 * max(1.0, float(got.abs().max()))
         got = y_
+    if N % 16 == 0 and K % 64 == 0:  # the batched decode step: M <= 16 activation rows on the same planes (hi + lo bf16 operands: 2^-17)
+        wpf = ops.PackedBf12(w)
+        for M in (2, 7, 16):
+            xm = (torch.randn(M, K, generator=g) * 2.0).to(cuda)
+            rm = torch.randn(M, N, generator=g).to(cuda) if res else None
+            kwm = dict(act=act, residual=rm, rms=(gam, 1e-5) if rms else None)
+            ym = ops.linear_bf12(xm, wpf, **kwm)
+            xdm = xm.double()
+            if rms:
+                xdm = xdm * torch.rsqrt((xdm * xdm).mean(dim=1, keepdim=True) + 1e-5) * gam.double()
+            rf = xdm @ w.double().t()
+            if act == "swiglu":
+                rf = torch.nn.functional.silu(rf[:, 0::2]) * rf[:, 1::2]
+            if res:
+                rf = rf + rm.double()
+            em = float((ym.double() - rf).abs().max()) / float(rf.abs().max())
+            assert ym.shape == rf.shape and em < 3e-5, (M, em)
+            y16 = ops.linear(xm, w, out_f32=True, **kwm)  # the bf16-weight skinny kernel: same operands, other summation order
+            assert float((ym - y16).abs().max()) / float(rf.abs().max()) < 3e-5
     if N % 16 and K % 64 == 0 and not res:  # rows padded to 16 with zeros (the lm_head): fragment layout, N outputs
         wpad = ops.PackedBf12(w, pad_rows=True)
         assert wpad.frag and wpad.rows == N and wpad.shape[0] % 16 == 0

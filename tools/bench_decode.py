@@ -43,6 +43,8 @@ def main():
     llm.fuse_attn_oproj = a.fuse
     if a.precision != "default":
         llm.set_precision(a.precision)
+    if os.environ.get("P12M_T"):
+        _lib.load().ivlm_gemv16_bf12m_tuning(int(os.environ["P12M_T"]))
     if os.environ.get("PARTS_S"):
         assert _lib.load().ivlm_decode_parts_tuning(int(os.environ["PARTS_S"])) == 0
     if a.wide != -1:
