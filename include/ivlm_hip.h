@@ -596,6 +596,17 @@ int ivlm_llama_decode_attn_parts(const float *qkv, int cache_dtype, void *kcache
 int ivlm_gemv1_bf12m_parts(const float *parts, int D, const void *Pf, const void *Ef, const int32_t *ebase, const int32_t *patch_ptr,
                            const int32_t *patch_col, const void *patch_val, void *C, const void *bias, const void *residual, int N, int K,
                            int act, int out_f32, int flags, ivlm_stream_t stream);
+/* The packer (weight preparation, once per matrix): bf16 w [N_valid, K] -> what ivlm_gemv1_bf12m / ivlm_gemv16_bf12m /
+ * ivlm_llama_decode_step_bf12 read.  n_rows = N_valid rounded up to a multiple of 16 (the extra rows pack as zeros); K % 64 == 0.
+ *   1. ivlm_pack_bf12m_count: ebase [n_rows], patch_ptr [n_rows + 1] (row r's patches are entries patch_ptr[r] .. patch_ptr[r + 1]);
+ *   2. the caller reads patch_ptr[n_rows] (the number of nonzero weights outside their row's 15-binade window: ~1e-4 of a trained
+ *      matrix), allocates patch_col (int32) / patch_val (bf16) of max(1, that) entries and the planes Pf (n_rows * K bytes, 16-byte
+ *      aligned) / Ef (n_rows * K / 2 bytes);
+ *   3. ivlm_pack_bf12m_fill writes the planes in the fragment layout and the patches in column order.
+ * Lossless: ivlm_unpack_bf12 on the row-layout view of the same bytes returns every bf16 value bit for bit (-0.0 packs as +0.0). */
+int ivlm_pack_bf12m_count(const void *w, int N_valid, int n_rows, int K, int32_t *ebase, int32_t *patch_ptr, ivlm_stream_t stream);
+int ivlm_pack_bf12m_fill(const void *w, int N_valid, int n_rows, int K, const int32_t *ebase, const int32_t *patch_ptr, void *Pf, void *Ef,
+                         int32_t *patch_col, void *patch_val, ivlm_stream_t stream);
 /* The linears of the BATCHED decode step (M <= 16 fp32 activation rows: one token of each sequence) on the same planes: the weight
  * fragments are rebuilt once and meet all M rows (x = hi + lo bf16 operands to 2^-17, two MFMAs per fragment, fp32 accumulation);
  * blocks of 1 - 3 tiles of 16 weight rows x 8 waves over K.  out[M, N] = act(x . W^T + bias) + residual; N % 16 == 0, K % 64 == 0. */

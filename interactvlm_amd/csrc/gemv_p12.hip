@@ -806,3 +806,141 @@ extern "C" int ivlm_gemv16_bf12m(const float* x, int64_t lda, int M, const void*
 }
 
 extern "C" void ivlm_gemv16_bf12m_tuning(int tiles_per_block) { g_skinny_p12m_tiles = tiles_per_block > 3 ? 3 : tiles_per_block; }
+
+// =====================================================================================================================================
+// The packer (weight preparation, once per matrix): bf16 [N, K] -> fragment-layout planes + per-row exponent bases + CSR patches, so that
+// a C caller needs nothing but this library to build what ivlm_gemv1_bf12m / ivlm_llama_decode_step_bf12 read.  Two calls around one
+// host read of the patch total: ivlm_pack_bf12m_count (ebase, patch_ptr), ivlm_pack_bf12m_fill (planes, patch_col / patch_val in column
+// order).  Rows beyond N_valid (padding up to a multiple of 16) pack as zeros.
+namespace ivlm {
+namespace {
+
+__global__ __launch_bounds__(256) void p12_rowstats_kernel(const bf16_t* __restrict__ w, int n_valid, int K, int32_t* __restrict__ ebase,
+                                                           int32_t* __restrict__ cnt) {
+    __shared__ int s_red[4];
+    const int row = blockIdx.x;
+    int mx = 0;
+    if (row < n_valid)
+        for (int c = threadIdx.x; c < K; c += 256) mx = max(mx, (int)((w[(int64_t)row * K + c] >> 7) & 0xff));
+    for (int o = 32; o; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    const int eb = max(mx - 15, 0);
+    int n = 0;
+    if (row < n_valid)
+        for (int c = threadIdx.x; c < K; c += 256) {
+            const uint32_t b = w[(int64_t)row * K + c];
+            n += ((int)((b >> 7) & 0xff) - eb < 1) && (b & 0x7fffu);  // nonzero and outside the window
+        }
+    for (int o = 32; o; o >>= 1) n += __shfl_xor(n, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ebase[row] = eb;
+        cnt[row + 1] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        if (row == 0) cnt[0] = 0;
+    }
+}
+
+// in-place inclusive scan of cnt[1 .. N] (one block; N is at most a few 10^4 rows)
+__global__ __launch_bounds__(1024) void p12_scan_kernel(int32_t* __restrict__ ptr, int N) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 1; base <= N; base += 1024) {
+        const int i = base + threadIdx.x;
+        int v = i <= N ? ptr[i] : 0, x = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if ((int)(threadIdx.x & 63) >= o) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = x;
+        __syncthreads();
+        int off = s_carry;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) off += s_w[k];
+        if (i <= N) ptr[i] = x + off;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = x + off;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void p12_fill_kernel(const bf16_t* __restrict__ w, int n_valid, int K, const int32_t* __restrict__ ebase,
+                                                       const int32_t* __restrict__ patch_ptr, uint8_t* __restrict__ Pf,
+                                                       uint8_t* __restrict__ Ef, int32_t* __restrict__ patch_col,
+                                                       bf16_t* __restrict__ patch_val) {
+    __shared__ int s_cnt[4];
+    const int row = blockIdx.x, rb = row >> 4, r = row & 15, nsp = K >> 6;
+    const int eb = ebase[row];
+    int out = patch_ptr[row];
+    for (int c0 = 0; c0 < K; c0 += 512) {  // a thread packs the weight PAIR (c, c + 1): one P half-word, one E byte
+        const int c = c0 + 2 * threadIdx.x;
+        uint32_t b[2] = {0u, 0u};
+        if (row < n_valid && c < K) {
+            const uint32_t two = *reinterpret_cast<const uint32_t*>(w + (int64_t)row * K + c);
+            b[0] = two & 0xffffu;
+            b[1] = two >> 16;
+        }
+        uint32_t pbyte[2], code[2];
+        bool esc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cd = (int)((b[j] >> 7) & 0xff) - eb;
+            const bool in = cd >= 1;
+            esc[j] = !in && (b[j] & 0x7fffu);
+            pbyte[j] = in ? (((b[j] >> 8) & 0x80u) | (b[j] & 0x7fu)) : 0u;
+            code[j] = in ? (uint32_t)cd : 0u;
+        }
+        if (c < K) {
+            const int sp = c >> 6, h = (c >> 5) & 1, q = (c >> 3) & 3, i = c & 7;
+            const int64_t lane_rec = ((((int64_t)rb * nsp + sp) * 4 + q) * 16 + r);
+            *reinterpret_cast<uint16_t*>(Pf + lane_rec * 16 + h * 8 + i) = (uint16_t)(pbyte[0] | (pbyte[1] << 8));
+            Ef[lane_rec * 8 + h * 4 + (i >> 1)] = (uint8_t)(code[0] | (code[1] << 4));
+        }
+        // patches in column order: an exclusive scan of the escape flags over the 512 columns of this trip
+        const int mine = (int)esc[0] + (int)esc[1];
+        int x = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if ((int)(threadIdx.x & 63) >= o) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) s_cnt[threadIdx.x >> 6] = x;
+        __syncthreads();
+        int off = out + x - mine;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) off += s_cnt[k];
+        if (esc[0]) { patch_col[off] = c; patch_val[off] = (bf16_t)b[0]; ++off; }
+        if (esc[1]) { patch_col[off] = c + 1; patch_val[off] = (bf16_t)b[1]; }
+        out += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+}  // namespace ivlm
+
+// n_rows = the rows of the planes (a multiple of 16 >= N_valid); ebase [n_rows], patch_ptr [n_rows + 1] (the caller reads
+// patch_ptr[n_rows] = the number of patches, allocates patch_col / patch_val of at least max(1, that) entries, and calls _fill)
+extern "C" int ivlm_pack_bf12m_count(const void* w, int N_valid, int n_rows, int K, int32_t* ebase, int32_t* patch_ptr,
+                                     ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!w || !ebase || !patch_ptr || N_valid <= 0 || n_rows < N_valid || (n_rows & 15) || K <= 0 || (K & 63)) return IVLM_ERR_INVALID_ARG;
+    hipStream_t st = ivlm_stream(stream);
+    p12_rowstats_kernel<<<n_rows, 256, 0, st>>>(static_cast<const bf16_t*>(w), N_valid, K, ebase, patch_ptr);
+    p12_scan_kernel<<<1, 1024, 0, st>>>(patch_ptr, n_rows);
+    return ivlm_launch_status();
+}
+
+extern "C" int ivlm_pack_bf12m_fill(const void* w, int N_valid, int n_rows, int K, const int32_t* ebase, const int32_t* patch_ptr, void* Pf,
+                                    void* Ef, int32_t* patch_col, void* patch_val, ivlm_stream_t stream) {
+    ivlm_enter();
+    if (!w || !ebase || !patch_ptr || !Pf || !Ef || !patch_col || !patch_val || N_valid <= 0 || n_rows < N_valid || (n_rows & 15) ||
+        K <= 0 || (K & 63) || (reinterpret_cast<uintptr_t>(w) & 3))
+        return IVLM_ERR_INVALID_ARG;
+    p12_fill_kernel<<<n_rows, 256, 0, ivlm_stream(stream)>>>(static_cast<const bf16_t*>(w), N_valid, K, ebase, patch_ptr,
+                                                             static_cast<uint8_t*>(Pf), static_cast<uint8_t*>(Ef), patch_col,
+                                                             static_cast<bf16_t*>(patch_val));
+    return ivlm_launch_status();
+}

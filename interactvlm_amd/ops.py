@@ -536,11 +536,31 @@ class PackedBf12:
         """shapes the fragment layout (the MFMA kernel) takes: 16-row blocks, 64-column step pairs, x as three bf16 planes in LDS"""
         return N % 16 == 0 and K % 64 == 0 and K * 6 <= 100 * 1024
 
-    def __init__(self, w, fragments=True, pad_rows=False):
+    def __init__(self, w, fragments=True, pad_rows=False, packer="c"):
         """pad_rows: zero rows are appended up to a multiple of 16 so that the fragment layout takes the matrix (lm_head: 32003 rows);
         ``rows`` keeps the true count, ``linear_bf12`` returns that many outputs."""
         assert w.dtype == BF16 and w.dim() == 2 and w.is_cuda and w.shape[1] % 16 == 0
         self.rows = w.shape[0]
+        n_rows = -(-w.shape[0] // 16) * 16
+        if fragments and packer == "c" and (pad_rows or n_rows == w.shape[0]) and self.takes(n_rows, w.shape[1]):
+            # the library's own packer (ivlm_pack_bf12m_*: what a C caller uses): two launches around one host read, no temporaries
+            if not bool(torch.isfinite(w).all()):
+                raise IvlmError("PackedBf12: inf / nan weights cannot be packed")
+            lib, w, K = _lib.load(), w.contiguous(), w.shape[1]
+            self.ebase = torch.empty(n_rows, dtype=torch.int32, device=w.device)
+            self.patch_ptr = torch.empty(n_rows + 1, dtype=torch.int32, device=w.device)
+            check(lib.ivlm_pack_bf12m_count(w.data_ptr(), self.rows, n_rows, K, self.ebase.data_ptr(), self.patch_ptr.data_ptr(),
+                                            _stream()), "pack_bf12m_count")
+            self.n_patches = int(self.patch_ptr[-1])
+            self.patch_col = torch.zeros(max(1, self.n_patches), dtype=torch.int32, device=w.device)
+            self.patch_val = torch.zeros(max(1, self.n_patches), dtype=BF16, device=w.device)
+            self.P = torch.empty(n_rows // 16, K // 64, 4, 16, 2, 8, dtype=torch.uint8, device=w.device)
+            self.E = torch.empty(n_rows // 16, K // 64, 4, 16, 2, 4, dtype=torch.uint8, device=w.device)
+            check(lib.ivlm_pack_bf12m_fill(w.data_ptr(), self.rows, n_rows, K, self.ebase.data_ptr(), self.patch_ptr.data_ptr(),
+                                           self.P.data_ptr(), self.E.data_ptr(), self.patch_col.data_ptr(), self.patch_val.data_ptr(),
+                                           _stream()), "pack_bf12m_fill")
+            self.shape, self.frag = (n_rows, K), True
+            return
         if pad_rows and w.shape[0] % 16:
             w = torch.cat([w, torch.zeros(16 - w.shape[0] % 16, w.shape[1], dtype=BF16, device=w.device)])
         if not bool(torch.isfinite(w).all()):

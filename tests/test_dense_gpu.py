@@ -723,6 +723,13 @@ def test_gemv_bf12_is_lossless_and_equals_the_bf16_gemv(hip_lib, cuda, N, K, act
     kw = dict(act=act, residual=r, rms=(gam, 1e-5) if rms else None)
     ref16 = ops.linear(x, w, out_f32=True, **kw)
     got = None
+    if N % 16 == 0 and K % 64 == 0:  # the library's packer (what a C caller uses) == the torch restatement of the format, byte for byte
+        a_, b_ = ops.PackedBf12(w, packer="c"), ops.PackedBf12(w, packer="torch")
+        assert a_.frag and b_.frag and a_.n_patches == b_.n_patches
+        for f in ("P", "E", "ebase", "patch_ptr"):
+            assert torch.equal(getattr(a_, f).flatten(), getattr(b_, f).flatten()), f
+        assert torch.equal(a_.patch_col[: a_.n_patches], b_.patch_col[: a_.n_patches])
+        assert torch.equal(a_.patch_val[: a_.n_patches].view(torch.int16), b_.patch_val[: a_.n_patches].view(torch.int16))
     for fragments in (False, True):  # row layout (VALU kernel) and fragment layout (MFMA kernel: N % 16 == 0, K % 64 == 0)
         wp = ops.PackedBf12(w, fragments=fragments)
         assert wp.frag == (fragments and N % 16 == 0 and K % 64 == 0)
