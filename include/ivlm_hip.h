@@ -625,6 +625,8 @@ int ivlm_unpack_bf12(const void *P, int64_t ldp, const void *E, int64_t lde, con
 
 /* torch.argmax(logits, -1) of HF greedy search (first maximal index); x f32 [rows, cols] -> out i32 [rows]. */
 int ivlm_argmax_f32(const float *x, int rows, int cols, int32_t *out, ivlm_stream_t stream);
+/* ... and bump[row] += 1 in the same launch (bump i32 [rows], may be NULL): the device-side positions of a decode graph. */
+int ivlm_argmax_f32_bump(const float *x, int rows, int cols, int32_t *out, int32_t *bump, ivlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Data movement on the path (all bf16, 16-byte granules: cols/strides % 8 == 0)

@@ -491,7 +491,10 @@ static int launch_gemv1(const GemmArgs& g, hipStream_t st) {
 
 // first index of the row maximum (torch.argmax tie rule), one 1024-thread block per row, 16-byte loads
 // (the lm_head logits row is 128 KB: ~5 us instead of 38 us for the 256-thread scalar version)
-__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, int cols, int32_t* __restrict__ out) {
+// bump != NULL: bump[row] += 1 by the same launch (the decode graphs step their device-side positions here instead of with a launch of
+// their own)
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, int cols, int32_t* __restrict__ out,
+                                                      int32_t* __restrict__ bump) {
     __shared__ float sv[16];
     __shared__ int si[16];
     const float* r = x + (int64_t)blockIdx.x * cols;
@@ -538,6 +541,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
                 bi = si[w];
             }
         out[blockIdx.x] = bi;
+        if (bump) bump[blockIdx.x] += 1;
     }
 }
 
@@ -646,9 +650,9 @@ int gemv1_fp8w(const GemmArgs& g, hipStream_t st) {
     return ivlm_launch_status();
 }
 
-int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st) {
+int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st, int32_t* bump) {
     if (!x || !out || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
-    argmax_kernel<<<rows, 1024, 0, st>>>(x, cols, out);
+    argmax_kernel<<<rows, 1024, 0, st>>>(x, cols, out, bump);
     return ivlm_launch_status();
 }
 
@@ -689,5 +693,10 @@ extern "C" int ivlm_gemv_fp8w(const float* x, const void* Wq, int64_t ldw, const
 
 extern "C" int ivlm_argmax_f32(const float* x, int rows, int cols, int32_t* out, ivlm_stream_t stream) {
     ivlm_enter();
-    return ivlm::argmax_f32(x, rows, cols, out, ivlm_stream(stream));
+    return ivlm::argmax_f32(x, rows, cols, out, ivlm_stream(stream), nullptr);
+}
+
+extern "C" int ivlm_argmax_f32_bump(const float* x, int rows, int cols, int32_t* out, int32_t* bump, ivlm_stream_t stream) {
+    ivlm_enter();
+    return ivlm::argmax_f32(x, rows, cols, out, ivlm_stream(stream), bump);
 }

@@ -188,6 +188,6 @@ int gemv_bf16(const GemmArgs& g, hipStream_t st);
 int gemv1_fp8w(const GemmArgs& g, hipStream_t st);
 // skinny GEMM on MFMA (gemv_mfma.hip): M <= 16 activation rows, split-K inside the block, RMSNorm prologue optional
 int gemv_mfma_bf16(const GemmArgs& g, hipStream_t st);
-int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st);
+int argmax_f32(const float* x, int rows, int cols, int32_t* out, hipStream_t st, int32_t* bump = nullptr);
 
 }  // namespace ivlm

@@ -465,9 +465,7 @@ class Llama:
                 e = self.embed_ids(st["tok"])
                 h = self._decode_step(e, st["pos"])
                 st["hidden"] = h
-                st["nxt"] = ops.argmax(self.logits(h))
-                st["pos"].add_(1)
-                st["pos64"].add_(1)
+                st["nxt"] = ops.argmax(self.logits(h), bump=st["pos"])  # (+ position += 1 in the same launch)
                 if self._fused is not None:
                     self._fused["step"].add_(1)
 
@@ -546,8 +544,7 @@ class Llama:
             def body():
                 h = self.decode_step_batch(self.embed_ids(st["tok"]), st["pos"], kc, vc, lo)
                 st["hidden"] = h
-                st["nxt"] = ops.argmax(self.logits(h))
-                st["pos"].add_(1)
+                st["nxt"] = ops.argmax(self.logits(h), bump=st["pos"])  # (+ positions += 1 in the same launch)
 
             caches = [kc, vc] + (list(lo) if lo is not None else [])
             saved = [t[:, :, :1].clone() for t in caches]  # the warm-up / capture runs write row 0 of every slab

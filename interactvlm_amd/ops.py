@@ -887,11 +887,16 @@ def relpos_bias(q, tab_h, tab_w, SH, SW, cat=None, q_lo=None):
     return rel_h, rel_w
 
 
-def argmax(logits):
+def argmax(logits, bump=None):
+    """torch.argmax(logits, -1) as int32 [rows]; bump (int32 [rows] on the device): += 1 in the same launch (decode positions)."""
     lib = _lib.load()
     logits = _req(logits, torch.float32, "logits")
     rows, cols = logits.shape
     out = torch.empty(rows, dtype=torch.int32, device=logits.device)
+    if bump is not None:
+        assert bump.dtype == torch.int32 and bump.is_cuda and bump.numel() == rows and bump.is_contiguous()
+        check(lib.ivlm_argmax_f32_bump(logits.data_ptr(), rows, cols, out.data_ptr(), bump.data_ptr(), _stream()), "argmax_bump")
+        return out
     check(lib.ivlm_argmax_f32(logits.data_ptr(), rows, cols, out.data_ptr(), _stream()), "argmax")
     return out
 
