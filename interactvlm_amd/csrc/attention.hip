@@ -1320,10 +1320,10 @@ static int launch_win(const AttnArgs& a, hipStream_t st) {
                            (SPLIT ? 0 : (size_t)13 * 64 * 16 + 13 * 16 * 65 * 4 + 3 * 64 * 32 * 2);
     static_assert(lds <= 160 * 1024, "window tiles must fit the LDS");
     auto kfn = win_attn_kernel<SPLIT, F16, QLV>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ivlm_dev_mask_t attr_set{0};
+    if (ivlm_dev_pending(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        ivlm_dev_done(attr_set);
     }
     kfn<<<dim3(a.H * a.B), SPLIT ? 512 : 1024, lds, st>>>(a);
     return ivlm_launch_status();
@@ -1339,10 +1339,10 @@ int launch_split_k(const AttnArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(2 * 2 * KS * (kKV * 32 + 32) + 2 * 2 * DT * (kKV * 16 + 16)) * 2 +
                            (REL == 2 ? (size_t)kQPerBlock * kKV * 4 : (REL == 4 ? (size_t)8 * 16 * 65 * 4 : 0));
     auto kfn = attn_kernel<DQK, DV, CAUSAL, REL, false, true>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
+    static ivlm_dev_mask_t attr_set{0};  // per instantiation
+    if (ivlm_dev_pending(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        ivlm_dev_done(attr_set);
     }
     dim3 grid((a.Sq + kQPerBlock - 1) / kQPerBlock, a.H, a.B);
     kfn<<<grid, 512, lds, st>>>(a);

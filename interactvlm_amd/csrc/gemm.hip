@@ -209,11 +209,11 @@ int launch_cfg(const GemmArgs& g, hipStream_t st) {
     dim3 grid(tiles, 1, g.batch);
     auto kfn = gemm_bf16_kernel<ACT, OUT_F32, CFG, OPK>;
     if (CFG::kLdsBytes > 64 * 1024) {
-        static bool attr_set = false;  // per instantiation
-        if (!attr_set) {
+        static ivlm_dev_mask_t attr_set{0};  // per instantiation, one bit per device
+        if (ivlm_dev_pending(attr_set)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       CFG::kLdsBytes);
-            attr_set = true;
+            ivlm_dev_done(attr_set);
         }
     }
     ivlm_launch(kfn, grid, dim3(CFG::kThreads), CFG::kLdsBytes, st, g);

@@ -205,11 +205,11 @@ int launch256(const GemmArgs& g, hipStream_t st) {
 #define IVLM_GO(F32, F8)                                                                                         \
     do {                                                                                                         \
         auto kfn = gemm256_kernel<ACT, F32, F8>;                                                                 \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
+        static ivlm_dev_mask_t attr_set{0};                                                                      \
+        if (ivlm_dev_pending(attr_set)) {                                                                        \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       kLds256);                                                                  \
-            attr_set = true;                                                                                     \
+            ivlm_dev_done(attr_set);                                                                             \
         }                                                                                                        \
         ivlm_launch(kfn, grid, dim3(512), kLds256, st, g);                                                       \
     } while (0)

@@ -186,11 +186,11 @@ int launch320(const GemmArgs& g, hipStream_t st) {
 #define IVLM_GO(F32, OPK)                                                                                        \
     do {                                                                                                         \
         auto kfn = gemm320_kernel<ACT, F32, OPK>;                                                                \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
+        static ivlm_dev_mask_t attr_set{0};                                                                      \
+        if (ivlm_dev_pending(attr_set)) {                                                                        \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       kLds320);                                                                  \
-            attr_set = true;                                                                                     \
+            ivlm_dev_done(attr_set);                                                                             \
         }                                                                                                        \
         ivlm_launch(kfn, grid, dim3(512), kLds320, st, g);                                                       \
     } while (0)

@@ -463,11 +463,11 @@ int g_gemv1_lds_floor = 0;  // dynamic LDS requested by grids of <= one block pe
 
 template <bool RMS, int KS>
 static void launch_gemv1_ks(const GemmArgs& g, hipStream_t st) {
-    static bool set = false;
+    static ivlm_dev_mask_t set{0};
     auto kfn = gemv1_kernel<RMS, KS>;
-    if (!set) {
+    if (ivlm_dev_pending(set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        set = true;
+        ivlm_dev_done(set);
     }
     const int rows_per_block = kG1Waves / KS;
     const int blocks = (g.N + rows_per_block - 1) / rows_per_block;
@@ -584,11 +584,11 @@ static int launch_gemv(const GemmArgs& g, hipStream_t st) {
     do {                                                                                                              \
         auto kfn = gemv_kernel<M, ROWS, RMS, XL, AF>;                                                                 \
         if (lds > 48 * 1024) {                                                                                        \
-            static bool set = false;                                                                                  \
-            if (!set) {                                                                                               \
+            static ivlm_dev_mask_t set{0};                                                                            \
+            if (ivlm_dev_pending(set)) {                                                                              \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                           64 * 1024);                                                                 \
-                set = true;                                                                                           \
+                ivlm_dev_done(set);                                                                                   \
             }                                                                                                         \
         }                                                                                                             \
         ivlm_launch(kfn, dim3(blocks), dim3(256), lds, st, g);                                                        \
@@ -631,19 +631,19 @@ int gemv1_fp8w(const GemmArgs& g, hipStream_t st) {
     if (!g.A || !g.W || !g.C || !g.scale_w || g.M != 1 || !g.a_f32 || g.N <= 0 || g.K <= 0) return IVLM_ERR_INVALID_ARG;
     if ((g.K & 15) || (g.ldw & 15) || (size_t)g.K * 4 > 60 * 1024) return IVLM_ERR_UNSUPPORTED;
     if (g.act == ACT_SWIGLU && ((g.N & 1) || g.residual)) return IVLM_ERR_UNSUPPORTED;
-    static bool set0 = false, set1 = false;
+    static ivlm_dev_mask_t set0{0}, set1{0};
     if (g.rms_w) {
         auto kfn = gemv1_fp8w_kernel<true>;
-        if (!set1) {
+        if (ivlm_dev_pending(set1)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            set1 = true;
+            ivlm_dev_done(set1);
         }
         ivlm_launch(kfn, dim3((g.N + kG1Waves - 1) / kG1Waves), dim3(64 * kG1Waves), (size_t)g.K * 4, st, g);
     } else {
         auto kfn = gemv1_fp8w_kernel<false>;
-        if (!set0) {
+        if (ivlm_dev_pending(set0)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            set0 = true;
+            ivlm_dev_done(set0);
         }
         ivlm_launch(kfn, dim3((g.N + kG1Waves - 1) / kG1Waves), dim3(64 * kG1Waves), (size_t)g.K * 4, st, g);
     }

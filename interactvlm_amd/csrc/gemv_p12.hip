@@ -10,7 +10,7 @@
 //     patches  CSR     (column, bf16 value) of the nonzero weights outside the window (subnormals, the far tail)
 // = 1.5 bytes per weight instead of 2, and EVERY weight is reconstructed bit for bit (ivlm_unpack_bf12 is the proof: tests).
 // The kernel never rebuilds the bf16 value: a lane turns (P byte, code) into the fp32 number 1.m x 2^(code - 127) with four integer
-// operations (byte permute, mask, bit-field extract, shift-add; code 0 gives exactly 0.0), multiplies it with x * 2^100 (x is staged
+// operations (byte permute, mask, bit-field extract, shift-add; code 0 gives exactly 0.0), multiplies it with x * 2^64 (x is staged
 // once per block in LDS, pre-scaled by an exact power of two so that the tiny products stay normal fp32 numbers) and the row sum is
 // scaled back by 2^(ebase - 100) - exact power-of-two scalings, so the arithmetic is that of gemv1_kernel (bf16 weight x fp32
 // activation products, exact; fp32 accumulation) up to the summation order.  Same shape as gemv1_kernel: 1024-thread blocks, one row
@@ -28,7 +28,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
 
 constexpr int kWaves = 16;
-constexpr int kXScaleExp = 100;  // x is staged as x * 2^100
+// x is staged as x * 2^64: an exact power-of-two scaling, chosen in the MIDDLE of fp32's exponent range (2^100 turned any
+// |x| >= 2^28 ~ 2.7e8 into inf and the row into NaN, a range gemv1_kernel's plain fp32 x does not have).  A rebuilt weight is
+// 1.m x 2^(code - 127) with code 1 .. 15, i.e. 2^-126 .. 2^-111, so the products x * 2^64 * w are normal fp32 numbers for
+// 2^-64 <~ |x| < 2^64 (5e-20 .. 1.8e19) and every result inside that range is independent of the scale (the hi / lo / lo2 split and
+// the fp32 accumulation are scale-invariant): bit-identical to the 2^100 staging on every activation the model produces.
+constexpr int kXScaleExp = 64;
 
 struct P12 {
     const uint8_t* P;   // [N][ldp]
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(64 * kWaves, 8) void gemv1_p12_kernel(GemmArgs g, P
     }
     const int eb = p.ebase[rr];
     const int p0 = p.patch_ptr[rr], p1 = p.patch_ptr[rr + 1];
-    // ---- stage x * 2^100 (x * gamma * 2^100) in LDS, sum(x^2) of the unscaled row ----
+    // ---- stage x * 2^64 (x * gamma * 2^64) in LDS, sum(x^2) of the unscaled row ----
     const float xs = __builtin_ldexpf(1.0f, kXScaleExp);
     float ssq = 0.0f;
     for (int c = threadIdx.x; c < nchunk; c += 64 * kWaves) {
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(64 * kWaves, 8) void gemv1_p12_kernel(GemmArgs g, P
 // gemv1_p12_kernel spends five VALU operations per weight (four to rebuild the fp32 number + the FMA): it is issue-bound, not HBM-bound
 // (2.56 instead of 0.75 x 2.67 ms per token).  Here a lane rebuilds bf16 PAIRS (byte permute, and-or, multiply, and-or: two operations
 // per weight) and v_mfma_f32_16x16x32_bf16 does the products: B operand = 16 weight rows x 32 k, A operand = x as THREE bf16 rows
-// (hi + lo + lo2 of x * 2^100: 24 significant bits, i.e. the fp32 activation exactly), so lane j < 16 finds sum_k w[j][k] (hi + lo + lo2)[k]
+// (hi + lo + lo2 of x * 2^64: 24 significant bits, i.e. the fp32 activation exactly), so lane j < 16 finds sum_k w[j][k] (hi + lo + lo2)[k]
 // in its own accumulator registers d[0] + d[1] + d[2]: exact bf16 x bf16 products, fp32 accumulation - the arithmetic of gemv1_kernel
 // up to the summation order.  Rows 3 .. 15 of A repeat lo2 and are ignored.
 //
@@ -230,7 +235,7 @@ __device__ __forceinline__ bf16x8m_t frag_p12m(uint32_t x0, uint32_t x1, uint32_
 // llama_decode_attn_parts wrote: x[h][d] = sum_s e^(m_s - M) o_s[d] / sum_s e^(m_s - M) l_s (the o_proj of the decode step).
 template <bool RMS, int kWavesM, int U, bool PARTS = false>
 __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12m_kernel(GemmArgs g, P12M p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // x * 2^100 as three bf16 planes [3][K]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // x * 2^64 as three bf16 planes [3][K]
     __shared__ float s_red[kWavesM];
     __shared__ float s_part[kWavesM][16];
     __shared__ float s_patch[16];
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12
         }
         load_fin();
     }
-    // ---- stage x * 2^100 (x * gamma * 2^100) as hi + lo + lo2 bf16 planes, sum(x^2) of the unscaled row ----
+    // ---- stage x * 2^64 (x * gamma * 2^64) as hi + lo + lo2 bf16 planes, sum(x^2) of the unscaled row ----
     const float xs = __builtin_ldexpf(1.0f, kXScaleExp);
     float ssq = 0.0f;
     uint32_t* xw = reinterpret_cast<uint32_t*>(smem);
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12
     }
     if (lane < 16) s_part[wave][lane] = d[0] + d[1] + d[2];
     // ---- the tail: wave w owns the patches of row w (and w + 8 in the 8-wave form) of the block (the nonzero weights outside the row's exponent window:
-    //      exact bf16 values, on average < 1 per row) against (hi + lo + lo2)[col] = the fp32 activation * 2^100 (the three parts add up
+    //      exact bf16 values, on average < 1 per row) against (hi + lo + lo2)[col] = the fp32 activation * 2^64 (the three parts add up
     //      exactly); the 16 finishing lanes of wave 0 fetch their row's exponent base / bias / residual meanwhile ----
     if (!EARLY) load_fin();
     if (EARLY) {  // pin the first USE of the early loads here (the compiler hoists a shift / an address computation to the load, and
@@ -623,20 +628,20 @@ extern "C" int ivlm_gemv1_bf12(const float* x, const void* P, int64_t ldp, const
     P12 p{static_cast<const uint8_t*>(P), static_cast<const uint8_t*>(E), ldp, lde, ebase, patch_ptr, patch_col,
           static_cast<const bf16_t*>(patch_val)};
     hipStream_t st = ivlm_stream(stream);
-    static bool set0 = false, set1 = false;
+    static ivlm_dev_mask_t set0{0}, set1{0};
     const dim3 grid((N + kWaves - 1) / kWaves), block(64 * kWaves);
     if (rms_w) {
         auto kfn = gemv1_p12_kernel<true>;
-        if (!set1) {
+        if (ivlm_dev_pending(set1)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            set1 = true;
+            ivlm_dev_done(set1);
         }
         ivlm_launch(kfn, grid, block, (size_t)K * 4, st, g, p);
     } else {
         auto kfn = gemv1_p12_kernel<false>;
-        if (!set0) {
+        if (ivlm_dev_pending(set0)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            set0 = true;
+            ivlm_dev_done(set0);
         }
         ivlm_launch(kfn, grid, block, (size_t)K * 4, st, g, p);
     }
@@ -696,14 +701,14 @@ static int gemv1_bf12m(const float* x, const float* parts, int pD, const void* P
     hipStream_t st = ivlm_stream(stream);
     const dim3 grid(N / 16);
     const bool wide = grid.x <= (unsigned)g_p12m_wide_max_blocks;  // at most one block per CU: 16 waves per block
-    auto go = [&](auto kfn, int waves, bool& set) {
-        if (!set) {
+    auto go = [&](auto kfn, int waves, ivlm_dev_mask_t& set) {
+        if (ivlm_dev_pending(set)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-            set = true;
+            ivlm_dev_done(set);
         }
         ivlm_launch(kfn, grid, dim3(64 * waves), (size_t)K * 6, st, g, p);
     };
-    static bool set[8] = {false, false, false, false, false, false, false, false};
+    static ivlm_dev_mask_t set[8];  // (zero-initialised; one mask per instantiation, one bit per device)
     if (parts) {  // (the o_proj of a decode step: K = hidden, never the 8-deep form)
         if (wide) go(gemv1_p12m_kernel<false, 16, 4, true>, 16, set[6]);
         else go(gemv1_p12m_kernel<false, 8, 4, true>, 8, set[7]);
@@ -767,6 +772,8 @@ extern "C" int ivlm_gemv16_bf12m(const float* x, int64_t lda, int M, const void*
         return IVLM_ERR_INVALID_ARG;
     if ((N & 15) || (K & 63)) return IVLM_ERR_UNSUPPORTED;
     if (act == ACT_SWIGLU && residual) return IVLM_ERR_UNSUPPORTED;
+    //  the row strides of the output and of the residual must hold a whole row
+    if (ldc < (act == ACT_SWIGLU ? N / 2 : N) || (residual && ldr < N)) return IVLM_ERR_INVALID_ARG;
     GemmArgs g;
     g.A = reinterpret_cast<const bf16_t*>(x);
     g.a_f32 = 1;

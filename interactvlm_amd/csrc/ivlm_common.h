@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/ivlm_hip.h"
 
 #define IVLM_WAVE 64
@@ -44,6 +46,19 @@ static inline int ivlm_launch_status_at(const char* file, int line) {
     } while (0)
 
 static inline hipStream_t ivlm_stream(ivlm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Function attributes (hipFuncAttributeMaxDynamicSharedMemorySize) are per DEVICE: a process that drives several GPUs must set them
+// once on each (process-wide `static bool` flags left the second GPU's launches of > 64 KB LDS failing).  One bit per
+// device id in a static mask next to the kernel; the bit is published AFTER the attribute is set, so a concurrent first launch from
+// another thread at worst sets the attribute twice.
+typedef std::atomic<uint64_t> ivlm_dev_mask_t;
+static inline uint64_t ivlm_dev_bit() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return 1ull << (dev & 63);
+}
+static inline bool ivlm_dev_pending(const ivlm_dev_mask_t& m) { return !(m.load(std::memory_order_acquire) & ivlm_dev_bit()); }
+static inline void ivlm_dev_done(ivlm_dev_mask_t& m) { m.fetch_or(ivlm_dev_bit(), std::memory_order_release); }
 
 // Launch helper of the kernels whose duration bench.py reports (GEMM / GEMV / lift families): when the caller armed
 // ivlm_profile_launches(start, stop), the HIP events are attached to the KERNEL (hipExtLaunchKernelGGL: recorded by the command

@@ -18,6 +18,10 @@ from .constants import HUMAN_VIEW_DICT, IMAGE_TOKEN_INDEX, OBJS_VIEW_DICT, norma
 
 DEFAULT_IMAGE_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN = "<image>", "<im_start>", "<im_end>"  # utils/utils.py:12-17
 HCONTACT_PROMPT = "Which body parts are in contact with the {object}? Segment these contact areas."        # run_demo.py:282
+H2DCONTACT_PROMPT = "Segment the area on the human's body that is in direct contact with the {object} in this image."  # run_demo.py:254
+# run_demo.py:217 - the literal the reference sends INCLUDES the stray quotes and the trailing comma of its list entry
+OAFFORD_PROMPT = ('"What type of affordance does the human-object interaction suggest? Then, segment the area on the {class_name} where '
+                  'the human is making contact.",')
 # model/llava/conversation.py:355-365 (conv_llava_v1: SeparatorStyle.TWO, sep ' ', sep2 '</s>')
 _V1_SYSTEM = ("A chat between a curious human and an artificial intelligence assistant. "
               "The assistant gives helpful, detailed, and polite answers to the human's questions.")

@@ -172,6 +172,22 @@ class ClipTower:
         return ops.gather_rows(x, self._patch_rows[B], out_kind="bf16").view(B, T - 1, c.hidden)
 
 
+class _LayerW(dict):
+    """One LLaMA layer's tensors: ln1 / ln2, the four bf16 matrices (qkv, o, gu, down) and their derived copies (``*_h``: IEEE fp16
+    for the fp16-operand prefill, ``*_p``: ops.PackedBf12 planes for the decode step).  A bf16 matrix that ``Llama.release_unused``
+    dropped comes back on access, bit for bit, from its packed planes (``ivlm_unpack_bf12``: the 12-bit format is lossless)."""
+
+    MATS = ("qkv", "o", "gu", "down")
+
+    def __missing__(self, k):
+        p = dict.get(self, k + "_p") if k in self.MATS else None
+        if p is None:
+            raise KeyError(k)
+        w = p.unpack().contiguous()
+        self[k] = w
+        return w
+
+
 class Llama:
     """HF LlamaModel + lm_head with a KV cache, one sequence (batch 1) per instance call."""
 
@@ -188,7 +204,7 @@ class Llama:
             qkv = torch.cat([w[f"{p}.self_attn.{n}_proj.weight"] for n in "qkv"], 0)
             gu = torch.stack([w[p + ".mlp.gate_proj.weight"], w[p + ".mlp.up_proj.weight"]], 1).reshape(
                 2 * cfg.inter, cfg.hidden)  # rows (gate_j, up_j) interleaved for the SwiGLU epilogue
-            self.layers.append(dict(
+            self.layers.append(_LayerW(
                 ln1=_dev(w[p + ".input_layernorm.weight"], device), ln2=_dev(w[p + ".post_attention_layernorm.weight"], device),
                 qkv=_dev(qkv, device), o=_dev(w[p + ".self_attn.o_proj.weight"], device), gu=_dev(gu, device),
                 down=_dev(w[p + ".mlp.down_proj.weight"], device)))
@@ -212,9 +228,87 @@ class Llama:
         # reconstructed bit for bit, dots on the matrix cores: ivlm_gemv1_bf12m; copies made on the first decode step, +10 GB for
         # 7B): 2.69 -> 2.34 ms per token.  Matrices whose shape the fragment layout does not take (rows % 16, columns % 64) stay
         # on the bf16 kernel (the lm_head's rows are padded with zeros).  IVLM_DECODE_PACKED=0 / decode_packed = False: bf16 weights everywhere.
-        self.decode_packed = os.environ.get("IVLM_DECODE_PACKED", "1") != "0"
+        self._decode_packed = os.environ.get("IVLM_DECODE_PACKED", "1") != "0"
         self.decode_attn_parts = os.environ.get("IVLM_DECODE_ATTN_PARTS", "1") != "0"  # (with decode_packed: see _decode_step)
         self.decode_packed_batch = os.environ.get("IVLM_DECODE_PACKED_BATCH", "1") != "0"  # (the batched step: ivlm_gemv16_bf12m)
+
+    # captured decode graphs are kept per (precision, packed decode weights or not): their launches bake in the weight pointers
+    def _gkey(self):
+        return (self.precision, bool(self._decode_packed))
+
+    @property
+    def decode_packed(self):
+        return self._decode_packed
+
+    @decode_packed.setter
+    def decode_packed(self, flag):
+        flag = bool(flag)
+        if flag == self._decode_packed:
+            return
+        self._dgraphs[self._gkey()] = self._dgraph
+        self._decode_packed = flag
+        self._dgraph = self._dgraphs.get(self._gkey())
+        if hasattr(self, "_bgraphs"):
+            self._bgraphs = {}
+
+    # ---- which copies of the layer matrices are resident -----------------------------------------
+    # Three forms exist: the checkpoint's bf16 matrices (prefill of the bf16 / parity modes, bf16 decode), IEEE fp16 copies (prefill
+    # of the fp16-operand default mode), lossless 12-bit planes (the decode step of every mode).  ``prepare`` builds, NOW, what the
+    # active mode reads - so that an out-of-memory or an out-of-fp16-range weight surfaces at load / mode switch and not inside the
+    # first forward; ``release_unused`` drops what it does not read: in the default mode the bf16 originals of every matrix that
+    # has planes (13.5 GB for 7B; `_LayerW` rebuilds one bit for bit from its planes if a non-default path asks for it), in the
+    # other modes the fp16 copies.  InteractVLMForCausalLM.set_precision calls both.
+    def prepare(self):
+        if self.fp8 or self._calibrating:
+            return
+        for L in self.layers:
+            if self._decode_packed:
+                for n in _LayerW.MATS:
+                    if n + "_p" not in L:
+                        L[n + "_p"] = ops.PackedBf12(L[n]) if ops.PackedBf12.takes(*L[n].shape) else None
+            if self.precision == "f16":
+                self._f16(L)
+            else:  # bf16 / parity prefill reads the bf16 matrices (rebuilt from the planes if the default mode had released them)
+                for n in _LayerW.MATS:
+                    L[n]
+        if self._decode_packed and ops.PackedBf12.takes(16, self.cfg.hidden) and getattr(self, "lm_head_p", None) is None:
+            self.lm_head_p = ops.PackedBf12(self.lm_head, pad_rows=True)
+
+    def release_unused(self):
+        if self.fp8 or self._calibrating:
+            return
+        dropped = False
+        for L in self.layers:
+            for n in _LayerW.MATS:
+                if self.precision == "f16":
+                    wp = L.get(n + "_p")
+                    if self._decode_packed and wp is not None and wp.frag and dict.__contains__(L, n) and n + "_h" in L:
+                        del L[n]
+                        dropped = True
+                elif L.pop(n + "_h", None) is not None:
+                    dropped = True
+        if dropped:  # graphs of the bf16-weight decode step hold pointers into what was just released
+            self._dgraphs = {k: g for k, g in self._dgraphs.items() if k[1]}
+            if not self._decode_packed:
+                self._dgraph = None
+            if hasattr(self, "_bgraphs"):
+                self._bgraphs = {}
+
+    def resident_bytes(self):
+        """{form: bytes} of the language model's weights currently in HBM."""
+        out = {"bf16": self.embed.numel() * 2 + self.lm_head.numel() * 2 + self.norm.numel() * 2, "f16": 0, "bf12": 0}
+        for L in self.layers:
+            out["bf16"] += (L["ln1"].numel() + L["ln2"].numel()) * 2
+            for n in _LayerW.MATS:
+                if dict.__contains__(L, n):
+                    out["bf16"] += L[n].numel() * 2
+                if L.get(n + "_h") is not None:
+                    out["f16"] += L[n + "_h"].numel() * 2
+                if L.get(n + "_p") is not None:
+                    out["bf12"] += L[n + "_p"].bytes()
+        if getattr(self, "lm_head_p", None) is not None:
+            out["bf12"] += self.lm_head_p.bytes()
+        return out
 
     # ---- "parity" precision (opt-in): the prefill GEMMs take hi + lo bf16 activation operands, the attention three MFMAs per
     # fragment, and K / V are cached as hi + lo planes (also read by the decode kernels) - no activation is rounded to bf16.
@@ -225,9 +319,9 @@ class Llama:
         assert mode in ("default", "parity", "f16")
         if mode == self.precision:
             return
-        self._dgraphs[self.precision] = self._dgraph
+        self._dgraphs[self._gkey()] = self._dgraph
         self.precision = mode
-        self._dgraph = self._dgraphs.get(mode)
+        self._dgraph = self._dgraphs.get(self._gkey())
         if hasattr(self, "_bgraphs"):
             self._bgraphs = {}
         if mode == "parity" and self.kcache_lo is None:
@@ -591,7 +685,7 @@ class Llama:
                 x = ops.linear_fp8w(h, L["down_q"], L["down_s"], residual=x)
             return ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
         kc_, vc_ = self._caches()
-        if self.decode_packed and fz is None:
+        if self._decode_packed and fz is None:
             def lin(x_, L, n, **kw):  # (packed where the fragment layout takes the matrix, bf16 otherwise)
                 if n + "_p" not in L:
                     N_, K_ = L[n].shape

@@ -69,7 +69,7 @@ class _CamPoseEncoder:
 
 class InteractVLMForCausalLM:
     def __init__(self, config: IvlmCfg, weights: dict, device="cuda:0", lift_tables=None, metadata_root="./data",
-                 max_len=1024):
+                 max_len=1024, precision=None):
         c = self.config = config
         self.device = dev = torch.device(device)
         w = weights
@@ -142,7 +142,9 @@ class InteractVLMForCausalLM:
         if self.base_token_type in ("Gen-Hu-Obj", "Gen-Int"):
             self.attention_splitter = {n: _Lin(w, "attention_splitter." + n, dev) for n in
                                        ("input_proj", "query_human", "query_object", "key", "value", "output_proj")}
-        self.set_precision(os.environ.get("IVLM_PRECISION", "default"))
+        # start-up precision mode (its weight copies are built here: a checkpoint with a weight outside fp16's range raises NOW -
+        # construct it with precision="bf16" or a parity mode instead)
+        self.set_precision(precision or os.environ.get("IVLM_PRECISION", "default"))
 
     # ------------------------------------------------------------------------------------------
     def eval(self):
@@ -174,6 +176,19 @@ class InteractVLMForCausalLM:
         enc = self.model.visual_model.image_encoder
         enc.precision = "default" if mode == "bf16" else "parity"  # ("parity" = the site-driven forward of the encoder)
         enc.parity_sites = {"parity": enc.PARITY_SITES, "f16": enc.SITES_F16, "default": enc.SITES_F16Q}.get(mode, enc.PARITY_SITES_FAST)
+        # the weight copies this mode reads are built NOW (a failure - memory, a weight outside fp16's range - surfaces here, not in
+        # the first forward), the ones it does not read are released (default mode: the bf16 originals of the LLaMA matrices, which
+        # the fp16 prefill copies + the lossless 12-bit decode planes replace: 36 -> 23 GB of language-model weights for 7B)
+        if self.device.type == "cuda" and not self.fp8:
+            self.llm.prepare()
+            if self.free_unused_weights:
+                self.llm.release_unused()
+
+    free_unused_weights = os.environ.get("IVLM_KEEP_ALL_WEIGHTS", "0") != "1"
+
+    def resident_weight_bytes(self):
+        """Language-model weight bytes resident in HBM, by form (`hbm_resident_gb` of the bench line)."""
+        return self.llm.resident_bytes()
 
     # fp8 variant (BASELINE.json configs[4], opt-in; never a parity claim): e4m3 operands for the GEMMs of the SAM ViT-H encoder,
     # the CLIP tower and the LLaMA prefill, e4m3 WEIGHTS for the batch-1 decode linears.  Activation scales are calibrated on the
@@ -204,28 +219,38 @@ class InteractVLMForCausalLM:
         return (self.nonfinite_guard and not self.fp8 and self.precision in ("default", "f16", "parity-fast")
                 and not getattr(self, "_in_guard", False))
 
-    def _guarded(self, fn, args, kwargs):
+    def _guarded(self, fn, args, kwargs, supplied_embeddings=None):
         """fp16 operands have 5 exponent bits (max 65504; bf16: 8, as fp32), and the kernels do not clamp: an activation outside
         that range becomes inf and everything downstream NaN.  One flag per call - the tower outputs (LLaMA hidden states, SAM
         embeddings) and the contacts are all finite - read back where the caller would read the result anyway: a call that fails it
-        is recomputed in the `bf16` mode (same arithmetic, fp32's exponent range) and reported."""
+        is recomputed in the `bf16` mode (same arithmetic, fp32's exponent range; the decode step on the bf16 weights, whose fp32
+        activations have the full fp32 range - the packed planes stage x * 2^64) and reported.  Embeddings the CALLER supplied
+        (`image_embeddings=`) cannot be fixed by recomputing: non-finite ones raise."""
         self._in_guard = True
         self._finite_flags = []
         try:
             out = fn(*args, **kwargs)
             outs = out if isinstance(out, list) else [out]
-            flags = self._finite_flags + [torch.isfinite(o["pred_contact_3d"]).all() for o in outs
-                                          if o.get("pred_contact_3d") is not None]
+            flags = self._finite_flags + [torch.isfinite(o[k]).all() for o in outs
+                                          for k in ("pred_contact_3d", "pred_human_3d_contact", "pred_object_3d_contact",
+                                                    "pred_object_3d_afford") if o.get(k) is not None]
             if flags and not bool(torch.stack(flags).all()):
                 import warnings
 
+                if supplied_embeddings is not None:
+                    embs = supplied_embeddings if isinstance(supplied_embeddings, (list, tuple)) else [supplied_embeddings]
+                    if not all(bool(torch.isfinite(e).all()) for e in embs):
+                        raise ops.IvlmError("image_embeddings passed by the caller are not finite (an fp16-mode encoder pass that "
+                                            "overflowed?): re-encode them, e.g. model.precompute_visual_embs(views) - which checks")
                 warnings.warn(f"non-finite contacts in precision mode {self.precision!r} (an activation left fp16's exponent "
                               "range): this call is recomputed with bf16 operands; consider model.set_precision('bf16')")
-                mode = self.precision
+                mode, packed = self.precision, self.llm.decode_packed
+                self.llm.decode_packed = False
                 self.set_precision("bf16")
                 try:
                     out = fn(*args, **kwargs)
                 finally:
+                    self.llm.decode_packed = packed
                     self.set_precision(mode)
                 for o in (out if isinstance(out, list) else [out]):
                     o["recomputed_in_bf16"] = True
@@ -233,17 +258,36 @@ class InteractVLMForCausalLM:
         finally:
             self._in_guard = False
 
+    def _finite_or_bf16(self, fn):
+        """tensor-returning encoder entry points under the fp16 exponent-range guard: a non-finite result is recomputed with bf16
+        operands (one flag read back per call)"""
+        out = fn()
+        if self._guard_applies() and not bool(torch.isfinite(out).all()):
+            import warnings
+
+            warnings.warn(f"non-finite SAM embeddings in precision mode {self.precision!r}: recomputed with bf16 operands")
+            mode = self.precision
+            self._in_guard = True
+            self.set_precision("bf16")
+            try:
+                out = fn()
+            finally:
+                self.set_precision(mode)
+                self._in_guard = False
+        return out
+
     def get_visual_embs(self, pixel_values):
         """[B,V,3,S,S] -> image embeddings; returned in the reference's [B,V,256,g,g] shape (a strided view of the
         channels-last buffer the decoder consumes) — InteractVLM.py:251-261."""
         B, V = pixel_values.shape[:2]
         g = self.config.sam.grid
-        emb = self.model.visual_model.image_encoder(pixel_values.reshape((B * V,) + tuple(pixel_values.shape[2:])))
+        emb = self._finite_or_bf16(lambda: self.model.visual_model.image_encoder(
+            pixel_values.reshape((B * V,) + tuple(pixel_values.shape[2:]))))
         return emb.view(B, V, g, g, -1).permute(0, 1, 4, 2, 3)
 
     def precompute_visual_embs(self, images_views):
         """[V,3,S,S] -> channels-last SAM embeddings [V, g*g, 256] to pass as evaluate(image_embeddings=...)."""
-        return self.model.visual_model.image_encoder(images_views.to(self.device))
+        return self._finite_or_bf16(lambda: self.model.visual_model.image_encoder(images_views.to(self.device)))
 
     def forward(self, **kwargs):
         if "past_key_values" in kwargs:  # InteractVLM.py:263-266: the HF causal-LM forward (what HF generate() calls per step)
@@ -398,6 +442,10 @@ class InteractVLMForCausalLM:
         """Teacher-forced single pass (InteractVLM.py:296-474); inference=True only (training is out of scope)."""
         if not inference:
             raise NotImplementedError("training (loss) path is out of scope of the inference hot path")
+        if self._guard_applies():  # (fp16 exponent range: see _guarded)
+            return self._guarded(self.model_forward, (images, images_clip, input_ids, labels, attention_masks, offset, masks_list,
+                                                      label_list, gt_contact_3d_list, cam_params, resize_list, ds_name_list,
+                                                      mask_paths_list, inference), kwargs)
         B = images.shape[0]
         assert offset is None or B == len(offset) - 1
         assert images_clip.shape[0] == 1 or images_clip.shape[0] == B
@@ -436,6 +484,13 @@ class InteractVLMForCausalLM:
             result["pred_object_3d_contact"] = self.object_3d_contact_predictor(pred_masks, ds_name_list, mask_paths_list)
             result["pred_object_3d_afford"] = self.object_3d_afford_predictor(pred_masks, ds_name_list, mask_paths_list)
         return result
+
+    def _id_ring(self, n):
+        """pinned host int32 array of >= n generated ids (written by asynchronous device-to-host copies, read one step late)"""
+        r = getattr(self, "_ring", None)
+        if r is None or r.numel() < n:
+            r = self._ring = torch.empty(max(n, 64), dtype=torch.int32).pin_memory()
+        return r
 
     @torch.no_grad()
     def generate(self, images_clip, input_ids, max_new_tokens=32, eos_token_id=2, forced_new_tokens=None,
@@ -480,22 +535,56 @@ class InteractVLMForCausalLM:
                 fz["counters"].zero_()
                 fz["status"].zero_()
             nxt = ops.argmax(self.llm.logits(last))
-            for step in range(n_max):
-                self.last_argmax.append(nxt)
-                if forced_new_tokens is not None:
-                    tok = int(forced_new_tokens[step])
-                    tok_t = forced_dev[step: step + 1]
-                else:
-                    tok = int(nxt.item())
-                    tok_t = nxt
-                new_ids.append(tok)
-                if tok == eos_token_id or step == n_max - 1:
-                    break
-                dg["tok"].copy_(tok_t)
-                dg["graph"].replay()
-                hidden_all[pos: pos + 1].copy_(dg["hidden"])
-                nxt = dg["nxt"].clone()
-                pos += 1
+            if forced_new_tokens is not None:
+                for step in range(n_max):
+                    self.last_argmax.append(nxt)
+                    new_ids.append(int(forced_new_tokens[step]))
+                    if new_ids[-1] == eos_token_id or step == n_max - 1:
+                        break
+                    dg["tok"].copy_(forced_dev[step: step + 1])
+                    dg["graph"].replay()
+                    hidden_all[pos: pos + 1].copy_(dg["hidden"])
+                    nxt = dg["nxt"].clone()
+                    pos += 1
+            else:
+                # Free-running greedy search WITHOUT a host round trip per token (reference loop: InteractVLM.py:524-531,
+                # stop on EOS or max_new_tokens).  The argmax of step s stays on the device and is the token of step s + 1
+                # (`tok.copy_(nxt)`: device to device); every id is also copied - asynchronously - into a pinned host array.  The host
+                # keeps ONE replay queued ahead of the one it is waiting for: before it enqueues step s + 1 it waits for the event of
+                # step s - 1 and reads id s - 1 from the pinned array - so the GPU never idles between replays, and when id k turns
+                # out to be EOS exactly one speculative step (the one that consumed EOS) has been enqueued: its hidden row and KV
+                # row lie beyond the returned length and are dropped.
+                ring = self._id_ring(n_max)
+                evs = [torch.cuda.Event() for _ in range(n_max)]
+                cur = torch.cuda.current_stream(self.device)
+                ids_dev = torch.empty(n_max, dtype=torch.int32, device=self.device)
+                ids_dev[0:1].copy_(nxt)
+                ring[0:1].copy_(nxt, non_blocking=True)
+                evs[0].record(cur)
+                n_tok, enq = None, 0  # n_tok: number of new ids once known; enq: decode steps enqueued
+                for step in range(n_max):
+                    # (a) id `step - 1` (one step late): stop at EOS
+                    if step >= 1:
+                        evs[step - 1].synchronize()
+                        if int(ring[step - 1]) == eos_token_id:
+                            n_tok = step
+                            break
+                    if step == n_max - 1:
+                        break
+                    # (b) enqueue the decode step that consumes id `step` and produces id `step + 1`
+                    dg["tok"].copy_(ids_dev[step: step + 1])
+                    dg["graph"].replay()
+                    hidden_all[pos + enq: pos + enq + 1].copy_(dg["hidden"])
+                    ids_dev[step + 1: step + 2].copy_(dg["nxt"])
+                    ring[step + 1: step + 2].copy_(dg["nxt"], non_blocking=True)
+                    evs[step + 1].record(cur)
+                    enq += 1
+                if n_tok is None:  # no EOS among ids 0 .. n_max - 2: the last id decides nothing (max_new_tokens reached)
+                    evs[n_max - 1].synchronize()
+                    n_tok = n_max
+                new_ids = [int(t) for t in ring[:n_tok].tolist()]
+                self.last_argmax = [ids_dev[i: i + 1] for i in range(n_tok)]
+                pos += n_tok - 1  # decode steps whose hidden rows count (a speculative step past EOS is dropped)
             if fz is not None and int(fz["status"].item()) != 0:
                 # a bounded device-side wait of the fused attention + o_proj launch expired (its blocks were not co-resident,
                 # e.g. a third stream holding the CUs): drop to the two-launch path for good and redo this generation
@@ -575,18 +664,56 @@ class InteractVLMForCausalLM:
         nxt = ops.argmax(self.llm.logits(last))
         new_ids = [[] for _ in range(B)]
         done = [False] * B
-        for step in range(n_max):
-            if forced_dev is not None:
-                tok_t = forced_dev[step]
-                toks = [pad[b][step] for b in range(B)]
-            else:
-                tok_t = nxt
-                toks = nxt.tolist()  # host sync per step, as in generate()
+
+        def absorb(toks):  # the ids of one step, in order: append to the sequences still running, mark those that stop
             for b in range(B):
                 if not done[b]:
                     new_ids[b].append(int(toks[b]))
                     if toks[b] == eos_token_id or len(new_ids[b]) >= n_seq[b]:
                         done[b] = True
+
+        if use_graph and forced_dev is None:
+            # free-running: no host round trip per token (see generate): ids stay on the device, a pinned host copy is read one
+            # step late, one speculative step at most is enqueued after the last sequence has stopped
+            ring = self._id_ring(n_max * B)[: n_max * B].view(n_max, B)
+            evs = [torch.cuda.Event() for _ in range(n_max)]
+            cur = torch.cuda.current_stream(dev)
+            ids_dev = torch.empty(n_max, B, dtype=torch.int32, device=dev)
+            ids_dev[0].copy_(nxt)
+            ring[0].copy_(nxt, non_blocking=True)
+            evs[0].record(cur)
+            absorbed = 0
+            for step in range(n_max):
+                if step >= 1:
+                    evs[step - 1].synchronize()
+                    absorb(ring[step - 1].tolist())
+                    absorbed = step
+                    if all(done):
+                        break
+                if step == n_max - 1:
+                    break
+                dg["tok"].copy_(ids_dev[step])
+                idx = dg["pos"].to(torch.int64)  # positions BEFORE the step's += 1
+                dg["graph"].replay()
+                hidden_all[rows, idx] = dg["hidden"]
+                ids_dev[step + 1].copy_(dg["nxt"])
+                ring[step + 1].copy_(dg["nxt"], non_blocking=True)
+                evs[step + 1].record(cur)
+            if not all(done):
+                evs[n_max - 1].synchronize()
+                for st_ in range(absorbed, n_max):
+                    absorb(ring[st_].tolist())
+            n_steps = 0  # (the stepping loop below is skipped)
+        else:
+            n_steps = n_max
+        for step in range(n_steps):
+            if forced_dev is not None:
+                tok_t = forced_dev[step]
+                toks = [pad[b][step] for b in range(B)]
+            else:
+                tok_t = nxt
+                toks = nxt.tolist()  # (eager launches: the host is the bottleneck anyway)
+            absorb(toks)
             if all(done):
                 break
             # (finished sequences keep stepping - their rows are ignored; a sequence whose position has reached the end of its
@@ -624,7 +751,8 @@ class InteractVLMForCausalLM:
         if self._guard_applies():  # (fp16 exponent range: see _guarded)
             return self._guarded(self.evaluate_batch, (images_clip, images, input_ids_list, cam_params, resize_list,
                                                        original_size_list, contact_type, max_new_tokens, forced_new_tokens,
-                                                       eos_token_id, lift2d_dict_path, image_embeddings), {})
+                                                       eos_token_id, lift2d_dict_path, image_embeddings), {},
+                                 supplied_embeddings=image_embeddings)
         B = len(input_ids_list)
         if B > 16:  # larger batches run as consecutive calls of <= 16 sequences (the decode kernels' row limit)
             if images_clip.shape[0] == 1:
@@ -705,7 +833,7 @@ class InteractVLMForCausalLM:
         if self._guard_applies():
             return self._guarded(self.evaluate, (images_clip, images, input_ids, cam_params, resize_list, original_size_list,
                                                  lift2d_dict_path, contact_type, max_new_tokens, tokenizer, forced_new_tokens,
-                                                 eos_token_id, image_embeddings), {})
+                                                 eos_token_id, image_embeddings), {}, supplied_embeddings=image_embeddings)
         # The SAM ViT-H encoder (MFMA-bound, ~60 ms) does not depend on the language model (CLIP -> prefill -> decode:
         # HBM-bound weight streaming that leaves the matrix cores idle): run it on a second HIP stream and join
         # before the mask decoder.  The reference runs them back to back (InteractVLM.py:524-531, 578).

@@ -35,8 +35,10 @@ class LlamaStages:
         self.llm = llm
         c = llm.cfg
         self.cfg = LlamaCfg(c.layers, c.hidden, c.heads, c.inter, llm.max_len, c.eps, c.theta, 1 if llm.fuse_attn_oproj else 0)
-        self.layers = (LlamaLayer * c.layers)(*[LlamaLayer(*[L[k].data_ptr() for k in ("ln1", "qkv", "o", "ln2", "gu", "down")])
-                                                for L in llm.layers])
+        # (the structs hold raw device pointers: keep the tensors alive - the host model may release weight copies its active
+        #  precision mode does not read, llava.Llama.release_unused)
+        self._keep = [[L[k] for k in ("ln1", "qkv", "o", "ln2", "gu", "down")] for L in llm.layers]
+        self.layers = (LlamaLayer * c.layers)(*[LlamaLayer(*[t.data_ptr() for t in ts]) for ts in self._keep])
         lib = _lib.load()
         self._dws = torch.zeros(lib.ivlm_llama_decode_workspace_bytes(C.byref(self.cfg)), dtype=torch.uint8, device=llm.device)
 
@@ -61,6 +63,7 @@ class LlamaStages:
         """the layer table with qkv / o / gu / down pointing to the fp16 copies of the weights (ivlm_llama_prefill_f16)"""
         if not hasattr(self, "layers16"):
             Ls = [self.llm._f16(L) for L in self.llm.layers]
+            self._keep16 = [[L[n + "_h"] for n in ("qkv", "o", "gu", "down")] for L in Ls]
             self.layers16 = (LlamaLayer * len(Ls))(*[LlamaLayer(L["ln1"].data_ptr(), L["qkv_h"].data_ptr(), L["o_h"].data_ptr(),
                                                                  L["ln2"].data_ptr(), L["gu_h"].data_ptr(), L["down_h"].data_ptr())
                                                       for L in Ls])
@@ -98,10 +101,12 @@ class LlamaStages:
             from . import ops
 
             rows = []
+            self._keep12 = []
             for L in self.llm.layers:
                 for n in ("qkv", "o", "gu", "down"):
                     if L.get(n + "_p") is None:
                         L[n + "_p"] = ops.PackedBf12(L[n])
+                    self._keep12.append(L[n + "_p"])
                     if not L[n + "_p"].frag:
                         raise ops.IvlmError("decode_step_bf12: a matrix does not take the fragment layout (rows % 16, columns % 64)")
                 rows.append(LlamaLayerBf12(L["ln1"].data_ptr(), L["ln2"].data_ptr(),

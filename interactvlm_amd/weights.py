@@ -80,13 +80,14 @@ class IvlmCfg:
     oC_sam_view_type: str = "4MV-Z_HM"
     hC_loss_weight: float = 1.0
     oC_loss_weight: float = 0.0
-    # '-DifDe' checkpoints carry mask_decoder.*, human_mask_decoder.* and object_mask_decoder.*.  "separate" (default): each decoder
-    # holds ITS OWN tensors and ModifiedSAM.forward's selection by dataset name (InteractVLM.py:46-52) picks among them - what the
-    # separately trained copies are for.  "reference": the reference's own inference construction - from_pretrained loads the three key
-    # sets into ALIASED modules (InteractVLM.py:30-32: human_/object_mask_decoder ARE mask_decoder until initialize_separate_decoders,
-    # which evaluate.py:557-563 calls AFTER the load), so all three end up holding the key set loaded last, object_mask_decoder.*
-    # (module order of ModifiedSAM).  The two differ only for a checkpoint whose copies differ; checkpoint.load_weights warns then.
-    difde_load: str = "separate"
+    # '-DifDe' checkpoints carry mask_decoder.*, human_mask_decoder.* and object_mask_decoder.*.  "reference" (default): the
+    # reference's own inference construction - from_pretrained loads the three key sets into ALIASED modules (InteractVLM.py:30-32:
+    # human_/object_mask_decoder ARE mask_decoder until initialize_separate_decoders, which evaluate.py:557-563 calls AFTER the load),
+    # so all three end up holding the key set loaded last, object_mask_decoder.* (module order of ModifiedSAM) - what the reference
+    # evaluates on the same checkpoint, hence the drop-in default.  "separate" (opt-in): each decoder holds ITS OWN tensors and
+    # ModifiedSAM.forward's selection by dataset name (InteractVLM.py:46-52) picks among them - what the separately trained copies
+    # are for.  The two differ only for a checkpoint whose copies differ; checkpoint.load_weights warns then.
+    difde_load: str = "reference"
     use_fusion: bool = False       # LLaVASAMFusion head (InteractVLM.py:149; off in every released configuration)
     use_uncertainty: bool = False  # UncertaintyModule head (InteractVLM.py:150)
 

@@ -588,11 +588,64 @@ def gen_optional_heads():
     _save("optional_heads.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# Prompt construction: conv_templates["llava_v1"] (model/llava/conversation.py:355-365) and tokenizer_image_token
+# (model/llava/mm_utils.py:31-56) as run_demo.py:313-324 drives them, on the demo's own three questions
+# ------------------------------------------------------------------------------------------
+def gen_prompt():
+    import ast
+    import json
+
+    _ref_shims.install(full_model=True)  # (model.llava's package import pulls the LLaVA model classes in)
+    from model.llava import conversation as conversation_lib
+    from model.llava.mm_utils import tokenizer_image_token
+    from utils.utils import DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_TOKEN, IMAGE_TOKEN_INDEX
+
+    from stub_tokenizer import StubTokenizer
+
+    # the three BASE_PROMPT lists are literals inside run_demo.main(): read the VALUES out of its syntax tree (data, not code)
+    tree = ast.parse(open(os.path.join(_ref_shims.REFERENCE_ROOT, "run_demo.py")).read())
+    base = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "BASE_PROMPT" for t in node.targets):
+            base.append((node.lineno, ast.literal_eval(node.value)[0]))
+    base.sort()
+    assert len(base) == 3, base
+    names = ("oafford", "h2dcontact", "hcontact")  # (their order in the file: run_demo.py:217, 254, 282)
+    cases = []
+    for (lineno, question), name in zip(base, names):
+        q = question.format(class_name="chair", object="chair")
+        for mm in (True, False):
+            conv = conversation_lib.conv_templates["llava_v1"].copy()  # run_demo.py:313-324
+            conv.messages = []
+            prompt = DEFAULT_IMAGE_TOKEN + "\n" + q
+            if mm:
+                prompt = prompt.replace(DEFAULT_IMAGE_TOKEN, DEFAULT_IM_START_TOKEN + DEFAULT_IMAGE_TOKEN + DEFAULT_IM_END_TOKEN)
+            conv.append_message(conv.roles[0], prompt)
+            conv.append_message(conv.roles[1], "")
+            text = conv.get_prompt()
+            ids = {("bos" if bos else "nobos"): tokenizer_image_token(text, StubTokenizer(bos), return_tensors="pt").tolist()
+                   for bos in (True, False)}
+            cases.append({"kind": name, "line": lineno, "template": question, "question": q, "use_mm_start_end": mm, "prompt": text,
+                          "ids": ids})
+    # the splice logic on its own: several placeholders, one at the very start / end, none at all
+    splice = []
+    for text in ("a b <image> c d <image> e", "<image> a", "a <image>", "a b c", "<image>"):
+        splice.append({"text": text, "ids": {("bos" if bos else "nobos"): tokenizer_image_token(text, StubTokenizer(bos))
+                                             for bos in (True, False)}})
+    out = {"image_token_index": IMAGE_TOKEN_INDEX, "tokens": [DEFAULT_IMAGE_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN],
+           "cases": cases, "splice": splice}
+    path = os.path.join(HERE, "prompts.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"  wrote prompts.json ({len(cases)} prompts, {len(splice)} splice cases)")
+
+
 GENERATORS = {"optional_heads": gen_optional_heads, "lift": gen_lift, "lift_points": gen_lift_points, "sam_decoder": gen_sam_decoder, "cam": gen_cam,
               "sam_encoder": gen_sam_encoder, "sam_encoder_full": gen_sam_encoder_full, "model_forward": gen_model_forward,
               "model_forward_oafford": lambda: gen_model_forward(batch2=True),
               "model_forward_huobj": lambda: gen_model_forward(huobj=True), "metrics": gen_metrics,
-              "state_keys": gen_state_keys, "preprocess": gen_preprocess}
+              "state_keys": gen_state_keys, "preprocess": gen_preprocess, "prompt": gen_prompt}
 
 
 def main():

@@ -40,6 +40,38 @@ def test_prompt_and_image_token_splicing():
     assert cams.shape == (1, 4, 5) and abs(float(cams[0, 0, 0]) - 0.2) < 1e-6   # d / 10 (base_contact_dataset.py:37-50)
 
 
+def test_prompt_construction_equals_the_reference(golden_dir):
+    """``demo.build_prompt`` / ``demo.tokenizer_image_token`` against what the REFERENCE's own
+    ``conv_templates["llava_v1"]`` (model/llava/conversation.py:355-365) and ``tokenizer_image_token`` (model/llava/mm_utils.py:31-56)
+    produce when driven as run_demo.py:313-324 drives them - on the demo's three questions (run_demo.py:217, 254, 282; the texts
+    themselves were read out of the reference), with use_mm_start_end on / off, with and without a BOS id, plus the splice logic on
+    texts with several / leading / trailing / no image placeholders.  Fixture: tests/golden/prompts.json (make_golden.py gen_prompt)."""
+    import json
+    import sys
+
+    sys.path.insert(0, golden_dir)
+    from stub_tokenizer import StubTokenizer
+
+    with open(os.path.join(golden_dir, "prompts.json")) as f:
+        g = json.load(f)
+    assert g["image_token_index"] == demo.IMAGE_TOKEN_INDEX
+    assert g["tokens"] == [demo.DEFAULT_IMAGE_TOKEN, demo.DEFAULT_IM_START_TOKEN, demo.DEFAULT_IM_END_TOKEN]
+    templates = {"oafford": demo.OAFFORD_PROMPT, "h2dcontact": demo.H2DCONTACT_PROMPT, "hcontact": demo.HCONTACT_PROMPT}
+    assert len(g["cases"]) == 6
+    for c in g["cases"]:
+        assert templates[c["kind"]] == c["template"]  # the question texts are the reference's, character for character
+        q = templates[c["kind"]].format(class_name="chair", object="chair")
+        assert q == c["question"]
+        p = demo.build_prompt(q, use_mm_start_end=c["use_mm_start_end"])
+        assert p == c["prompt"]
+        for key, bos in (("bos", True), ("nobos", False)):
+            assert demo.tokenizer_image_token(p, StubTokenizer(bos)).tolist() == c["ids"][key], (c["kind"], key)
+            assert c["ids"][key].count(-200) == 1
+    for c in g["splice"]:
+        for key, bos in (("bos", True), ("nobos", False)):
+            assert demo.tokenizer_image_token(c["text"], StubTokenizer(bos)).tolist() == c["ids"][key], (c["text"], key)
+
+
 @pytest.mark.gpu
 def test_run_sample_writes_reference_outputs(hip_lib, cuda, tmp_path):
     from interactvlm_amd import model as M

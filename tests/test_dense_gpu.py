@@ -777,3 +777,37 @@ def test_gemv_bf12_is_lossless_and_equals_the_bf16_gemv(hip_lib, cuda, N, K, act
     print(f"\\n[bf12 GEMV {N}x{K} {act}] vs fp64: packed {e12:.2e}, bf16 GEMV {e16:.2e}; patches {wp.n_patches}")
     assert got.shape == ref16.shape and e12 < 3e-6 and e16 < 3e-6
     assert float((got - ref16).abs().max()) / scale < 3e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("big", [1.0e9, 3.0e15, 1.0e-12])
+def test_gemv_bf12_activation_range(hip_lib, cuda, big):
+    """the packed kernels stage x times an exact power of two.  With 2^100 one activation of 1e9 overflowed fp32 and the
+    whole output row turned NaN, a range the bf16-weight GEMV (plain fp32 x) does not have.  The scale is now 2^64 - the middle of
+    fp32's exponent range: rows with one element around 1e9 / 3e15, and a row of tiny activations (1e-12), come out finite and equal
+    to fp64 like the bf16 GEMV's - batch-1 MFMA form, VALU form and the M <= 16 form."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    N, K = 256, 1024
+    g = torch.Generator().manual_seed(11)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(cuda)
+    x = torch.randn(1, K, generator=g)
+    if big >= 1.0:
+        x[0, 17] = big
+    else:
+        x = x * big
+    x = x.to(cuda)
+    ref = x.double() @ w.double().t()
+    scale = float(ref.abs().max())
+    y16 = ops.linear(x, w, out_f32=True)
+    for fragments in (True, False):
+        y = ops.linear_bf12(x, ops.PackedBf12(w, fragments=fragments))
+        assert bool(torch.isfinite(y).all()), fragments
+        assert float((y.double() - ref).abs().max()) / scale < 3e-6, fragments
+        assert float((y - y16).abs().max()) / scale < 3e-6
+    xm = x.repeat(3, 1) * torch.tensor([[1.0], [-0.5], [2.0]], device=cuda)
+    ym = ops.linear_bf12(xm, ops.PackedBf12(w))
+    assert bool(torch.isfinite(ym).all())
+    assert float((ym.double() - xm.double() @ w.double().t()).abs().max()) / (2 * scale) < 3e-5

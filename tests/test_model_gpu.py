@@ -749,7 +749,7 @@ def test_difde_decoders_selected_by_dataset_name(hip_lib, cuda):
     from interactvlm_amd import synth, synthetic
     from interactvlm_amd import weights as Wt
 
-    cfg = dataclasses.replace(synthetic.config_tiny(), token_type="Gen-DifDe")
+    cfg = dataclasses.replace(synthetic.config_tiny(), token_type="Gen-DifDe", difde_load="separate")
     w = Wt.synth_weights(Wt.ivlm_spec(cfg))
     assert any(".human_mask_decoder." in k for k in w) and any(".object_mask_decoder." in k for k in w)
     tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
@@ -781,10 +781,10 @@ def test_difde_decoders_selected_by_dataset_name(hip_lib, cuda):
 
 
 def test_difde_reference_load_semantics_switch(hip_lib, cuda):
-    """a '-DifDe' checkpoint whose three decoder copies DIFFER.  Default (difde_load = "separate"): each decoder its own
-    tensors.  difde_load = "reference": the reference's from_pretrained-into-aliased-modules-then-deepcopy construction
-    (InteractVLM.py:30-32, evaluate.py:557-563) - all three decoders hold object_mask_decoder.*; the loader warns that the copies
-    differ and says which semantics is applied."""
+    """a '-DifDe' checkpoint whose three decoder copies DIFFER.  Default (difde_load = "reference"): the reference's
+    from_pretrained-into-aliased-modules-then-deepcopy construction (InteractVLM.py:30-32, evaluate.py:557-563) - all three decoders
+    hold object_mask_decoder.*, i.e. what the reference evaluates on the same checkpoint.  difde_load = "separate" (opt-in): each
+    decoder its own tensors.  The loader warns that the copies differ and says which semantics is applied."""
     import dataclasses
     import warnings
 
@@ -800,14 +800,15 @@ def test_difde_reference_load_semantics_switch(hip_lib, cuda):
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
         assert checkpoint.warn_if_difde_copies_differ(w, cfg)
-    assert any("difde_load='separate'" in str(r.message) for r in rec)
+    assert cfg.difde_load == "reference"  # (the drop-in default)
+    assert any("difde_load='reference'" in str(r.message) for r in rec)
     tables = synth.synth_mesh_tables(4, 1024, 1024, 6890, fg=0.4, seed=0, patch=8)
     ids, forced = synthetic.prompt_ids(cfg, n_prompt=40, n_answer=8)
     cams = synthetic.human_cam_params()
     ic, im = synthetic.images(cfg, cuda)
     ev = lambda m_: m_.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], contact_type="hcontact", forced_new_tokens=forced)
-    sep = ev(M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables))
-    ref_sem = ev(M.InteractVLMForCausalLM(dataclasses.replace(cfg, difde_load="reference"), w, cuda, lift_tables=tables))
+    sep = ev(M.InteractVLMForCausalLM(dataclasses.replace(cfg, difde_load="separate"), w, cuda, lift_tables=tables))
+    ref_sem = ev(M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables))
     # "reference": hcontact goes through a decoder holding object_mask_decoder.* == a plain model whose mask_decoder.* are those tensors
     pre = Wt.SAM_PREFIX
     w_obj = {k: v for k, v in w.items() if "human_mask_decoder" not in k and "object_mask_decoder" not in k}
@@ -913,6 +914,62 @@ def test_free_running_generation_vs_oracle_greedy(hip_lib, cuda, golden_dir):
         e = float((outs[b]["pred_contact_3d"].float().cpu() - ref).abs().max())
         print(f"[evaluate_batch(16) image {b} vs oracle] max |dp| = {e:.2e}")
         assert e < 1e-3
+
+
+def test_free_running_generation_stops_on_eos_one_step_late(hip_lib, cuda, golden_dir):
+    """the graph-replay greedy loop no longer reads the new id back before it enqueues the next step - ids stay on
+    the device, a pinned host copy is polled ONE step late, so when id k is EOS one speculative step has been enqueued and must be
+    dropped.  Random weights never emit a given EOS, so the EOS id is chosen from what the model generates: for every cut point
+    k the graph loop must return exactly the eager loop's result (ids up to and including the first EOS, hidden rows up to the row
+    that predicted it), for generate() and for generate_batch() with sequences that stop at different steps - and the next call
+    must not see anything of the dropped step (same result again)."""
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import weights as Wt
+
+    torch.set_grad_enabled(False)
+    d, cfg, ids, images_clip, images, cams, tables = _toy(golden_dir)
+    w = Wt.synth_weights(Wt.ivlm_spec(cfg))
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    bf = torch.bfloat16
+    prompts = [ids[:40], torch.cat([ids[:30], ids[34:40]]), ids[:38]]
+    ics = [images_clip.to(bf).to(cuda), (images_clip * 0.5 + 0.1).to(bf).to(cuda), (-images_clip).to(bf).to(cuda)]
+    n_new = 9
+    m.graph_decode = True
+    free = [m.generate(ics[b], prompts[b][None], max_new_tokens=n_new, eos_token_id=-1) for b in range(3)]
+    for b in range(3):
+        L = prompts[b].shape[0]
+        new = free[b][0][0, L:].tolist()
+        assert len(new) == n_new and free[b][1].shape[0] == L + cfg.img_emb_len + n_new - 1
+        for k in (0, 1, 4, n_new - 2, n_new - 1):
+            eos = new[k]
+            first = new.index(eos)  # (an id may repeat: the loop stops at its FIRST occurrence)
+            for graph in (True, False, True):
+                m.graph_decode = graph
+                got_ids, hidden = m.generate(ics[b], prompts[b][None], max_new_tokens=n_new, eos_token_id=eos)
+                assert got_ids[0, L:].tolist() == new[: first + 1], (b, k, graph)
+                assert hidden.shape[0] == L + cfg.img_emb_len + first
+                assert torch.equal(hidden, free[b][1][: hidden.shape[0]]), (b, k, graph)
+    # batched: the three sequences stop at different steps (an EOS id that sequence 1 emits at step 2; the others may never emit it)
+    m.graph_decode = False
+    free_b = m.generate_batch(torch.cat(ics), prompts, max_new_tokens=n_new, eos_token_id=-1)
+    L1 = prompts[1].shape[0]
+    eos = free_b[1][0][0, L1 + 2].item()
+    want = []
+    for b in range(3):
+        new = free_b[b][0][0, prompts[b].shape[0]:].tolist()
+        assert len(new) == n_new
+        want.append(new[: new.index(eos) + 1] if eos in new else new)
+    assert len(want[1]) <= 3
+    for graph in (True, False, True):
+        m.graph_decode = graph
+        outs = m.generate_batch(torch.cat(ics), prompts, max_new_tokens=n_new, eos_token_id=eos)
+        for b in range(3):
+            L = prompts[b].shape[0]
+            assert outs[b][0][0, L:].tolist() == want[b], (b, graph)
+            assert outs[b][1].shape[0] == L + cfg.img_emb_len + len(want[b]) - 1
+            assert torch.equal(outs[b][1], free_b[b][1][: outs[b][1].shape[0]]), (b, graph)
 
 
 @pytest.mark.parametrize("cache_dtype", ["bf16", "f16"])
@@ -1056,6 +1113,7 @@ def test_nonfinite_result_of_an_fp16_mode_is_recomputed_in_bf16(hip_lib, cuda, g
                                 [(1024, 1024)] * 2, [(1024, 1024)] * 2, forced_new_tokens=ids[40:].tolist())
     assert all(o.get("recomputed_in_bf16") and bool(torch.isfinite(o["pred_contact_3d"]).all()) for o in outs)
     m.set_precision("bf16")
+    m.llm.decode_packed = False  # (the recomputation also decodes on the bf16 weights: fp32 activations with the full fp32 range)
     ref = m.evaluate(*args, **kw)
     assert torch.equal(out["pred_contact_3d"], ref["pred_contact_3d"]) and torch.equal(out["output_ids"], ref["output_ids"])
     assert float((outs[1]["pred_contact_3d"] - ref["pred_contact_3d"]).abs().max()) < 1e-3

@@ -364,14 +364,19 @@ def test_evaluate_parity_mode_vs_oracle(hip_lib, cuda):
         assert float((o["pred_contact_3d"].float().cpu() - ref).abs().max()) < 1e-4
 
 
-def test_full_depth_end_to_end_vs_oracle(hip_lib, cuda):
+@pytest.mark.parametrize("seed,oracle", [(3, True), (12, False), (24, False)])
+def test_full_depth_end_to_end_vs_oracle(hip_lib, cuda, seed, oracle):
     """End-to-end parity at the REAL depths: SAM ViT-H with all 32 blocks at its real width on the four views,
     a 32-layer LLaMA (width 1024: the fp32 oracle of the 7B width needs 27 GB of host weights - bench.py's
     `parity_vs_oracle_full_depth` leg does exactly that on the headline model), a 23-layer CLIP, the real mask decoder, 4 x 1024^2
     masks and the 6890-vertex lift: evaluate() against the fp32 CPU oracle on identical bf16-valued weights.
     EVERY listed mode except "bf16" must hold the north star's 1e-3 on per-vertex probabilities: the DEFAULT mode (fp16 operands,
-    exact q path) with a margin (< 7e-4 asserted; 4 - 6e-4 measured over seeds), "parity" / "parity-fast" with exactly equal
-    vertex-id sets; the bf16-operand mode's error at this depth (the reference's own GPU dtype class) is printed and sanity-bounded."""
+    exact q path: 4.1 - 6.7e-4 over 16 seeded sets, profiles/r04_default_mode_seeds.txt), "parity" / "parity-fast" with exactly
+    equal vertex-id sets; the bf16-operand mode's error at this depth (the reference's own GPU dtype class) is printed and
+    sanity-bounded.
+    THREE weight / image seeds (the bound is the north star's 1e-3 itself over several seeds - among them the
+    family's worst, 12 and 24 - not one seed at a hand-tuned 7e-4).  Seed 3 runs the fp32 CPU oracle (~100 s); for the other two the
+    reference is this build's "parity" mode, which seed 3 pins to < 2e-5 of the oracle, with that distance taken off the bound."""
     import time
 
     import torch
@@ -386,20 +391,26 @@ def test_full_depth_end_to_end_vs_oracle(hip_lib, cuda):
     torch.set_grad_enabled(False)
     cfg = Wt.IvlmCfg(llama=Wt.LlamaCfg(hidden=1024, layers=32, heads=8, inter=2752, vocab=32003),
                      clip=Wt.ClipCfg(hidden=256, layers=24, heads=4, inter=512), sam=Wt.SamEncCfg())
-    wd = synthetic.device_weights(cfg, cuda, seed=3)
+    wd = synthetic.device_weights(cfg, cuda, seed=seed)
     tables = synthetic.body_lift_tables(cuda)
     m = M.InteractVLMForCausalLM(cfg, wd, cuda, lift_tables=tables)
     ids, forced = synthetic.prompt_ids(cfg)
     cams = synthetic.human_cam_params()
-    ic, im = synthetic.images(cfg, cuda, seed=5)
+    ic, im = synthetic.images(cfg, cuda, seed=seed + 2)
     got = {}
-    for mode in m.precision_modes:
+    for mode in (m.precision_modes if oracle else ("default", "parity")):
         m.set_precision(mode)
         o = m.evaluate(ic, im, ids, cams, [(1024, 1024)], [(1024, 1024)], forced_new_tokens=forced)
         plan = m.human_3d_contact_predictor._get_plan(cuda)
         _, nv = ops.lift_mesh_plan(o["pred_masks"][0][None].contiguous(), plan, want_nviews=True)
         got[mode] = (o["pred_contact_3d"].float().cpu(), nv[0].cpu() > 0)
     del m
+    if not oracle:  # reference = the parity mode (pinned to the oracle by the seed-3 case below: < 2e-5)
+        e = float((got["default"][0] - got["parity"][0]).abs().max())
+        print(f"\n[full depth, seed {seed}] default mode vs the parity mode: max |dp| = {e:.2e}")
+        assert e < 1e-3 - 2e-5
+        assert torch.equal(got["default"][1], got["parity"][1])  # visibility set: bit-exact
+        return
     t0 = time.time()
     w = {k: v.float().cpu() for k, v in wd.items()}
     full_ids = torch.cat([ids[0], torch.tensor(forced)])
@@ -418,8 +429,8 @@ def test_full_depth_end_to_end_vs_oracle(hip_lib, cuda):
           f"operands, exact q) {err['default']:.2e}, bf16 {err['bf16']:.2e}, parity-fast {err['parity-fast']:.2e}, parity "
           f"{err['parity']:.2e} (oracle {time.time() - t0:.0f} s)")
     c, vis = got["parity"]
-    assert err["default"] < 7e-4  # the mode `value` of bench.py is quoted on: inside the north star's 1e-3 with a margin
-    assert err["parity"] < 1e-3 and err["parity-fast"] < 1e-3
+    assert err["default"] < 1e-3  # the mode `value` of bench.py is quoted on: the north star's bound itself (see the docstring)
+    assert err["parity"] < 2e-5 and err["parity-fast"] < 1e-3  # ("parity" is the other seeds' reference)
     assert torch.equal(got["default"][1], vis) and torch.equal(got["parity-fast"][1], vis)
     assert torch.equal(vis, torch.from_numpy(nviews[0] > 0))  # visibility set: bit-exact (every mode)
     for mode in ("parity", "default"):
@@ -462,3 +473,89 @@ def test_gemm_fp16_operands_and_output(hip_lib, cuda, M, N, K, act):
     xf = (torch.randn(64, K, generator=g) * 2).to(cuda)
     lw, lb = (1 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).to(cuda), (0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).to(cuda)
     assert torch.equal(ops.layernorm(xf, lw, lb, 1e-6, out_f16=True), ops.layernorm(xf, lw, lb, 1e-6, out_f32=True).to(torch.float16))
+
+
+def test_headline_model_7b_default_mode(hip_lib, cuda):
+    """the HEADLINE model at its real widths under pytest - LLaMA 32 x 4096 (inter 11008, vocab 32003), CLIP ViT-L/14
+    (1024), SAM ViT-H, 4 x 1024^2 views, the 6890-vertex lift (`synthetic.config_7b()`, BASELINE configs[1]; reference path
+    model/InteractVLM.py:510-638).  The fp32 CPU oracle of this model takes ~110 s and 27 GB (bench.py's parity leg runs it); here,
+    without it: (i) the DEFAULT mode's result is finite; (ii) default vs the "parity" mode < 1e-3 (parity sits 8e-6 from the oracle
+    on this very model - BENCH `parity_vs_oracle_full_depth` - so this is the oracle check by proxy); (iii) evaluate_batch(2) ==
+    evaluate per image < 1e-3, ids equal; (iv) the lift of its own masks through the C oracle (`cref.lift_mesh_soft`): contacts
+    1e-5, the visibility set bit-exact; (v) the packed decode step vs the bf16-weight step (`decode_packed = False`) on the hidden
+    states - same exact products, other fp32 summation order (matrix-core accumulation vs wave reduction), so equal to rounding, not
+    bit for bit; (vi) free-running greedy generation (no forced ids, no per-token host sync) == the eager loop, token for token;
+    (vii) the default mode holds no bf16 copy of a packed LLaMA matrix (resident weight bytes by form)."""
+    import numpy as np
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import ops, synthetic
+    from oracle import cref
+
+    torch.set_grad_enabled(False)
+    cfg = synthetic.config_7b()
+    w = synthetic.device_weights(cfg, cuda, seed=0)
+    tables = synthetic.body_lift_tables(cuda)
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    del w
+    torch.cuda.empty_cache()
+    assert m.precision == "default"
+    ids, forced = synthetic.prompt_ids(cfg)
+    cams = synthetic.human_cam_params()
+    ic, im = synthetic.images(cfg, cuda, seed=0)
+    S = cfg.sam.img_size
+    ev = lambda: m.evaluate(ic, im, ids, cams, [(S, S)], [(S, S)], forced_new_tokens=forced)
+    # (vii) residency: fp16 prefill copies + 12-bit decode planes, no bf16 originals of the packed matrices
+    rb = m.resident_weight_bytes()
+    n_mat = sum(L[n + "_h"].numel() for L in m.llm.layers for n in ("qkv", "o", "gu", "down"))
+    assert rb["f16"] == 2 * n_mat and 1.45 * n_mat < rb["bf12"] < 1.6 * n_mat + 1.6 * m.llm.lm_head.numel()
+    assert rb["bf16"] < 2.1 * (m.llm.embed.numel() + m.llm.lm_head.numel())  # embed_tokens + lm_head + norms only
+    # (i) default mode
+    out = ev()
+    pc = out["pred_contact_3d"].float().cpu()
+    assert "recomputed_in_bf16" not in out and pc.shape == (1, 6890) and bool(torch.isfinite(pc).all())
+    assert 0.0 <= float(pc.min()) and float(pc.max()) <= 1.0 and float(pc.std()) > 1e-3  # (not a constant map)
+    # (iv) the lift of its own masks, C oracle
+    masks = out["pred_masks"][0]
+    assert masks.shape == (4, S, S) and masks.dtype == torch.float32
+    ref, nviews = cref.lift_mesh_soft(masks.cpu().numpy()[None], tables[0].cpu().numpy().astype(np.int32), tables[1].cpu().numpy(), 6890)
+    assert float((pc - torch.from_numpy(ref)).abs().max()) < 1e-5
+    plan = m.human_3d_contact_predictor._get_plan(cuda)
+    _, nv = ops.lift_mesh_plan(masks[None].contiguous(), plan, want_nviews=True)
+    assert torch.equal(nv[0].cpu() > 0, torch.from_numpy(nviews[0] > 0))
+    # (iii) two images per call
+    ic2, im2 = synthetic.images(cfg, cuda, seed=1)
+    outs = m.evaluate_batch(torch.cat([ic, ic2]), torch.cat([im, im2]), [ids[0], ids[0]], [cams[0], cams[0]], [(S, S)] * 2, [(S, S)] * 2,
+                            forced_new_tokens=forced)
+    single2 = m.evaluate(ic2, im2, ids, cams, [(S, S)], [(S, S)], forced_new_tokens=forced)
+    for o, one in zip(outs, (out, single2)):
+        assert torch.equal(o["output_ids"], one["output_ids"])
+        e = float((o["pred_contact_3d"] - one["pred_contact_3d"]).abs().max())
+        assert e < 1e-3, e
+    # (v) packed decode weights vs bf16 decode weights: hidden states of the whole forced generation
+    _, h_packed = m.generate(ic, ids, forced_new_tokens=forced)
+    m.llm.decode_packed = False
+    _, h_bf16 = m.generate(ic, ids, forced_new_tokens=forced)
+    m.llm.decode_packed = True
+    T0 = ids.shape[1] - 1 + cfg.img_emb_len + 1
+    assert torch.equal(h_packed[:T0], h_bf16[:T0])  # (the prefill does not depend on the decode weights' form)
+    d = (h_packed[T0:] - h_bf16[T0:]).abs().max() / h_bf16[T0:].abs().max()
+    assert float(d) < 2e-4, float(d)  # (fp32 summation order only, compounded over 32 layers x 23 steps; a lost bit of a weight: > 1e-2)
+    # (vi) free-running greedy search: graph replay without per-token host sync == eager loop
+    n_new = 12
+    m.graph_decode = True
+    g_ids, g_hidden = m.generate(ic, ids, max_new_tokens=n_new, eos_token_id=2)
+    m.graph_decode = False
+    e_ids, e_hidden = m.generate(ic, ids, max_new_tokens=n_new, eos_token_id=2)
+    m.graph_decode = True
+    assert torch.equal(g_ids, e_ids) and torch.equal(g_hidden, e_hidden)
+    # (ii) the oracle by proxy: parity mode (bf16 originals rebuilt, bit for bit, from the packed planes)
+    m.set_precision("parity")
+    rb2 = m.resident_weight_bytes()
+    assert rb2["f16"] == 0 and rb2["bf16"] >= 2 * n_mat
+    par = ev()["pred_contact_3d"].float().cpu()
+    e = float((pc - par).abs().max())
+    print(f"\n[7B headline model] default mode vs parity mode: max |dp| = {e:.2e}; resident LLaMA weights default mode "
+          f"{sum(rb.values()) / 1e9:.1f} GB (bf16 {rb['bf16'] / 1e9:.1f}, fp16 {rb['f16'] / 1e9:.1f}, 12-bit {rb['bf12'] / 1e9:.1f})")
+    assert e < 1e-3 - 2e-5

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4; mkdir -p $O
 cd $R
 timeout 1500 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
-timeout 300 python tools/bench_lift.py > $O/lift.json 2>&1
+timeout 300 python tools/bench_lift.py > $O/lift.json 2> $O/lift.err
 cd /tmp
 # the headline loop alone, HIP graphs ON (the regime `value` is measured in)
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-variants --no-roofline > $O/bench_kt.json 2> $O/kt.err
