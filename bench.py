@@ -474,6 +474,42 @@ def main():
     if workload == "dp64" and world > 1:
         one_gpu = one_gpu_same_workload(N_IMG, PER_CALL, dp_chunk, rank, world, dev, res, dt, args.steps, prefetch=dp_image)
 
+    # ---- weight residency of the mode `value` is quoted on and the free-running greedy loop (item 4): the
+    # reference stops on EOS (InteractVLM.py:524-531) - no forced ids, every next id is the device-side argmax of the previous step,
+    # the host polls a pinned copy one step late (model.generate); timed against the forced schedule of the same length
+    def resident_gb():
+        rb_ = model.resident_weight_bytes()
+        return {"llama_bf16": round(rb_["bf16"] / 1e9, 2), "llama_f16": round(rb_["f16"] / 1e9, 2),
+                "llama_bf12_planes": round(rb_["bf12"] / 1e9, 2), "llama_total": round(sum(rb_.values()) / 1e9, 2)}
+
+    hbm_resident = {"default": resident_gb(), "torch_allocated_total": round(torch.cuda.memory_allocated(dev) / 1e9, 2),
+                    "note": "language-model weight bytes held by the model, by form (embed_tokens + lm_head + norms stay bf16; the "
+                            "default mode holds fp16 prefill copies + lossless 12-bit decode planes and NO bf16 original of a packed "
+                            "matrix - a switch to 'bf16' / 'parity' rebuilds them bit for bit from the planes); torch_allocated_total "
+                            "also counts this script's own bf16 state dict (kept for the CPU-oracle leg), CLIP, SAM, KV caches"}
+    free_running = None
+    if workload == "b1" and world == 1 and not args.no_variants:
+        n_tok = len(forced)
+
+        def gen_ms(reps=3, **kw):
+            model.generate(images_clip, ids, **kw)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                model.generate(images_clip, ids, **kw)
+            sync()
+            return (time.perf_counter() - t1) / reps * 1e3
+        t_pre = gen_ms(max_new_tokens=1, eos_token_id=-1)  # CLIP + prefill + the first argmax: no decode step
+        t_free = gen_ms(max_new_tokens=n_tok, eos_token_id=-1)  # (-1: never stops early - random weights would stop at random)
+        t_forced = gen_ms(forced_new_tokens=forced)  # (same length: the schedule's EOS is its last id)
+        free_running = {"tokens": n_tok, "model": args.model, "ms_per_token": round((t_free - t_pre) / (n_tok - 1), 4),
+                        "ms_per_token_forced_schedule": round((t_forced - t_pre) / (n_tok - 1), 4),
+                        "ms_generate": round(t_free, 3), "ms_generate_forced_schedule": round(t_forced, 3),
+                        "ms_clip_prefill_first_id": round(t_pre, 3),
+                        "note": "greedy search as the reference runs it (ids fed back on the device, EOS polled from a pinned host "
+                                "copy one step late, at most one speculative step) vs the forced-id schedule `value` is timed on; "
+                                "language path alone, no SAM encoder on the side stream"}
+
     # ---- variant (reported separately, never the headline): SAM embeddings of the 4 canonical body renders cached
     cached = None
     if workload == "b1" and not args.no_roofline and not args.no_variants:
@@ -695,6 +731,7 @@ def main():
             for _ in range(args.steps):
                 step_b1()
             sync()
+            hbm_resident[mode] = resident_gb()
             gpu_modes[mode] = {"contact": o["pred_contact_3d"].float().cpu(), "nviews": nv_[0].cpu(),
                                "masks": o["pred_masks"][0].float().cpu(),
                                "images_per_s": round(args.steps / (time.perf_counter() - t1), 4)}
@@ -768,7 +805,7 @@ def main():
                          else roof),
             "roofline_mfma": roof, "roofline_gemv": roof_gemv, "roofline_lift": roof_lift, "cpu_baseline": cpu,
             "roofline_serial": roof_serial, "variant_cached_sam_embeddings": cached, "variant_fp8": fp8v,
-            "dp64_one_gpu": dp64_one,
+            "dp64_one_gpu": dp64_one, "free_running": free_running, "hbm_resident_gb": hbm_resident,
             "one_gpu_same_workload": one_gpu, "parity_vs_oracle": parity,
             "parity_vs_oracle_full_depth": parity_full,
         }
