@@ -220,6 +220,16 @@ int ivlm_gemm_bf16_splitk(const void *A, int64_t lda, const void *W, int64_t ldw
                           const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
                           int act, int out_f32, int splits, void *workspace, size_t workspace_bytes, int flags,
                           ivlm_stream_t stream);
+/* ... with the reduction FUSED into the GEMM launch (no second launch, no second pass over the product): every block stores its fp32
+ * partial tile and counts its arrival on the tile's counter; the block that arrives last sums the tile's slices in slice order and
+ * applies the epilogue - the same values as ivlm_gemm_bf16_splitk, bit for bit.  `counters`: IVLM_SPLITK_COUNTERS int32 words
+ * that the caller zeroes ONCE (hipMemset); every call leaves them at zero.  One array per stream: launches that may run
+ * concurrently must not share it.  (M = 330 LLaMA prefill / M = 257 CLIP: 199 launches fewer per image.) */
+#define IVLM_SPLITK_COUNTERS 4096
+int ivlm_gemm_bf16_splitk_fused(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
+                                const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,
+                                int act, int out_f32, int splits, void *workspace, size_t workspace_bytes, int32_t *counters,
+                                int flags, ivlm_stream_t stream);
 /* Benchmark hook of the GEMV grid shaping: resident blocks per CU assumed (default 4) and the N above which a wave takes two
  * weight rows per step (default 8192); 0 = default.  max_blocks_per_cu < 0: the persistent kernel also serves M = 1 fp32 rows
  * (which otherwise take gemv1_kernel: one row per wave, 1024-thread blocks, no persistence). */

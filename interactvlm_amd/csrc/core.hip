@@ -36,7 +36,7 @@ int ivlm_profile_launches(void* start_event, void* stop_event) {
 // 2: fp32 residual streams / fp32 activation flags (round 2); 3: ivlm_sam_block.rel_cat padded to a multiple of 64 rows and read by
 // the window attention's table mode (round 3); 4: rel_cat also read by the 64 x 64 grid's table mode (>= 254 rows), fp16-operand
 // entry points (*_f16), larger streaming-lift workspaces (one slab per block), ivlm_attention_f16_qsplit (round 4)
-int ivlm_abi_version(void) { return 4; }
+int ivlm_abi_version(void) { return 5; }
 
 const char* ivlm_build_arch(void) { return "gfx950"; }
 

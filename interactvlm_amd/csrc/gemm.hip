@@ -155,9 +155,16 @@ __global__ __launch_bounds__(CFG::kThreads, CFG::kMinBlocks) void gemm_bf16_kern
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t fa[MI], fw[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) fw[i] = *reinterpret_cast<const bf16x8_t*>(tw + (offW[i] ^ (kk << 6)));
+            for (int i = 0; i < NI; ++i) fw[i] = gemm_frag_read(tw + (offW[i] ^ (kk << 6)));
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(ta + (offA[i] ^ (kk << 6)));
+            for (int i = 0; i < MI; ++i) fa[i] = gemm_frag_read(ta + (offA[i] ^ (kk << 6)));
+#ifdef IVLM_ABL_NOMFMA
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) IVLM_ABL_MFMA_USE(fw[ni], fw[ni]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) IVLM_ABL_MFMA_USE(fa[mi], fa[mi]);
+            continue;
+#endif
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -171,7 +178,19 @@ __global__ __launch_bounds__(CFG::kThreads, CFG::kMinBlocks) void gemm_bf16_kern
         }
     }
 
+#ifdef IVLM_ABL_NOEPI
+    if (g.M > 0) {  // (one dummy store per lane keeps the accumulators live)
+        float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sacc == 123.456f) static_cast<float*>(g.C)[tid] = sacc;
+        return;
+    }
+#endif
     // ---- epilogue: whole lines through LDS where the wave's rows are 128 / 256 bytes (gemm_common.h) ----------------
+    bool stored = false;
     {
         constexpr int kRowBytes = NI * 16 * (OUT_F32 ? 4 : 2);
         if constexpr (kRowBytes == 128 || kRowBytes == 256) {
@@ -183,20 +202,25 @@ __global__ __launch_bounds__(CFG::kThreads, CFG::kMinBlocks) void gemm_bf16_kern
                     __syncthreads();  // every wave is done with the last K tile
                     gemm_store_lines<ACT, OUT_F32, MI, NI, kPass>(g, smem + wave * kBudget, m0 + wm * (MI * 16), n0 + wn * (NI * 16),
                                                                   lane, acc);
-                    return;
+                    stored = true;
                 }
             }
         }
     }
-    // direct fragment stores: lane holds C[m][n..n+3], m = l&15, n = (l>>4)*4
+    if (!stored) {  // direct fragment stores: lane holds C[m][n..n+3], m = l&15, n = (l>>4)*4
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * (MI * 16) + mi * 16 + (lane & 15);
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * (MI * 16) + mi * 16 + (lane & 15);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wn * (NI * 16) + ni * 16 + (lane >> 4) * 4;
-            gemm_epilogue4<ACT, OUT_F32>(g, bz, m, n, acc[ni][mi]);
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = n0 + wn * (NI * 16) + ni * 16 + (lane >> 4) * 4;
+                gemm_epilogue4<ACT, OUT_F32>(g, bz, m, n, acc[ni][mi]);
+            }
         }
+    }
+    // fused split-K (the fp32 partial-tile instantiations only): count this block's arrival, the tile's last block reduces it
+    if constexpr (ACT == ACT_NONE && OUT_F32 && OPK != 1) {
+        if (g.sk.count) splitk_fixup<BM, BN, CFG::kThreads>(g, m0, n0);
     }
 }
 
@@ -409,39 +433,14 @@ template <bool OUT_F32>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, GemmArgs g) {
     const int n4 = g.N >> 2;
     const int64_t total = (int64_t)g.M * n4;
-    const int64_t slice = (int64_t)g.M * g.N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
-        const float* p = part + (int64_t)m * g.N + n;
-        float4 acc = *reinterpret_cast<const float4*>(p);
-        for (int sidx = 1; sidx < splits; ++sidx) {
-            const float4 t = *reinterpret_cast<const float4*>(p + sidx * slice);
-            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-        }
-        float v[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (g.bias) v[j] += bf16_to_f32(g.bias[n + j]);
-            v[j] = gemm_act(v[j], g.act);
-            if (g.residual) {
-                const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
-                v[j] += gemm_residual_at(g, g.residual, rrow * g.ldr + n + j);
-            }
-        }
-        const int64_t o = (int64_t)m * g.ldc + n;
-        if (OUT_F32 && g.out_split) {
-            uint32_t h0, l0, h1, l1;
-            split_16x2(v[0], v[1], h0, l0, g.out_f16);
-            split_16x2(v[2], v[3], h1, l1, g.out_f16);
-            *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o + g.c_lo) = make_uint2(l0, l1);
-        } else if (OUT_F32) *reinterpret_cast<float4*>(static_cast<float*>(g.C) + o) = make_float4(v[0], v[1], v[2], v[3]);
-        else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(pack_16x2(v[0], v[1], g.out_f16), pack_16x2(v[2], v[3], g.out_f16));
+        splitk_finish4<OUT_F32>(g, part, splits, m, n);
     }
 }
 }  // namespace
 
-int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st) {
+int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st, int32_t* counters) {
     if (splits < 2 || g.batch != 1 || g.act == ACT_SWIGLU || g.rms_w || g.out_rows || g.a_rows || !workspace) return IVLM_ERR_INVALID_ARG;
     if (g.K % (splits * 8) != 0 || (g.N & 3) || (g.ldc & 3)) return IVLM_ERR_UNSUPPORTED;
     if (ws_bytes < (size_t)splits * g.M * g.N * sizeof(float)) return IVLM_ERR_WORKSPACE;
@@ -460,6 +459,21 @@ int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_
     p.bias = nullptr;
     p.residual = nullptr;
     p.act = ACT_NONE;
+    if (counters && !g.fp8 && (g.N & 3) == 0) {
+        // fused reduction: the tile kernels of gemm.hip only (they carry the fixup), and a tile count the counter array covers
+        int t = choose_tile(p);
+        if (t == 512 || t == 256 || t == 320) t = 128;
+        const long tiles = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);  // (the smallest tile any of them uses: an upper bound)
+        if (tiles <= kSplitKCounters) {
+            p.tile = t;
+            p.sk.count = counters;
+            p.sk.C = g.C; p.sk.bias = g.bias; p.sk.residual = g.residual;
+            p.sk.ldc = g.ldc; p.sk.ldr = g.ldr; p.sk.c_lo = g.c_lo;
+            p.sk.res_mod = g.res_mod; p.sk.act = g.act; p.sk.out_f32 = g.out_f32; p.sk.out_f16 = g.out_f16; p.sk.out_split = g.out_split;
+            p.sk.res_f32 = g.res_f32;
+            return gemm_bf16(p, st);
+        }
+    }
     const int rc = gemm_bf16(p, st);
     if (rc != IVLM_OK) return rc;
     const int64_t total = (int64_t)g.M * (g.N >> 2);
@@ -621,10 +635,10 @@ extern "C" size_t ivlm_gemm_splitk_workspace_bytes(int M, int N, int splits) {
     return (size_t)(splits < 1 ? 1 : splits) * (size_t)M * (size_t)N * sizeof(float);
 }
 
-extern "C" int ivlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+static int splitk_entry(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                                      const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N,
                                      int K, int act, int out_f32, int splits, void* workspace, size_t workspace_bytes,
-                                     int flags, ivlm_stream_t stream) {
+                                     int flags, ivlm_stream_t stream, int32_t* counters) {
     ivlm_enter();
     if (flags & IVLM_GEMM_A_F32) return IVLM_ERR_UNSUPPORTED;
     ivlm::GemmArgs g;
@@ -647,5 +661,24 @@ extern "C" int ivlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, 
     g.M = M; g.N = N; g.K = K;
     g.act = act;
     g.out_f32 = out_f32;
-    return ivlm::gemm_bf16_splitk(g, splits, static_cast<float*>(workspace), workspace_bytes, ivlm_stream(stream));
+    return ivlm::gemm_bf16_splitk(g, splits, static_cast<float*>(workspace), workspace_bytes, ivlm_stream(stream), counters);
+}
+
+extern "C" int ivlm_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                     const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N,
+                                     int K, int act, int out_f32, int splits, void* workspace, size_t workspace_bytes,
+                                     int flags, ivlm_stream_t stream) {
+    return splitk_entry(A, lda, W, ldw, C, ldc, bias, residual, ldr, res_mod, M, N, K, act, out_f32, splits, workspace, workspace_bytes,
+                        flags, stream, nullptr);
+}
+
+// ... with the reduction fused into the GEMM launch: `counters` = IVLM_SPLITK_COUNTERS int32 words, zeroed ONCE by the caller (every
+// call leaves them at zero), not shared by launches that may run concurrently (one array per stream).  Same results, bit for bit.
+extern "C" int ivlm_gemm_bf16_splitk_fused(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                           const void* bias, const void* residual, int64_t ldr, int res_mod, int M, int N,
+                                           int K, int act, int out_f32, int splits, void* workspace, size_t workspace_bytes,
+                                           int32_t* counters, int flags, ivlm_stream_t stream) {
+    if (!counters) return IVLM_ERR_INVALID_ARG;
+    return splitk_entry(A, lda, W, ldw, C, ldc, bias, residual, ldr, res_mod, M, N, K, act, out_f32, splits, workspace, workspace_bytes,
+                        flags, stream, counters);
 }

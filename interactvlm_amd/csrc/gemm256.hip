@@ -103,16 +103,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
-                fa[i][kk] = *reinterpret_cast<const bf16x8_t*>(slot + ((offA + i * 2048) ^ (kk << 6)));
+                fa[i][kk] = gemm_frag_read(slot + ((offA + i * 2048) ^ (kk << 6)));
     };
     auto read_b = [&](int nq, const unsigned char* slot) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
-                fb[nq][j][kk] = *reinterpret_cast<const bf16x8_t*>(slot + ((offB + j * 2048) ^ (kk << 6)));
+                fb[nq][j][kk] = gemm_frag_read(slot + ((offB + j * 2048) ^ (kk << 6)));
     };
     auto mfma_quadrant = [&](int mq, int nq) {
+#ifdef IVLM_ABL_NOMFMA
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) IVLM_ABL_MFMA_USE(fb[nq][j][kk], fb[nq][j][kk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) IVLM_ABL_MFMA_USE(fa[i][kk], fa[i][kk]);
+        }
+        return;
+#endif
         if (FP8) {  // the same fragments as bytes: one 16x16x128 e4m3 step instead of two 16x16x32 bf16 steps
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -179,6 +189,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #undef IVLM_PHASE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero-chunk DMAs must not outlive the block's LDS
 
+#ifdef IVLM_ABL_NOEPI
+    if (g.M > 0) {  // (one dummy store per lane keeps the accumulators live)
+        float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sacc == 123.456f) static_cast<float*>(g.C)[tid] = sacc;
+        return;
+    }
+#endif
     // ---- epilogue: whole lines through LDS (gemm_common.h), direct fragment stores for what that does not cover --------------
     if (gemm_whole_lines_ok<OUT_F32>(g, ACT)) {
         __syncthreads();  // every wave is done with the K tiles

@@ -103,14 +103,21 @@ __global__ __launch_bounds__(512, 2) void gemm320_kernel(GemmArgs g) {
 
     auto read_a = [&](const unsigned char* tb, int mq, int kk) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(tb + ((offA + (mq * 4 + i) * 2048) ^ (kk << 6)));
+        for (int i = 0; i < 4; ++i) fa[i] = gemm_frag_read(tb + ((offA + (mq * 4 + i) * 2048) ^ (kk << 6)));
     };
     auto read_w = [&](const unsigned char* tb, int kk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(tb + kABytes + ((offW + j * 2048) ^ (kk << 6)));
-        fw[4] = *reinterpret_cast<const bf16x8_t*>(tb + kABytes + (offW4 ^ (kk << 6)));
+        for (int j = 0; j < 4; ++j) fw[j] = gemm_frag_read(tb + kABytes + ((offW + j * 2048) ^ (kk << 6)));
+        fw[4] = gemm_frag_read(tb + kABytes + (offW4 ^ (kk << 6)));
     };
     auto mfma_rows = [&](int mq) {
+#ifdef IVLM_ABL_NOMFMA
+#pragma unroll
+        for (int j = 0; j < 5; ++j) IVLM_ABL_MFMA_USE(fw[j], fw[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) IVLM_ABL_MFMA_USE(fa[i], fa[i]);
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
@@ -169,6 +176,17 @@ __global__ __launch_bounds__(512, 2) void gemm320_kernel(GemmArgs g) {
     // which every wave stores 32 rows.  (The dispatcher only sends problems for which gemm_whole_lines_ok holds: no per-fragment
     //  fallback here - a second, not fully unrolled loop over the accumulators would index them dynamically and push all 160
     //  registers through scratch.)
+#ifdef IVLM_ABL_NOEPI
+    if (g.M > 0) {  // (one dummy store per lane keeps the accumulators live)
+        float sacc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sacc += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+        if (sacc == 123.456f) static_cast<float*>(g.C)[tid] = sacc;
+        return;
+    }
+#endif
     const int mw = m0 + wr * 128;
     __syncthreads();  // every wave is done with the K tiles
     gemm_store_lines<ACT, OUT_F32, 8, 4, OUT_F32 ? 4 : 8, 5, 0>(g, smem + wave * 16384, mw, n0 + wc * 64, lane, acc);

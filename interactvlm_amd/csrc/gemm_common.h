@@ -72,9 +72,38 @@ __device__ __forceinline__ float gemm_act(float x, int act) {
 // 16 zero bytes: DMA source for the K tail (K % 64 != 0) so that partial tiles contribute nothing
 __device__ __attribute__((aligned(16))) const uint32_t kGemmZeroChunk[4] = {0u, 0u, 0u, 0u};
 
+// ---- ablation switches of the tile GEMMs (per-shape ceiling table, profiles/r05_gemm_ceilings.txt): NEVER defined in the product
+// build; tools/experiments/build_variant.sh compiles gemm.hip / gemm256.hip / gemm320.hip with -DIVLM_ABL_... into a side library.
+//   IVLM_ABL_NODMA   the global -> LDS copies are not issued (the counted waits fall through)
+//   IVLM_ABL_NOLDS   fragments are lane constants instead of LDS reads
+//   IVLM_ABL_NOMFMA  the matrix instructions are replaced by a register use of their operands (keeps the reads alive)
+//   IVLM_ABL_NOEPI   the epilogue stores one dummy value per lane instead of the tile
+// (results of such a library are garbage by construction: timing only)
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+#ifndef IVLM_ABL_NODMA
     __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+#endif
 }
+// one fragment read (ds_read_b128); ablated: a lane-dependent constant the compiler cannot fold into the MFMA chain
+__device__ __forceinline__ bf16x8_t gemm_frag_read(const unsigned char* p) {
+#ifdef IVLM_ABL_NOLDS
+    uint32_t v = (uint32_t)(uintptr_t)p * 0x9e3779b1u | 0x3c003c00u;
+    asm volatile("" : "+v"(v));
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4_t;
+    return __builtin_bit_cast(bf16x8_t, u4_t{v, v, v, v});
+#else
+    return *reinterpret_cast<const bf16x8_t*>(p);
+#endif
+}
+// ablated MFMA: the operands are "used" (so that their reads stay), the accumulator is left alone
+#ifdef IVLM_ABL_NOMFMA
+#define IVLM_ABL_MFMA_USE(a, b)                                                          \
+    do {                                                                                 \
+        auto a_ = (a);                                                                   \
+        auto b_ = (b);                                                                   \
+        asm volatile("" ::"v"(a_), "v"(b_));                                             \
+    } while (0)
+#endif
 
 // XCD-aware, grouped tile raster (see gemm.hip): block id -> tile origin
 __device__ __forceinline__ void gemm_tile_origin(const GemmArgs& g, int BM, int BN, int& m0, int& n0) {
@@ -97,6 +126,70 @@ __device__ __forceinline__ void gemm_tile_origin(const GemmArgs& g, int BM, int 
 // one residual element (bf16 or fp32 stream)
 __device__ __forceinline__ float gemm_residual_at(const GemmArgs& g, const bf16_t* R, int64_t idx) {
     return g.res_f32 ? reinterpret_cast<const float*>(R)[idx] : bf16_to_f32(R[idx]);
+}
+
+// split-K: columns n .. n + 3 of row m - the slices summed in slice order, then bias / activation / residual / output conversion of
+// `g` (the GEMM's REAL arguments).  One function for the reduction launch and for the fused fixup: the same values either way.
+template <bool OUT_F32>
+__device__ __forceinline__ void splitk_finish4(const GemmArgs& g, const float* __restrict__ part, int splits, int m, int n) {
+    const int64_t slice = (int64_t)g.M * g.N;
+    const float* p = part + (int64_t)m * g.N + n;
+    float4 acc = *reinterpret_cast<const float4*>(p);
+    for (int sidx = 1; sidx < splits; ++sidx) {
+        const float4 t = *reinterpret_cast<const float4*>(p + sidx * slice);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (g.bias) v[j] += bf16_to_f32(g.bias[n + j]);
+        v[j] = gemm_act(v[j], g.act);
+        if (g.residual) {
+            const int64_t rrow = g.res_mod > 0 ? (m % g.res_mod) : m;
+            v[j] += gemm_residual_at(g, g.residual, rrow * g.ldr + n + j);
+        }
+    }
+    const int64_t o = (int64_t)m * g.ldc + n;
+    if (OUT_F32 && g.out_split) {
+        uint32_t h0, l0, h1, l1;
+        split_16x2(v[0], v[1], h0, l0, g.out_f16);
+        split_16x2(v[2], v[3], h1, l1, g.out_f16);
+        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o + g.c_lo) = make_uint2(l0, l1);
+    } else if (OUT_F32) *reinterpret_cast<float4*>(static_cast<float*>(g.C) + o) = make_float4(v[0], v[1], v[2], v[3]);
+    else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(g.C) + o) = make_uint2(pack_16x2(v[0], v[1], g.out_f16), pack_16x2(v[2], v[3], g.out_f16));
+}
+
+// Fused split-K fixup (SplitKFused): called by EVERY thread of a block after its partial tile has been stored.  The block counts its
+// arrival; the last one of the tile reduces it.  Release / acquire at agent scope (the slices of a tile run on different XCDs, whose
+// L2s are not coherent with each other): fence -> barrier -> one atomic per block; the last block fences again before it reads.
+template <int BM, int BN, int THREADS>
+__device__ __forceinline__ void splitk_fixup(const GemmArgs& g, int m0, int n0) {
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = atomicAdd(g.sk.count + blockIdx.x, 1);
+        const int last = old == g.batch - 1;
+        if (last) g.sk.count[blockIdx.x] = 0;  // every arrival is in: leave the counter at zero for the next launch
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    GemmArgs f = g;  // the real epilogue (uniform values)
+    f.C = g.sk.C; f.bias = g.sk.bias; f.residual = g.sk.residual;
+    f.ldc = g.sk.ldc; f.ldr = g.sk.ldr; f.c_lo = g.sk.c_lo;
+    f.res_mod = g.sk.res_mod; f.act = g.sk.act; f.out_f32 = g.sk.out_f32; f.out_f16 = g.sk.out_f16; f.out_split = g.sk.out_split;
+    f.res_f32 = g.sk.res_f32;
+    const float* part = static_cast<const float*>(g.C);
+    constexpr int kQ = BN / 4;
+    for (int i = threadIdx.x; i < BM * kQ; i += THREADS) {
+        const int m = m0 + i / kQ, n = n0 + (i % kQ) * 4;
+        if (m >= g.M || n >= g.N) continue;  // (N % 4 == 0)
+        if (f.out_f32) splitk_finish4<true>(f, part, g.batch, m, n);
+        else splitk_finish4<false>(f, part, g.batch, m, n);
+    }
 }
 
 // bias + activation of one accumulator fragment (the lane owns columns n .. n+3; N % 4 == 0, n < N): the value part of the

@@ -284,7 +284,18 @@ __global__ __launch_bounds__(64 * kWavesM, kWavesM == 16 ? 4 : 6) void gemv1_p12
     const float xs = __builtin_ldexpf(1.0f, kXScaleExp);
     float ssq = 0.0f;
     uint32_t* xw = reinterpret_cast<uint32_t*>(smem);
+#ifdef IVLM_ABL_XSTAGE  // (ablation, never in the product build: the upper bound of what producer-side x staging could save -
+                        //  no x / gamma loads, no hi + lo + lo2 split, no sum of squares; the planes get a constant)
+    for (int c = threadIdx.x; c < (K >> 2) && !PARTS; c += 64 * kWavesM) {
+        *reinterpret_cast<u32x2_t*>(xw + 2 * c) = u32x2_t{0x5f805f80u, 0x5f805f80u};
+        *reinterpret_cast<u32x2_t*>(xw + (K >> 1) + 2 * c) = u32x2_t{0u, 0u};
+        *reinterpret_cast<u32x2_t*>(xw + K + 2 * c) = u32x2_t{0u, 0u};
+        ssq = 1.0f;
+    }
+    for (int c = threadIdx.x; c < (PARTS ? (K >> 2) : 0); c += 64 * kWavesM) {
+#else
     for (int c = threadIdx.x; c < (K >> 2); c += 64 * kWavesM) {
+#endif
         f32x4v_t xv4;
         if (PARTS) {
             const int k = c << 2, hd = k / p.pD, d0 = k - hd * p.pD, ps = p.pD + 4;

@@ -7,6 +7,20 @@ namespace ivlm {
 // ---- epilogue activation codes (also exposed through the C ABI) --------------------------------
 enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICK_GELU = 2, ACT_RELU = 3, ACT_SILU = 4, ACT_SWIGLU = 5, ACT_SIGMOID = 6 };
 
+// Fused split-K (gemm_bf16_splitk with a counter array): blockIdx.z = K slice.  Every block stores its fp32 partial tile to the
+// workspace, then counts its arrival on the tile's counter; the block that arrives LAST sums the slices of that tile in slice order
+// (the arithmetic of splitk_reduce_kernel: bit-identical) and applies this epilogue - no reduction launch, no second pass over the
+// whole product.  `count` != null switches it on; the counters are zero on entry and left at zero.
+struct SplitKFused {
+    int32_t* count = nullptr;  // [tiles of one slice]
+    void* C = nullptr;         // the GEMM's real output and epilogue (the kernel's own C / bias / ... describe the partials)
+    const bf16_t* bias = nullptr;
+    const bf16_t* residual = nullptr;
+    int64_t ldc = 0, ldr = 0, c_lo = 0;
+    int res_mod = 0, act = 0, out_f32 = 0, out_f16 = 0, out_split = 0, res_f32 = 0;
+};
+constexpr int kSplitKCounters = 4096;  // counters a fused split-K launch may use (tiles per K slice)
+
 struct GemmArgs {
     const bf16_t* A = nullptr;  // activations [M,K], row stride lda (elements); float when a_f32 (skinny paths only)
     const bf16_t* W = nullptr;  // weights     [N,K], row stride ldw  (nn.Linear layout)
@@ -61,6 +75,7 @@ struct GemmArgs {
     // GEMV path only: fuse the preceding RMSNorm, out = W . (x * rsqrt(mean(x^2)+eps) * rms_w)
     const bf16_t* rms_w = nullptr;
     float rms_eps = 0.0f;
+    SplitKFused sk;  // (set by gemm_bf16_splitk only)
 };
 
 // bf16 x bf16 -> fp32-accumulate MFMA GEMM with fused bias/activation/residual epilogue.
@@ -68,8 +83,9 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st);
 // 256x256 tile with the 8-phase ping-pong K loop (gemm256.hip); same contract as gemm_bf16
 int gemm_bf16_256p(const GemmArgs& g, hipStream_t st);
 int gemm_bf16_320p(const GemmArgs& g, hipStream_t st);  // 256 x 320 tiles (gemm320.hip)
-// split-K variant for small M (fp32 partials in `workspace`, >= splits*M*N*4 bytes); act != SWIGLU
-int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st);
+// split-K variant for small M (fp32 partials in `workspace`, >= splits*M*N*4 bytes); act != SWIGLU.  counters != null
+// (kSplitKCounters zeroed int32, left at zero): the reduction is fused into the GEMM launch (SplitKFused), else a second launch
+int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_bytes, hipStream_t st, int32_t* counters = nullptr);
 // nn.Linear dispatch: GEMV (M <= 8) or the MFMA tile kernel
 int linear_bf16(const GemmArgs& g, hipStream_t st);
 

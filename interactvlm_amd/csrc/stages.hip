@@ -57,6 +57,20 @@ struct Carver {
     }
 };
 
+// The arrival counters of the fused split-K GEMMs (SplitKFused, kernels.h) live in the LAST 16 KB of a sequencer's split-K region:
+// every stage call zeroes them once (sk_counters_zero, right after the region is carved) and the GEMMs leave them at zero; a
+// product whose partials would reach into them takes the two-launch form.  The workspace sizes are unchanged.
+int32_t* sk_counters(float* sk, size_t skb, size_t partial_bytes) {
+    const size_t cb = (size_t)kSplitKCounters * 4;
+    if (!sk || skb < partial_bytes + cb + 16) return nullptr;
+    return reinterpret_cast<int32_t*>(reinterpret_cast<char*>(sk) + ((skb - cb) & ~(size_t)15));
+}
+int sk_counters_zero(float* sk, size_t skb, hipStream_t st) {
+    int32_t* c = sk_counters(sk, skb, 0);
+    if (c) IVLM_HIP_TRY(hipMemsetAsync(c, 0, (size_t)kSplitKCounters * 4, st));
+    return IVLM_OK;
+}
+
 int lin(const void* A, int a_f32, int64_t lda, const void* W, int64_t ldw, void* C, int out_f32, int64_t ldc, const void* res,
         int res_f32, int M, int N, int K, int act, const void* rms_w, float eps, float* splitk_ws, size_t splitk_bytes,
         hipStream_t st, int f16 = 0, int out_f16 = 0) {
@@ -76,7 +90,8 @@ int lin(const void* A, int a_f32, int64_t lda, const void* W, int64_t ldw, void*
     g.rms_w = static_cast<const bf16_t*>(rms_w);
     g.rms_eps = eps;
     const int sp = a_f32 ? 1 : gemm_splitk_choice(M, N, K, act, rms_w != nullptr);
-    if (sp > 1 && (ldc & 3) == 0) return gemm_bf16_splitk(g, sp, splitk_ws, splitk_bytes, st);
+    if (sp > 1 && (ldc & 3) == 0)
+        return gemm_bf16_splitk(g, sp, splitk_ws, splitk_bytes, st, sk_counters(splitk_ws, splitk_bytes, (size_t)sp * M * N * 4));
     return linear_bf16(g, st);
 }
 
@@ -127,6 +142,7 @@ static int llama_prefill(const ivlm_llama_cfg* c, const ivlm_llama_layer* layers
     float* xb = static_cast<float*>(cv.take((size_t)T * Hd * 4));
     const size_t skb = (size_t)8 * T * std::max(Hd, I) * 4;
     float* sk = static_cast<float*>(cv.take(skb));
+    if (int rc0 = sk_counters_zero(sk, skb, st)) return rc0;
     if (!cv.ok) return IVLM_ERR_WORKSPACE;
     const int64_t cache_layer = (int64_t)c->max_len * Hd;
     const float* x = x_in;
@@ -396,7 +412,8 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int ou
     g.out_rows = out_rows;
     g.a_rows = a_rows;
     const int sp = (out_rows || a_rows) ? 1 : gemm_splitk_choice(M, N, K, act, 0);
-    if (sp > 1 && (ldc & 3) == 0 && sk && skb >= (size_t)sp * M * N * 4) return gemm_bf16_splitk(g, sp, sk, skb, st);
+    if (sp > 1 && (ldc & 3) == 0 && sk && skb >= (size_t)sp * M * N * 4)
+        return gemm_bf16_splitk(g, sp, sk, skb, st, sk_counters(sk, skb, (size_t)sp * M * N * 4));
     return linear_bf16(g, st);
 }
 
@@ -427,6 +444,7 @@ static int clip_encode(const ivlm_clip_cfg* c, const ivlm_clip_head* hd, const i
     bf16_t* hh = static_cast<bf16_t*>(cv.take((size_t)R * I * 2));
     const size_t skb = (size_t)8 * R * std::max(3 * Hd, I) * 4;
     float* sk = static_cast<float*>(cv.take(skb));
+    if (int rc0 = sk_counters_zero(sk, skb, st)) return rc0;
     int32_t* prow = static_cast<int32_t*>(cv.take((size_t)R * 4));
     if (!cv.ok) return IVLM_ERR_WORKSPACE;
     int rc;
@@ -908,6 +926,9 @@ extern "C" int ivlm_sam_decode(const ivlm_sam_dec* w, int V, int grid, int n_tex
     x.st = st; x.stream = stream; x.cv = &cv;
     x.skb = (size_t)8 * V * Nt * std::max(w->layers[0].lin1.n, C) * 4;
     x.sk = static_cast<float*>(x.take(x.skb));
+    if (x.sk) {
+        if (int rc0 = sk_counters_zero(x.sk, x.skb, st)) return rc0;
+    }
     // tokens = [iou token ; mask tokens ; text embeds], the same set for every view
     float* tokens = static_cast<float*>(x.take((size_t)Nt * C * 4));
     float* query_pe = static_cast<float*>(x.take((size_t)V * Nt * C * 4));

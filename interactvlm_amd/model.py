@@ -353,8 +353,8 @@ class InteractVLMForCausalLM:
     def _input_embeds(self, ids_row, image_features):
         """prepare_inputs_labels_for_multimodal, mm_use_im_start_end branch (llava_arch.py:185-208):
         embed_tokens gather with the single IMAGE_TOKEN_INDEX replaced by the 256 projected CLIP rows."""
+        pos = int((ids_row.cpu() == IMAGE_TOKEN_INDEX).nonzero()[0])  # (host ids: no device round trip behind the CLIP launch)
         ids = ids_row.to(self.device)
-        pos = int((ids == IMAGE_TOKEN_INDEX).nonzero()[0])
         n_img = image_features.shape[0]
         L = ids.numel()
         x = torch.empty(L - 1 + n_img, self.config.llama.hidden, dtype=F32, device=self.device)  # fp32 residual stream
@@ -379,14 +379,17 @@ class InteractVLMForCausalLM:
         return [i for i in ids if i is not None]
 
     def _seg_rows(self, ids, extra_false_col):
-        """Boolean row mask over the (len(ids) - 1 [+1]) + img_emb_len hidden rows (InteractVLM.py:331-341/545-549)."""
+        """Boolean row mask over the (len(ids) - 1 [+1]) + img_emb_len hidden rows (InteractVLM.py:331-341/545-549).
+        Computed on the HOST (the ids of evaluate() are host values; a device tensor is read back once): no device round trip
+        between the decode loop and the mask decoder - the tail of evaluate() is enqueued while the last decode steps still run."""
+        ids = ids.cpu()
         m = torch.zeros_like(ids, dtype=torch.bool)
         for s in self._seg_token_ids():
             m |= ids == s
         m = m[1:]
         if extra_false_col:
-            m = torch.cat([m, torch.zeros(1, dtype=torch.bool, device=m.device)])
-        return torch.cat([torch.zeros(self.img_emb_len, dtype=torch.bool, device=m.device), m])
+            m = torch.cat([m, torch.zeros(1, dtype=torch.bool)])
+        return torch.cat([torch.zeros(self.img_emb_len, dtype=torch.bool), m])
 
     def _mask_decoder_for(self, ds_name):
         """ModifiedSAM.forward's decoder choice (InteractVLM.py:46-54): with '-DifDe' the human decoder serves 'hcontact' samples,
@@ -405,7 +408,8 @@ class InteractVLMForCausalLM:
         rows the fusion head attends to when ``use_fusion`` (ModifiedSAM.forward, InteractVLM.py:41-44)."""
         if getattr(self, "_in_guard", False):  # (evaluate / evaluate_batch under the fp16 exponent-range guard: see _guarded)
             self._finite_flags.append(torch.isfinite(hidden).all() & torch.isfinite(image_embeddings).all())
-        rows = rows_mask.nonzero().flatten()
+        rows = rows_mask.cpu().nonzero().flatten()  # (host mask: see _seg_rows)
+        ids = ids.cpu()
         V = self.multiview_channels
         if rows.numel() == 0:
             return torch.zeros((0,) + tuple(original_size), dtype=torch.float32, device=self.device), None
@@ -499,7 +503,7 @@ class InteractVLMForCausalLM:
         forced_new_tokens (extension for weight-free benchmarking): feed these ids instead of the argmax (the
         argmax/lm_head work is still done every step), like the reference's inference_type='forward'."""
         feats = self.encode_images(images_clip)[0]
-        ids = input_ids[0].to(self.device)
+        ids = input_ids[0]
         x = self._input_embeds(ids, feats)
         T0 = x.shape[0]
         n_max = len(forced_new_tokens) if forced_new_tokens is not None else max_new_tokens
@@ -798,7 +802,7 @@ class InteractVLMForCausalLM:
         outs, lows = [], []
         ctypes = [contact_type] * B if isinstance(contact_type, str) else list(contact_type)
         for b, (output_ids, hidden) in enumerate(gens):
-            rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)
+            rows = self._seg_rows(output_ids[0], extra_false_col=False)
             pm, _ = self._decode_sample(hidden, rows, output_ids[0], cam_params[b], embs[b], resize_list[b],
                                         original_size_list[b], ds_name=ctypes[b], llava_features=self._eval_llava_features(hidden, 0))
             outs.append({"output_ids": output_ids, "pred_masks": [pm], "pred_contact_3d": None})
@@ -878,7 +882,7 @@ class InteractVLMForCausalLM:
                        box, side, after_prefill):
         output_ids, hidden = self.generate(images_clip, input_ids, max_new_tokens, eos_token_id, forced_new_tokens,
                                            after_prefill=after_prefill)
-        rows = self._seg_rows(output_ids[0].to(self.device), extra_false_col=False)
+        rows = self._seg_rows(output_ids[0], extra_false_col=False)
         image_embeddings = box["emb"]
         if side is not None:
             torch.cuda.current_stream(self.device).wait_event(box["ev"])

@@ -5,6 +5,8 @@ requires CUDA(HIP) tensors and raises if the extension is missing — there is n
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -316,7 +318,35 @@ ACT = {"none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "swiglu": 5,
 BF16 = torch.bfloat16
 
 
-SPLITK = True  # small-M GEMMs (prefill, CLIP): cut K so that >= ~3 tiles per CU are in flight
+SPLITK = os.environ.get("IVLM_SPLITK", "1") != "0"  # small-M GEMMs (prefill, CLIP): cut K so that >= ~3 tiles per CU are in flight
+# fused reduction (the tile's last block sums the slices inside the GEMM launch: ivlm_gemm_bf16_splitk_fused) - bit-identical, one launch
+# instead of two, and 2 - 3 x SLOWER on MI355X (round 5: prefill 12.0 -> 26.3 ms; down_proj 64 -> 192 us): the agent-scope release /
+# acquire every block needs (L2 write-back + invalidate: the slices of a tile run on different XCDs) costs far more than the reduction
+# launch it saves.  Opt-in, kept for the record and for single-XCD parts.
+SPLITK_FUSED = os.environ.get("IVLM_SPLITK_FUSED", "0") == "1"
+_SPLITK_CNT = {}
+_SPLITK_CNT_CAPTURE = {}
+
+
+def _splitk_counters(device):
+    """IVLM_SPLITK_COUNTERS zeroed int32 words: the arrival counters of the fused split-K GEMMs (every launch leaves them at zero).
+    Launches that may run concurrently must not share an array, so there is one per (device, stream).  While a HIP graph is being
+    captured the array is created INSIDE the capture (memory of the graph's own pool, one array per capture, its zero fill is
+    a node of the graph): two graphs - which may be replayed on different streams at the same time - never share counters, and
+    the launches inside one captured stream are ordered."""
+    if torch.cuda.is_current_stream_capturing():
+        key = (device.index, _stream())
+        c = _SPLITK_CNT_CAPTURE.get(key)
+        if c is None:
+            c = _SPLITK_CNT_CAPTURE[key] = torch.zeros(4096, dtype=torch.int32, device=device)
+        return c
+    if _SPLITK_CNT_CAPTURE:
+        _SPLITK_CNT_CAPTURE.clear()  # (no capture in progress: the next capture gets arrays of its own)
+    key = (device.index, _stream())
+    c = _SPLITK_CNT.get(key)
+    if c is None:
+        c = _SPLITK_CNT[key] = torch.zeros(4096, dtype=torch.int32, device=device)
+    return c
 
 
 def _splitk_choice(M, N, K, act, rms):
@@ -401,10 +431,17 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     splits = _splitk_choice(M, N, K, act, rms) if (x.dtype in (BF16, F16) and out_rows is None and a_rows is None) else 1
     if splits > 1 and o2.stride(0) % 4 == 0:
         ws = torch.empty(splits * M * N, dtype=F32, device=x.device)  # caching allocator: stream-safe
-        call = lambda: check(lib.ivlm_gemm_bf16_splitk(
-            x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
-            _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, splits, ws.data_ptr(),
-            ws.numel() * 4, flags, _stream()), "gemm_bf16_splitk")
+        if SPLITK_FUSED:  # reduction inside the GEMM launch (the tile's last block sums its slices): same values, one launch
+            cnt = _splitk_counters(x.device)
+            call = lambda: check(lib.ivlm_gemm_bf16_splitk_fused(
+                x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
+                _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, splits, ws.data_ptr(),
+                ws.numel() * 4, cnt.data_ptr(), flags, _stream()), "gemm_bf16_splitk_fused")
+        else:
+            call = lambda: check(lib.ivlm_gemm_bf16_splitk(
+                x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
+                _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, splits, ws.data_ptr(),
+                ws.numel() * 4, flags, _stream()), "gemm_bf16_splitk")
     if TIMER.enabled:  # work = algorithmic FLOPs (MFMA path) or weight bytes (GEMV path)
         if M > 16:  # (a split A operand doubles the MFMA work of the same algorithmic product: counted once)
             TIMER.time("gemm_bf16_mfma", 2.0 * M * N * K, call, tag=(M, N, K, act, "split" if a_split else ""))

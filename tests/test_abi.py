@@ -20,7 +20,7 @@ def test_builds_and_exports_every_declared_symbol():
 
 def test_identity_and_error_strings():
     lib = _lib.load()
-    assert lib.ivlm_abi_version() == 4  # (bumped whenever a struct / buffer contract of include/ivlm_hip.h changes: see core.hip)
+    assert lib.ivlm_abi_version() == 5  # (bumped whenever a struct / buffer contract of include/ivlm_hip.h changes: see core.hip)
     assert lib.ivlm_build_arch() == b"gfx950"
     assert lib.ivlm_error_string(0) == b"ok"
     assert b"workspace" in lib.ivlm_error_string(-2)

@@ -811,3 +811,35 @@ def test_gemv_bf12_activation_range(hip_lib, cuda, big):
     ym = ops.linear_bf12(xm, ops.PackedBf12(w))
     assert bool(torch.isfinite(ym).all())
     assert float((ym.double() - xm.double() @ w.double().t()).abs().max()) / (2 * scale) < 3e-5
+
+
+@pytest.mark.parametrize("M,N,K,res", [(330, 4096, 4096, True), (257, 1024, 4096, True), (330, 12288, 4096, False), (40, 256, 1024, False)])
+def test_fused_splitk_equals_two_launch_splitk(hip_lib, cuda, M, N, K, res):
+    """ivlm_gemm_bf16_splitk_fused (the tile's last-arriving block sums the K slices inside the GEMM launch; arrival counters that
+    every launch leaves at zero) == ivlm_gemm_bf16_splitk (a reduction launch) BIT FOR BIT - the same slices summed in the same order
+    - on fp16 and bf16 operands, with fp32-residual / 16-bit outputs, repeatedly on the same counters."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(M + N)
+    for dt in (torch.float16, torch.bfloat16):
+        x = torch.randn(M, K, generator=g).to(dt).to(cuda)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).to(cuda)
+        r = torch.randn(M, N, generator=g).to(cuda) if res else None
+        kw = dict(residual=r, out_f32=True) if res else (dict(out_f16=True) if dt == torch.float16 else {})
+        if ops._splitk_choice(M, N, K, "none", None) < 2:
+            pytest.skip("shape not split")
+        prev = ops.SPLITK_FUSED
+        try:
+            ops.SPLITK_FUSED = False
+            ref = ops.linear(x, w, **kw)
+            ops.SPLITK_FUSED = True
+            for _ in range(3):
+                got = ops.linear(x, w, **kw)
+                assert torch.equal(got, ref)
+            assert int(ops._splitk_counters(x.device).abs().sum()) == 0  # left at zero
+        finally:
+            ops.SPLITK_FUSED = prev
+    ref64 = x.double() @ w.double().t() + (r.double() if res else 0)
+    assert float((got.double() - ref64).abs().max()) / float(ref64.abs().max()) < 1e-2

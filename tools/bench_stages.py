@@ -48,7 +48,7 @@ def main():
         ev[3].record(main_s)
         if with_sam:
             main_s.wait_event(sam_done)
-        rows = m._seg_rows(out_ids[0].to(dev), extra_false_col=False)
+        rows = m._seg_rows(out_ids[0], extra_false_col=False)
         pm, _ = m._decode_sample(hidden, rows, out_ids[0], cams[0], box["emb"], (S, S), (S, S))
         pc = m.human_3d_contact_predictor([pm])
         pc.cpu()
