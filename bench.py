@@ -445,9 +445,11 @@ def main():
             return torch.zeros(0, 6890, device=dev)
         icb = torch.cat([dp_image(i)[0] for i in idx])
         imb = torch.cat([dp_image(i)[1] for i in idx])
-        outs = model.evaluate_batch(icb, imb, [ids[0]] * len(idx), [cams[0]] * len(idx), [(S, S)] * len(idx),
-                                    [(S, S)] * len(idx), contact_type="hcontact", forced_new_tokens=forced)
-        return torch.cat([o["pred_contact_3d"] for o in outs])
+        # deferred: CLIP / prefill / batched decode and the SAM encoder of this chunk are enqueued now, the tail (16 mask decoders,
+        # the lift) when evaluate_sharded has begun the NEXT chunk - its encoder then runs under this chunk's tail
+        fin = model.evaluate_batch(icb, imb, [ids[0]] * len(idx), [cams[0]] * len(idx), [(S, S)] * len(idx),
+                                   [(S, S)] * len(idx), contact_type="hcontact", forced_new_tokens=forced, deferred=True)
+        return lambda: torch.cat([o["pred_contact_3d"] for o in fin()])
 
     def step_dp64(r=None, w=None):
         allc = evaluate_sharded(N_IMG, PER_CALL, dp_chunk, rank=r, world=w)

@@ -46,13 +46,23 @@ def gather_contacts(local: torch.Tensor, n_items: int | None = None, group=None)
 
 def evaluate_sharded(n_items: int, per_call: int, eval_chunk, rank: int | None = None, world: int | None = None, group=None):
     """The data-parallel job of BASELINE.json configs[2] (reference: evaluate.py:202-210, 346): this rank's contiguous shard
-    of the items [0, n_items) is evaluated ``per_call`` items at a time by ``eval_chunk(indices) -> [len(indices), Nv]``,
-    then ONE all-gather brings every rank the [n_items, Nv] result in input order."""
+    of the items [0, n_items) is evaluated ``per_call`` items at a time by ``eval_chunk(indices) -> [len(indices), Nv]`` (or a
+    function returning that: a deferred chunk, see below), then ONE all-gather brings every rank the [n_items, Nv] result in input order."""
     ini = dist.is_available() and dist.is_initialized()
     rank = (dist.get_rank(group) if ini else 0) if rank is None else rank
     world = (dist.get_world_size(group) if ini else 1) if world is None else world
     lo, hi = shard_range(n_items, rank, world)
-    parts = [eval_chunk(list(range(i, min(i + per_call, hi)))) for i in range(lo, hi, per_call)]
+    # eval_chunk may return its [len(indices), Nv] result or a FUNCTION that returns it (a deferred chunk: its independent work is
+    # already enqueued - InteractVLMForCausalLM.evaluate_batch(deferred=True)): chunk c + 1 is begun before chunk c is finished,
+    # so that the next chunk's SAM encoder runs under the previous chunk's mask-decoder launches
+    parts, pending = [], None
+    for i in range(lo, hi, per_call):
+        r = eval_chunk(list(range(i, min(i + per_call, hi))))
+        if pending is not None:
+            parts.append(pending() if callable(pending) else pending)
+        pending = r
+    if pending is not None:
+        parts.append(pending() if callable(pending) else pending)
     if parts:
         local = torch.cat(parts, 0)
     else:  # an empty tail shard still takes part in the collective

@@ -230,33 +230,44 @@ class InteractVLMForCausalLM:
         self._finite_flags = []
         try:
             out = fn(*args, **kwargs)
-            outs = out if isinstance(out, list) else [out]
-            flags = self._finite_flags + [torch.isfinite(o[k]).all() for o in outs
-                                          for k in ("pred_contact_3d", "pred_human_3d_contact", "pred_object_3d_contact",
-                                                    "pred_object_3d_afford") if o.get(k) is not None]
-            if flags and not bool(torch.stack(flags).all()):
-                import warnings
-
-                if supplied_embeddings is not None:
-                    embs = supplied_embeddings if isinstance(supplied_embeddings, (list, tuple)) else [supplied_embeddings]
-                    if not all(bool(torch.isfinite(e).all()) for e in embs):
-                        raise ops.IvlmError("image_embeddings passed by the caller are not finite (an fp16-mode encoder pass that "
-                                            "overflowed?): re-encode them, e.g. model.precompute_visual_embs(views) - which checks")
-                warnings.warn(f"non-finite contacts in precision mode {self.precision!r} (an activation left fp16's exponent "
-                              "range): this call is recomputed with bf16 operands; consider model.set_precision('bf16')")
-                mode, packed = self.precision, self.llm.decode_packed
-                self.llm.decode_packed = False
-                self.set_precision("bf16")
-                try:
-                    out = fn(*args, **kwargs)
-                finally:
-                    self.llm.decode_packed = packed
-                    self.set_precision(mode)
-                for o in (out if isinstance(out, list) else [out]):
-                    o["recomputed_in_bf16"] = True
+            if not self._guard_ok(out, supplied_embeddings):
+                out = self._recompute_bf16(lambda: fn(*args, **kwargs))
             return out
         finally:
             self._in_guard = False
+
+    def _guard_ok(self, out, supplied_embeddings=None):
+        """the one flag of a guarded call (tower outputs collected by _decode_sample + every contact tensor of the result finite);
+        non-finite embeddings that the CALLER supplied raise"""
+        outs = out if isinstance(out, list) else [out]
+        flags = self._finite_flags + [torch.isfinite(o[k]).all() for o in outs
+                                      for k in ("pred_contact_3d", "pred_human_3d_contact", "pred_object_3d_contact",
+                                                "pred_object_3d_afford") if o.get(k) is not None]
+        if not flags or bool(torch.stack(flags).all()):
+            return True
+        if supplied_embeddings is not None:
+            embs = supplied_embeddings if isinstance(supplied_embeddings, (list, tuple)) else [supplied_embeddings]
+            if not all(bool(torch.isfinite(e).all()) for e in embs):
+                raise ops.IvlmError("image_embeddings passed by the caller are not finite (an fp16-mode encoder pass that "
+                                    "overflowed?): re-encode them, e.g. model.precompute_visual_embs(views) - which checks")
+        return False
+
+    def _recompute_bf16(self, fn):
+        import warnings
+
+        warnings.warn(f"non-finite contacts in precision mode {self.precision!r} (an activation left fp16's exponent "
+                      "range): this call is recomputed with bf16 operands; consider model.set_precision('bf16')")
+        mode, packed = self.precision, self.llm.decode_packed
+        self.llm.decode_packed = False
+        self.set_precision("bf16")
+        try:
+            out = fn()
+        finally:
+            self.llm.decode_packed = packed
+            self.set_precision(mode)
+        for o in (out if isinstance(out, list) else [out]):
+            o["recomputed_in_bf16"] = True
+        return out
 
     def _finite_or_bf16(self, fn):
         """tensor-returning encoder entry points under the fp16 exponent-range guard: a non-finite result is recomputed with bf16
@@ -742,7 +753,7 @@ class InteractVLMForCausalLM:
 
     def evaluate_batch(self, images_clip, images, input_ids_list, cam_params, resize_list, original_size_list,
                        contact_type="hcontact", max_new_tokens=32, forced_new_tokens=None, eos_token_id=2,
-                       lift2d_dict_path=None, image_embeddings=None):
+                       lift2d_dict_path=None, image_embeddings=None, deferred=False):
         """``evaluate`` for B images in one call: images_clip [B,3,h,w], images [B,V,3,S,S], one prompt per image.
         The SAM encoder of every image runs on the side stream while the B sequences decode together; the masks of all
         images are lifted in one launch.  -> [{'output_ids','pred_masks','pred_contact_3d'}] * B, each equal to what
@@ -752,31 +763,61 @@ class InteractVLMForCausalLM:
         may then be lists, one entry per prompt.
         image_embeddings: pre-computed SAM embeddings, one [V, g*g, 256] tensor for all samples (the four
         canonical body renders of hcontact are the same for every image) or a list of B; ``images`` is then not encoded."""
-        if self._guard_applies():  # (fp16 exponent range: see _guarded)
-            return self._guarded(self.evaluate_batch, (images_clip, images, input_ids_list, cam_params, resize_list,
-                                                       original_size_list, contact_type, max_new_tokens, forced_new_tokens,
-                                                       eos_token_id, lift2d_dict_path, image_embeddings), {},
-                                 supplied_embeddings=image_embeddings)
+        # deferred=True: everything that does not depend on the encoder is ENQUEUED now (SAM encoder on the side stream, CLIP +
+        # prefill + the batched decode loop on the caller's stream) and a function is returned that enqueues the tail (mask decoders,
+        # lift) and returns the results.  A caller with several chunks begins chunk c + 1 before it finishes chunk c
+        # (dist.evaluate_sharded, and the > 16 split below): the side stream then runs encoder after encoder without waiting for
+        # the ~35 ms of tiny mask-decoder launches of the previous chunk, which run under it.
+        args = (images_clip, images, input_ids_list, cam_params, resize_list, original_size_list, contact_type, max_new_tokens,
+                forced_new_tokens, eos_token_id, lift2d_dict_path, image_embeddings)
         B = len(input_ids_list)
-        if B > 16:  # larger batches run as consecutive calls of <= 16 sequences (the decode kernels' row limit)
+        if B > 16:  # larger batches run as consecutive (pipelined) calls of <= 16 sequences (the decode kernels' row limit)
             if images_clip.shape[0] == 1:
                 raise ops.IvlmError("evaluate_batch: more than 16 prompts about ONE picture are not supported")
-            outs = []
+            subs = []
             for lo in range(0, B, 16):
                 hi = min(lo + 16, B)
                 fn = forced_new_tokens
                 if fn is not None and isinstance(fn[0], (list, tuple)):
                     fn = fn[lo:hi]
                 emb = image_embeddings[lo:hi] if isinstance(image_embeddings, (list, tuple)) else image_embeddings
-                outs += self.evaluate_batch(images_clip[lo:hi], None if images is None else images[lo:hi], input_ids_list[lo:hi],
-                                            cam_params[lo:hi],
-                                            resize_list[lo:hi], original_size_list[lo:hi],
-                                            contact_type if isinstance(contact_type, str) else contact_type[lo:hi], max_new_tokens,
-                                            fn, eos_token_id,
-                                            lift2d_dict_path[lo:hi] if isinstance(lift2d_dict_path, (list, tuple)) else lift2d_dict_path,
-                                            emb)
-            return outs
+                subs.append((images_clip[lo:hi], None if images is None else images[lo:hi], input_ids_list[lo:hi], cam_params[lo:hi],
+                             resize_list[lo:hi], original_size_list[lo:hi],
+                             contact_type if isinstance(contact_type, str) else contact_type[lo:hi], max_new_tokens, fn, eos_token_id,
+                             lift2d_dict_path[lo:hi] if isinstance(lift2d_dict_path, (list, tuple)) else lift2d_dict_path, emb))
+
+            def finish_all():
+                outs, pending = [], None
+                for sub in subs:
+                    nxt_ = self.evaluate_batch(*sub, deferred=True)
+                    if pending is not None:
+                        outs.extend(pending())
+                    pending = nxt_
+                outs.extend(pending())
+                return outs
+            return finish_all if deferred else finish_all()
+        guard = self._guard_applies()  # (fp16 exponent range: see _guarded)
+        st = self._evaluate_batch_begin(*args)
+
+        def finish():
+            if not guard:
+                return self._evaluate_batch_finish(st)
+            self._in_guard = True
+            self._finite_flags = []
+            try:
+                outs = self._evaluate_batch_finish(st)
+                if not self._guard_ok(outs, image_embeddings):
+                    outs = self._recompute_bf16(lambda: self.evaluate_batch(*args))
+                return outs
+            finally:
+                self._in_guard = False
+        return finish if deferred else finish()
+
+    def _evaluate_batch_begin(self, images_clip, images, input_ids_list, cam_params, resize_list, original_size_list,
+                              contact_type, max_new_tokens, forced_new_tokens, eos_token_id, lift2d_dict_path, image_embeddings):
+        B = len(input_ids_list)
         main = torch.cuda.current_stream(self.device)
+        ev = allv = None
         if image_embeddings is not None:
             embs = list(image_embeddings) if isinstance(image_embeddings, (list, tuple)) else [image_embeddings] * B
             gens = self.generate_batch(images_clip, input_ids_list, max_new_tokens, eos_token_id, forced_new_tokens)
@@ -793,12 +834,21 @@ class InteractVLMForCausalLM:
                 allv = self.model.visual_model.image_encoder(
                     images.to(self.device).reshape((B * V_,) + tuple(images.shape[2:])))
                 embs = [allv[b * V_: (b + 1) * V_] for b in range(B)]
-                ev = torch.cuda.Event()
-                ev.record(side)
+                if side is not main:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
             gens = self.generate_batch(images_clip, input_ids_list, max_new_tokens, eos_token_id, forced_new_tokens)
-            if side is not main:
-                main.wait_event(ev)
-                allv.record_stream(main)
+        return dict(B=B, gens=gens, embs=embs, ev=ev, allv=allv, cam_params=cam_params, resize_list=resize_list,
+                    original_size_list=original_size_list, contact_type=contact_type, lift2d_dict_path=lift2d_dict_path)
+
+    def _evaluate_batch_finish(self, st):
+        B, gens, embs = st["B"], st["gens"], st["embs"]
+        cam_params, resize_list, original_size_list = st["cam_params"], st["resize_list"], st["original_size_list"]
+        contact_type, lift2d_dict_path = st["contact_type"], st["lift2d_dict_path"]
+        main = torch.cuda.current_stream(self.device)
+        if st["ev"] is not None:
+            main.wait_event(st["ev"])
+            st["allv"].record_stream(main)
         outs, lows = [], []
         ctypes = [contact_type] * B if isinstance(contact_type, str) else list(contact_type)
         for b, (output_ids, hidden) in enumerate(gens):

@@ -603,6 +603,25 @@ def test_evaluate_batch_of_16_and_chunking(hip_lib, cuda, golden_dir, B):
         assert torch.equal(outs[b]["output_ids"], one["output_ids"])
         e = float((outs[b]["pred_contact_3d"] - one["pred_contact_3d"]).abs().max())
         assert e < 1e-3, (b, e)
+    if B == 17:
+        # deferred chunks: chunk c + 1 is begun (its SAM encoder, CLIP, prefill and decode loop enqueued) before
+        # chunk c's tail - the mask decoders and the lift - is enqueued; same results, bit for bit, as the calls one after the other
+        from interactvlm_amd import dist as D
+
+        sl = lambda lo, hi: (ic[lo:hi], im[lo:hi], prompts[lo:hi], [cams[0]] * (hi - lo), sizes[lo:hi], sizes[lo:hi])
+        fins = [m.evaluate_batch(*sl(0, 6), forced_new_tokens=forced[0:6], deferred=True)]
+        fins.append(m.evaluate_batch(*sl(6, 11), forced_new_tokens=forced[6:11], deferred=True))  # begun before chunk 0 is finished
+        piped = fins[0]() + fins[1]()
+        plain = m.evaluate_batch(*sl(0, 6), forced_new_tokens=forced[0:6]) + m.evaluate_batch(*sl(6, 11), forced_new_tokens=forced[6:11])
+        for a_, b_ in zip(piped, plain):
+            assert torch.equal(a_["output_ids"], b_["output_ids"]) and torch.equal(a_["pred_contact_3d"], b_["pred_contact_3d"])
+            assert torch.equal(a_["pred_masks"][0], b_["pred_masks"][0])
+        # ... and through dist.evaluate_sharded, whose chunk callback may return the deferred function
+        chunk = lambda idx: (lambda f: (lambda: torch.cat([o["pred_contact_3d"] for o in f()])))(
+            m.evaluate_batch(ic[idx], im[idx], [prompts[i] for i in idx], [cams[0]] * len(idx), [sizes[i] for i in idx],
+                             [sizes[i] for i in idx], forced_new_tokens=[forced[i] for i in idx], deferred=True))
+        got = D.evaluate_sharded(11, 4, chunk, rank=0, world=1)
+        assert torch.equal(got, torch.cat([o["pred_contact_3d"] for o in plain]))
 
 
 def test_full_depth_towers_vs_oracle(hip_lib, cuda):

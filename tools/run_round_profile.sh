@@ -2,7 +2,7 @@
 # passes (graphs off: counter collection crashes on replayed graphs), two-stream timeline.  Results under gpurun_out/r4/.
 set -x
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5; mkdir -p $O
 cd $R
 timeout 1500 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 timeout 300 python tools/bench_lift.py > $O/lift.json 2> $O/lift.err
