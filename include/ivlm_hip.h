@@ -54,6 +54,11 @@ extern "C" {
                                  halves are IEEE halves (IVLM_F16_SPLIT rows).  IVLM_GEMM_F16 | IVLM_GEMM_A_SPLIT: A rows are
                                  IVLM_F16_SPLIT (the "exact q" projection of the fp16 mode: q = W_q . (hi + lo)) */
 
+#define IVLM_GEMM_W_PANEL 64  /* tile GEMM: W is stored as K/64 panels of [N][64] (element (n, k) at (k/64) * 64 N + n * 64 + k % 64;
+                                 K % 64 == 0, ldw ignored): a wave's DMA instruction then reads 1 KB contiguous instead of eight
+                                 128-byte lines a row stride apart (78 vs 52 - 64 GB/s of L2-hit feed per CU).  Static weights are
+                                 panelised once at load (the LLaMA prefill of the host model); same results as the row-major layout */
+
 typedef void *ivlm_stream_t;
 
 /* library identity --------------------------------------------------------------------------- */

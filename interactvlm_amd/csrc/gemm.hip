@@ -396,7 +396,9 @@ int gemm_bf16(const GemmArgs& g, hipStream_t st) {
         if (g.out_split && (!g.out_f32 || (g.c_lo & 1) || g.c_lo <= 0)) return IVLM_ERR_INVALID_ARG;
     }
     if (g.a_kstep || g.w_kstep || g.c_panel) {  // K-panel layouts: bf16, whole 64-wide panels, plain epilogues
-        if (g.fp8 || g.out_fp8 || (g.K & 63) || g.batch != 1 || g.act == ACT_SWIGLU) return IVLM_ERR_UNSUPPORTED;
+        // (A / C panels: one problem, plain epilogues; W panels alone also serve the split-K slices and the SwiGLU epilogue)
+        if (g.fp8 || g.out_fp8 || (g.K & 63)) return IVLM_ERR_UNSUPPORTED;
+        if ((g.a_kstep || g.c_panel) && (g.batch != 1 || g.act == ACT_SWIGLU)) return IVLM_ERR_UNSUPPORTED;
         if ((g.a_kstep && (g.a_kstep < (int64_t)64 * g.M || (g.a_kstep & 7) || g.a_rows)) || (g.w_kstep && (g.w_kstep < (int64_t)64 * g.N || (g.w_kstep & 7))))
             return IVLM_ERR_INVALID_ARG;
         if (g.c_panel && (g.out_f32 || (g.N & 63) || g.c_panel < (int64_t)64 * g.M || g.out_rows)) return IVLM_ERR_UNSUPPORTED;
@@ -448,7 +450,7 @@ int gemm_bf16_splitk(const GemmArgs& g, int splits, float* workspace, size_t ws_
     p.K = g.K / splits;
     p.batch = splits;
     p.strideA = p.K;
-    p.strideW = p.K;
+    p.strideW = g.w_kstep ? (int64_t)(p.K / 64) * g.w_kstep : p.K;  // (K-panel W: slice z starts z * (K / splits / 64) panels in)
     p.strideC = (int64_t)g.M * g.N;
     p.strideR = 0;
     p.C = workspace;
@@ -561,6 +563,11 @@ extern "C" int ivlm_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     if (flags & IVLM_GEMM_OUT_SPLIT) { g.out_split = 1; g.c_lo = act == ivlm::ACT_SWIGLU ? N / 2 : N; out_f32 = 1; }
     if (flags & IVLM_GEMM_F16) g.f16 = 1;
     if (flags & IVLM_GEMM_OUT_F16) g.out_f16 = 1;
+    if (flags & IVLM_GEMM_W_PANEL) {
+        if (M <= 16 || (K & 63) || batch > 1) return IVLM_ERR_UNSUPPORTED;
+        g.w_kstep = (int64_t)64 * N;
+        ldw = 64;
+    }
     if ((g.a_split || g.out_split || g.f16 || g.out_f16) && M <= 16) return IVLM_ERR_UNSUPPORTED;  // tile GEMM path only
     g.rms_w = static_cast<const bf16_t*>(rms_w);
     g.rms_eps = rms_eps;
@@ -649,6 +656,11 @@ static int splitk_entry(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (flags & IVLM_GEMM_OUT_F16) {
         if (out_f32 && !g.out_split) return IVLM_ERR_INVALID_ARG;
         g.out_f16 = 1;
+    }
+    if (flags & IVLM_GEMM_W_PANEL) {
+        if (K % (splits * 64) != 0) return IVLM_ERR_UNSUPPORTED;  // (whole panels per K slice)
+        g.w_kstep = (int64_t)64 * N;
+        ldw = 64;
     }
     g.tile = g_tile_override;
     g.A = static_cast<const bf16_t*>(A);

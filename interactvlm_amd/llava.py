@@ -267,7 +267,7 @@ class Llama:
                     if n + "_p" not in L:
                         L[n + "_p"] = ops.PackedBf12(L[n]) if ops.PackedBf12.takes(*L[n].shape) else None
             if self.precision == "f16":
-                self._f16(L)
+                self._f16w(L)
             else:  # bf16 / parity prefill reads the bf16 matrices (rebuilt from the planes if the default mode had released them)
                 for n in _LayerW.MATS:
                     L[n]
@@ -282,11 +282,16 @@ class Llama:
             for n in _LayerW.MATS:
                 if self.precision == "f16":
                     wp = L.get(n + "_p")
-                    if self._decode_packed and wp is not None and wp.frag and dict.__contains__(L, n) and n + "_h" in L:
+                    have16 = n + "_h" in L or n + "_hp" in L
+                    if self._decode_packed and wp is not None and wp.frag and dict.__contains__(L, n) and have16:
                         del L[n]
                         dropped = True
-                elif L.pop(n + "_h", None) is not None:
-                    dropped = True
+                    if n + "_hp" in L and L.pop(n + "_h", None) is not None:  # (the panels replace the row-major copy)
+                        dropped = True
+                else:
+                    for k in (n + "_h", n + "_hp"):
+                        if L.pop(k, None) is not None:
+                            dropped = True
         if dropped:  # graphs of the bf16-weight decode step hold pointers into what was just released
             self._dgraphs = {k: g for k, g in self._dgraphs.items() if k[1]}
             if not self._decode_packed:
@@ -302,8 +307,9 @@ class Llama:
             for n in _LayerW.MATS:
                 if dict.__contains__(L, n):
                     out["bf16"] += L[n].numel() * 2
-                if L.get(n + "_h") is not None:
-                    out["f16"] += L[n + "_h"].numel() * 2
+                for k in (n + "_h", n + "_hp"):
+                    if L.get(k) is not None:
+                        out["f16"] += L[k].numel() * 2
                 if L.get(n + "_p") is not None:
                     out["bf12"] += L[n + "_p"].bytes()
         if getattr(self, "lm_head_p", None) is not None:
@@ -369,25 +375,42 @@ class Llama:
         return self.kcache, self.vcache
 
     def _f16(self, L):
-        if "qkv_h" not in L:
-            for n in ("qkv", "o", "gu", "down"):
+        """row-major fp16 copies ``*_h`` of the four matrices (the C sequencers' layout; rebuilt from bf16 if they were released)"""
+        for n in _LayerW.MATS:
+            if n + "_h" not in L:
                 L[n + "_h"] = ops.f16_weight(L[n], "llama " + n)
         return L
+
+    # K-panel layout of the fp16 prefill copies (VERDICT r4 item 1): [K / 64, N, 64] instead of [N, K] - the same bytes, a wave's
+    # DMA instruction reads 1 KB contiguous.  The prefill GEMMs (M = 330) are bound by each CU's L1 fill path
+    # (profiles/r05_gemm_ceilings.txt), which serves contiguous kilobytes faster than eight lines a row stride apart.
+    prefill_panels = os.environ.get("IVLM_PREFILL_PANELS", "1") != "0"
+
+    def _f16w(self, L):
+        """-> {n: the fp16 weight the Python prefill passes to ops.linear} (panels when ``prefill_panels``, else row-major)"""
+        if not self.prefill_panels or self.cfg.hidden % 64 or self.cfg.inter % 64:
+            self._f16(L)
+            return {n: L[n + "_h"] for n in _LayerW.MATS}
+        for n in _LayerW.MATS:
+            if n + "_hp" not in L:
+                h = L.pop(n + "_h") if n + "_h" in L else ops.f16_weight(L[n], "llama " + n)
+                L[n + "_hp"] = ops.panel_weight(h)  # (the row-major copy is not kept: _f16 rebuilds it for the C sequencers)
+        return {n: L[n + "_hp"] for n in _LayerW.MATS}
 
     def _layer_f16(self, L, x, T, pos0, kc, vc, a_out=None):
         """one prefill layer on fp16 operands: x fp32 [T, hidden] -> fp32 [T, hidden]; kc / vc = this layer's fp16 cache planes"""
         c = self.cfg
         H, hd = c.heads, c.hidden // c.heads
-        L = self._f16(L)
-        qkv = ops.linear(ops.rmsnorm(x, L["ln1"], c.eps, out_f16=True), L["qkv_h"], out_f16=True)
+        W = self._f16w(L)
+        qkv = ops.linear(ops.rmsnorm(x, L["ln1"], c.eps, out_f16=True), W["qkv"], out_f16=True)
         ops.rope_kv(qkv, H, hd, pos0, c.theta, kc, vc, table=self.rope)
         q = qkv.view(T, 3, H, hd)[:, 0].permute(1, 0, 2).unsqueeze(0)
         k = kc[: pos0 + T].permute(1, 0, 2).unsqueeze(0)
         v = vc[: pos0 + T].permute(1, 0, 2).unsqueeze(0)
         a = ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=pos0).permute(0, 2, 1, 3).reshape(T, c.hidden)
-        x = ops.linear(a, L["o_h"], residual=x, out_f32=True)
-        h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps, out_f16=True), L["gu_h"], act="swiglu", out_f16=True)
-        return ops.linear(h, L["down_h"], residual=x, out_f32=True)
+        x = ops.linear(a, W["o"], residual=x, out_f32=True)
+        h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps, out_f16=True), W["gu"], act="swiglu", out_f16=True)
+        return ops.linear(h, W["down"], residual=x, out_f32=True)
 
     def batch_cache_lo(self, B):
         bc = getattr(self, "_bcache_lo", None)
@@ -485,8 +508,8 @@ class Llama:
         x = torch.cat(xs, 0)
         if self.precision == "f16":  # fp16 operands (see _layer_f16); kc / vc are fp16 views of the slabs
             for li, L in enumerate(self.layers):
-                L = self._f16(L)
-                qkv = ops.linear(ops.rmsnorm(x, L["ln1"], c.eps, out_f16=True), L["qkv_h"], out_f16=True)
+                W = self._f16w(L)
+                qkv = ops.linear(ops.rmsnorm(x, L["ln1"], c.eps, out_f16=True), W["qkv"], out_f16=True)
                 a = torch.empty(offs[-1], c.hidden, dtype=torch.float16, device=x.device)
                 for b, T in enumerate(lens):
                     qb = qkv[offs[b]: offs[b + 1]]
@@ -496,9 +519,9 @@ class Llama:
                     v = vc[li, b, :T].permute(1, 0, 2).unsqueeze(0)
                     ops.attention(q, k, v, hd ** -0.5, causal=True, q_pos0=0,
                                   out=a[offs[b]: offs[b + 1]].view(1, T, H, hd).permute(0, 2, 1, 3))
-                x = ops.linear(a, L["o_h"], residual=x, out_f32=True)
-                h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps, out_f16=True), L["gu_h"], act="swiglu", out_f16=True)
-                x = ops.linear(h, L["down_h"], residual=x, out_f32=True)
+                x = ops.linear(a, W["o"], residual=x, out_f32=True)
+                h = ops.linear(ops.rmsnorm(x, L["ln2"], c.eps, out_f16=True), W["gu"], act="swiglu", out_f16=True)
+                x = ops.linear(h, W["down"], residual=x, out_f32=True)
             x = ops.rmsnorm(x, self.norm, c.eps, out_f32=True)
             return [x[offs[b]: offs[b + 1]] for b in range(len(lens))]
         if self.precision == "parity":  # fp32-activation arithmetic (see _layer_parity), lo = (kc_lo, vc_lo) slabs

@@ -368,7 +368,15 @@ def _splitk_choice(M, N, K, act, rms):
     return best
 
 
-GEMM_A_F32, GEMM_RES_F32, GEMM_A_SPLIT, GEMM_OUT_SPLIT, GEMM_F16, GEMM_OUT_F16 = 1, 2, 4, 8, 16, 32
+GEMM_A_F32, GEMM_RES_F32, GEMM_A_SPLIT, GEMM_OUT_SPLIT, GEMM_F16, GEMM_OUT_F16, GEMM_W_PANEL = 1, 2, 4, 8, 16, 32, 64
+
+
+def panel_weight(w):
+    """[N, K] (K % 64 == 0) -> the K-panel layout [K / 64, N, 64] of the same values (IVLM_GEMM_W_PANEL): what ``linear`` takes as a
+    3-D weight.  One wave DMA instruction of a K tile then reads 1 KB contiguous instead of 8 lines a row stride apart."""
+    N, K = w.shape
+    assert K % 64 == 0
+    return w.view(N, K // 64, 64).permute(1, 0, 2).contiguous()
 F16 = torch.float16
 F32 = torch.float32
 
@@ -380,8 +388,13 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     "Parity" precision (tile GEMM, M > 16): a_split - x is [..., 2K] = [hi | lo] bf16 rows (fp32 activations, see split_rows)
     against the plain [N, K] weight; out_split - the fp32 result is written as [hi | lo] bf16 rows [..., 2 n_out]."""
     lib = _lib.load()
-    N = weight.shape[0]
-    K = weight.shape[1]
+    w_panel = weight.dim() == 3  # K-panel layout [K / 64, N, 64] (``panel_weight``): tile GEMM only, same results as [N, K]
+    if w_panel:
+        assert weight.shape[2] == 64 and weight.is_contiguous()
+        N, K = weight.shape[1], weight.shape[0] * 64
+    else:
+        N = weight.shape[0]
+        K = weight.shape[1]
     f16 = weight.dtype == F16  # IEEE-half operands (tile GEMM): x must be fp16 too
     assert x.shape[-1] == (2 * K if a_split else K) and x.dtype in (BF16, F32, F16) and weight.dtype in (BF16, F16)
     assert (x.dtype == F16) == f16  # (f16 with a_split: [hi | lo] IEEE halves, the IVLM_F16_SPLIT rows of layernorm(out_split, out_f16))
@@ -404,6 +417,10 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     if out_f16:  # (with out_split: the fp32 result as [hi | lo] IEEE halves)
         assert not out_f32 or out_split
         flags |= GEMM_OUT_F16
+    if w_panel:
+        if M <= 16 or out_rows is not None or a_split or out_split:
+            raise IvlmError("linear: K-panel weights serve the plain tile GEMMs (M > 16) only")
+        flags |= GEMM_W_PANEL
     n_out = N // 2 if act == "swiglu" else N
     if out_split:
         flags |= GEMM_OUT_SPLIT
@@ -415,6 +432,7 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     assert not out_split or out.dtype == (F16 if out_f16 else BF16)
     o2 = out.reshape(-1, n_cols)
     assert o2.stride(-1) == 1 and weight.stride(-1) == 1
+    ldw = 64 if w_panel else weight.stride(0)
     r2, ldr = None, 0
     if residual is not None:
         r2 = residual.reshape(-1, N)
@@ -425,7 +443,7 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
     if bias is not None:
         assert bias.dtype == BF16 and bias.is_contiguous()
     call = lambda: check(lib.ivlm_gemm_bf16(
-        x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
+        x2.data_ptr(), x2.stride(0), weight.data_ptr(), ldw, o2.data_ptr(), o2.stride(0), _p(bias),
         _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, 1, 0, 0, 0, 0,
         _p(rms[0]) if rms else 0, float(rms[1]) if rms else 0.0, flags, _p(out_rows), _p(a_rows), _stream()), "gemm_bf16")
     splits = _splitk_choice(M, N, K, act, rms) if (x.dtype in (BF16, F16) and out_rows is None and a_rows is None) else 1
@@ -434,12 +452,12 @@ def linear(x, weight, bias=None, act="none", residual=None, res_mod=0, out=None,
         if SPLITK_FUSED:  # reduction inside the GEMM launch (the tile's last block sums its slices): same values, one launch
             cnt = _splitk_counters(x.device)
             call = lambda: check(lib.ivlm_gemm_bf16_splitk_fused(
-                x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
+                x2.data_ptr(), x2.stride(0), weight.data_ptr(), ldw, o2.data_ptr(), o2.stride(0), _p(bias),
                 _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, splits, ws.data_ptr(),
                 ws.numel() * 4, cnt.data_ptr(), flags, _stream()), "gemm_bf16_splitk_fused")
         else:
             call = lambda: check(lib.ivlm_gemm_bf16_splitk(
-                x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), o2.data_ptr(), o2.stride(0), _p(bias),
+                x2.data_ptr(), x2.stride(0), weight.data_ptr(), ldw, o2.data_ptr(), o2.stride(0), _p(bias),
                 _p(r2), ldr, int(res_mod), M, N, K, ACT[act], 1 if out.dtype == F32 else 0, splits, ws.data_ptr(),
                 ws.numel() * 4, flags, _stream()), "gemm_bf16_splitk")
     if TIMER.enabled:  # work = algorithmic FLOPs (MFMA path) or weight bytes (GEMV path)

@@ -843,3 +843,27 @@ def test_fused_splitk_equals_two_launch_splitk(hip_lib, cuda, M, N, K, res):
             ops.SPLITK_FUSED = prev
     ref64 = x.double() @ w.double().t() + (r.double() if res else 0)
     assert float((got.double() - ref64).abs().max()) / float(ref64.abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(330, 12288, 4096, "none", False), (330, 4096, 4096, "none", True), (330, 22016, 4096, "swiglu", False),
+                                           (330, 4096, 11008, "none", True), (5280, 4096, 4096, "none", True), (40, 512, 256, "none", False)])
+def test_k_panel_weights_equal_row_major(hip_lib, cuda, M, N, K, act, res):
+    """IVLM_GEMM_W_PANEL: the weight stored as K/64 panels of [N][64] (ops.panel_weight) through every tiling the
+    LLaMA prefill uses - 176 x 128 with and without K slices, 128 x 64 with four K slices, the 256-row tiles of the packed 16-prompt
+    prefill - gives the row-major result BIT FOR BIT (same tiles, same arithmetic, other addresses), fp16 and bf16, SwiGLU epilogue
+    and fp32 residual."""
+    import torch
+
+    from interactvlm_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    for dt in (torch.float16, torch.bfloat16):
+        x = torch.randn(M, K, generator=g).to(dt).to(cuda)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).to(cuda)
+        r = torch.randn(M, N, generator=g).to(cuda) if res else None
+        kw = dict(residual=r, out_f32=True) if res else dict(act=act)
+        wp = ops.panel_weight(w)
+        assert wp.shape == (K // 64, N, 64) and torch.equal(wp.permute(1, 0, 2).reshape(N, K), w)
+        assert torch.equal(ops.linear(x, wp, **kw), ops.linear(x, w, **kw)), dt
+    with pytest.raises(ops.IvlmError):
+        ops.linear(x[:8], wp)  # (M <= 16: the weight-streaming kernels take row-major weights)

@@ -508,7 +508,8 @@ def test_headline_model_7b_default_mode(hip_lib, cuda):
     ev = lambda: m.evaluate(ic, im, ids, cams, [(S, S)], [(S, S)], forced_new_tokens=forced)
     # (vii) residency: fp16 prefill copies + 12-bit decode planes, no bf16 originals of the packed matrices
     rb = m.resident_weight_bytes()
-    n_mat = sum(L[n + "_h"].numel() for L in m.llm.layers for n in ("qkv", "o", "gu", "down"))
+    assert m.llm.prefill_panels and all("qkv_h" not in L for L in m.llm.layers)  # (fp16 prefill copies in the K-panel layout only)
+    n_mat = sum(L[n + "_hp"].numel() for L in m.llm.layers for n in ("qkv", "o", "gu", "down"))
     assert rb["f16"] == 2 * n_mat and 1.45 * n_mat < rb["bf12"] < 1.6 * n_mat + 1.6 * m.llm.lm_head.numel()
     assert rb["bf16"] < 2.1 * (m.llm.embed.numel() + m.llm.lm_head.numel())  # embed_tokens + lm_head + norms only
     # (i) default mode
