@@ -1,5 +1,5 @@
 # Round profile: GPU tests, the driver-style bench line, rocprofv3 kernel trace of the headline loop (graphs ON), PMC traffic
-# passes (graphs off: counter collection crashes on replayed graphs), two-stream timeline.  Results under gpurun_out/r4/.
+# passes (graphs off: counter collection crashes on replayed graphs), two-stream timeline.  Results under gpurun_out/r5/.
 set -x
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5; mkdir -p $O
