@@ -74,7 +74,8 @@ def test_single_process_is_identity():
 
 def _bench_worker(rank, world, port, n_img, q):
     """bench.py's N > 1 bookkeeping (timed region with the MAX over ranks, the one-GPU denominator of the dp64 job) on gloo with a
-    stub chunk evaluator: rank r sleeps (r + 1) * 50 ms per chunk, so the slowest rank defines the time."""
+    stub chunk evaluator: rank r sleeps (r + 1) * 150 ms per chunk, so the slowest rank defines the time (sleeps long enough that
+    the scheduling jitter of a busy 8-core container - tens of ms per call - stays well inside the tolerances)."""
     import time
 
     sys.path.insert(0, REPO)
@@ -87,22 +88,22 @@ def _bench_worker(rank, world, port, n_img, q):
 
     def chunk(idx):
         calls.append(list(idx))
-        time.sleep(0.05 * (rank + 1))
+        time.sleep(0.15 * (rank + 1))
         return torch.stack([torch.full((6890,), float(i)) for i in idx]) if idx else torch.zeros(0, 6890)
 
     step = lambda: evaluate_sharded(n_img, 2, chunk)
     dt, res = bench.timed_steps(step, 1, 3, world, "cpu")
     assert tuple(res.shape) == (n_img, 6890) and res[:, 0].tolist() == [float(i) for i in range(n_img)]
-    slowest = max(0.05 * (r + 1) * -(-(shard_range(n_img, r, world)[1] - shard_range(n_img, r, world)[0]) // 2) for r in range(world))
+    slowest = max(0.15 * (r + 1) * -(-(shard_range(n_img, r, world)[1] - shard_range(n_img, r, world)[0]) // 2) for r in range(world))
     assert dt >= 3 * slowest * 0.95, (dt, slowest)  # the MAX over ranks, not this rank's own time
     one = bench.one_gpu_same_workload(n_img, 2, chunk, rank, world, "cpu", res, dt, 3)
     if rank == 0:
         assert one is not None and one["max_abs_dp_sharded_vs_one_gpu"] == 0.0
         assert abs(one["images_per_s"] - n_img / one["seconds"]) < 2e-2 * one["images_per_s"]
         assert abs(one["speedup_of_this_run"] - (n_img * 3 / dt) / one["images_per_s"]) < 2e-2 * one["speedup_of_this_run"]
-        # rank 0 alone runs every chunk at 50 ms; sharded, the slowest rank defines the step: the speedup is what the sleeps say
-        expect = (0.05 * -(-n_img // 2)) / slowest
-        assert abs(one["speedup_of_this_run"] - expect) < 0.25 * expect, (one, expect)
+        # rank 0 alone runs every chunk at 150 ms; sharded, the slowest rank defines the step: the speedup is what the sleeps say
+        expect = (0.15 * -(-n_img // 2)) / slowest
+        assert abs(one["speedup_of_this_run"] - expect) < 0.3 * expect, (one, expect)
         q.put((dt, one))
     else:
         assert one is None
