@@ -578,6 +578,12 @@ int ivlm_sam_decode(const ivlm_sam_dec *weights, int V, int grid, int n_text, co
 
 /* The split-K rule of the small-M tile GEMMs (number of K slices, 1 = none): shared by the sequencers and the Python host. */
 int ivlm_gemm_splitk_choice(int M, int N, int K, int act, int has_rms);
+/* The split-K products of the stage sequencers (ivlm_clip_encode, ivlm_llama_prefill, ivlm_sam_decode and their _f16 forms) take the
+ * two-launch form (partials + ordered reduction) by default.  on = 1 selects the reduction FUSED into the GEMM launch
+ * (ivlm_gemm_bf16_splitk_fused: same values bit for bit, one launch less, measured 2 - 3 x slower on MI355X; the arrival counters then
+ * live in the last 16 KB of the sequencer's split-K region and every stage call zeroes them once); on = 0 switches back; any other
+ * value only queries.  Default: the environment's IVLM_SPLITK_FUSED=1 at first use, else off.  Returns the previous setting. */
+int ivlm_stages_splitk_fused(int on);
 
 /* Batch-1 decode linear over LOSSLESSLY packed bf16 weights ("bf12", 1.5 bytes per weight instead of 2; the decode step of
  * InteractVLM.evaluate's greedy search, model/InteractVLM.py:524-531, is pure weight streaming).  A row of W [N, K] is stored as

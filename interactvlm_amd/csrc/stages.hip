@@ -14,6 +14,7 @@
 // is allocated, nothing synchronises.  Same kernels and the same launch order as interactvlm_amd/llava.py: the results are
 // bit-identical to the Python-sequenced path (tests/test_stages_gpu.py).
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -57,17 +58,46 @@ struct Carver {
     }
 };
 
-// The arrival counters of the fused split-K GEMMs (SplitKFused, kernels.h) live in the LAST 16 KB of a sequencer's split-K region:
-// every stage call zeroes them once (sk_counters_zero, right after the region is carved) and the GEMMs leave them at zero; a
-// product whose partials would reach into them takes the two-launch form.  The workspace sizes are unchanged.
+// The fused split-K reduction (SplitKFused, kernels.h) is OPT-IN for the stage sequencers, as it is for the host model
+// (ops.SPLITK_FUSED): on MI355X it measured 2 - 3 x SLOWER than the two-launch form (down_proj 64 -> 192 us, prefill 12.0 -> 26.3 ms;
+// tools/experiments/README.md) - each block's agent-scope release / acquire around its arrival costs more than the launch it saves.
+// Switch: ivlm_stages_splitk_fused(1), or IVLM_SPLITK_FUSED=1 in the environment at first use.  Off (default): no counters, no
+// memset, the two-launch form everywhere.
+// When it is on, the arrival counters live in the LAST 16 KB of a sequencer's split-K region: every stage call zeroes them once
+// (sk_counters_zero, right after the region is carved) and the GEMMs leave them at zero; a product whose partials would reach into
+// them takes the two-launch form on the region BELOW the counters (sk_partial_bytes), so the partials can never overwrite them.
+int g_sk_fused = -1;  // -1: not read yet
+bool sk_fused_on() {
+    if (g_sk_fused < 0) {
+        const char* e = getenv("IVLM_SPLITK_FUSED");
+        g_sk_fused = (e && e[0] == '1' && e[1] == 0) ? 1 : 0;
+    }
+    return g_sk_fused == 1;
+}
+constexpr size_t kSkCounterBytes = (size_t)kSplitKCounters * 4;
 int32_t* sk_counters(float* sk, size_t skb, size_t partial_bytes) {
-    const size_t cb = (size_t)kSplitKCounters * 4;
-    if (!sk || skb < partial_bytes + cb + 16) return nullptr;
-    return reinterpret_cast<int32_t*>(reinterpret_cast<char*>(sk) + ((skb - cb) & ~(size_t)15));
+    if (!sk_fused_on() || !sk || skb < partial_bytes + kSkCounterBytes + 16) return nullptr;
+    return reinterpret_cast<int32_t*>(reinterpret_cast<char*>(sk) + ((skb - kSkCounterBytes) & ~(size_t)15));
+}
+// bytes of the region the PARTIALS may use: everything when the fused form is off, the part below the counters when it is on
+size_t sk_partial_bytes(size_t skb) {
+    if (!sk_fused_on() || skb < kSkCounterBytes + 16) return skb;
+    return (skb - kSkCounterBytes) & ~(size_t)15;
+}
+int sk_counters_zero(float* sk, size_t skb, hipStream_t st);
+// one split-K product of a sequencer: fused when the switch is on and the partials stay below the counters, else the two-launch
+// form - on the region below the counters, or (partials larger than that) on the whole region with the counters re-zeroed after
+int sk_gemm(const GemmArgs& g, int sp, float* sk, size_t skb, hipStream_t st) {
+    const size_t pb = (size_t)sp * g.M * g.N * 4;
+    int32_t* c = sk_counters(sk, skb, pb);
+    if (c) return gemm_bf16_splitk(g, sp, sk, skb, st, c);
+    if (pb <= sk_partial_bytes(skb)) return gemm_bf16_splitk(g, sp, sk, sk_partial_bytes(skb), st, nullptr);
+    if (int rc = gemm_bf16_splitk(g, sp, sk, skb, st, nullptr)) return rc;
+    return sk_counters_zero(sk, skb, st);  // (only reachable with the switch on: the partials ran over the counter words)
 }
 int sk_counters_zero(float* sk, size_t skb, hipStream_t st) {
     int32_t* c = sk_counters(sk, skb, 0);
-    if (c) IVLM_HIP_TRY(hipMemsetAsync(c, 0, (size_t)kSplitKCounters * 4, st));
+    if (c) IVLM_HIP_TRY(hipMemsetAsync(c, 0, kSkCounterBytes, st));
     return IVLM_OK;
 }
 
@@ -91,7 +121,7 @@ int lin(const void* A, int a_f32, int64_t lda, const void* W, int64_t ldw, void*
     g.rms_eps = eps;
     const int sp = a_f32 ? 1 : gemm_splitk_choice(M, N, K, act, rms_w != nullptr);
     if (sp > 1 && (ldc & 3) == 0)
-        return gemm_bf16_splitk(g, sp, splitk_ws, splitk_bytes, st, sk_counters(splitk_ws, splitk_bytes, (size_t)sp * M * N * 4));
+        return sk_gemm(g, sp, splitk_ws, splitk_bytes, st);
     return linear_bf16(g, st);
 }
 
@@ -104,6 +134,12 @@ __global__ void bump_kernel(int32_t* a, int32_t* b) {
 }  // namespace ivlm
 
 using namespace ivlm;
+
+extern "C" int ivlm_stages_splitk_fused(int on) {
+    const int prev = sk_fused_on() ? 1 : 0;
+    if (on == 0 || on == 1) g_sk_fused = on;
+    return prev;
+}
 
 extern "C" int ivlm_gemm_splitk_choice(int M, int N, int K, int act, int has_rms) {
     return gemm_splitk_choice(M, N, K, act, has_rms);
@@ -413,7 +449,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int ou
     g.a_rows = a_rows;
     const int sp = (out_rows || a_rows) ? 1 : gemm_splitk_choice(M, N, K, act, 0);
     if (sp > 1 && (ldc & 3) == 0 && sk && skb >= (size_t)sp * M * N * 4)
-        return gemm_bf16_splitk(g, sp, sk, skb, st, sk_counters(sk, skb, (size_t)sp * M * N * 4));
+        return sk_gemm(g, sp, sk, skb, st);
     return linear_bf16(g, st);
 }
 

@@ -214,3 +214,33 @@ def test_llama_decode_step_bf12_equals_python_packed_path(hip_lib, cuda, precisi
                                              1, b.rope[0].data_ptr(), b.rope[1].data_ptr(), emb.data_ptr(), pos.data_ptr(), 0,
                                              hb[0].data_ptr(), st._dws.data_ptr(), st._dws.numel(), 0)
     assert rc != 0
+
+
+def test_stage_splitk_fused_switch_is_opt_in_and_bit_identical(hip_lib, cuda):
+    """the C sequencers take the two-launch split-K form unless ivlm_stages_splitk_fused(1) (or IVLM_SPLITK_FUSED=1)
+    asks for the fused reduction; both forms give the same bits (the fused one sums a tile's slices in slice order too)."""
+    import os
+
+    import torch
+
+    from interactvlm_amd import llava, stages
+    from interactvlm_amd import weights as Wt
+
+    if os.environ.get("IVLM_SPLITK_FUSED") != "1":
+        assert hip_lib.ivlm_stages_splitk_fused(-1) == 0  # a query: off by default
+    lc = Wt.LlamaCfg(hidden=1024, layers=2, heads=8, inter=1376, vocab=1000)
+    w = {k: v.to(torch.bfloat16).float() for k, v in Wt.synth_weights(Wt.llama_spec(lc)).items()}
+    g = torch.Generator().manual_seed(9)
+    emb = (torch.randn(330, 1024, generator=g) * 0.5).to(torch.bfloat16).float().to(cuda)
+    outs = []
+    prev = hip_lib.ivlm_stages_splitk_fused(-1)
+    try:
+        for on in (0, 1, 0):
+            hip_lib.ivlm_stages_splitk_fused(on)
+            assert hip_lib.ivlm_stages_splitk_fused(-1) == on
+            b = llava.Llama(w, lc, cuda, max_len=512)
+            outs.append((stages.LlamaStages(b).prefill(emb, 0).clone(), b.kcache[:, :330].clone()))
+    finally:
+        hip_lib.ivlm_stages_splitk_fused(prev)
+    for h, k in outs[1:]:
+        assert torch.equal(h, outs[0][0]) and torch.equal(k, outs[0][1])
