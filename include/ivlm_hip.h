@@ -229,7 +229,10 @@ int ivlm_gemm_bf16_splitk(const void *A, int64_t lda, const void *W, int64_t ldw
  * partial tile and counts its arrival on the tile's counter; the block that arrives last sums the tile's slices in slice order and
  * applies the epilogue - the same values as ivlm_gemm_bf16_splitk, bit for bit.  `counters`: IVLM_SPLITK_COUNTERS int32 words
  * that the caller zeroes ONCE (hipMemset); every call leaves them at zero.  One array per stream: launches that may run
- * concurrently must not share it.  (M = 330 LLaMA prefill / M = 257 CLIP: 199 launches fewer per image.) */
+ * concurrently must not share it.  (M = 330 LLaMA prefill / M = 257 CLIP: 199 launches fewer per image.)
+ * Tiling: only the tile kernels of gemm.hip carry the fix-up, so a chosen or FORCED (ivlm_gemm_tile_override) 256 / 320 / 512 tile
+ * is remapped to 128 x 128 here - the partial GEMMs of this entry point can run another tiling than ivlm_gemm_bf16_splitk's
+ * (same values); a tile-override benchmark of the fused form measures the remapped tiling. */
 #define IVLM_SPLITK_COUNTERS 4096
 int ivlm_gemm_bf16_splitk_fused(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
                                 const void *bias, const void *residual, int64_t ldr, int res_mod, int M, int N, int K,

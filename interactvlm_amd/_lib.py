@@ -65,7 +65,12 @@ def load():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:  # header/library drift is a build error, not a soft failure
-            if os.environ.get("IVLM_LIB_PATH"):  # (an experiment library built from an older tree - tools/experiments: timing only)
+            # (an experiment library built from an older tree - tools/experiments, timing only - may lack newer symbols: allowed only
+            #  with BOTH an explicit library path and IVLM_ALLOW_MISSING_SYMBOLS=1, and never silently)
+            if os.environ.get("IVLM_LIB_PATH") and os.environ.get("IVLM_ALLOW_MISSING_SYMBOLS") == "1":
+                import warnings
+
+                warnings.warn(f"{LIB_PATH} does not export {name} (declared in ivlm_hip.h): skipped (IVLM_ALLOW_MISSING_SYMBOLS=1)")
                 continue
             raise IvlmError(f"libivlm_hip.so does not export {name} declared in ivlm_hip.h") from e
         fn.restype = _to_ctype(ret) if ret != "void" else None

@@ -257,14 +257,23 @@ class InteractVLMForCausalLM:
 
         warnings.warn(f"non-finite contacts in precision mode {self.precision!r} (an activation left fp16's exponent "
                       "range): this call is recomputed with bf16 operands; consider model.set_precision('bf16')")
-        mode, packed = self.precision, self.llm.decode_packed
+        # The mode switch is TEMPORARY: nothing is released for it (the fp16 copies / packed planes of `mode` stay, the bf16
+        # matrices are rebuilt from the planes and kept until the next explicit set_precision) - a fallback must not churn tens of GB
+        # of weights, least of all under a pipelined evaluate_batch whose next chunk is already enqueued on the copies of `mode`
+        # (ADVICE r5).  In that deferred mode a fallback also SERIALISES the pipeline: the recomputation is enqueued behind the
+        # next chunk's work and that chunk's captured decode graphs are re-captured after the switch back.
+        mode, packed, free = self.precision, self.llm.decode_packed, self.free_unused_weights
         self.llm.decode_packed = False
-        self.set_precision("bf16")
+        self.free_unused_weights = False
         try:
+            self.set_precision("bf16")
             out = fn()
         finally:
             self.llm.decode_packed = packed
-            self.set_precision(mode)
+            try:
+                self.set_precision(mode)
+            finally:
+                self.free_unused_weights = free
         for o in (out if isinstance(out, list) else [out]):
             o["recomputed_in_bf16"] = True
         return out

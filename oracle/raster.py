@@ -5,6 +5,10 @@ installed here and the reference holds no golden tables, so this follows pytorch
 `look_at_view_transform` + `FoVPerspectiveCameras`, `rasterize_meshes` naive path, `rasterize_points`) and is checked
 by self-consistency only.  Call sites restated: preprocess_data/render_mesh_utils.py:115-174,
 preprocess_data/utils_obj_pc.py:28-42,88-113, utils/demo_utils.py:128-143,171-257.
+Second witness [r6]: `oracle/raycast.py` computes pix_to_face + barycentrics by another algorithm (fp64 world-space rays) from the
+same conventions; `tests/test_raster.py::test_oracle_raster_agrees_with_an_independent_fp64_ray_caster` holds the two (and the
+HIP kernel) together on the four HUMAN_VIEW_DICT cameras.  That guards against a slip in THIS restatement; it is not a pin to
+pytorch3d, and the label above stays.
 """
 from __future__ import annotations
 

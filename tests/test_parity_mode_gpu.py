@@ -410,6 +410,11 @@ def test_full_depth_end_to_end_vs_oracle(hip_lib, cuda, seed, oracle):
         print(f"\n[full depth, seed {seed}] default mode vs the parity mode: max |dp| = {e:.2e}")
         assert e < 1e-3 - 2e-5
         assert torch.equal(got["default"][1], got["parity"][1])  # visibility set: bit-exact
+        for thr, op in ((0.5, torch.ge), (0.3, torch.gt)):  # threshold sets of the default mode against the parity mode's: off-band equal
+            same = op(got["default"][0], thr) == op(got["parity"][0], thr)
+            band = (got["parity"][0] - thr).abs() <= e + 2e-5
+            assert bool(same[~band].all())
+            print(f"[full depth, seed {seed}] default: {int((~same).sum())} of {int(band.sum())} band vertices flip at {thr} (vs parity mode)")
         return
     t0 = time.time()
     w = {k: v.float().cpu() for k, v in wd.items()}
@@ -433,12 +438,19 @@ def test_full_depth_end_to_end_vs_oracle(hip_lib, cuda, seed, oracle):
     assert err["parity"] < 2e-5 and err["parity-fast"] < 1e-3  # ("parity" is the other seeds' reference)
     assert torch.equal(got["default"][1], vis) and torch.equal(got["parity-fast"][1], vis)
     assert torch.equal(vis, torch.from_numpy(nviews[0] > 0))  # visibility set: bit-exact (every mode)
-    for mode in ("parity", "default"):
+    # The north star's "vertex-id sets bit-exact" ({p >= 0.5} eval_utils.py:75, {p > 0.3} run_demo.py:459), per mode
+    # [r6, VERDICT r5 item 4]: the `parity` mode's sets EQUAL the oracle's, exactly; the default mode's are equal outside its error band
+    # and the number of band vertices that land on the other side is printed (bench.py: value_sets_exactly_equal / value_sets_detail).
+    for mode in ("parity", "parity-fast", "default"):
         cm = got[mode][0]
-        for thr, op in ((0.5, torch.ge), (0.3, torch.gt)):  # metric / demo thresholds: equal off the error band of the mode
+        for thr, op in ((0.5, torch.ge), (0.3, torch.gt)):
+            same = op(cm, thr) == op(ref, thr)
             band = (ref - thr).abs() <= err[mode]
-            assert bool((op(cm, thr) == op(ref, thr))[~band].all())
-            assert mode != "parity" or int(band.sum()) <= 4
+            assert bool(same[~band].all())
+            if mode == "parity":
+                assert bool(same.all()), f"parity mode: {int((~same).sum())} vertices flip at {thr}"
+            else:
+                print(f"[full depth, seed {seed}] {mode}: {int((~same).sum())} of {int(band.sum())} band vertices flip at {thr}")
     assert err["bf16"] < 5e-2
 
 
@@ -560,3 +572,67 @@ def test_headline_model_7b_default_mode(hip_lib, cuda):
     print(f"\n[7B headline model] default mode vs parity mode: max |dp| = {e:.2e}; resident LLaMA weights default mode "
           f"{sum(rb.values()) / 1e9:.1f} GB (bf16 {rb['bf16'] / 1e9:.1f}, fp16 {rb['f16'] / 1e9:.1f}, 12-bit {rb['bf12'] / 1e9:.1f})")
     assert e < 1e-3 - 2e-5
+
+
+def test_headline_model_13b_default_mode(hip_lib, cuda):
+    """the RELEASED checkpoints' size (LLaVA-1.5-13B: 40 x 5120, inter 13824, 40 heads - run_demo.py:33,
+    scripts/run_train.sh:58; `synthetic.config_13b()`) under pytest, the checks (i) - (iv) and (vii) of the 7B test above: (i) the
+    DEFAULT mode's result is finite and not constant; (ii) default vs the "parity" mode < 1e-3 (the oracle by proxy - `bench.py --model
+    13b` runs the fp32 CPU oracle itself: profiles/r06_bench_13b.json `parity_vs_oracle_full_depth`), threshold sets equal off the
+    error band, visibility set bit-exact; (iii) evaluate_batch(2) == evaluate per image; (iv) the lift of its own masks through the C
+    oracle; (vii) residency by form (no bf16 copy of a packed matrix in the default mode)."""
+    import numpy as np
+    import torch
+
+    from interactvlm_amd import model as M
+    from interactvlm_amd import ops, synthetic
+    from oracle import cref
+
+    torch.set_grad_enabled(False)
+    cfg = synthetic.config_13b()
+    w = synthetic.device_weights(cfg, cuda, seed=0)
+    tables = synthetic.body_lift_tables(cuda)
+    m = M.InteractVLMForCausalLM(cfg, w, cuda, lift_tables=tables)
+    del w
+    torch.cuda.empty_cache()
+    assert m.precision == "default" and len(m.llm.layers) == 40
+    ids, forced = synthetic.prompt_ids(cfg)
+    cams = synthetic.human_cam_params()
+    ic, im = synthetic.images(cfg, cuda, seed=0)
+    S = cfg.sam.img_size
+    ev = lambda: m.evaluate(ic, im, ids, cams, [(S, S)], [(S, S)], forced_new_tokens=forced)
+    rb = m.resident_weight_bytes()  # (vii)
+    n_mat = sum(L[n + "_hp"].numel() for L in m.llm.layers for n in ("qkv", "o", "gu", "down"))
+    assert rb["f16"] == 2 * n_mat and 1.45 * n_mat < rb["bf12"] < 1.6 * n_mat + 1.6 * m.llm.lm_head.numel()
+    assert rb["bf16"] < 2.1 * (m.llm.embed.numel() + m.llm.lm_head.numel())
+    out = ev()  # (i)
+    pc = out["pred_contact_3d"].float().cpu()
+    assert "recomputed_in_bf16" not in out and pc.shape == (1, 6890) and bool(torch.isfinite(pc).all())
+    assert 0.0 <= float(pc.min()) and float(pc.max()) <= 1.0 and float(pc.std()) > 1e-3
+    masks = out["pred_masks"][0]  # (iv)
+    ref, nviews = cref.lift_mesh_soft(masks.cpu().numpy()[None], tables[0].cpu().numpy().astype(np.int32), tables[1].cpu().numpy(), 6890)
+    assert float((pc - torch.from_numpy(ref)).abs().max()) < 1e-5
+    plan = m.human_3d_contact_predictor._get_plan(cuda)
+    _, nv = ops.lift_mesh_plan(masks[None].contiguous(), plan, want_nviews=True)
+    assert torch.equal(nv[0].cpu() > 0, torch.from_numpy(nviews[0] > 0))
+    ic2, im2 = synthetic.images(cfg, cuda, seed=1)  # (iii)
+    outs = m.evaluate_batch(torch.cat([ic, ic2]), torch.cat([im, im2]), [ids[0], ids[0]], [cams[0], cams[0]], [(S, S)] * 2, [(S, S)] * 2,
+                            forced_new_tokens=forced)
+    single2 = m.evaluate(ic2, im2, ids, cams, [(S, S)], [(S, S)], forced_new_tokens=forced)
+    for o, one in zip(outs, (out, single2)):
+        assert torch.equal(o["output_ids"], one["output_ids"])
+        e = float((o["pred_contact_3d"] - one["pred_contact_3d"]).abs().max())
+        assert e < 1e-3, e
+    m.set_precision("parity")  # (ii)
+    op = ev()
+    par = op["pred_contact_3d"].float().cpu()
+    _, nvp = ops.lift_mesh_plan(op["pred_masks"][0][None].contiguous(), plan, want_nviews=True)
+    e = float((pc - par).abs().max())
+    print(f"\n[13B model] default mode vs parity mode: max |dp| = {e:.2e}; resident LLaMA weights (default mode) {sum(rb.values()) / 1e9:.1f} GB")
+    assert e < 1e-3 - 2e-5
+    assert torch.equal(nv[0] > 0, nvp[0] > 0)
+    for thr, cmp in ((0.5, torch.ge), (0.3, torch.gt)):
+        same = cmp(pc, thr) == cmp(par, thr)
+        band = (par - thr).abs() <= e + 2e-5
+        assert bool(same[~band].all())
+        print(f"[13B model] default: {int((~same).sum())} of {int(band.sum())} band vertices flip at {thr} (vs parity mode)")

@@ -43,6 +43,74 @@ def test_oracle_points_nearest_wins():
     assert (m == 1).sum() == 0 and (m == 2).sum() > 0
 
 
+def _body_and_cams():
+    from interactvlm_amd import constants, synthetic
+
+    v, f = synthetic.body_mesh()
+    return v.numpy(), f.numpy(), constants.HUMAN_VIEW_DICT["4MV-Z_Vitru"]["cam_params"]
+
+
+def test_oracle_raster_agrees_with_an_independent_fp64_ray_caster():
+    """a second witness for the (unpinned) rasteriser restatement.  oracle/raycast.py gets pix_to_face and the
+    barycentrics of the 6890-vertex stand-in body under the four HUMAN_VIEW_DICT cameras by another algorithm (world-space rays,
+    Moeller-Trumbore in fp64, camera stated as eye / left / up / forward) from the same conventions (SURVEY 8c;
+    render_mesh_utils.py:115-174); oracle/raster.py (fp32 edge functions on projected vertices, 1/z-corrected barycentrics) must
+    give the same face in every pixel but edge ties, the same barycentrics, the same silhouette.  This does not pin the restatement
+    to pytorch3d - nothing here can - it removes the single-restatement risk."""
+    from oracle import raycast as RC
+
+    v, f, cams = _body_and_cams()
+    H = W = 160
+    fg = {}
+    for name, cam in cams.items():
+        Rm, T = R.look_at_view_transform(*cam)
+        p2v, bary, p2f = R.rasterize_mesh(v, f, Rm, T, H, W)
+        cf, cb, ct = RC.cast_mesh(v, f, RC.camera(*cam), H, W)
+        mism = p2f != cf
+        # a pixel may differ only where the fp64 hit lies on an edge (min barycentric ~ 0: the fp32 edge function can fall on the
+        # other side) - on this mesh there are none at this resolution; the bound allows a handful
+        assert int(mism.sum()) <= 4, (name, int(mism.sum()))
+        if mism.any():
+            assert float(np.abs(cb[mism]).min(-1).max()) < 1e-3
+        both = (p2f >= 0) & ~mism
+        fg[name] = float((p2f >= 0).mean())
+        assert abs(fg[name] - float((cf >= 0).mean())) <= 4.0 / (H * W)  # the silhouette: same foreground
+        d = np.abs(bary[both] - cb[both])
+        assert float(d.max()) < 2e-3 and float(np.median(d)) < 2e-5, (name, float(d.max()), float(np.median(d)))
+        assert np.array_equal(p2v[both], f[cf[both]])
+        # depth: the ray parameter is the view depth of the hit = the interpolated vertex depth
+        zv = (v.astype(np.float64) @ Rm.astype(np.float64) + T)[:, 2]
+        zi = (zv[f[cf[both]]] * cb[both]).sum(-1)
+        assert float(np.abs(zi - ct[both]).max()) < 1e-5
+    # the stand-in body covers ~18 % of a view (what the lift tables of bench.py are built from), whichever algorithm draws it
+    assert 0.15 < min(fg.values()) and max(fg.values()) < 0.21, fg
+    assert abs(fg["topfront"] - fg["topback"]) < 2e-3 and abs(fg["bottomfront"] - fg["bottomback"]) < 2e-3  # (a symmetric body)
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_raster_vs_fp64_ray_caster(hip_lib, cuda):
+    """The HIP rasteriser itself (the producer of bench.py's lift tables) against the ray caster, body mesh, one camera at 384^2."""
+    import torch
+
+    from interactvlm_amd import render
+    from oracle import raycast as RC
+
+    v, f, cams = _body_and_cams()
+    cam = cams["bottomfront"]  # (the shifted one: ty = 0.3)
+    H = W = 384
+    p2v, bary, p2f = render.rasterize_mesh(torch.from_numpy(v).to(cuda), torch.from_numpy(f).to(cuda), cam, (H, W), want_faces=True)
+    p2f, p2v, bary = p2f.cpu().numpy(), p2v.cpu().numpy(), bary.cpu().numpy()
+    cf, cb, _ = RC.cast_mesh(v, f, RC.camera(*cam), H, W)
+    same = p2f == cf
+    assert same.mean() > 0.9995, same.mean()
+    if (~same).any():
+        hit = ~same & (cf >= 0)
+        assert not hit.any() or float(np.abs(cb[hit]).min(-1).max()) < 2e-3  # differences sit on edges only
+    both = same & (cf >= 0)
+    assert np.array_equal(p2v[both], f[cf[both]])
+    assert float(np.abs(bary[both] - cb[both]).max()) < 2e-3
+
+
 @pytest.mark.gpu
 def test_gpu_mesh_raster_vs_oracle(hip_lib, cuda):
     import torch
