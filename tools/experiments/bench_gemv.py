@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from interactvlm_amd import ops  # noqa: E402
 
 SHAPES = [("qkv+rms", 12288, 4096, "none", True), ("o+res", 4096, 4096, "none", False),

@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from interactvlm_amd import _lib, ops  # noqa: E402
 from interactvlm_amd.ops import ACT, _p, _stream, check  # noqa: E402
 

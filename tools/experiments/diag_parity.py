@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from interactvlm_amd import model as M  # noqa: E402
 from interactvlm_amd import synth, synthetic  # noqa: E402

@@ -14,7 +14,7 @@ import sys
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 SITES = ("n1q", "n1kv", "qrel", "qqk", "k", "v", "qs", "rel", "p", "o", "n2", "h")
 

@@ -13,7 +13,7 @@ import sys
 import torch
 import torch.nn.functional as F
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from interactvlm_amd import synth, synthetic  # noqa: E402
 from interactvlm_amd import weights as Wt  # noqa: E402

@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from interactvlm_amd import ops  # noqa: E402
 from exp_cumask import masked_stream  # noqa: E402
 
