@@ -262,10 +262,6 @@ int ivlm_gemm_nsplit(int on);
 int ivlm_gemm_tile_override(int tile);
 /* Benchmark/test hook: automatic choice of the 256 x 320 tile for N % 320 == 0 (SAM ViT-H widths; default on). Returns the previous value. */
 int ivlm_gemm_tile320(int on);
-/* Benchmark/test hook: fp32-input LayerNorm / RMSNorm rows through the line-contiguous kernel (norm4_kernel: one wave instruction =
- * 1 KB of consecutive bytes; default on) or, with 0, through the 32-bytes-per-lane kernel that also serves bf16 rows.  Same
- * per-element arithmetic; the statistics may differ in the last bit (other grouping of the partial sums).  Returns the previous value. */
-int ivlm_norm_line_loads(int on);
 
 /* nn.LayerNorm over the last dim (also SAM LayerNorm2d with NHWC activations, common.py:32-42);
  * x / y bf16 or fp32 (dtype codes), fp32 statistics, cols % 8 == 0, cols <= 8192.  gelu_after != 0 fuses the exact-erf GELU

@@ -125,116 +125,6 @@ __global__ __launch_bounds__(256) void norm_kernel(const void* __restrict__ xv, 
     }
 }
 
-// [r6] fp32-input rows, LINE-CONTIGUOUS wave loads: lane l of chunk c reads the float4 at element 4 (64 c + l), so one wave
-// instruction covers 1 KB of consecutive bytes (norm_kernel's fp32 path gives every lane 32 consecutive bytes - two instructions
-// that each touch every 128-byte line of a 2 KB span HALF: twice the line look-ups in the CU's L1 for the same bytes, and the L1 fill
-// path - 50 - 64 GB/s per CU - is what a streaming kernel runs into first on this chip: the SAM encoder's norms moved 2.7 TB/s).
-// Outputs are 8 bytes per lane (16-bit kinds: 512 B contiguous per wave instruction) or 16 (fp32).  Same arithmetic per element as
-// norm_kernel; the per-lane partial sums group other elements, so mean / variance can differ in the last bit.
-// NC4 = chunks of 256 columns (cols <= 256 NC4, cols % 4 == 0).
-template <bool RMS, int NC4, bool YF32>
-__global__ __launch_bounds__(256) void norm4_kernel(const float* __restrict__ x, const bf16_t* __restrict__ w,
-                                                    const bf16_t* __restrict__ b, void* __restrict__ yv, int64_t rows, int cols,
-                                                    float eps, const int32_t* __restrict__ out_rows, int y_split) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int n4 = cols >> 2;
-    const float4* xr = reinterpret_cast<const float4*>(x + row * cols);
-    float4 v[NC4];
-    float s = 0.0f;
-#pragma unroll
-    for (int c = 0; c < NC4; ++c) {
-        const int idx = c * 64 + lane;
-        if (idx < n4) {
-            v[c] = xr[idx];
-            s += RMS ? (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w) : (v[c].x + v[c].y) + (v[c].z + v[c].w);
-        }
-    }
-    s = wave_sum(s);
-    float mean = 0.0f, rstd;
-    if (RMS) {
-        rstd = rsqrtf(s / (float)cols + eps);
-    } else {
-        mean = s / (float)cols;
-        float q = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NC4; ++c)
-            if (c * 64 + lane < n4) {
-                const float d0 = v[c].x - mean, d1 = v[c].y - mean, d2 = v[c].z - mean, d3 = v[c].w - mean;
-                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            }
-        q = wave_sum(q);
-        rstd = rsqrtf(q / (float)cols + eps);
-    }
-    const int64_t orow = out_rows ? (int64_t)out_rows[row] : row;
-    uint2* yr = reinterpret_cast<uint2*>(static_cast<bf16_t*>(yv) + orow * ((y_split & 1) ? 2 * cols : cols));
-    float4* yr4 = reinterpret_cast<float4*>(static_cast<float*>(yv) + orow * cols);
-    const uint2* wr = reinterpret_cast<const uint2*>(w);
-    const uint2* br = reinterpret_cast<const uint2*>(b);
-#pragma unroll
-    for (int c = 0; c < NC4; ++c) {
-        const int idx = c * 64 + lane;
-        if (idx < n4) {
-            const uint2 wu = wr[idx];
-            const float w0 = __uint_as_float(wu.x << 16), w1 = __uint_as_float(wu.x & 0xffff0000u);
-            const float w2 = __uint_as_float(wu.y << 16), w3 = __uint_as_float(wu.y & 0xffff0000u);
-            float o0, o1, o2, o3;
-            if (RMS) {  // (fp32 rows: the normalised value is not rounded before the weight multiply - as norm_kernel<.., XF32>)
-                o0 = v[c].x * rstd * w0; o1 = v[c].y * rstd * w1; o2 = v[c].z * rstd * w2; o3 = v[c].w * rstd * w3;
-            } else {
-                const uint2 bu = br[idx];
-                o0 = (v[c].x - mean) * rstd * w0 + __uint_as_float(bu.x << 16);
-                o1 = (v[c].y - mean) * rstd * w1 + __uint_as_float(bu.x & 0xffff0000u);
-                o2 = (v[c].z - mean) * rstd * w2 + __uint_as_float(bu.y << 16);
-                o3 = (v[c].w - mean) * rstd * w3 + __uint_as_float(bu.y & 0xffff0000u);
-            }
-            if (YF32) {
-                yr4[idx] = make_float4(o0, o1, o2, o3);
-            } else if (y_split == 2) {  // IEEE fp16 row
-                yr[idx] = make_uint2(pack_f16x2(o0, o1), pack_f16x2(o2, o3));
-            } else if (y_split) {  // 1: [hi | lo] bf16 halves, 3: [hi | lo] IEEE halves
-                uint32_t h0, l0, h1, l1;
-                split_16x2(o0, o1, h0, l0, y_split == 3);
-                split_16x2(o2, o3, h1, l1, y_split == 3);
-                yr[idx] = make_uint2(h0, h1);
-                yr[n4 + idx] = make_uint2(l0, l1);
-            } else {
-                yr[idx] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
-            }
-        }
-    }
-}
-
-static int g_norm4 = 1;  // benchmark hook (ivlm_norm_line_loads): 0 = the 32-bytes-per-lane kernel for fp32 rows too
-
-template <bool RMS>
-static bool launch_norm4(const void* x, const bf16_t* w, const bf16_t* b, void* y, int y_f32, int64_t rows, int cols, float eps,
-                         hipStream_t st, const int32_t* out_rows) {
-    if (!g_norm4 || (cols & 3) || cols > 8192 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
-        (reinterpret_cast<uintptr_t>(w) & 7) || (b && (reinterpret_cast<uintptr_t>(b) & 7)))
-        return false;
-    if (y_f32 != 1 && (cols & 7)) return false;  // (16-bit rows: whole 16-byte granules per row, as norm_kernel requires)
-    const unsigned grid = (unsigned)((rows + 3) / 4);
-    const int y_split = y_f32 == 2 ? 1 : (y_f32 == 4 ? 2 : (y_f32 == 5 ? 3 : 0));
-    const float* xf = static_cast<const float*>(x);
-#define IVLM_N4(NC)                                                                                                          \
-    do {                                                                                                                     \
-        if (y_f32 == 1) norm4_kernel<RMS, NC, true><<<grid, 256, 0, st>>>(xf, w, b, y, rows, cols, eps, out_rows, 0);        \
-        else norm4_kernel<RMS, NC, false><<<grid, 256, 0, st>>>(xf, w, b, y, rows, cols, eps, out_rows, y_split);            \
-    } while (0)
-    if (cols <= 256) IVLM_N4(1);
-    else if (cols <= 512) IVLM_N4(2);
-    else if (cols <= 1024) IVLM_N4(4);
-    else if (cols <= 1280) IVLM_N4(5);
-    else if (cols <= 2048) IVLM_N4(8);
-    else if (cols <= 4096) IVLM_N4(16);
-    else if (cols <= 5120) IVLM_N4(20);
-    else IVLM_N4(32);
-#undef IVLM_N4
-    return true;
-}
-
 }  // namespace
 
 template <bool RMS, int MAXC, bool GELU>
@@ -253,7 +143,6 @@ int layernorm(const void* x, int x_f32, const bf16_t* w, const bf16_t* b, void* 
               hipStream_t st, int gelu, const int32_t* out_rows, const float* fp8_scale) {
     if (!x || !w || !b || !y || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
     if ((cols & 7) || cols > kMaxChunks * 512) return IVLM_ERR_UNSUPPORTED;
-    if (!gelu && x_f32 && !fp8_scale && launch_norm4<false>(x, w, b, y, y_f32, rows, cols, eps, st, out_rows)) return ivlm_launch_status();
     if (gelu) {
         if (cols > 4 * 512) return IVLM_ERR_UNSUPPORTED;
         launch_norm<false, 4, true>(x, x_f32, w, b, y, y_f32, rows, cols, eps, st, out_rows);
@@ -270,7 +159,6 @@ int rmsnorm(const void* x, int x_f32, const bf16_t* w, void* y, int y_f32, int64
     if (!x || !w || !y || rows <= 0 || cols <= 0) return IVLM_ERR_INVALID_ARG;
     if ((cols & 7) || cols > kMaxChunks * 512) return IVLM_ERR_UNSUPPORTED;
     if (fp8_scale && y_f32) return IVLM_ERR_INVALID_ARG;  // (fp8_scale: y is e4m3 bytes of the normalised row / *fp8_scale)
-    if (x_f32 && !fp8_scale && launch_norm4<true>(x, w, nullptr, y, y_f32, rows, cols, eps, st, nullptr)) return ivlm_launch_status();
     if (cols <= 4 * 512) launch_norm<true, 4, false>(x, x_f32, w, nullptr, y, y_f32, rows, cols, eps, st, nullptr, fp8_scale);
     else launch_norm<true, kMaxChunks, false>(x, x_f32, w, nullptr, y, y_f32, rows, cols, eps, st, nullptr, fp8_scale);
     return ivlm_launch_status();
@@ -279,12 +167,6 @@ int rmsnorm(const void* x, int x_f32, const bf16_t* w, void* y, int y_f32, int64
 }  // namespace ivlm
 
 extern "C" {
-
-int ivlm_norm_line_loads(int on) {
-    const int prev = ivlm::g_norm4;
-    if (on == 0 || on == 1) ivlm::g_norm4 = on;
-    return prev;
-}
 
 int ivlm_layernorm(const void* x, int x_dtype, const void* w, const void* b, void* y, int y_dtype, int64_t rows, int cols,
                    float eps, int gelu, const int32_t* out_rows, const float* fp8_scale, ivlm_stream_t stream) {
