@@ -452,9 +452,13 @@ def main():
     S = cfg.sam.img_size
     T0 = ids.shape[1] + cfg.img_emb_len
 
+    guard = {"recomputed": 0}  # calls that left fp16's exponent range and were recomputed with bf16 operands (a parity failure)
+
     def step_b1():
         out = model.evaluate(images_clip, images, ids, cams, [(S, S)], [(S, S)], contact_type="hcontact",
                              forced_new_tokens=forced)
+        if out.get("recomputed_in_bf16"):
+            guard["recomputed"] += 1
         allc = gather_contacts(out["pred_contact_3d"])  # ONE all-gather of [1,6890] fp32 per rank
         return allc.cpu() if rank == 0 else allc
 
@@ -833,7 +837,11 @@ def main():
             "scaling": "weak" if workload == "b1" else "strong",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic", "config": wl,
             "value_precision_mode": "default",
-            "value_within_1e-3_of_fp32_oracle": (parity_full["default"]["within_1e-3"] if parity_full else None),
+            # (a call whose fp16 operands overflowed is recomputed with bf16 operands - the mode that FAILS 1e-3 at this depth - and
+            #  says so in its result; any such call among the timed ones voids the parity claim of `value`)
+            "value_calls_recomputed_in_bf16": guard["recomputed"],
+            "value_within_1e-3_of_fp32_oracle": ((parity_full["default"]["within_1e-3"] and guard["recomputed"] == 0)
+                                                 if parity_full else None),
             # [r6] the north star's second half ("vertex-id sets bit-exact"; sets: SURVEY App. A - {nviews > 0}, {p >= 0.5}
             # (eval_utils.py:75), {p > 0.3} (run_demo.py:459)): `value`'s mode keeps the visibility set exact in every case and can flip
             # a vertex that sits within its error band of a threshold; the `parity` mode's figure is the throughput WITH exact sets
