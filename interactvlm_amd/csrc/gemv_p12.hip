@@ -447,9 +447,9 @@ __device__ __forceinline__ void split_pair_p12(float a, float b, uint32_t& hi, u
     lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 
-template <bool RMS, int T, bool PIPE = false, int U_ = 2>
+template <bool RMS, int T>
 __global__ __launch_bounds__(512, 2) void skinny_p12m_kernel(GemmArgs g, P12M p) {
-    constexpr int kW = 8, U = U_;  // waves per block; step pairs in flight per lane (4 MFMA k-steps)
+    constexpr int kW = 8, U = 2;  // waves per block; step pairs in flight per lane (4 MFMA k-steps)
     __shared__ float s_part[kW][16][17];  // [wave][m][n]
     __shared__ float s_ssq[kW][16];
     __shared__ float s_fin[16][17];
@@ -476,7 +476,6 @@ __global__ __launch_bounds__(512, 2) void skinny_p12m_kernel(GemmArgs g, P12M p)
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f32x4m_t{0.0f, 0.0f, 0.0f, 0.0f};
     float ssq = 0.0f;
-  if constexpr (!PIPE) {
     for (int sp = s0; sp < s1; sp += U) {
         u32x4_t pw[U][T], xa[U][2], xb[U][2], gm[U][2];
         u32x2_t ew[U][T];
@@ -532,68 +531,6 @@ __global__ __launch_bounds__(512, 2) void skinny_p12m_kernel(GemmArgs g, P12M p)
             }
         }
     }
-  } else {
-    // [r6] U step pairs ALWAYS in flight: the buffers of step pair u are refilled (with step pair sp + U + u) right after its MFMAs
-    // instead of all buffers at the top of the next iteration - the MFMAs / splits of one step pair run under the loads of the other
-    // (the loop of gemv1_p12m_kernel).  Same order of the MFMAs per accumulator: bit-identical sums.
-    u32x4_t pw[U][T], xa[U][2], xb[U][2], gm[U][2];
-    u32x2_t ew[U][T];
-    auto issue = [&](int u, int spn) {  // (spn wave-uniform)
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            pw[u][t] = __builtin_nontemporal_load(pp[t] + (int64_t)spn * 64);
-            ew[u][t] = __builtin_nontemporal_load(ep[t] + (int64_t)spn * 64);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {  // the lane's 8 fp32 activations of MFMA step 2 spn + h: k = spn * 64 + h * 32 + kg * 8 ..
-            const int c = spn * 8 + h * 4 + kg;  // 8-element chunk index
-            xa[u][h] = xrow ? xp[2 * c] : zero;
-            xb[u][h] = xrow ? xp[2 * c + 1] : zero;
-            if (RMS) gm[u][h] = gp[c];
-        }
-    };
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (s0 + u < s1) issue(u, s0 + u);
-    for (int sp = s0; sp < s1; sp += U) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (sp + u >= s1) break;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float f[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f[j] = __uint_as_float(xa[u][h][j]);
-                    f[4 + j] = __uint_as_float(xb[u][h][j]);
-                }
-                if (RMS) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ssq += f[2 * j] * f[2 * j] + f[2 * j + 1] * f[2 * j + 1];
-                        f[2 * j] *= __uint_as_float(gm[u][h][j] << 16);
-                        f[2 * j + 1] *= __uint_as_float(gm[u][h][j] & 0xffff0000u);
-                    }
-                }
-                u32x4_t hi, lo;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t h2, l2;
-                    split_pair_p12(f[2 * j] * xs, f[2 * j + 1] * xs, h2, l2);
-                    hi[j] = h2;
-                    lo[j] = l2;
-                }
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const bf16x8m_t wf = frag_p12m(pw[u][t][2 * h], pw[u][t][2 * h + 1], ew[u][t][h]);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8m_t, hi), acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8m_t, lo), acc[t], 0, 0, 0);
-                }
-            }
-            if (sp + U + u < s1) issue(u, sp + U + u);
-        }
-    }
-  }
     // lane holds C[m = r][n = 4 * kg + i] of this wave's K slice, per tile
     if (RMS) {
         ssq += __shfl_xor(ssq, 16);
@@ -735,7 +672,6 @@ extern "C" int ivlm_unpack_bf12(const void* P, int64_t ldp, const void* E, int64
     return ivlm_launch_status();
 }
 
-int g_skinny_p12m_pipe = 0;         // loop form of skinny_p12m_kernel (experiment hook, see ivlm_gemv16_bf12m_tuning)
 int g_skinny_p12m_tiles = 0;       // 0 = rule in ivlm_gemv16_bf12m (A/B hook: ivlm_gemv16_bf12m_tuning)
 int g_p12m_wide_max_blocks = 256;  // A/B hooks: ivlm_gemv1_bf12m_tuning
 int g_p12m_deep = 1;
@@ -875,30 +811,19 @@ extern "C" int ivlm_gemv16_bf12m(const float* x, int64_t lda, int M, const void*
         }
     }
     const dim3 grid((tiles + T - 1) / T), block(512);
-#define IVLM_SK(RMS_, T_)                                                                                        \
-    do {                                                                                                         \
-        if (g_skinny_p12m_pipe == 1) ivlm_launch(skinny_p12m_kernel<RMS_, T_, true, 2>, grid, block, 0, st, g, p);  \
-        else if (g_skinny_p12m_pipe == 2) ivlm_launch(skinny_p12m_kernel<RMS_, T_, true, (T_ == 1 ? 4 : 3)>, grid, block, 0, st, g, p); \
-        else ivlm_launch(skinny_p12m_kernel<RMS_, T_, false, 2>, grid, block, 0, st, g, p);                        \
-    } while (0)
     if (rms_w) {
-        if (T == 1) IVLM_SK(true, 1);
-        else if (T == 2) IVLM_SK(true, 2);
-        else IVLM_SK(true, 3);
+        if (T == 1) ivlm_launch(skinny_p12m_kernel<true, 1>, grid, block, 0, st, g, p);
+        else if (T == 2) ivlm_launch(skinny_p12m_kernel<true, 2>, grid, block, 0, st, g, p);
+        else ivlm_launch(skinny_p12m_kernel<true, 3>, grid, block, 0, st, g, p);
     } else {
-        if (T == 1) IVLM_SK(false, 1);
-        else if (T == 2) IVLM_SK(false, 2);
-        else IVLM_SK(false, 3);
+        if (T == 1) ivlm_launch(skinny_p12m_kernel<false, 1>, grid, block, 0, st, g, p);
+        else if (T == 2) ivlm_launch(skinny_p12m_kernel<false, 2>, grid, block, 0, st, g, p);
+        else ivlm_launch(skinny_p12m_kernel<false, 3>, grid, block, 0, st, g, p);
     }
-#undef IVLM_SK
     return ivlm_launch_status();
 }
 
-extern "C" void ivlm_gemv16_bf12m_tuning(int tiles_per_block) {
-    // (experiment hook, round 6: 100 + v selects the loop form - 0 product, 1 refill-after-use with 2 step pairs in flight, 2 with 3 - 4)
-    if (tiles_per_block >= 100) { g_skinny_p12m_pipe = tiles_per_block - 100; return; }
-    g_skinny_p12m_tiles = tiles_per_block > 3 ? 3 : tiles_per_block;
-}
+extern "C" void ivlm_gemv16_bf12m_tuning(int tiles_per_block) { g_skinny_p12m_tiles = tiles_per_block > 3 ? 3 : tiles_per_block; }
 
 // =====================================================================================================================================
 // The packer (weight preparation, once per matrix): bf16 [N, K] -> fragment-layout planes + per-row exponent bases + CSR patches, so that
