@@ -7,7 +7,7 @@ import sys
 import torch
 import torch.distributed as dist
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from interactvlm_amd import model as M, synth, synthetic, weights as Wt  # noqa: E402
 from interactvlm_amd.dist import gather_contacts  # noqa: E402
 
