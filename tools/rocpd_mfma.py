@@ -50,6 +50,16 @@ def main():
         cu = d.get("SQ_BUSY_CU_CYCLES")
         rows.append((d["n"] * d["dur"], key, d, u_time, u_grbm, cu))
     rows.sort(reverse=True)
+    tb = sum(d["n"] * d["SQ_VALU_MFMA_BUSY_CYCLES"] for _, _, d, _, _, cu in rows if cu)
+    tc = sum(d["n"] * cu for _, _, d, _, _, cu in rows if cu)
+    print("# MFMA-pipe utilisation by hardware counter, per kernel of the headline loop (graphs off for counter collection).")
+    print("# THE column to read is the last: SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) = fraction of a busy CU's SIMD-cycles in which")
+    print("# the matrix pipe is busy (both counters come from the same SQ instances, so their ratio is scale-free).  The two time-normalised")
+    print("# columns are ~32 x low: this rocprofv3 reports the SQ counters of one shader engine of 32, not the chip sum - uncalibrated, kept")
+    print("# for the record.  NOT the algorithmic-FLOP fraction of bench.py's roofline_mfma (that one also pays the clock sag, padding rows,")
+    print("# the hi + lo second passes and everything that is not an MFMA cycle).")
+    if tc:
+        print(f"# all kernels below, time-weighted: {tb / (N_SIMD * tc):.3f}")
     print(f"{'kernel':<58} {'grid':>8} {'n':>5} {'us(pmc)':>8} {'MFMA busy / (1024 SIMDs x 2.4 GHz x t)':>40} {'/ GRBM_GUI_ACTIVE':>18} {'/ SQ_BUSY_CU_CYCLES':>20}")
     for _, key, d, ut, ug, cu in rows[:24]:
         busy = d["SQ_VALU_MFMA_BUSY_CYCLES"]
